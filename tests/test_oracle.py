@@ -1,0 +1,174 @@
+"""CPU tests: the oracle against (i) the vectors produced by the imported reference, (ii) independent
+implementations present in the image (torch.stft/istft, scipy), (iii) closed-form known answers
+(SURVEY 8(c))."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from scipy import signal
+
+from oracle import aggregate as oagg
+from oracle import lowpass as olp
+from oracle import metrics as om
+from oracle import resample as ors
+from oracle import ssim as ossim
+from oracle import stft as ostft
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EV_CASES = ["noise48k", "noise44k", "noise16k", "speech48k_fftlp6k", "speech44k_fftlp4k_ragged", "speech24k_scaled"]
+
+
+def test_integer_tables(golden):
+    for rate, (n_fft, hop) in zip(golden["a1_rates"], golden["a1_nfft_hop"]):
+        assert om.stft_params(int(rate)) == (int(n_fft), int(hop))
+    assert om.stft_params(48000) == (2229, 480)
+    for hc, fs, cut in golden["lp_cut_table"]:
+        assert olp.cut_bin(int(hc), int(fs)) == int(cut)
+    assert ostft.num_frames(192000, 2048, 512) == 376
+    assert ostft.num_frames(192000, 2229, 480) == 400
+    assert ostft.num_frames(176400, 2048, 441) == 401
+
+
+@pytest.mark.parametrize("name", EV_CASES)
+def test_evaluation_matches_reference(golden, name):
+    est, tgt, rate = golden["ev_%s_est" % name], golden["ev_%s_tgt" % name], int(golden["ev_%s_rate" % name])
+    res = om.evaluation(est, tgt, rate)
+    got = np.array([res["lsd"], res["log_sispec"], res["sispec"], res["ssim"]])
+    np.testing.assert_allclose(got, golden["ev_%s_out" % name], rtol=1e-6)
+
+
+def test_reductions_on_spectrograms_match_reference(golden):
+    e, t = torch.tensor(golden["sp_est"]), torch.tensor(golden["sp_tgt"])
+    np.testing.assert_array_equal(om.lsd(e, t).numpy(), golden["sp_lsd"])
+    assert float(om.sispec(e, t)) == float(golden["sp_sispec"])
+    np.testing.assert_array_equal(om.to_log(e).numpy(), golden["sp_to_log"])
+    np.testing.assert_array_equal(om.ssim(e, t).numpy(), golden["sp_ssim"])
+
+
+@pytest.mark.parametrize("n_fft,hop,n", [(2048, 512, 9000), (2229, 480, 7001), (743, 160, 4000), (2048, 441, 5000)])
+def test_stft_vs_torch(n_fft, hop, n):
+    x = np.random.default_rng(1).standard_normal(n).astype(np.float32)
+    ours = ostft.librosa_stft(x, n_fft, hop)
+    ref = torch.stft(torch.tensor(x, dtype=torch.float64), n_fft, hop, window=torch.hann_window(n_fft, dtype=torch.float64),
+                     center=True, pad_mode="reflect", return_complex=True).numpy()
+    assert ours.shape == ref.shape == (n_fft // 2 + 1, ostft.num_frames(n, n_fft, hop))
+    assert ours.dtype == np.complex64
+    assert np.max(np.abs(ours - ref)) <= 2e-7 * np.max(np.abs(ref))
+
+
+def test_stft_known_answer_bin_centre_tone():
+    n_fft, hop, k0, A = 2048, 512, 100, 0.37
+    m = np.arange(20000)
+    x = (A * np.cos(2 * np.pi * k0 * m / n_fft)).astype(np.float32)
+    mag = ostft.stft_mag_TF(x, n_fft, hop)
+    interior = mag[4:-4, k0]
+    np.testing.assert_allclose(interior, A * n_fft / 4, rtol=2e-6)
+
+
+def test_istft_vs_torch():
+    n, n_fft, hop = 9000, 2048, 441
+    x = np.random.default_rng(2).standard_normal(n).astype(np.float32)
+    re, im = ostft.tl_stft(x[None], n_fft, hop)
+    re[..., 557:] = 0
+    im[..., 557:] = 0
+    ours = ostft.tl_istft(re, im, n, n_fft, hop)[0]
+    spec = torch.tensor(re[0, 0].astype(np.float64) + 1j * im[0, 0].astype(np.float64)).T
+    ref = torch.istft(spec, n_fft, hop, window=torch.hann_window(n_fft, dtype=torch.float64), center=True, length=n).numpy()
+    np.testing.assert_allclose(ours, ref, atol=1e-6)
+
+
+def test_librosa_istft_roundtrip():
+    x = np.random.default_rng(3).standard_normal(6000).astype(np.float32)
+    y = ostft.librosa_istft(ostft.librosa_stft(x), length=6000)
+    np.testing.assert_allclose(y, x, atol=2e-6)
+
+
+def test_ssim_two_formulations_and_identity():
+    rng = np.random.default_rng(4)
+    a = np.abs(rng.standard_normal((40, 90))).astype(np.float32) * 30
+    b = (a * (1 + 0.1 * rng.standard_normal(a.shape))).astype(np.float32)
+    s1 = ossim.structural_similarity(a, b)
+    s2 = ossim.structural_similarity_direct(a, b)
+    assert abs(s1 - s2) < 1e-12
+    assert abs(ossim.structural_similarity(a, a) - 1.0) < 1e-12
+    assert abs(ossim.C1 - 4e-4) < 1e-18 and abs(ossim.C2 - 3.6e-3) < 1e-18
+    with pytest.raises(ValueError):
+        ossim.structural_similarity(a[:6], b[:6])
+
+
+def test_known_answers_lsd_sispec():
+    rng = np.random.default_rng(6)
+    t = torch.tensor(np.abs(rng.standard_normal((1, 1, 30, 50))).astype(np.float32) + 0.1)
+    c = 0.25
+    assert abs(float(om.lsd(c * t, t)) - 2 * abs(np.log10(c))) < 1e-5
+    e = torch.tensor(np.abs(rng.standard_normal((1, 1, 30, 50))).astype(np.float32))
+    assert abs(float(om.sispec(e, t)) - float(om.sispec(e, 3.0 * t))) < 1e-4
+    tt = t.double()
+    n = torch.tensor(rng.standard_normal((1, 1, 30, 50)))
+    n = n - (n * tt).sum() / (tt * tt).sum() * tt
+    val = float(om.sispec((tt + 0.1 * n).float(), t))
+    assert abs(val - 10 * np.log10(float((tt * tt).sum() / (0.01 * n * n).sum()))) < 1e-3
+
+
+def test_resample_plan_and_restated_bit_exact():
+    for up, down, n, taps, pre_pad, pre_rm in [(160, 147, 4410, 3201, 17, 11), (441, 160, 1600, 8821, 70, 28)]:
+        p = ors.poly_plan(n, up, down)
+        assert (len(p["h"]), p["n_pre_pad"], p["n_pre_remove"]) == (taps, pre_pad, pre_rm)
+        assert p["n_out"] == -(-n * up // down)
+    x = np.random.default_rng(7).standard_normal(900).astype(np.float32)
+    for up, down in [(160, 147), (441, 160), (80, 147), (147, 80), (2, 1), (1, 3)]:
+        np.testing.assert_array_equal(ors.resample_poly_restated(x, up, down), signal.resample_poly(x, up, down))
+
+
+def test_resample_matches_reference_vectors(golden):
+    y1 = ors.librosa_resample_polyphase(golden["rs_x16k"], 16000, 44100)
+    np.testing.assert_array_equal(y1, golden["rs_16k_to_44k"])
+    np.testing.assert_array_equal(ors.librosa_resample_polyphase(y1, 44100, 48000), golden["rs_44k_to_48k"])
+    assert y1.shape[0] == 17640 and golden["rs_44k_to_48k"].shape[0] == 19200
+
+
+def test_lowpass_matches_reference_vectors(golden):
+    x = golden["lp_x"]
+    for hc, fs in [(4000, 44100), (12000, 44100), (6000, 48000)]:
+        # float: numpy-vs-torch fp32 elementwise ops (pow 0.5, mag*cos) differ by <= 1 ulp
+        np.testing.assert_allclose(olp.lowpass(x, hc, fs, order=1, _type="stft_hard"), golden["lp_y_%d_%d" % (hc, fs)], atol=3e-8)
+    xs = golden["ss_x"]
+    for hc in (2000, 4000, 12000):
+        np.testing.assert_array_equal(np.asarray(olp.lowpass(xs, hc, 44100, 1, "subsampling"), np.float32), golden["ss_y_%d" % hc])
+    for ft in ("butter", "cheby1", "ellip", "bessel"):
+        np.testing.assert_array_equal(olp.lowpass(xs, 4000, 44100, 6, ft), golden["iir_%s" % ft])
+    np.testing.assert_array_equal(olp.align_length(np.arange(7.0), np.arange(4.0)), golden["al_pad"])
+    np.testing.assert_array_equal(olp.align_length(np.arange(4.0), np.arange(7.0)), golden["al_cut"])
+    mag, cos, sin = olp.spectrogram_phase(golden["fd_x"][None])
+    np.testing.assert_allclose(mag[0, 0], golden["fd_mag"], rtol=2e-7)
+    np.testing.assert_allclose(cos[0, 0], golden["fd_cos"], atol=2e-7)
+
+
+def test_lowpass_really_removes_the_band(golden):
+    x = golden["lp_x"]
+    y = olp.lowpass(x, 4000, 44100, 1, "stft_hard")
+    assert y.shape == x.shape and y.dtype == np.float32
+    sp = np.abs(np.fft.rfft(y[2048:2048 + 4096] * np.hanning(4096)))
+    f = np.fft.rfftfreq(4096, 1 / 44100)
+    assert sp[f > 5000].max() < 1e-3 * sp[f < 3000].max()
+
+
+def test_aggregation_matches_reference():
+    with open(os.path.join(ROOT, "tests", "golden", "aggregate.json")) as f:
+        g = json.load(f)
+    final = {}
+    for spk in g["speakers"]:
+        final[spk] = {fn: g["per_file"][os.path.join(spk, fn)] for fn in g["files"][spk]}
+    each, avg = oagg.aggregate(final)
+    for spk in g["speakers"]:
+        for k in each[spk]:
+            for m in each[spk][k]:
+                assert each[spk][k][m] == g["each_speaker"][spk][k][m]
+    for k in avg:
+        for m in avg[k]:
+            assert avg[k][m] == g["averaged"][k][m]
+    # mean of speaker means differs from the global mean when speakers have different counts
+    allv = [v["proc_fft_24000_44100"]["lsd"] for v in g["per_file"].values()]
+    assert abs(np.mean(allv) - g["averaged"]["proc_fft_24000_44100"]["lsd"]) > 1e-6

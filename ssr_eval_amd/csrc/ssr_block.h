@@ -1,0 +1,85 @@
+// Block-execution abstraction shared by every kernel body in this directory.
+//
+// A kernel body is written once as a sequence of PHASES.  Inside a phase every thread of the
+// workgroup runs the same statement on its own `tid`; threads only READ what earlier phases wrote
+// and only WRITE locations no other thread touches in that phase.  Consecutive phases are separated
+// by a workgroup barrier.
+//
+//  * hipcc (gfx950):   SSR_PHASE(...) = { statement } __syncthreads();
+//  * g++ -DSSR_HOST_EMU: SSR_PHASE(...) = for (tid = 0 .. NT-1) { statement }   (sequential emulation)
+//
+// The emulation build exists so that the arithmetic of every kernel body (FFT passes, Bluestein,
+// SSIM windows, polyphase indices ...) is parity-tested against the oracle on a CPU-only machine
+// (tests/test_emu_*.py).  It is test infrastructure; the shipped library contains device code only.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#ifdef SSR_HOST_EMU
+#include <vector>
+#include <cstring>
+#define SSR_DEV static inline
+#define SSR_BODY static inline
+#define SSR_MEMBER inline
+struct SsrBlk { int nt; };
+#define SSR_REGS(TYPE, name, blk) std::vector<TYPE> name((blk).nt)
+#define SSR_PHASE(blk, regs, ...)                                  \
+  for (int tid = 0; tid < (blk).nt; ++tid) {                       \
+    auto& R = (regs)[tid]; (void)R;                                \
+    __VA_ARGS__;                                                   \
+  }
+static inline float ssr_fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float ssr_fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+#else
+#include <hip/hip_runtime.h>
+#define SSR_DEV __device__ __forceinline__
+#define SSR_BODY __device__ __forceinline__
+#define SSR_MEMBER __device__ __forceinline__
+struct SsrBlk { int tid; };
+#define SSR_REGS(TYPE, name, blk) TYPE name
+#define SSR_PHASE(blk, regs, ...)                                  \
+  {                                                                \
+    const int tid = (blk).tid; auto& R = (regs); (void)R; (void)tid; \
+    __VA_ARGS__;                                                   \
+  }                                                                \
+  __syncthreads();
+SSR_DEV float ssr_fmul_rn(float a, float b) { return __fmul_rn(a, b); }
+SSR_DEV float ssr_fadd_rn(float a, float b) { return __fadd_rn(a, b); }
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// complex helpers
+template <typename T> struct cx { T x, y; };
+template <typename T> SSR_DEV cx<T> cadd(cx<T> a, cx<T> b) { return {a.x + b.x, a.y + b.y}; }
+template <typename T> SSR_DEV cx<T> csub(cx<T> a, cx<T> b) { return {a.x - b.x, a.y - b.y}; }
+template <typename T> SSR_DEV cx<T> cmul(cx<T> a, cx<T> b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+template <typename T> SSR_DEV cx<T> cmul_negi(cx<T> a) { return {a.y, -a.x}; }   // a * (-i)
+
+// LDS index padding: one extra element per 16 keeps the strided stores of the early Stockham
+// passes off a single bank group ("LDS layout").
+SSR_DEV int ssr_pad(int i) { return i + (i >> 4); }
+SSR_DEV constexpr int ssr_padded_len(int n) { return n + (n >> 4) + 1; }
+
+// centred-STFT reflect padding of sample index s into [0, n)  (requires n > n_fft/2)
+SSR_DEV int ssr_reflect(int s, int n) {
+  if (s < 0) s = -s;
+  if (s >= n) s = 2 * (n - 1) - s;
+  return s;
+}
+
+// Block-wide sum of NV doubles per thread, one value at a time (3 phases each).
+// sc0: NT doubles, sc1: 16 doubles, result: out[0..NV) (LDS), valid for every thread after the call.
+#define SSR_BLOCK_SUM(blk, regs, NT_, NV_, sc0, sc1, out, GETTER)                            \
+  for (int q_ = 0; q_ < (NV_); ++q_) {                                                       \
+    SSR_PHASE(blk, regs, (sc0)[tid] = GETTER(q_));                                           \
+    SSR_PHASE(blk, regs, if (tid < 16) {                                                     \
+      double s_ = 0.0;                                                                       \
+      for (int i_ = tid; i_ < (NT_); i_ += 16) s_ += (sc0)[i_];                              \
+      (sc1)[tid] = s_;                                                                       \
+    });                                                                                      \
+    SSR_PHASE(blk, regs, if (tid == 0) {                                                     \
+      double s_ = 0.0;                                                                       \
+      for (int i_ = 0; i_ < 16; ++i_) s_ += (sc1)[i_];                                       \
+      (out)[q_] = s_;                                                                        \
+    });                                                                                      \
+  }

@@ -1,0 +1,161 @@
+// In-LDS power-of-two complex FFT for one workgroup (Stockham autosort, radix 8 with one leading
+// radix-2/4 pass), forward transform exp(-2*pi*i*j*k/N).
+//
+// Geometry: N = 2^LOGN points, NT = N/8 threads, every thread owns 8 points per pass in registers.
+// Data lives in two LDS arrays (re[], im[], structure-of-arrays, index-padded by ssr_pad); the
+// transform is in place: a pass is  load -> twiddle -> butterfly  |barrier|  store  |barrier|.
+// The first pass takes its 8 points straight from registers (the caller loaded them from HBM in
+// first-pass order), so a frame costs no LDS staging before the transform.
+// An inverse transform is the same code with the re/im array pointers exchanged
+// (IFFT(z) = swap(FFT(swap(z))) / N).
+//
+// Twiddles: table tw[i] = exp(-2*pi*i * i / N), i < N, computed on the host in long double and kept in
+// HBM/L2 (16 B loads for double).  A radix-8 butterfly loads w^1, w^2, w^4 and forms the other four
+// powers with one complex multiply each (error <= 2 ulp of the working type).
+#pragma once
+#include "ssr_block.h"
+
+template <typename T> SSR_DEV void ssr_bfly2(cx<T>* v) {
+  cx<T> a = v[0], b = v[1];
+  v[0] = cadd(a, b);
+  v[1] = csub(a, b);
+}
+
+template <typename T> SSR_DEV void ssr_bfly4(cx<T>* v) {
+  cx<T> b0 = cadd(v[0], v[2]), b1 = csub(v[0], v[2]);
+  cx<T> b2 = cadd(v[1], v[3]), b3 = cmul_negi(csub(v[1], v[3]));
+  v[0] = cadd(b0, b2);
+  v[1] = cadd(b1, b3);
+  v[2] = csub(b0, b2);
+  v[3] = csub(b1, b3);
+}
+
+template <typename T> SSR_DEV void ssr_bfly8(cx<T>* v) {
+  const T h = (T)0.70710678118654752440;
+  cx<T> u[4], d[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    u[n] = cadd(v[n], v[n + 4]);
+    d[n] = csub(v[n], v[n + 4]);
+  }
+  // d[n] *= exp(-2*pi*i*n/8)
+  d[1] = {h * (d[1].x + d[1].y), h * (d[1].y - d[1].x)};
+  d[2] = cmul_negi(d[2]);
+  d[3] = {h * (d[3].y - d[3].x), -h * (d[3].x + d[3].y)};
+  ssr_bfly4(u);
+  ssr_bfly4(d);
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    v[2 * n] = u[n];
+    v[2 * n + 1] = d[n];
+  }
+}
+
+template <int R, typename T> SSR_DEV void ssr_bfly(cx<T>* v) {
+  if constexpr (R == 8) ssr_bfly8(v);
+  else if constexpr (R == 4) ssr_bfly4(v);
+  else ssr_bfly2(v);
+}
+
+// pass schedule ----------------------------------------------------------------------------------
+template <int LOGN> struct SsrFftPlan {
+  static constexpr int N = 1 << LOGN;
+  static constexpr int NT = N / 8;
+  static constexpr int R0 = (LOGN % 3 == 0) ? 8 : (1 << (LOGN % 3));
+  static constexpr int NPASS = LOGN / 3 + ((LOGN % 3) ? 1 : 0);
+  static constexpr int radix(int p) { return p == 0 ? R0 : 8; }
+  static constexpr int ns(int p) {  // product of the radices of the passes before p
+    int s = 1;
+    for (int i = 0; i < p; ++i) s *= radix(i);
+    return s;
+  }
+};
+
+// Order in which a thread's 8 registers map onto natural input indices for pass 0:
+// register b*R0+q  <->  index  tid + b*NT + q*(N/R0).
+template <int LOGN> SSR_DEV int ssr_fft_first_index(int tid, int reg) {
+  using P = SsrFftPlan<LOGN>;
+  const int b = reg / P::R0, q = reg % P::R0;
+  return tid + b * P::NT + q * (P::N / P::R0);
+}
+
+template <typename T, int LOGN, int PASS>
+SSR_DEV void ssr_fft_load(int tid, const T* re, const T* im, cx<T>* v) {
+  using P = SsrFftPlan<LOGN>;
+  constexpr int R = P::radix(PASS), NB = 8 / R;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int j = tid + b * P::NT;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int idx = ssr_pad(j + q * (P::N / R));
+      v[b * R + q] = {re[idx], im[idx]};
+    }
+  }
+}
+
+template <typename T, int LOGN, int PASS>
+SSR_DEV void ssr_fft_compute(int tid, cx<T>* v, const cx<T>* __restrict__ tw) {
+  using P = SsrFftPlan<LOGN>;
+  constexpr int R = P::radix(PASS), NB = 8 / R, NS = P::ns(PASS);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if constexpr (NS > 1) {
+      static_assert(R == 8 || NS == 1, "only the leading pass may be radix 2/4");
+      const int j = tid + b * P::NT;
+      const int k = j & (NS - 1);
+      const int base = k * (P::N / (NS * R));
+      const cx<T> w1 = tw[base], w2 = tw[2 * base], w4 = tw[4 * base];
+      const cx<T> w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4);
+      const cx<T> w7 = cmul(w3, w4);
+      cx<T>* x = v + b * R;
+      x[1] = cmul(x[1], w1);
+      x[2] = cmul(x[2], w2);
+      x[3] = cmul(x[3], w3);
+      x[4] = cmul(x[4], w4);
+      x[5] = cmul(x[5], w5);
+      x[6] = cmul(x[6], w6);
+      x[7] = cmul(x[7], w7);
+    }
+    ssr_bfly<R>(v + b * R);
+  }
+}
+
+// natural output index of register `reg` after pass PASS
+template <int LOGN, int PASS> SSR_DEV int ssr_fft_out_index(int tid, int reg) {
+  using P = SsrFftPlan<LOGN>;
+  constexpr int R = P::radix(PASS), NS = P::ns(PASS);
+  const int b = reg / R, q = reg % R;
+  const int j = tid + b * P::NT;
+  const int k = j & (NS - 1);
+  return (j - k) * R + k + q * NS;
+}
+
+template <typename T, int LOGN, int PASS>
+SSR_DEV void ssr_fft_store(int tid, T* re, T* im, const cx<T>* v) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int idx = ssr_pad(ssr_fft_out_index<LOGN, PASS>(tid, r));
+    re[idx] = v[r].x;
+    im[idx] = v[r].y;
+  }
+}
+
+// Passes PASS..NPASS-2 complete (load, compute, store); the LAST pass is left loaded+computed in
+// registers so the caller can fuse its own epilogue into the final store
+// (ssr_fft_out_index<LOGN, NPASS-1> gives each register's natural frequency index).
+// Pre-condition: pass 0 results already stored to (re, im) and a barrier passed.
+// Regs must expose `cx<T> v[8]`.
+template <typename T, int LOGN, int PASS, typename BLK, typename REGS>
+SSR_BODY void ssr_fft_mid_passes(BLK& blk, REGS& regs, T* re, T* im, const cx<T>* tw) {
+  using P = SsrFftPlan<LOGN>;
+  if constexpr (PASS < P::NPASS - 1) {
+    SSR_PHASE(blk, regs, ssr_fft_load<T, LOGN, PASS>(tid, re, im, R.v);
+              ssr_fft_compute<T, LOGN, PASS>(tid, R.v, tw));
+    SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, PASS>(tid, re, im, R.v));
+    ssr_fft_mid_passes<T, LOGN, PASS + 1>(blk, regs, re, im, tw);
+  } else {
+    SSR_PHASE(blk, regs, ssr_fft_load<T, LOGN, PASS>(tid, re, im, R.v);
+              ssr_fft_compute<T, LOGN, PASS>(tid, R.v, tw));
+  }
+}

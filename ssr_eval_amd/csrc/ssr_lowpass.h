@@ -1,0 +1,136 @@
+// Kernel bodies K6: STFT-domain hard low-pass and inverse STFT.
+//
+// Reference semantics: ssr_eval/lowpass.py:17-28 (stft_hard_lowpass_v0) on FDomainHelper(2048, 441)
+// (ssr_eval/dsp.py:76-119 -> torchlibrosa STFT / ISTFT): centred reflect-padded frames, periodic Hann
+// analysis window, bins >= cut set to zero, inverse DFT fused with the Hann synthesis window,
+// overlap-add at stride hop, division by the overlap-added squared window clamped to 1e-11, samples
+// [n_fft/2, n_fft/2 + length).  mag*cos / mag*sin of the reference reassemble (re, im) up to float32
+// rounding, so the zeroing is applied to the complex spectrum directly.
+//
+// Stage 1 (this body): per pair of frames (2g, 2g+1) packed as re/im of ONE complex transform:
+//     forward FFT -> zero cut <= k <= n_fft - cut -> inverse FFT -> * window / n_fft -> frames[t][m]
+//   or, in ISTFT mode, Hermitian-extend two given half spectra, pack, inverse FFT -> frames.
+// Stage 2 (ssr_ola_sample): deterministic gather overlap-add + normalisation, one thread per sample.
+#pragma once
+#include "ssr_stft.h"
+
+template <typename T> struct SsrLowpassParams {
+  const float* in;           // signals (analysis mode)
+  const int64_t* in_off;     // [n_items]
+  const int32_t* len;        // [n_items] samples (defines the number of frames)
+  const int32_t* cut;        // [n_items] first zeroed bin (analysis mode)
+  const int64_t* frame_off;  // [n_items] first row of item i in `frames` / spec_re / spec_im
+  int n_fft, hop, pairs_per_chunk, n_chunks;
+  const T* window;
+  const cx<T>* tw;
+  const float* spec_re;      // ISTFT mode: [rows, F] real parts (null in analysis mode)
+  const float* spec_im;
+  float* frames;             // [rows, n_fft] windowed inverse frames
+};
+
+// grid = (n_chunks, n_items), block = n_fft / 8
+template <typename T, int LOGN, typename BLK>
+SSR_BODY void ssr_lowpass_frames_body(const SsrLowpassParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
+  using P = SsrFftPlan<LOGN>;
+  constexpr int N = P::N, LAST = P::NPASS - 1, F = N / 2 + 1;
+  using Regs = SsrStftRegs<T>;
+  SsrStftLds<T, LOGN> L(lds_base);
+  const int n = p.len[item], hop = p.hop;
+  const int n_frames = ssr_num_frames_dev(n, N, hop);
+  const int n_pairs = (n_frames + 1) / 2;
+  const int g0 = chunk * p.pairs_per_chunk;
+  const int g1 = (g0 + p.pairs_per_chunk < n_pairs) ? g0 + p.pairs_per_chunk : n_pairs;
+  const int64_t row0 = p.frame_off[item];
+  const bool analysis = (p.spec_re == nullptr);
+  const float* sig = analysis ? p.in + p.in_off[item] : nullptr;
+  const int cut = analysis ? p.cut[item] : F;
+  const T inv_n = (T)1 / (T)N;
+
+  SSR_REGS(Regs, regs, blk);
+  for (int g = g0; g < g1; ++g) {
+    const int ta = 2 * g, tb = 2 * g + 1;
+    const bool b_valid = tb < n_frames;
+    if (analysis) {
+      SSR_PHASE(blk, regs, {
+        for (int r = 0; r < 8; ++r) {
+          const int m = ssr_fft_first_index<LOGN>(tid, r);
+          const T w = p.window[m];
+          R.v[r] = {ssr_frame_sample<T>(sig, n, ta, n_frames, m, N, hop) * w,
+                    ssr_frame_sample<T>(sig, n, tb, n_frames, m, N, hop) * w};
+        }
+        ssr_fft_compute<T, LOGN, 0>(tid, R.v, p.tw);
+        ssr_fft_store<T, LOGN, 0>(tid, L.re, L.im, R.v);
+      });
+      ssr_fft_mid_passes<T, LOGN, 1>(blk, regs, L.re, L.im, p.tw);
+      SSR_PHASE(blk, regs, {
+        for (int r = 0; r < 8; ++r) {
+          const int k = ssr_fft_out_index<LOGN, LAST>(tid, r);
+          const bool zero = (k >= cut) && (k <= N - cut);
+          L.re[ssr_pad(k)] = zero ? (T)0 : R.v[r].x;
+          L.im[ssr_pad(k)] = zero ? (T)0 : R.v[r].y;
+        }
+      });
+      // inverse = forward engine on exchanged arrays
+      SSR_PHASE(blk, regs, ssr_fft_load<T, LOGN, 0>(tid, L.im, L.re, R.v);
+                ssr_fft_compute<T, LOGN, 0>(tid, R.v, p.tw));
+    } else {
+      // ISTFT mode: pack Z = Xa + i*Xb (Hermitian-extended) straight into inverse pass-0 registers
+      SSR_PHASE(blk, regs, {
+        for (int r = 0; r < 8; ++r) {
+          const int k = ssr_fft_first_index<LOGN>(tid, r);
+          const int kk = (k <= N / 2) ? k : N - k;
+          const T sgn = (k <= N / 2) ? (T)1 : (T)-1;
+          const bool edge = (kk == 0) || (kk == N / 2);
+          const int64_t ia = (row0 + ta) * F + kk, ib = (row0 + tb) * F + kk;
+          const T ar = (T)p.spec_re[ia], ai = edge ? (T)0 : sgn * (T)p.spec_im[ia];
+          const T br = b_valid ? (T)p.spec_re[ib] : (T)0;
+          const T bi = (b_valid && !edge) ? sgn * (T)p.spec_im[ib] : (T)0;
+          // Z = (ar - bi) + i (ai + br); inverse engine input is swap(Z)
+          R.v[r] = {ai + br, ar - bi};
+        }
+        ssr_fft_compute<T, LOGN, 0>(tid, R.v, p.tw);
+      });
+    }
+    SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, 0>(tid, L.im, L.re, R.v));
+    ssr_fft_mid_passes<T, LOGN, 1>(blk, regs, L.im, L.re, p.tw);
+    // registers: swap(N * IFFT): frame ta = .y, frame tb = .x.  Window, scale, write (coalesced).
+    SSR_PHASE(blk, regs, {
+      for (int r = 0; r < 8; ++r) {
+        const int m = ssr_fft_out_index<LOGN, LAST>(tid, r);
+        const T w = p.window[m] * inv_n;
+        p.frames[(row0 + ta) * N + m] = (float)(R.v[r].y * w);
+        if (b_valid) p.frames[(row0 + tb) * N + m] = (float)(R.v[r].x * w);
+      }
+    });
+  }
+}
+
+struct SsrOlaParams {
+  const float* frames;       // [rows, n_fft]
+  const int64_t* frame_off;  // [n_items]
+  const int32_t* len;        // [n_items] output samples
+  const int64_t* out_off;    // [n_items]
+  int n_fft, hop;
+  const double* window;      // [n_fft]
+  float* out;
+};
+
+SSR_DEV void ssr_ola_sample(const SsrOlaParams& p, int item, int s) {
+  const int n = p.len[item];
+  if (s >= n) return;
+  const int N = p.n_fft, hop = p.hop;
+  const int n_frames = ssr_num_frames_dev(n, N, hop);
+  const int pos = s + N / 2;
+  int t_hi = pos / hop;
+  if (t_hi > n_frames - 1) t_hi = n_frames - 1;
+  const int t_lo = (pos < N) ? 0 : (pos - N) / hop + 1;
+  const float* fr = p.frames + p.frame_off[item] * (int64_t)N;
+  double acc = 0.0, wss = 0.0;
+  for (int t = t_lo; t <= t_hi; ++t) {
+    const int m = pos - t * hop;
+    acc += (double)fr[(int64_t)t * N + m];
+    wss += p.window[m] * p.window[m];
+  }
+  if (wss < 1e-11) wss = 1e-11;
+  p.out[p.out_off[item] + s] = (float)(acc / wss);
+}

@@ -1,0 +1,234 @@
+// Kernel bodies K3-K5 on materialised [T, F] float32 spectrograms: SSIM (7x7 uniform window),
+// LSD / SISpec / log-SISpec reductions, and the per-item finalisation of the partial records.
+//
+// SSIM semantics (ssr_eval/metrics.py:123-132 -> skimage.metrics.structural_similarity(win_size=7),
+// float images, no data_range): data_range = 2 -> C1 = 4e-4, C2 = 3.6e-3; uniform 7x7 window; sample
+// covariance (49/48); only windows that lie fully inside the image survive the 3-pixel border crop, so
+// exactly the (T-6) x (F-6) valid windows are evaluated; float64 moments; mean in float64.
+#pragma once
+#include "ssr_stft.h"
+
+#define SSR_SSIM_NT 256
+#define SSR_SSIM_MAXC 5
+#define SSR_SSIM_SW (SSR_SSIM_NT * SSR_SSIM_MAXC)  // input columns per strip (1280 >= 1115 bins of n_fft 2229)
+#define SSR_SSIM_WIN 7
+
+struct SsrSsimParams {
+  const float* x;            // est spectrograms  [rows, F]
+  const float* y;            // target spectrograms
+  const int64_t* frame_off;  // [n_items] first row of item i
+  const int32_t* n_rows;     // [n_items] T_i
+  int F;
+  int rows_per_tile, n_row_tiles, n_strips;
+  double* part;              // [n_items, n_row_tiles * n_strips] sum of S over the tile
+};
+
+struct SsrSsimRegs {
+  double cs[SSR_SSIM_MAXC][5];  // running 7-row column sums of x, y, xx, yy, xy for the thread's columns
+  double s;                     // sum of S over the thread's outputs
+};
+
+struct SsrSsimLds {
+  static constexpr int PW = SSR_SSIM_SW + 8;
+  static constexpr size_t bytes() { return sizeof(double) * (5 * PW + SSR_SSIM_NT + 16 + 8); }
+  double* col; double* sc0; double* sc1; double* res;
+  SSR_MEMBER explicit SsrSsimLds(char* base) {
+    col = reinterpret_cast<double*>(base);
+    sc0 = col + 5 * PW;
+    sc1 = sc0 + SSR_SSIM_NT;
+    res = sc1 + 16;
+  }
+};
+
+SSR_DEV void ssr_ssim_row_update(const SsrSsimParams& p, SsrSsimRegs& R, int tid, const float* x, const float* y,
+                                 int64_t row, int c_in0, int ncol_in, double sign) {
+#pragma unroll
+  for (int i = 0; i < SSR_SSIM_MAXC; ++i) {
+    const int c = tid + SSR_SSIM_NT * i;
+    if (c < ncol_in) {
+      const double a = (double)x[row * p.F + c_in0 + c];
+      const double b = (double)y[row * p.F + c_in0 + c];
+      R.cs[i][0] += sign * a;
+      R.cs[i][1] += sign * b;
+      R.cs[i][2] += sign * (a * a);
+      R.cs[i][3] += sign * (b * b);
+      R.cs[i][4] += sign * (a * b);
+    }
+  }
+}
+
+SSR_DEV double ssr_ssim_value(double sx, double sy, double sxx, double syy, double sxy) {
+  const double C1 = (0.01 * 2.0) * (0.01 * 2.0), C2 = (0.03 * 2.0) * (0.03 * 2.0);
+  const double inv = 1.0 / 49.0, cov = 49.0 / 48.0;
+  const double ux = sx * inv, uy = sy * inv;
+  const double vx = cov * (sxx * inv - ux * ux);
+  const double vy = cov * (syy * inv - uy * uy);
+  const double vxy = cov * (sxy * inv - ux * uy);
+  const double a1 = 2.0 * ux * uy + C1, a2 = 2.0 * vxy + C2;
+  const double b1 = ux * ux + uy * uy + C1, b2 = vx + vy + C2;
+  return (a1 * a2) / (b1 * b2);
+}
+
+// grid = (n_row_tiles * n_strips, n_items); block = SSR_SSIM_NT
+template <typename BLK>
+SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item, char* lds_base) {
+  constexpr int NT = SSR_SSIM_NT, PW = SsrSsimLds::PW;
+  SsrSsimLds L(lds_base);
+  const int row_tile = tile / p.n_strips, strip = tile % p.n_strips;
+  const int T = p.n_rows[item];
+  const int out_rows = T - (SSR_SSIM_WIN - 1);
+  const int r0 = row_tile * p.rows_per_tile;
+  const int r1 = (r0 + p.rows_per_tile < out_rows) ? r0 + p.rows_per_tile : out_rows;
+  const int c_in0 = strip * (SSR_SSIM_SW - (SSR_SSIM_WIN - 1));
+  const int ncol_in = (p.F - c_in0 < SSR_SSIM_SW) ? p.F - c_in0 : SSR_SSIM_SW;
+  const int ncol_out = ncol_in - (SSR_SSIM_WIN - 1);
+  double* part = p.part + (int64_t)item * p.n_row_tiles * p.n_strips + tile;
+  const float* x = p.x + p.frame_off[item] * p.F;
+  const float* y = p.y + p.frame_off[item] * p.F;
+
+  SSR_REGS(SsrSsimRegs, regs, blk);
+  if (r0 >= r1 || ncol_out <= 0) {
+    SSR_PHASE(blk, regs, if (tid == 0) *part = 0.0);
+    return;
+  }
+  // warm-up: rows r0 .. r0+5
+  SSR_PHASE(blk, regs, {
+    for (int i = 0; i < SSR_SSIM_MAXC; ++i)
+      for (int q = 0; q < 5; ++q) R.cs[i][q] = 0.0;
+    R.s = 0.0;
+    for (int rr = r0; rr < r0 + SSR_SSIM_WIN - 1; ++rr) ssr_ssim_row_update(p, R, tid, x, y, rr, c_in0, ncol_in, 1.0);
+  });
+  for (int r = r0; r < r1; ++r) {
+    SSR_PHASE(blk, regs, {
+      ssr_ssim_row_update(p, R, tid, x, y, r + SSR_SSIM_WIN - 1, c_in0, ncol_in, 1.0);
+      if (r > r0) ssr_ssim_row_update(p, R, tid, x, y, r - 1, c_in0, ncol_in, -1.0);
+      for (int i = 0; i < SSR_SSIM_MAXC; ++i) {
+        const int c = tid + NT * i;
+        if (c < ncol_in)
+          for (int q = 0; q < 5; ++q) L.col[q * PW + c] = R.cs[i][q];
+      }
+    });
+    SSR_PHASE(blk, regs, {
+      for (int i = 0; i < SSR_SSIM_MAXC; ++i) {
+        const int j = tid + NT * i;
+        if (j < ncol_out) {
+          double h[5];
+          for (int q = 0; q < 5; ++q) {
+            double s = 0.0;
+            for (int d = 0; d < SSR_SSIM_WIN; ++d) s += L.col[q * PW + j + d];
+            h[q] = s;
+          }
+          R.s += ssr_ssim_value(h[0], h[1], h[2], h[3], h[4]);
+        }
+      }
+    });
+  }
+#define SSR_GET_S(q) R.s
+  SSR_BLOCK_SUM(blk, regs, NT, 1, L.sc0, L.sc1, L.res, SSR_GET_S);
+#undef SSR_GET_S
+  SSR_PHASE(blk, regs, if (tid == 0) *part = L.res[0]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LSD / SISpec / log-SISpec on given spectrogram pairs (backs AudioMetrics.lsd / .sispec called
+// directly on tensors).  Produces the same partial record as the fused STFT epilogue.
+struct SsrSpecRedParams {
+  const float* x; const float* y;
+  const int64_t* frame_off; const int32_t* n_rows;
+  int F, metric_mask, rows_per_chunk, n_chunks;
+  double* part;  // [n_items, n_chunks, SSR_NPART]
+};
+struct SsrSpecRedRegs { double acc[7]; double lsd_sum; };
+struct SsrSpecRedLds {
+  static constexpr int NT = 256;
+  static constexpr size_t bytes() { return sizeof(double) * (NT + 16 + 8); }
+  double* sc0; double* sc1; double* res;
+  SSR_MEMBER explicit SsrSpecRedLds(char* base) {
+    sc0 = reinterpret_cast<double*>(base); sc1 = sc0 + NT; res = sc1 + 16;
+  }
+};
+
+template <typename BLK>
+SSR_BODY void ssr_specred_body(const SsrSpecRedParams& p, BLK& blk, int chunk, int item, char* lds_base) {
+  constexpr int NT = SsrSpecRedLds::NT;
+  SsrSpecRedLds L(lds_base);
+  const int T = p.n_rows[item];
+  const int t0 = chunk * p.rows_per_chunk;
+  const int t1 = (t0 + p.rows_per_chunk < T) ? t0 + p.rows_per_chunk : T;
+  const float* x = p.x + p.frame_off[item] * p.F;
+  const float* y = p.y + p.frame_off[item] * p.F;
+  double* part = p.part + ((int64_t)item * p.n_chunks + chunk) * SSR_NPART;
+  const bool want_lsd = p.metric_mask & SSR_M_LSD;
+  SSR_REGS(SsrSpecRedRegs, regs, blk);
+  SSR_PHASE(blk, regs, for (int q = 0; q < 7; ++q) R.acc[q] = 0.0; R.lsd_sum = 0.0);
+  for (int t = t0; t < t1; ++t) {
+    SSR_PHASE(blk, regs, {
+      R.acc[0] = 0.0;
+      for (int k = tid; k < p.F; k += NT)
+        ssr_accumulate_metrics(x[(int64_t)t * p.F + k], y[(int64_t)t * p.F + k], p.metric_mask, R.acc);
+      L.sc0[tid] = R.acc[0];
+    });
+    if (want_lsd) {
+      SSR_PHASE(blk, regs, if (tid < 16) {
+        double s = 0.0;
+        for (int i = tid; i < NT; i += 16) s += L.sc0[i];
+        L.sc1[tid] = s;
+      });
+      SSR_PHASE(blk, regs, if (tid == 0) {
+        double s = 0.0;
+        for (int i = 0; i < 16; ++i) s += L.sc1[i];
+        R.lsd_sum += sqrt(s / (double)p.F);
+      });
+    }
+  }
+#define SSR_GET_ACC(q) R.acc[(q) + 1]
+  SSR_BLOCK_SUM(blk, regs, NT, 6, L.sc0, L.sc1, L.res, SSR_GET_ACC);
+#undef SSR_GET_ACC
+  SSR_PHASE(blk, regs, if (tid == 0) {
+    part[0] = R.lsd_sum;
+    for (int q = 0; q < 6; ++q) part[1 + q] = L.res[q];
+    part[7] = 0.0;
+  });
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Finalisation: one thread per item.  out[item*4 + {0,1,2,3}] = lsd, log_sispec, sispec, ssim
+// (the key order of ssr_eval/metrics.py:98-103).  Entries whose metric bit is clear are left as NaN.
+struct SsrFinalizeParams {
+  const double* part; int n_chunks;        // [n_items, n_chunks, SSR_NPART] (may be null)
+  const double* ssim_part; int n_tiles;    // [n_items, n_tiles] (may be null)
+  const int32_t* n_rows;                   // T_i
+  int F, metric_mask, n_items;
+  double* out;                             // [n_items, 4]
+};
+
+SSR_DEV double ssr_sispec_from_sums(double see, double stt, double set) {
+  // ssr_eval/metrics.py:114-121 with energy_unify (utils.py:79-82): scaled = (Set * t) / (Stt + EPS)
+  const double EPS = 1e-12;
+  const double alpha = set / (stt + EPS);
+  const double tt = alpha * alpha * stt;
+  double nn = see - 2.0 * alpha * set + alpha * alpha * stt;
+  if (nn < 0.0) nn = 0.0;
+  return 10.0 * log10(tt / (nn + EPS) + EPS);
+}
+
+SSR_DEV void ssr_finalize_item(const SsrFinalizeParams& p, int item) {
+  const double nan_ = NAN;
+  double* o = p.out + (int64_t)item * 4;
+  o[0] = o[1] = o[2] = o[3] = nan_;
+  const int T = p.n_rows[item];
+  if (p.part) {
+    double s[SSR_NPART];
+    for (int q = 0; q < SSR_NPART; ++q) s[q] = 0.0;
+    for (int c = 0; c < p.n_chunks; ++c)
+      for (int q = 0; q < SSR_NPART; ++q) s[q] += p.part[((int64_t)item * p.n_chunks + c) * SSR_NPART + q];
+    if (p.metric_mask & SSR_M_LSD) o[0] = s[0] / (double)T;
+    if (p.metric_mask & SSR_M_LOG_SISPEC) o[1] = ssr_sispec_from_sums(s[4], s[5], s[6]);
+    if (p.metric_mask & SSR_M_SISPEC) o[2] = ssr_sispec_from_sums(s[1], s[2], s[3]);
+  }
+  if (p.ssim_part && (p.metric_mask & SSR_M_SSIM)) {
+    double s = 0.0;
+    for (int c = 0; c < p.n_tiles; ++c) s += p.ssim_part[(int64_t)item * p.n_tiles + c];
+    o[3] = s / ((double)(T - 6) * (double)(p.F - 6));
+  }
+}

@@ -1,0 +1,278 @@
+// Kernel bodies K1-K4: framed-window STFT of TWO real sequences per complex FFT, magnitude /
+// complex output, and the fused LSD + SISpec / log-SISpec accumulation.
+//
+// Reference semantics reproduced (ssr_eval/metrics.py:26-30 -> librosa.stft; ssr_eval/dsp.py:72-81 ->
+// torchlibrosa STFT): centred frames with reflect padding of n_fft//2, periodic Hann window,
+// frame stride `hop`, bins 0..n_fft/2; float64 transform rounded once to float32 (precision f64) or
+// a float32 transform (precision f32).  |X| is taken as hypotf on the rounded float32 (re, im), the
+// way numpy.abs acts on complex64.
+//
+// Two-for-one packing: z = x_a + i*x_b is transformed once; X_a[k] = (Z[k] + conj(Z[n-k]))/2,
+// X_b[k] = (Z[k] - conj(Z[n-k]))/(2i).
+//   mode PAIR   : x_a = est frame t, x_b = target frame t        (metrics path)
+//   mode SINGLE : x_a = frame 2g,    x_b = frame 2g+1 of one signal (wav_to_spectrogram, FDomainHelper)
+//
+// Two transform engines share the epilogue:
+//   direct    : n_fft = 2^LOGN, FFT of length n_fft.
+//   bluestein : any n_fft; chirp-z through two FFTs of length M = 2^LOGM >= 2*n_fft-1
+//               (2229 = 3*743 for AudioMetrics(48000), 743 / 1114 / 1486 for 16/24/32 kHz).
+#pragma once
+#include "ssr_fft.h"
+
+enum { SSR_MODE_PAIR = 0, SSR_MODE_SINGLE = 1 };
+enum { SSR_OUT_NONE = 0, SSR_OUT_MAG = 1, SSR_OUT_COMPLEX = 2 };
+enum { SSR_M_LSD = 1, SSR_M_LOG_SISPEC = 2, SSR_M_SISPEC = 4, SSR_M_SSIM = 8 };
+
+#define SSR_NPART 8  // doubles per (item, chunk) partial record
+// partial record layout: [0] sum over frames of sqrt(mean_f d^2)   (LSD numerator)
+//                        [1] See [2] Stt [3] Set            (raw magnitudes)
+//                        [4] Slele [5] Sltlt [6] Slelt      (log10(mag + 1e-12))
+//                        [7] unused
+
+template <typename T> struct SsrStftParams {
+  const float* a;            // signal buffer A (est, or the only signal in SINGLE mode)
+  const float* b;            // signal buffer B (target); unused in SINGLE mode
+  const int64_t* a_off;      // [n_items] element offset of item i in a
+  const int64_t* b_off;      // [n_items] element offset of item i in b
+  const int32_t* len;        // [n_items] samples per item
+  const int64_t* frame_off;  // [n_items] first output row (frame) of item i
+  int mode, out_kind, metric_mask;
+  int n_fft, hop, n_bins;
+  int units_per_chunk;       // frames (PAIR) or frame pairs (SINGLE) per workgroup
+  int n_chunks;              // gridDim.x
+  const T* window;           // [n_fft] periodic Hann (direct engine)
+  const cx<T>* tw;           // [N or M] twiddles
+  // bluestein tables (null for the direct engine)
+  const cx<T>* wchirp;       // [n_fft]  window[m] * exp(-i*pi*m^2/n_fft)
+  const cx<T>* bfilt;        // [M]      FFT_M(exp(+i*pi*m^2/n_fft) wrapped) / M
+  const cx<T>* chirp;        // [n_fft]  exp(-i*pi*k^2/n_fft)
+  float* out_a;              // PAIR: est magnitudes [frames, F]; SINGLE: mag or re
+  float* out_b;              // PAIR: target magnitudes;          SINGLE: im (COMPLEX) or unused
+  double* part;              // [n_items, n_chunks, SSR_NPART] or null
+};
+
+template <typename T> struct SsrStftRegs {
+  cx<T> v[8];
+  double acc[7];   // [0]: per-frame LSD partial (reset every frame); [1..6]: SISpec sums (whole chunk)
+  double lsd_sum;  // thread 0 only: sum over frames of the per-frame LSD
+};
+
+SSR_DEV int ssr_num_frames_dev(int n, int n_fft, int hop) { return 1 + (n + 2 * (n_fft / 2) - n_fft) / hop; }
+
+// one windowed, reflect-padded sample of frame `t` (0 if the frame does not exist)
+template <typename T>
+SSR_DEV T ssr_frame_sample(const float* sig, int n, int t, int n_frames, int m, int n_fft, int hop) {
+  if (t >= n_frames) return (T)0;
+  return (T)sig[ssr_reflect(t * hop + m - n_fft / 2, n)];
+}
+
+// ---- shared epilogue: one bin of the separated spectra ---------------------------------------------
+template <typename T> struct SsrBinOut { float ar, ai, br, bi; };
+
+template <typename T> SSR_DEV SsrBinOut<T> ssr_separate(cx<T> zk, cx<T> zn) {
+  SsrBinOut<T> o;
+  o.ar = (float)((zk.x + zn.x) * (T)0.5);
+  o.ai = (float)((zk.y - zn.y) * (T)0.5);
+  o.br = (float)((zk.y + zn.y) * (T)0.5);
+  o.bi = (float)((zn.x - zk.x) * (T)0.5);
+  return o;
+}
+
+// LSD term and SISpec sums for one (est, target) magnitude pair, float32 elementwise arithmetic in
+// the order of ssr_eval/metrics.py:110 and ssr_eval/utils.py:43-44; accumulation in float64.
+SSR_DEV void ssr_accumulate_metrics(float e, float t, int mask, double* acc) {
+  const float EPSF = 1e-12f;
+  if (mask & SSR_M_LSD) {
+    const float ee = e + EPSF;
+    const float r = (t * t) / (ee * ee) + EPSF;
+    const float d = log10f(r);
+    acc[0] += (double)(d * d);
+  }
+  if (mask & SSR_M_SISPEC) {
+    acc[1] += (double)e * (double)e;
+    acc[2] += (double)t * (double)t;
+    acc[3] += (double)e * (double)t;
+  }
+  if (mask & SSR_M_LOG_SISPEC) {
+    const float le = log10f(e + EPSF), lt = log10f(t + EPSF);
+    acc[4] += (double)le * (double)le;
+    acc[5] += (double)lt * (double)lt;
+    acc[6] += (double)le * (double)lt;
+  }
+}
+
+// Emit bin k of the current unit.  zk = Z[k], zn = Z[(n-k) mod n].
+template <typename T>
+SSR_DEV void ssr_emit_bin(const SsrStftParams<T>& p, SsrStftRegs<T>& R, int k, cx<T> zk, cx<T> zn,
+                          int64_t row_a, int64_t row_b, bool b_valid) {
+  const SsrBinOut<T> o = ssr_separate<T>(zk, zn);
+  if (p.mode == SSR_MODE_PAIR) {
+    const float e = hypotf(o.ar, o.ai), t = hypotf(o.br, o.bi);
+    if (p.out_kind == SSR_OUT_MAG) {
+      p.out_a[row_a * p.n_bins + k] = e;
+      p.out_b[row_b * p.n_bins + k] = t;
+    }
+    ssr_accumulate_metrics(e, t, p.metric_mask, R.acc);
+  } else {
+    if (p.out_kind == SSR_OUT_MAG) {
+      p.out_a[row_a * p.n_bins + k] = hypotf(o.ar, o.ai);
+      if (b_valid) p.out_a[row_b * p.n_bins + k] = hypotf(o.br, o.bi);
+    } else if (p.out_kind == SSR_OUT_COMPLEX) {
+      p.out_a[row_a * p.n_bins + k] = o.ar;
+      p.out_b[row_a * p.n_bins + k] = o.ai;
+      if (b_valid) {
+        p.out_a[row_b * p.n_bins + k] = o.br;
+        p.out_b[row_b * p.n_bins + k] = o.bi;
+      }
+    }
+  }
+}
+
+// LDS carve-out (doubles first so every array stays 8-byte aligned)
+template <typename T, int LOGN> struct SsrStftLds {
+  static constexpr int NT = (1 << LOGN) / 8;
+  static constexpr int PN = ssr_padded_len(1 << LOGN);
+  static constexpr size_t bytes() { return sizeof(double) * (NT + 16 + 8) + sizeof(T) * 2 * PN; }
+  double* sc0; double* sc1; double* res; T* re; T* im;
+  SSR_MEMBER explicit SsrStftLds(char* base) {
+    sc0 = reinterpret_cast<double*>(base);
+    sc1 = sc0 + NT;
+    res = sc1 + 16;
+    re = reinterpret_cast<T*>(res + 8);
+    im = re + PN;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// The body.  LOGN: FFT length of the engine (n_fft for direct, M for bluestein).
+// grid = (n_chunks, n_items); block = 2^LOGN / 8 threads.
+template <typename T, int LOGN, bool BLUESTEIN, typename BLK>
+SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
+  using P = SsrFftPlan<LOGN>;
+  constexpr int N = P::N, NT = P::NT, LAST = P::NPASS - 1;
+  using Regs = SsrStftRegs<T>;
+  SsrStftLds<T, LOGN> L(lds_base);
+
+  const int n = p.len[item];
+  const int n_fft = p.n_fft, hop = p.hop, F = p.n_bins;
+  const int n_frames = ssr_num_frames_dev(n, n_fft, hop);
+  const int n_units = (p.mode == SSR_MODE_PAIR) ? n_frames : (n_frames + 1) / 2;
+  const int u0 = chunk * p.units_per_chunk;
+  const int u1 = (u0 + p.units_per_chunk < n_units) ? u0 + p.units_per_chunk : n_units;
+  const float* sa = p.a + p.a_off[item];
+  const float* sb = (p.mode == SSR_MODE_PAIR) ? p.b + p.b_off[item] : sa;
+  const int64_t row0 = p.frame_off[item];
+  double* part = p.part ? p.part + ((int64_t)item * p.n_chunks + chunk) * SSR_NPART : nullptr;
+  const bool want_lsd = (p.mode == SSR_MODE_PAIR) && (p.metric_mask & SSR_M_LSD);
+
+  SSR_REGS(Regs, regs, blk);
+  SSR_PHASE(blk, regs, for (int q = 0; q < 7; ++q) R.acc[q] = 0.0; R.lsd_sum = 0.0);
+
+  for (int u = u0; u < u1; ++u) {
+    const int ta = (p.mode == SSR_MODE_PAIR) ? u : 2 * u;
+    const int tb = (p.mode == SSR_MODE_PAIR) ? u : 2 * u + 1;
+    const bool b_valid = tb < n_frames;
+
+    // ---- phase 1: HBM -> registers (first-pass order), window, pass 0, store.
+    // Also folds the previous frame's per-thread LSD partials 256 -> 16 (sc0 was written in the
+    // previous epilogue; barriers since then make it visible).
+    SSR_PHASE(blk, regs, {
+      for (int r = 0; r < 8; ++r) {
+        const int m = ssr_fft_first_index<LOGN>(tid, r);
+        cx<T> z = {(T)0, (T)0};
+        if (m < n_fft) {
+          const T xa = ssr_frame_sample<T>(sa, n, ta, n_frames, m, n_fft, hop);
+          const T xb = ssr_frame_sample<T>(sb, n, tb, n_frames, m, n_fft, hop);
+          if constexpr (BLUESTEIN) {
+            const cx<T> wc = p.wchirp[m];
+            z = cmul(cx<T>{xa, xb}, wc);
+          } else {
+            const T w = p.window[m];
+            z = {xa * w, xb * w};
+          }
+        }
+        R.v[r] = z;
+      }
+      ssr_fft_compute<T, LOGN, 0>(tid, R.v, p.tw);
+      ssr_fft_store<T, LOGN, 0>(tid, L.re, L.im, R.v);
+      if (want_lsd && u > u0 && tid < 16) {
+        double s = 0.0;
+        for (int i = tid; i < NT; i += 16) s += L.sc0[i];
+        L.sc1[tid] = s;
+      }
+    });
+    // remaining forward passes; last pass stays in registers
+    ssr_fft_mid_passes<T, LOGN, 1>(blk, regs, L.re, L.im, p.tw);
+
+    if constexpr (BLUESTEIN) {
+      // forward spectrum * filter, stored as the INPUT of the inverse transform.  The inverse is the
+      // forward engine on exchanged (im, re) arrays.
+      SSR_PHASE(blk, regs, {
+        for (int r = 0; r < 8; ++r) {
+          const int k = ssr_fft_out_index<LOGN, LAST>(tid, r);
+          const cx<T> y = cmul(R.v[r], p.bfilt[k]);
+          L.re[ssr_pad(k)] = y.x;
+          L.im[ssr_pad(k)] = y.y;
+        }
+      });
+      SSR_PHASE(blk, regs, ssr_fft_load<T, LOGN, 0>(tid, L.im, L.re, R.v);
+                ssr_fft_compute<T, LOGN, 0>(tid, R.v, p.tw));
+      SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, 0>(tid, L.im, L.re, R.v));
+      ssr_fft_mid_passes<T, LOGN, 1>(blk, regs, L.im, L.re, p.tw);
+      // registers hold swap(IFFT*M): true real part = .y, true imaginary part = .x
+      SSR_PHASE(blk, regs, {
+        for (int r = 0; r < 8; ++r) {
+          const int k = ssr_fft_out_index<LOGN, LAST>(tid, r);
+          if (k < n_fft) {
+            const cx<T> zk = cmul(cx<T>{R.v[r].y, R.v[r].x}, p.chirp[k]);
+            L.re[ssr_pad(k)] = zk.x;
+            L.im[ssr_pad(k)] = zk.y;
+          }
+        }
+      });
+    } else {
+      SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, LAST>(tid, L.re, L.im, R.v));
+    }
+
+    // ---- epilogue: separate the two spectra, emit, accumulate.
+    // Thread 0 also finishes the PREVIOUS frame's LSD (sc1 was written in phase 1 of this frame).
+    SSR_PHASE(blk, regs, {
+      if (want_lsd && u > u0 && tid == 0) {
+        double s = 0.0;
+        for (int i = 0; i < 16; ++i) s += L.sc1[i];
+        R.lsd_sum += sqrt(s / (double)F);
+      }
+      R.acc[0] = 0.0;
+      for (int k = tid; k < F; k += NT) {
+        const int kn = (k == 0) ? 0 : n_fft - k;
+        const cx<T> zk = {L.re[ssr_pad(k)], L.im[ssr_pad(k)]};
+        const cx<T> zn = {L.re[ssr_pad(kn)], L.im[ssr_pad(kn)]};
+        ssr_emit_bin<T>(p, R, k, zk, zn, row0 + ta, row0 + tb, b_valid);
+      }
+      if (want_lsd) L.sc0[tid] = R.acc[0];
+    });
+  }
+
+  if (part == nullptr) return;
+  // ---- chunk tail: last frame's LSD, then block-sum the SISpec accumulators.
+  if (want_lsd && u1 > u0) {
+    SSR_PHASE(blk, regs, if (tid < 16) {
+      double s = 0.0;
+      for (int i = tid; i < NT; i += 16) s += L.sc0[i];
+      L.sc1[tid] = s;
+    });
+    SSR_PHASE(blk, regs, if (tid == 0) {
+      double s = 0.0;
+      for (int i = 0; i < 16; ++i) s += L.sc1[i];
+      R.lsd_sum += sqrt(s / (double)F);
+    });
+  }
+#define SSR_GET_ACC(q) R.acc[(q) + 1]
+  SSR_BLOCK_SUM(blk, regs, NT, 6, L.sc0, L.sc1, L.res, SSR_GET_ACC);
+#undef SSR_GET_ACC
+  SSR_PHASE(blk, regs, if (tid == 0) {
+    part[0] = R.lsd_sum;
+    for (int q = 0; q < 6; ++q) part[1 + q] = L.res[q];
+    part[7] = 0.0;
+  });
+}

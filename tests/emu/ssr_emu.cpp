@@ -1,0 +1,152 @@
+// Host emulation harness (TEST INFRASTRUCTURE): runs the kernel bodies of ssr_eval_amd/csrc/*.h
+// phase by phase on the CPU (g++ -DSSR_HOST_EMU) so their arithmetic can be parity-checked against
+// the oracle without a GPU.  LDS is a heap buffer pre-filled with NaN bytes so a read of anything
+// an earlier phase did not write poisons the result.
+#define SSR_HOST_EMU 1
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../ssr_eval_amd/csrc/ssr_metrics.h"
+#include "../../ssr_eval_amd/csrc/ssr_lowpass.h"
+#include "../../ssr_eval_amd/csrc/ssr_resample.h"
+#include "../../ssr_eval_amd/csrc/ssr_tables.h"
+
+static std::vector<char> poisoned(size_t bytes) { return std::vector<char>(bytes + 64, (char)0xFF); }
+
+template <typename T, int LOGN, bool BLU>
+static void run_stft(SsrStftParams<T> p, int n_items) {
+  SsrBlk blk{SsrFftPlan<LOGN>::NT};
+  for (int item = 0; item < n_items; ++item)
+    for (int c = 0; c < p.n_chunks; ++c) {
+      auto lds = poisoned(SsrStftLds<T, LOGN>::bytes());
+      ssr_stft_body<T, LOGN, BLU>(p, blk, c, item, lds.data());
+    }
+}
+
+template <typename T>
+static int emu_stft_t(int n_fft, int hop, int mode, int out_kind, int mask, const float* a, const float* b,
+                      const int64_t* a_off, const int64_t* b_off, const int32_t* len, const int64_t* frame_off,
+                      int n_items, int units_per_chunk, int n_chunks, float* out_a, float* out_b, double* part) {
+  SsrTables<T> t;
+  if (!ssr_build_tables<T>(n_fft, t)) return -3;
+  SsrStftParams<T> p{};
+  p.a = a; p.b = b; p.a_off = a_off; p.b_off = b_off; p.len = len; p.frame_off = frame_off;
+  p.mode = mode; p.out_kind = out_kind; p.metric_mask = mask;
+  p.n_fft = n_fft; p.hop = hop; p.n_bins = n_fft / 2 + 1;
+  p.units_per_chunk = units_per_chunk; p.n_chunks = n_chunks;
+  p.window = t.window.data(); p.tw = t.tw.data();
+  p.wchirp = t.wchirp.data(); p.bfilt = t.bfilt.data(); p.chirp = t.chirp.data();
+  p.out_a = out_a; p.out_b = out_b; p.part = part;
+#define CASE(L)                                                         \
+  case L:                                                               \
+    if (t.eng.bluestein) run_stft<T, L, true>(p, n_items);              \
+    else run_stft<T, L, false>(p, n_items);                             \
+    return 0;
+  switch (t.eng.logn) { CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) }
+#undef CASE
+  return -3;
+}
+
+extern "C" int emu_stft(int precision, int n_fft, int hop, int mode, int out_kind, int mask, const float* a,
+                        const float* b, const int64_t* a_off, const int64_t* b_off, const int32_t* len,
+                        const int64_t* frame_off, int n_items, int units_per_chunk, int n_chunks, float* out_a,
+                        float* out_b, double* part) {
+  if (precision == 1)
+    return emu_stft_t<double>(n_fft, hop, mode, out_kind, mask, a, b, a_off, b_off, len, frame_off, n_items,
+                              units_per_chunk, n_chunks, out_a, out_b, part);
+  return emu_stft_t<float>(n_fft, hop, mode, out_kind, mask, a, b, a_off, b_off, len, frame_off, n_items,
+                           units_per_chunk, n_chunks, out_a, out_b, part);
+}
+
+extern "C" int emu_ssim(const float* x, const float* y, const int64_t* frame_off, const int32_t* n_rows, int n_items,
+                        int F, int rows_per_tile, int n_row_tiles, int n_strips, double* part) {
+  SsrSsimParams p{x, y, frame_off, n_rows, F, rows_per_tile, n_row_tiles, n_strips, part};
+  SsrBlk blk{SSR_SSIM_NT};
+  for (int item = 0; item < n_items; ++item)
+    for (int t = 0; t < n_row_tiles * n_strips; ++t) {
+      auto lds = poisoned(SsrSsimLds::bytes());
+      ssr_ssim_body(p, blk, t, item, lds.data());
+    }
+  return 0;
+}
+
+extern "C" int emu_specred(const float* x, const float* y, const int64_t* frame_off, const int32_t* n_rows,
+                           int n_items, int F, int mask, int rows_per_chunk, int n_chunks, double* part) {
+  SsrSpecRedParams p{x, y, frame_off, n_rows, F, mask, rows_per_chunk, n_chunks, part};
+  SsrBlk blk{SsrSpecRedLds::NT};
+  for (int item = 0; item < n_items; ++item)
+    for (int c = 0; c < n_chunks; ++c) {
+      auto lds = poisoned(SsrSpecRedLds::bytes());
+      ssr_specred_body(p, blk, c, item, lds.data());
+    }
+  return 0;
+}
+
+extern "C" int emu_finalize(const double* part, int n_chunks, const double* ssim_part, int n_tiles,
+                            const int32_t* n_rows, int F, int mask, int n_items, double* out) {
+  SsrFinalizeParams p{part, n_chunks, ssim_part, n_tiles, n_rows, F, mask, n_items, out};
+  for (int i = 0; i < n_items; ++i) ssr_finalize_item(p, i);
+  return 0;
+}
+
+// ---- FFT low-pass / ISTFT ---------------------------------------------------------------------------
+template <typename T>
+static int emu_lowpass_frames_t(int n_fft, int hop, const float* in, const int64_t* in_off, const int32_t* len,
+                                const int32_t* cut, const int64_t* frame_off, int n_items, int pairs_per_chunk,
+                                int n_chunks, const float* re_in, const float* im_in, float* frames) {
+  SsrTables<T> t;
+  if (!ssr_build_tables<T>(n_fft, t) || t.eng.bluestein) return -3;
+  SsrLowpassParams<T> p{};
+  p.in = in; p.in_off = in_off; p.len = len; p.cut = cut; p.frame_off = frame_off;
+  p.n_fft = n_fft; p.hop = hop; p.pairs_per_chunk = pairs_per_chunk; p.n_chunks = n_chunks;
+  p.window = t.window.data(); p.tw = t.tw.data(); p.spec_re = re_in; p.spec_im = im_in; p.frames = frames;
+#define CASE(L)                                                               \
+  case L: {                                                                   \
+    SsrBlk blk{SsrFftPlan<L>::NT};                                            \
+    for (int item = 0; item < n_items; ++item)                                \
+      for (int c = 0; c < n_chunks; ++c) {                                    \
+        auto lds = poisoned(SsrStftLds<T, L>::bytes());                       \
+        ssr_lowpass_frames_body<T, L>(p, blk, c, item, lds.data());           \
+      }                                                                       \
+    return 0;                                                                 \
+  }
+  switch (t.eng.logn) { CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) }
+#undef CASE
+  return -3;
+}
+
+extern "C" int emu_lowpass_frames(int precision, int n_fft, int hop, const float* in, const int64_t* in_off,
+                                  const int32_t* len, const int32_t* cut, const int64_t* frame_off, int n_items,
+                                  int pairs_per_chunk, int n_chunks, const float* re_in, const float* im_in,
+                                  float* frames) {
+  if (precision == 1)
+    return emu_lowpass_frames_t<double>(n_fft, hop, in, in_off, len, cut, frame_off, n_items, pairs_per_chunk,
+                                        n_chunks, re_in, im_in, frames);
+  return emu_lowpass_frames_t<float>(n_fft, hop, in, in_off, len, cut, frame_off, n_items, pairs_per_chunk, n_chunks,
+                                     re_in, im_in, frames);
+}
+
+extern "C" int emu_ola(int n_fft, int hop, const float* frames, const int64_t* frame_off, const int32_t* len,
+                       const int64_t* out_off, int n_items, int max_len, float* out) {
+  SsrTables<double> t;
+  if (!ssr_build_tables<double>(n_fft, t)) return -3;
+  SsrOlaParams p{frames, frame_off, len, out_off, n_fft, hop, t.window.data(), out};
+  for (int item = 0; item < n_items; ++item)
+    for (int s = 0; s < max_len; ++s) ssr_ola_sample(p, item, s);
+  return 0;
+}
+
+// ---- polyphase resampler ------------------------------------------------------------------------------
+extern "C" int emu_resample(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
+                            const int32_t* out_len, int n_items, int up, int down, const float* taps, int n_taps,
+                            int n_pre_remove, int outs_per_block, int n_blocks, float* out) {
+  SsrResampleParams p{in, in_off, in_len, out_off, out_len, up, down, taps, n_taps, n_pre_remove, outs_per_block, out};
+  SsrBlk blk{SSR_RESAMPLE_NT};
+  for (int item = 0; item < n_items; ++item)
+    for (int b = 0; b < n_blocks; ++b) {
+      auto lds = poisoned(ssr_resample_lds_bytes(p));
+      ssr_resample_body(p, blk, b, item, lds.data());
+    }
+  return 0;
+}

@@ -1,0 +1,169 @@
+"""ctypes driver for the host emulation of the kernel bodies (tests/emu/ssr_emu.cpp).  Test infrastructure."""
+import ctypes as C
+import glob
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "emu", "ssr_emu.cpp")
+SO = os.path.join(ROOT, "tests", "emu", "libssr_emu.so")
+
+M_LSD, M_LOG_SISPEC, M_SISPEC, M_SSIM = 1, 2, 4, 8
+M_ALL = 15
+
+
+def build(force=False):
+    deps = [SRC] + glob.glob(os.path.join(ROOT, "ssr_eval_amd", "csrc", "*.h"))
+    if force or not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wno-unknown-pragmas", "-o", SO, SRC])
+    return SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def num_frames(n, n_fft, hop):
+    return 1 + (n + 2 * (n_fft // 2) - n_fft) // hop
+
+
+def ragged(arrs):
+    lens = np.array([len(a) for a in arrs], np.int32)
+    off = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int64)
+    return np.concatenate(arrs).astype(np.float32), off, lens
+
+
+def stft(sigs_a, sigs_b, n_fft, hop, precision=1, mode=0, out_kind=1, mask=0, units_per_chunk=8):
+    """mode 0 (pair): returns (mag_a list, mag_b list, part); mode 1 (single): (out_a list, out_b list, None)."""
+    a, a_off, lens = ragged(sigs_a)
+    if mode == 0:
+        b, b_off, lens_b = ragged(sigs_b)
+        assert (lens == lens_b).all()
+    else:
+        b, b_off = a, a_off
+    T = np.array([num_frames(int(n), n_fft, hop) for n in lens])
+    F = n_fft // 2 + 1
+    frame_off = np.concatenate(([0], np.cumsum(T)[:-1])).astype(np.int64)
+    units = T if mode == 0 else (T + 1) // 2
+    n_chunks = int(-(-units.max() // units_per_chunk))
+    out_a = np.full((int(T.sum()), F), np.nan, np.float32)
+    out_b = np.full((int(T.sum()), F), np.nan, np.float32)
+    part = np.full((len(lens), n_chunks, 8), np.nan, np.float64) if mode == 0 else None
+    rc = lib().emu_stft(precision, n_fft, hop, mode, out_kind, mask, _p(a, C.c_float), _p(b, C.c_float),
+                        _p(a_off, C.c_int64), _p(b_off, C.c_int64), _p(lens, C.c_int32), _p(frame_off, C.c_int64),
+                        len(lens), units_per_chunk, n_chunks, _p(out_a, C.c_float), _p(out_b, C.c_float),
+                        _p(part, C.c_double))
+    assert rc == 0, rc
+    split = lambda o: [o[frame_off[i]:frame_off[i] + T[i]] for i in range(len(lens))]
+    return split(out_a), split(out_b), part
+
+
+def spectro_desc(sps):
+    T = np.array([s.shape[0] for s in sps], np.int32)
+    frame_off = np.concatenate(([0], np.cumsum(T)[:-1])).astype(np.int64)
+    return np.ascontiguousarray(np.concatenate(sps).astype(np.float32)), frame_off, T
+
+
+def ssim_parts(xs, ys, rows_per_tile=16):
+    x, frame_off, T = spectro_desc(xs)
+    y, _, _ = spectro_desc(ys)
+    F = xs[0].shape[1]
+    n_row_tiles = int(-(-(T.max() - 6) // rows_per_tile))
+    n_strips = int(-(-(F - 6) // (1280 - 6)))
+    part = np.full((len(xs), n_row_tiles * n_strips), np.nan)
+    rc = lib().emu_ssim(_p(x, C.c_float), _p(y, C.c_float), _p(frame_off, C.c_int64), _p(T, C.c_int32), len(xs), F,
+                        rows_per_tile, n_row_tiles, n_strips, _p(part, C.c_double))
+    assert rc == 0
+    return part, T
+
+
+def specred_parts(xs, ys, mask=7, rows_per_chunk=8):
+    x, frame_off, T = spectro_desc(xs)
+    y, _, _ = spectro_desc(ys)
+    F = xs[0].shape[1]
+    n_chunks = int(-(-T.max() // rows_per_chunk))
+    part = np.full((len(xs), n_chunks, 8), np.nan)
+    rc = lib().emu_specred(_p(x, C.c_float), _p(y, C.c_float), _p(frame_off, C.c_int64), _p(T, C.c_int32), len(xs), F,
+                           mask, rows_per_chunk, n_chunks, _p(part, C.c_double))
+    assert rc == 0
+    return part, T
+
+
+def finalize(part, ssim_part, T, F, mask):
+    T = np.asarray(T, np.int32)
+    n = len(T)
+    out = np.zeros((n, 4))
+    rc = lib().emu_finalize(_p(part, C.c_double), part.shape[1] if part is not None else 0,
+                            _p(ssim_part, C.c_double), ssim_part.shape[1] if ssim_part is not None else 0,
+                            _p(T, C.c_int32), F, mask, n, _p(out, C.c_double))
+    assert rc == 0
+    return out
+
+
+def pair_metrics(ests, tgts, n_fft, hop, precision=1, mask=M_ALL, units_per_chunk=8, rows_per_tile=16):
+    ea, tb, part = stft(ests, tgts, n_fft, hop, precision, 0, 1, mask, units_per_chunk)
+    sp, T = ssim_parts(ea, tb, rows_per_tile) if mask & M_SSIM else (None, np.array([e.shape[0] for e in ea]))
+    return finalize(part, sp, T, n_fft // 2 + 1, mask)
+
+
+def lowpass(sigs, cuts, n_fft=2048, hop=441, precision=1, pairs_per_chunk=4):
+    a, off, lens = ragged(sigs)
+    T = np.array([num_frames(int(n), n_fft, hop) for n in lens])
+    frame_off = np.concatenate(([0], np.cumsum(T)[:-1])).astype(np.int64)
+    cuts = np.asarray(cuts, np.int32)
+    frames = np.full((int(T.sum()), n_fft), np.nan, np.float32)
+    n_chunks = int(-(-((T.max() + 1) // 2) // pairs_per_chunk))
+    rc = lib().emu_lowpass_frames(precision, n_fft, hop, _p(a, C.c_float), _p(off, C.c_int64), _p(lens, C.c_int32),
+                                  _p(cuts, C.c_int32), _p(frame_off, C.c_int64), len(lens), pairs_per_chunk, n_chunks,
+                                  None, None, _p(frames, C.c_float))
+    assert rc == 0
+    out = np.full(int(lens.sum()), np.nan, np.float32)
+    rc = lib().emu_ola(n_fft, hop, _p(frames, C.c_float), _p(frame_off, C.c_int64), _p(lens, C.c_int32),
+                       _p(off, C.c_int64), len(lens), int(lens.max()), _p(out, C.c_float))
+    assert rc == 0
+    return [out[off[i]:off[i] + lens[i]] for i in range(len(lens))]
+
+
+def istft(res, ims, lengths, n_fft=2048, hop=441, precision=1, pairs_per_chunk=4):
+    re, frame_off, T = spectro_desc(res)
+    im, _, _ = spectro_desc(ims)
+    lens = np.asarray(lengths, np.int32)
+    assert all(num_frames(int(n), n_fft, hop) == t for n, t in zip(lens, T))
+    off = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int64)
+    frames = np.full((int(T.sum()), n_fft), np.nan, np.float32)
+    n_chunks = int(-(-((T.max() + 1) // 2) // pairs_per_chunk))
+    rc = lib().emu_lowpass_frames(precision, n_fft, hop, None, None, _p(lens, C.c_int32), None, _p(frame_off, C.c_int64),
+                                  len(lens), pairs_per_chunk, n_chunks, _p(re, C.c_float), _p(im, C.c_float),
+                                  _p(frames, C.c_float))
+    assert rc == 0
+    out = np.full(int(lens.sum()), np.nan, np.float32)
+    rc = lib().emu_ola(n_fft, hop, _p(frames, C.c_float), _p(frame_off, C.c_int64), _p(lens, C.c_int32),
+                       _p(off, C.c_int64), len(lens), int(lens.max()), _p(out, C.c_float))
+    assert rc == 0
+    return [out[off[i]:off[i] + lens[i]] for i in range(len(lens))]
+
+
+def resample(sigs, up, down, taps_full, n_pre_remove, outs_per_block=512):
+    a, off, lens = ragged(sigs)
+    out_len = np.array([-(-int(n) * up // down) for n in lens], np.int32)
+    out_off = np.concatenate(([0], np.cumsum(out_len)[:-1])).astype(np.int64)
+    out = np.full(int(out_len.sum()), np.nan, np.float32)
+    taps = np.ascontiguousarray(taps_full, np.float32)
+    n_blocks = int(-(-out_len.max() // outs_per_block))
+    rc = lib().emu_resample(_p(a, C.c_float), _p(off, C.c_int64), _p(lens, C.c_int32), _p(out_off, C.c_int64),
+                            _p(out_len, C.c_int32), len(lens), up, down, _p(taps, C.c_float), len(taps), n_pre_remove,
+                            outs_per_block, n_blocks, _p(out, C.c_float))
+    assert rc == 0
+    return [out[out_off[i]:out_off[i] + out_len[i]] for i in range(len(lens))]

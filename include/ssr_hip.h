@@ -1,0 +1,138 @@
+/* libssrhip - C ABI of the MI355X (gfx950) implementation of the ssr_eval DSP / metric hot path.
+ *
+ * This header is the drop-in boundary.  Every entry point names the reference interface
+ * (haoheliu/ssr_eval v0.0.6, file:line) whose arithmetic it replaces; the Python classes in
+ * ssr_eval_amd/ (AudioMetrics, FDomainHelper, lowpass, SSR_Eval_Helper) bind these symbols through
+ * ctypes and nothing else (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *  - plain C, no exceptions, no ownership transfer; every function returns SSR_OK (0) or a negative
+ *    error code, with a thread-local message available from ssr_last_error();
+ *  - every `const float*`, `float*`, `double*`, offset and length ARRAY argument is a DEVICE pointer
+ *    (HBM) valid on the current HIP device; scalar arguments are host values;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is enqueued on it and
+ *    nothing synchronises with the host;
+ *  - batches are ragged: item i occupies elements [off[i], off[i] + len[i]) of its buffer; spectrogram
+ *    rows of item i start at row frame_off[i] of a [total_rows, n_bins] float32 matrix;
+ *  - a plan is immutable after creation and may be shared between host threads.
+ */
+#ifndef SSR_HIP_H_
+#define SSR_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSR_OK 0
+#define SSR_ERR_INVALID_ARG (-1)
+#define SSR_ERR_UNSUPPORTED (-2)
+#define SSR_ERR_HIP (-3)
+#define SSR_ERR_WORKSPACE (-4)
+
+/* transform precision: SSR_F64 reproduces librosa's float64 pocketfft -> complex64 rounding (parity
+ * mode, default); SSR_F32 is a float32 transform (faster, not parity-safe on band-limited input). */
+#define SSR_F32 0
+#define SSR_F64 1
+
+/* metric_mask bits; outputs are always laid out [n_items][4] = lsd, log_sispec, sispec, ssim
+ * (key order of ssr_eval/metrics.py:98-103); unrequested entries are NaN. */
+#define SSR_METRIC_LSD 1u
+#define SSR_METRIC_LOG_SISPEC 2u
+#define SSR_METRIC_SISPEC 4u
+#define SSR_METRIC_SSIM 8u
+#define SSR_METRIC_ALL 15u
+
+/* ssr_stft output kinds */
+#define SSR_STFT_MAG 1     /* out_a = |X|                       (ssr_eval/metrics.py:27) */
+#define SSR_STFT_COMPLEX 2 /* out_a = Re X, out_b = Im X        (ssr_eval/dsp.py:64,73,77) */
+
+typedef struct ssr_plan ssr_plan;
+
+const char* ssr_last_error(void);
+int ssr_version(void);
+
+/* STFT plan: centred, reflect-padded, periodic-Hann, win_length = n_fft.
+ * Replaces the parameter choice of AudioMetrics.__init__ (ssr_eval/metrics.py:16-19: rate -> n_fft, hop),
+ * FDomainHelper.__init__ (ssr_eval/dsp.py:7-59: 2048 / 441) and librosa.stft defaults (eval.py:29: 2048 / 512).
+ * Any 2 <= n_fft <= 4096 is accepted: powers of two run a direct FFT, everything else (2229, 1486,
+ * 1114, 743 ...) runs Bluestein over a power-of-two length >= 2 n_fft - 1. */
+int ssr_plan_create(int n_fft, int hop, int precision, ssr_plan** plan);
+int ssr_plan_destroy(ssr_plan* plan);
+int ssr_plan_query(const ssr_plan* plan, int* n_fft, int* hop, int* n_bins, int* fft_len, int* bluestein,
+                   int* precision);
+/* T = 1 + (n + 2*(n_fft/2) - n_fft) / hop  (librosa / torchlibrosa frame count; bit-exact integer) */
+int64_t ssr_num_frames(const ssr_plan* plan, int64_t n_samples);
+
+/* K1+K2.  Batched STFT of ragged float32 waveforms -> [total_rows, n_bins] float32.
+ * Replaces AudioMetrics.wav_to_spectrogram (ssr_eval/metrics.py:26-30 -> librosa.stft + abs + transpose)
+ * and FDomainHelper.complex_spectrogram / spectrogram / spectrogram_phase (ssr_eval/dsp.py:61-81 ->
+ * torchlibrosa STFT).  Every item needs len > n_fft/2 (reflect padding). */
+int ssr_stft(const ssr_plan* plan, const float* wav, const int64_t* wav_off, const int32_t* wav_len,
+             const int64_t* frame_off, int n_items, int max_len, int out_kind, float* out_a, float* out_b,
+             void* stream);
+
+/* K2'.  mag = sqrt(max(re^2 + im^2, eps)), cos = re / mag, sin = im / mag   (ssr_eval/dsp.py:76-81). */
+int ssr_magphase(const float* re, const float* im, int64_t n, float eps, float* mag, float* cosv, float* sinv,
+                 void* stream);
+
+/* K1-K5 fused driver: the four metrics of AudioMetrics.evaluation (ssr_eval/metrics.py:51-107) for a
+ * ragged batch of (est, target) waveform pairs already truncated to a common length len[i]
+ * (metrics.py:89-90).  out: double [n_items][4].  total_rows = sum_i T_i, frame_off = exclusive prefix
+ * sum of T_i.  workspace: at least ssr_pair_metrics_workspace_bytes(...) bytes of device memory. */
+size_t ssr_pair_metrics_workspace_bytes(const ssr_plan* plan, int n_items, int max_len, int64_t total_rows);
+int ssr_pair_metrics(const ssr_plan* plan, const float* est, const int64_t* est_off, const float* tgt,
+                     const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off, int n_items, int max_len,
+                     int64_t total_rows, unsigned metric_mask, double* out, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* Same, restricted to a subset of its three launches (bit 0: STFT + fused LSD/SISpec epilogue, bit 1:
+ * SSIM, bit 2: finalisation) so that bench.py can time the dominant kernel on its own stream with
+ * HIP events.  stages = 7 is ssr_pair_metrics. */
+int ssr_pair_metrics_stages(const ssr_plan* plan, const float* est, const int64_t* est_off, const float* tgt,
+                            const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off, int n_items,
+                            int max_len, int64_t total_rows, unsigned metric_mask, double* out, void* workspace,
+                            size_t workspace_bytes, void* stream, int stages);
+
+/* K3-K5 on precomputed [T_i, n_bins] magnitude spectrograms: AudioMetrics.lsd / .sispec (incl. the
+ * to_log variant) / .ssim (ssr_eval/metrics.py:109-132, ssr_eval/utils.py:43-92).  est first, target second.
+ * SSIM needs T_i >= 7 and n_bins >= 7. */
+size_t ssr_spectrogram_metrics_workspace_bytes(int n_items, int max_rows, int n_bins);
+int ssr_spectrogram_metrics(const float* est_sp, const float* tgt_sp, const int64_t* frame_off, const int32_t* n_rows,
+                            int n_items, int max_rows, int n_bins, unsigned metric_mask, double* out, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* K6.  STFT-domain hard low-pass: stft_hard_lowpass_v0 (ssr_eval/lowpass.py:17-28) through
+ * FDomainHelper.wav_to_spectrogram_phase / spectrogram_phase_to_wav (ssr_eval/dsp.py:83-119).
+ * cut[i] = first zeroed bin = int(n_bins * highcut / int(fs/2)) (lowpass.py:24,193-194; computed by the
+ * caller, bit-exact integer).  Output has the input's layout (same off / len).  Power-of-two n_fft only.
+ * workspace: ssr_ola_workspace_bytes(plan, total_rows). */
+size_t ssr_ola_workspace_bytes(const ssr_plan* plan, int64_t total_rows);
+int ssr_fft_lowpass(const ssr_plan* plan, const float* in, const int64_t* off, const int32_t* len, const int32_t* cut,
+                    const int64_t* frame_off, int n_items, int max_len, int64_t total_rows, float* out,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* K6'.  Inverse STFT: torchlibrosa ISTFT.forward(real, imag, length) as used by
+ * FDomainHelper.spectrogram_phase_to_wav / reverse_complex_spectrogram (ssr_eval/dsp.py:67-70,107-119).
+ * re/im: [total_rows, n_bins]; item i has ssr_num_frames(len[i]) rows. */
+int ssr_istft(const ssr_plan* plan, const float* re, const float* im, const int64_t* frame_off, const int32_t* len,
+              const int64_t* out_off, int n_items, int max_len, int64_t total_rows, float* out, void* workspace,
+              size_t workspace_bytes, void* stream);
+
+/* K7.  Polyphase resampler = scipy.signal.resample_poly(x, up, down) for float32 x, i.e.
+ * librosa.resample(..., res_type="polyphase") (ssr_eval/eval.py:145-150) and subsampling()
+ * (ssr_eval/lowpass.py:134-144).  ssr_resample_plan reproduces SciPy's integer plan on the host;
+ * `taps` is the DEVICE copy of zeros(n_pre_pad) ++ firwin(2*half_len+1, 1/max(up,down), kaiser 5.0)*up
+ * as float32 (the caller designs the taps exactly as SciPy does).  Output bit-identical to SciPy. */
+int ssr_resample_plan(int64_t n_in, int up, int down, int* up_reduced, int* down_reduced, int64_t* n_out,
+                      int* half_len, int* n_pre_pad, int* n_pre_remove);
+int ssr_resample_poly(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
+                      const int32_t* out_len, int n_items, int max_out_len, int up, int down, const float* taps,
+                      int n_taps, int n_pre_remove, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSR_HIP_H_ */

@@ -1,0 +1,70 @@
+"""ctypes binding of libssrhip.so (the C ABI declared in include/ssr_hip.h).
+
+The library is built in-tree by ``ssr_eval_amd.build.build()`` (``hipcc --offload-arch=gfx950``).
+There is NO fallback: if the shared object is missing or no HIP device is present every entry
+point raises.  Nothing here imports ``oracle``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libssrhip.so")
+
+SSR_F32, SSR_F64 = 0, 1
+M_LSD, M_LOG_SISPEC, M_SISPEC, M_SSIM, M_ALL = 1, 2, 4, 8, 15
+STFT_MAG, STFT_COMPLEX = 1, 2
+
+_vp, _i, _i64, _sz, _u = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_uint
+
+# name -> (restype, argtypes): exactly the symbols include/ssr_hip.h declares
+SIGNATURES = {
+    "ssr_last_error": (C.c_char_p, []),
+    "ssr_version": (_i, []),
+    "ssr_plan_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
+    "ssr_plan_destroy": (_i, [_vp]),
+    "ssr_plan_query": (_i, [_vp] + [C.POINTER(_i)] * 6),
+    "ssr_num_frames": (_i64, [_vp, _i64]),
+    "ssr_stft": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ssr_magphase": (_i, [_vp, _vp, _i64, C.c_float, _vp, _vp, _vp, _vp]),
+    "ssr_pair_metrics_workspace_bytes": (_sz, [_vp, _i, _i, _i64]),
+    "ssr_pair_metrics": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _u, _vp, _vp, _sz, _vp]),
+    "ssr_pair_metrics_stages": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _u, _vp, _vp, _sz, _vp, _i]),
+    "ssr_spectrogram_metrics_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ssr_spectrogram_metrics": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u, _vp, _vp, _sz, _vp]),
+    "ssr_ola_workspace_bytes": (_sz, [_vp, _i64]),
+    "ssr_fft_lowpass": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _vp, _vp, _sz, _vp]),
+    "ssr_istft": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _vp, _vp, _sz, _vp]),
+    "ssr_resample_plan": (_i, [_i64, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64), C.POINTER(_i),
+                               C.POINTER(_i), C.POINTER(_i)]),
+    "ssr_resample_poly": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+class SsrHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libssrhip.so and bind every declared symbol; raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SsrHipError(
+            "libssrhip.so not found at %s - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  ssr_eval_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().ssr_last_error()
+        raise SsrHipError("libssrhip error %d: %s" % (rc, msg.decode() if msg else "?"))

@@ -1,0 +1,321 @@
+"""Host-side plumbing between the reference-shaped Python API and libssrhip.so.
+
+PyTorch-ROCm is used for device memory, streams and (in ``ssr_eval_amd.dist``) RCCL; every number is
+produced by the HIP kernels behind the C ABI.  Batches are ragged: one flat float32 device buffer plus
+int64 offsets / int32 lengths, all resident in HBM.
+"""
+import ctypes as C
+import math
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import M_ALL, M_LOG_SISPEC, M_LSD, M_SISPEC, M_SSIM, SsrHipError  # noqa: F401
+
+_PREC = {"f32": _lib.SSR_F32, "f64": _lib.SSR_F64, _lib.SSR_F32: _lib.SSR_F32, _lib.SSR_F64: _lib.SSR_F64}
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise SsrHipError("ssr_eval_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
+
+
+def default_device():
+    require_gpu()
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _vp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def num_frames(n, n_fft, hop):
+    """T of a centred STFT (bit-exact integer)."""
+    return 1 + (int(n) + 2 * (n_fft // 2) - n_fft) // hop
+
+
+class Plan:
+    """An immutable ssr_plan (window / twiddle / Bluestein tables in HBM) for one (n_fft, hop, precision)."""
+
+    def __init__(self, n_fft, hop, precision="f64", device=None):
+        require_gpu()
+        self.lib = _lib.load()
+        self.device = torch.device(device) if device is not None else default_device()
+        self.n_fft, self.hop, self.n_bins = int(n_fft), int(hop), int(n_fft) // 2 + 1
+        self.precision = _PREC[precision]
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ssr_plan_create(self.n_fft, self.hop, self.precision, C.byref(h)))
+        self.handle = h
+        q = [C.c_int() for _ in range(6)]
+        _lib.check(self.lib.ssr_plan_query(h, *[C.byref(x) for x in q]))
+        self.fft_len, self.bluestein = q[3].value, bool(q[4].value)
+
+    def frames(self, n):
+        return num_frames(n, self.n_fft, self.hop)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) is not None and self.handle.value:
+                self.lib.ssr_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+_plans = {}
+_plans_lock = threading.Lock()
+
+
+def get_plan(n_fft, hop, precision="f64", device=None):
+    dev = torch.device(device) if device is not None else default_device()
+    key = (int(n_fft), int(hop), _PREC[precision], dev.index if dev.index is not None else torch.cuda.current_device())
+    with _plans_lock:
+        p = _plans.get(key)
+        if p is None:
+            p = _plans[key] = Plan(n_fft, hop, precision, dev)
+        return p
+
+
+class Ragged:
+    """A ragged batch of 1-D float32 signals resident on the device."""
+
+    def __init__(self, data, off, lens_dev, lens_host):
+        self.data, self.off, self.len = data, off, lens_dev
+        self.lens_host = np.asarray(lens_host, dtype=np.int64)
+        self.n = len(self.lens_host)
+        self.max_len = int(self.lens_host.max()) if self.n else 0
+        self.device = data.device
+
+    @staticmethod
+    def from_list(arrays, device=None):
+        dev = torch.device(device) if device is not None else default_device()
+        ts = []
+        for a in arrays:
+            t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+            if t.dim() != 1:
+                raise ValueError("expected 1-D signals, got shape %s" % (tuple(t.shape),))
+            ts.append(t.to(device=dev, dtype=torch.float32, non_blocking=True))
+        lens = np.array([t.shape[0] for t in ts], dtype=np.int64)
+        if len(ts) and lens.max() >= 2 ** 31:
+            raise ValueError("signal too long")
+        data = torch.cat(ts) if len(ts) else torch.empty(0, dtype=torch.float32, device=dev)
+        off = np.concatenate(([0], np.cumsum(lens)[:-1])) if len(ts) else np.zeros(0, np.int64)
+        return Ragged(data, torch.from_numpy(off.astype(np.int64)).to(dev),
+                      torch.from_numpy(lens.astype(np.int32)).to(dev), lens)
+
+    @staticmethod
+    def from_uniform(x):
+        """x: [N, n] float32 contiguous device tensor - no copy, descriptors built on the device."""
+        if x.dim() != 2 or x.dtype != torch.float32 or not x.is_contiguous() or not x.is_cuda:
+            raise ValueError("from_uniform needs a contiguous float32 [N, n] device tensor")
+        N, n = x.shape
+        off = torch.arange(N, device=x.device, dtype=torch.int64) * n
+        lens = torch.full((N,), n, device=x.device, dtype=torch.int32)
+        return Ragged(x.view(-1), off, lens, np.full(N, n, dtype=np.int64))
+
+    def split(self, flat=None):
+        flat = self.data if flat is None else flat
+        o = np.concatenate(([0], np.cumsum(self.lens_host)))
+        return [flat[o[i]:o[i + 1]] for i in range(self.n)]
+
+
+class _Rows:
+    """Row (frame) descriptors of a ragged batch under a plan."""
+
+    def __init__(self, plan, lens_host, device):
+        self.T = np.array([plan.frames(n) for n in lens_host], dtype=np.int64)
+        self.total = int(self.T.sum())
+        self.max_T = int(self.T.max()) if len(self.T) else 0
+        off = np.concatenate(([0], np.cumsum(self.T)[:-1])) if len(self.T) else np.zeros(0, np.int64)
+        self.off_host = off
+        self.off = torch.from_numpy(off.astype(np.int64)).to(device)
+
+
+def _check_reflect(plan, lens_host):
+    if len(lens_host) and int(np.min(lens_host)) <= plan.n_fft // 2:
+        raise ValueError("reflect padding needs every signal longer than n_fft//2 = %d samples" % (plan.n_fft // 2))
+
+
+# ------------------------------------------------------------------------------------------------------
+class PairBatch:
+    """(est, target) ragged batch + cached descriptors/workspace for repeated ssr_pair_metrics calls."""
+
+    def __init__(self, plan, est, tgt):
+        if est.n != tgt.n or not np.array_equal(est.lens_host, tgt.lens_host):
+            raise ValueError("est and target must have identical lengths (truncate to min_len first)")
+        _check_reflect(plan, est.lens_host)
+        self.plan, self.est, self.tgt = plan, est, tgt
+        self.rows = _Rows(plan, est.lens_host, est.device)
+        lib = plan.lib
+        self.ws_bytes = int(lib.ssr_pair_metrics_workspace_bytes(plan.handle, est.n, est.max_len, self.rows.total))
+        self.ws = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=est.device)
+        self.out = torch.empty((est.n, 4), dtype=torch.float64, device=est.device)
+
+    def run(self, mask=M_ALL, stages=7):
+        p, e, t = self.plan, self.est, self.tgt
+        if e.n == 0:
+            return self.out
+        if (mask & M_SSIM) and (self.rows.T.min() < 7 or p.n_bins < 7):
+            raise ValueError("win_size exceeds image extent")  # what skimage raises for images smaller than 7x7
+        _lib.check(p.lib.ssr_pair_metrics_stages(
+            p.handle, _vp(e.data), _vp(e.off), _vp(t.data), _vp(t.off), _vp(e.len), _vp(self.rows.off), e.n, e.max_len,
+            self.rows.total, mask, _vp(self.out), _vp(self.ws), self.ws_bytes, _stream(), stages))
+        return self.out
+
+
+def pair_metrics(plan, est_list, tgt_list, mask=M_ALL):
+    """[n, 4] float64 (lsd, log_sispec, sispec, ssim) for lists of equal-length (est, target) waveforms."""
+    with torch.cuda.device(plan.device):
+        b = PairBatch(plan, Ragged.from_list(est_list, plan.device), Ragged.from_list(tgt_list, plan.device))
+        return b.run(mask).cpu().numpy()
+
+
+def stft(plan, wavs, kind="mag"):
+    """STFT of a list of waveforms.  kind "mag": list of [T, F] tensors; "complex": (re list, im list)."""
+    with torch.cuda.device(plan.device):
+        r = wavs if isinstance(wavs, Ragged) else Ragged.from_list(wavs, plan.device)
+        _check_reflect(plan, r.lens_host)
+        rows = _Rows(plan, r.lens_host, r.device)
+        a = torch.empty((rows.total, plan.n_bins), dtype=torch.float32, device=r.device)
+        b = torch.empty_like(a) if kind == "complex" else None
+        _lib.check(plan.lib.ssr_stft(plan.handle, _vp(r.data), _vp(r.off), _vp(r.len), _vp(rows.off), r.n, r.max_len,
+                                     _lib.STFT_COMPLEX if kind == "complex" else _lib.STFT_MAG, _vp(a), _vp(b), _stream()))
+        cut = lambda m: [m[rows.off_host[i]:rows.off_host[i] + rows.T[i]] for i in range(r.n)]
+        return (cut(a), cut(b)) if kind == "complex" else cut(a)
+
+
+def magphase(re, im, eps):
+    """(mag, cos, sin) of ssr_eval/dsp.py:76-81 for float32 device tensors of any shape."""
+    re, im = re.contiguous(), im.contiguous()
+    mag, cos, sin = torch.empty_like(re), torch.empty_like(re), torch.empty_like(re)
+    with torch.cuda.device(re.device):
+        _lib.check(_lib.load().ssr_magphase(_vp(re), _vp(im), re.numel(), float(eps), _vp(mag), _vp(cos), _vp(sin), _stream()))
+    return mag, cos, sin
+
+
+def spectrogram_metrics(est_sps, tgt_sps, mask=M_ALL):
+    """Metrics on lists of [T_i, F] float32 magnitude spectrograms -> [n, 4] float64 device tensor."""
+    require_gpu()
+    lib = _lib.load()
+    dev = est_sps[0].device if isinstance(est_sps[0], torch.Tensor) and est_sps[0].is_cuda else default_device()
+    with torch.cuda.device(dev):
+        to_dev = lambda s: (s if isinstance(s, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(s))).to(
+            device=dev, dtype=torch.float32)
+        es, ts = [to_dev(s) for s in est_sps], [to_dev(s) for s in tgt_sps]
+        F = es[0].shape[1]
+        for e, t in zip(es, ts):
+            if e.shape != t.shape or e.dim() != 2 or e.shape[1] != F:
+                raise ValueError("spectrogram shape mismatch")
+        T = np.array([e.shape[0] for e in es], dtype=np.int64)
+        if (mask & M_SSIM) and (T.min() < 7 or F < 7):
+            raise ValueError("win_size exceeds image extent")
+        x = torch.cat([e.reshape(-1) for e in es])
+        y = torch.cat([t.reshape(-1) for t in ts])
+        off = torch.from_numpy(np.concatenate(([0], np.cumsum(T)[:-1])).astype(np.int64)).to(dev)
+        rows = torch.from_numpy(T.astype(np.int32)).to(dev)
+        n, max_T = len(es), int(T.max())
+        ws_bytes = int(lib.ssr_spectrogram_metrics_workspace_bytes(n, max_T, F))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        out = torch.empty((n, 4), dtype=torch.float64, device=dev)
+        _lib.check(lib.ssr_spectrogram_metrics(_vp(x), _vp(y), _vp(off), _vp(rows), n, max_T, F, mask, _vp(out), _vp(ws),
+                                               ws_bytes, _stream()))
+        return out
+
+
+def fft_lowpass(plan, wavs, cut_bins):
+    """STFT-domain hard low-pass (K6) of a list of waveforms; cut_bins: first zeroed bin per item."""
+    with torch.cuda.device(plan.device):
+        r = wavs if isinstance(wavs, Ragged) else Ragged.from_list(wavs, plan.device)
+        _check_reflect(plan, r.lens_host)
+        rows = _Rows(plan, r.lens_host, r.device)
+        cut = torch.from_numpy(np.asarray(cut_bins, dtype=np.int32)).to(r.device)
+        if cut.numel() != r.n:
+            raise ValueError("one cut bin per item")
+        ws_bytes = int(plan.lib.ssr_ola_workspace_bytes(plan.handle, rows.total))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=r.device)
+        out = torch.empty_like(r.data)
+        _lib.check(plan.lib.ssr_fft_lowpass(plan.handle, _vp(r.data), _vp(r.off), _vp(r.len), _vp(cut), _vp(rows.off), r.n,
+                                            r.max_len, rows.total, _vp(out), _vp(ws), ws_bytes, _stream()))
+        return r.split(out)
+
+
+def istft(plan, res, ims, lengths):
+    """Inverse STFT (K6') of lists of [T_i, F] float32 (re, im); lengths: output samples per item."""
+    with torch.cuda.device(plan.device):
+        dev = plan.device
+        lens = np.asarray(lengths, dtype=np.int64)
+        _check_reflect(plan, lens)
+        rows = _Rows(plan, lens, dev)
+        for r_, t_ in zip(res, rows.T):
+            if r_.shape[0] != t_ or r_.shape[1] != plan.n_bins:
+                raise ValueError("spectrogram rows do not match ssr_num_frames(length)")
+        re = torch.cat([r_.to(device=dev, dtype=torch.float32).reshape(-1) for r_ in res])
+        im = torch.cat([i_.to(device=dev, dtype=torch.float32).reshape(-1) for i_ in ims])
+        out_off = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int64)
+        out = torch.empty(int(lens.sum()), dtype=torch.float32, device=dev)
+        ws_bytes = int(plan.lib.ssr_ola_workspace_bytes(plan.handle, rows.total))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        _lib.check(plan.lib.ssr_istft(plan.handle, _vp(re), _vp(im), _vp(rows.off),
+                                      _vp(torch.from_numpy(lens.astype(np.int32)).to(dev)),
+                                      _vp(torch.from_numpy(out_off).to(dev)), len(lens), int(lens.max()), rows.total,
+                                      _vp(out), _vp(ws), ws_bytes, _stream()))
+        return [out[out_off[i]:out_off[i] + lens[i]] for i in range(len(lens))]
+
+
+# ------------------------------------------------------------------------------------------------------
+class ResamplePlan:
+    """Integer plan + taps of scipy.signal.resample_poly(x, up, down) for float32 x."""
+
+    _cache = {}
+
+    def __init__(self, up, down, device):
+        from scipy.signal import firwin  # tap design exactly as SciPy does it (host, once per rate pair)
+        lib = _lib.load()
+        u, d, n_out, hl, pp, pr = C.c_int(), C.c_int(), C.c_int64(), C.c_int(), C.c_int(), C.c_int()
+        _lib.check(lib.ssr_resample_plan(0, int(up), int(down), C.byref(u), C.byref(d), C.byref(n_out), C.byref(hl),
+                                         C.byref(pp), C.byref(pr)))
+        self.up, self.down, self.half_len = u.value, d.value, hl.value
+        self.n_pre_pad, self.n_pre_remove = pp.value, pr.value
+        self.identity = self.up == 1 and self.down == 1
+        h = firwin(2 * self.half_len + 1, 1.0 / max(self.up, self.down), window=("kaiser", 5.0)).astype(np.float32)
+        h *= self.up
+        self.taps_host = np.concatenate((np.zeros(self.n_pre_pad, np.float32), h))
+        self.taps = torch.from_numpy(self.taps_host).to(device)
+
+    @classmethod
+    def get(cls, up, down, device):
+        g = math.gcd(int(up), int(down))
+        key = (int(up) // g, int(down) // g, str(device))
+        p = cls._cache.get(key)
+        if p is None:
+            p = cls._cache[key] = cls(up, down, device)
+        return p
+
+    def n_out(self, n_in):
+        return -(-int(n_in) * self.up // self.down)
+
+
+def resample_poly(wavs, up, down, device=None):
+    """Polyphase resampling (K7) of a list of float32 waveforms; bit-identical to scipy.signal.resample_poly."""
+    dev = torch.device(device) if device is not None else default_device()
+    with torch.cuda.device(dev):
+        r = wavs if isinstance(wavs, Ragged) else Ragged.from_list(wavs, dev)
+        rp = ResamplePlan.get(up, down, dev)
+        if rp.identity:
+            return [w.clone() for w in r.split()]
+        out_len = np.array([rp.n_out(n) for n in r.lens_host], dtype=np.int64)
+        out_off = np.concatenate(([0], np.cumsum(out_len)[:-1])).astype(np.int64)
+        out = torch.empty(int(out_len.sum()), dtype=torch.float32, device=dev)
+        if r.n and out_len.max() > 0:
+            _lib.check(_lib.load().ssr_resample_poly(
+                _vp(r.data), _vp(r.off), _vp(r.len), _vp(torch.from_numpy(out_off).to(dev)),
+                _vp(torch.from_numpy(out_len.astype(np.int32)).to(dev)), r.n, int(out_len.max()), rp.up, rp.down,
+                _vp(rp.taps), int(rp.taps.numel()), rp.n_pre_remove, _vp(out), _stream()))
+        return [out[out_off[i]:out_off[i] + out_len[i]] for i in range(r.n)]

@@ -21,6 +21,7 @@
 #define SSR_DEV static inline
 #define SSR_BODY static inline
 #define SSR_MEMBER inline
+#define SSR_HD static inline
 struct SsrBlk { int nt; };
 #define SSR_REGS(TYPE, name, blk) std::vector<TYPE> name((blk).nt)
 #define SSR_PHASE(blk, regs, ...)                                  \
@@ -35,6 +36,7 @@ static inline float ssr_fadd_rn(float a, float b) { volatile float r = a + b; re
 #define SSR_DEV __device__ __forceinline__
 #define SSR_BODY __device__ __forceinline__
 #define SSR_MEMBER __device__ __forceinline__
+#define SSR_HD __host__ __device__ __forceinline__
 struct SsrBlk { int tid; };
 #define SSR_REGS(TYPE, name, blk) TYPE name
 #define SSR_PHASE(blk, regs, ...)                                  \
@@ -58,7 +60,7 @@ template <typename T> SSR_DEV cx<T> cmul_negi(cx<T> a) { return {a.y, -a.x}; }  
 // LDS index padding: one extra element per 16 keeps the strided stores of the early Stockham
 // passes off a single bank group ("LDS layout").
 SSR_DEV int ssr_pad(int i) { return i + (i >> 4); }
-SSR_DEV constexpr int ssr_padded_len(int n) { return n + (n >> 4) + 1; }
+SSR_HD constexpr int ssr_padded_len(int n) { return n + (n >> 4) + 1; }
 
 // centred-STFT reflect padding of sample index s into [0, n)  (requires n > n_fft/2)
 SSR_DEV int ssr_reflect(int s, int n) {

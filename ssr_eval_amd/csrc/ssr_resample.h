@@ -27,11 +27,11 @@ struct SsrResampleParams {
   float* out;
 };
 
-SSR_DEV int ssr_resample_hpp(const SsrResampleParams& p) { return (p.n_taps + p.up - 1) / p.up; }
-SSR_DEV int ssr_resample_win(const SsrResampleParams& p) {
+SSR_HD int ssr_resample_hpp(const SsrResampleParams& p) { return (p.n_taps + p.up - 1) / p.up; }
+SSR_HD int ssr_resample_win(const SsrResampleParams& p) {
   return (int)(((int64_t)p.outs_per_block * p.down) / p.up) + ssr_resample_hpp(p) + 2;
 }
-SSR_DEV size_t ssr_resample_lds_bytes(const SsrResampleParams& p) {
+SSR_HD size_t ssr_resample_lds_bytes(const SsrResampleParams& p) {
   return sizeof(float) * ((size_t)ssr_resample_hpp(p) * p.up + ssr_resample_win(p) + 8);
 }
 

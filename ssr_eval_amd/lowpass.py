@@ -1,0 +1,110 @@
+"""Degradations - drop-in for ssr_eval.lowpass (ssr_eval/lowpass.py:17-256) on MI355X.
+
+``lowpass(data, highcut, fs, order, _type)`` keeps the reference's dispatcher semantics (order clamp to
+[2, 10], 1-D check, *substring* match of ``_type``).  Hot-path types run in libssrhip.so:
+
+* ``stft_hard``   -> ``ssr_fft_lowpass`` (K6): STFT(2048/441) -> zero bins >= cut -> ISTFT.
+* ``subsampling`` -> ``ssr_resample_poly`` (K7) down then up, then align_length.
+
+The zero-phase IIR types (butter / cheby1 / ellip / bessel) are SURVEY 8(f) row N1 ("next"): they are NOT
+part of the accelerated path yet and run where the reference runs them - SciPy ``sosfiltfilt`` on the
+host (``_host_iir``).  No parity or performance claim is made for them.
+"""
+import numpy as np
+import torch
+
+from . import backend as B
+
+N_FFT, HOP = 2048, 441          # FDomainHelper() defaults used by the reference's global f_helper (lowpass.py:167)
+_precision = "f64"
+
+
+def cut_bin(lowpass_ratio, n_bins=N_FFT // 2 + 1):
+    """First zeroed bin: int(F * ratio) (lowpass.py:24) - integer, bit-exact with the reference."""
+    return int(n_bins * lowpass_ratio)
+
+
+def stft_hard_lowpass_v0(data, lowpass_ratio):
+    """lowpass.py:17-28.  data: 1-D ndarray / tensor -> float32 ndarray of the same length."""
+    return stft_hard_lowpass_batch([data], [lowpass_ratio])[0]
+
+
+def stft_hard_lowpass_batch(datas, ratios, device=None):
+    plan = B.get_plan(N_FFT, HOP, _precision, device)
+    ys = B.fft_lowpass(plan, [d if isinstance(d, torch.Tensor) else np.asarray(d, np.float32) for d in datas],
+                       [cut_bin(r) for r in ratios])
+    return [y.cpu().numpy() for y in ys]
+
+
+def align_length(x, y):
+    """Zero-pad or cut y to len(x) (lowpass.py:31-51)."""
+    if len(y) < len(x):
+        return np.pad(y, (0, len(x) - len(y)), mode="constant")
+    return y[:len(x)]
+
+
+def subsampling(data, lowpass_ratio, fs_ori=44100):
+    """Down- then up-sample through fs_down = int(ratio * 44100) (lowpass.py:134-144)."""
+    fs_down = int(lowpass_ratio * fs_ori)
+    x = np.asarray(data)
+    down = B.resample_poly([x.astype(np.float32)], fs_down, fs_ori)[0]
+    up = B.resample_poly([down], fs_ori, fs_down)[0].cpu().numpy().astype(x.dtype if x.dtype.kind == "f" else np.float32)
+    return align_length(x, up)
+
+
+def limit(integer, high, low):
+    return high if integer > high else (low if integer < low else int(integer))
+
+
+def _host_iir(x, highcut, fs, order, ftype, lowcut=None):
+    """SURVEY 8(f) N1 - zero-phase IIR on the HOST with SciPy, exactly as lowpass.py:54-131 does."""
+    from scipy import signal
+    nyq = 0.5 * fs
+    wn = highcut / nyq if lowcut is None else [lowcut / nyq, highcut / nyq]
+    bt = "low" if lowcut is None else "band"
+    design = {"butter": lambda: signal.butter(order, wn, btype=bt, output="sos"),
+              "cheby1": lambda: signal.cheby1(order, 0.1, wn, btype=bt, output="sos"),
+              "cheby2": lambda: signal.cheby2(order, 60, wn, btype=bt, output="sos"),
+              "ellip": lambda: signal.ellip(order, 0.1, 60, wn, btype=bt, output="sos"),
+              "bessel": lambda: signal.bessel(order, wn, btype=bt, output="sos")}
+    if ftype not in design:
+        raise Exception("The %s filter %s is not supported!" % ("lowpass" if lowcut is None else "bandpass", ftype))
+    return align_length(x, signal.sosfiltfilt(design[ftype](), x))
+
+
+def lowpass_filter(x, highcut, fs, order, ftype):
+    return _host_iir(x, highcut, fs, order, ftype)
+
+
+def bandpass_filter(x, lowcut, highcut, fs, order, ftype):
+    return _host_iir(x, highcut, fs, order, ftype, lowcut=lowcut)
+
+
+def _check_1d(data):
+    if len(list(data.shape)) != 1:
+        raise ValueError("Error (chebyshev_lowpass_filter): Data " + str(data.shape)
+                         + " should be type 1d time array, (samples,) , can not be (samples, 1)")
+
+
+def lowpass(data, highcut, fs, order=5, _type="butter"):
+    """lowpass.py:156-196."""
+    order = limit(order, high=10, low=2)
+    _check_1d(data)
+    for name in ("butter", "cheby1", "ellip", "bessel"):      # `_type in name`: substring test, as the reference
+        if _type in name:
+            return lowpass_filter(x=data, highcut=int(highcut), fs=fs, order=order, ftype=name)
+    if _type in "subsampling":
+        return subsampling(data, lowpass_ratio=highcut / int(fs / 2))
+    if _type in "stft_hard":
+        return stft_hard_lowpass_v0(data, lowpass_ratio=highcut / int(fs / 2))
+    raise ValueError("Error: Unexpected filter type " + _type)
+
+
+def bandpass(data, lowcut, highcut, fs, order=5, _type="butter"):
+    """lowpass.py:199-256."""
+    _check_1d(data)
+    for name in ("butter", "cheby1", "ellip", "bessel"):
+        if _type in name:
+            return bandpass_filter(x=data, lowcut=int(lowcut), highcut=int(highcut), fs=fs,
+                                   order=limit(order, high=10, low=2), ftype=name)
+    raise ValueError("Error: Unexpected filter type " + _type)

@@ -1,0 +1,121 @@
+"""AudioMetrics - drop-in for ssr_eval.metrics.AudioMetrics (ssr_eval/metrics.py:15-132) on MI355X.
+
+Same constructor, method names, argument order (estimate first, target second) and result keys as the
+reference.  All arithmetic runs in libssrhip.so (HIP, gfx950):
+
+* ``evaluation`` -> one ``ssr_pair_metrics`` call: STFT of both signals (two-for-one complex FFT),
+  fused LSD + SISpec + log-SISpec epilogue, SSIM kernel, finalisation.
+* ``wav_to_spectrogram`` -> ``ssr_stft``;  ``lsd`` / ``sispec`` / ``ssim`` on tensors ->
+  ``ssr_spectrogram_metrics``.
+
+Extras (keyword-only, not in the reference): ``precision`` ("f64" parity mode / "f32"), ``device``,
+``n_fft`` / ``hop_length`` overrides, and ``evaluation_batch`` for lists of pairs.
+"""
+import numpy as np
+import torch
+
+from . import backend as B
+
+EPS = 1e-12
+_KEYS = ("lsd", "log_sispec", "sispec", "ssim")
+
+
+class AudioMetrics:
+    def __init__(self, rate, *, precision="f64", device=None, n_fft=None, hop_length=None):
+        self.rate = rate
+        # integer table of ssr_eval/metrics.py:18-19 (bit-exact): 48000 -> (2229, 480), 44100 -> (2048, 441)
+        self.hop_length = int(rate / 100) if hop_length is None else int(hop_length)
+        self.n_fft = int(2048 / (44100 / rate)) if n_fft is None else int(n_fft)
+        self.precision = precision
+        self._device = device
+
+    # ---- plumbing
+    def _plan(self):
+        return B.get_plan(self.n_fft, self.hop_length, self.precision, self._device)
+
+    def read(self, est, target):
+        """ssr_eval/metrics.py:21-24 (file decode + resample is host I/O)."""
+        from .io import load_audio
+        return load_audio(est, self.rate), load_audio(target, self.rate)
+
+    # ---- reference API
+    def wav_to_spectrogram(self, wav, *, keep_on_device=False):
+        """[n] waveform -> magnitude spectrogram tensor [1, 1, T, F] float32 (metrics.py:26-30)."""
+        plan = self._plan()
+        sp = B.stft(plan, [np.asarray(wav) if not isinstance(wav, torch.Tensor) else wav])[0][None, None]
+        return sp if keep_on_device else sp.cpu()
+
+    def _prepare_pair(self, est, target):
+        if type(est) != type(target):
+            raise ValueError("The input value should either both be numpy array or strings")
+        if isinstance(est, str):
+            est, target = self.read(est, target)
+        assert len(est.shape) == 1 and len(target.shape) == 1, (
+            "The input numpy array shape should be [samples,]. Got input shape %s and %s. " % (est.shape, target.shape))
+        assert abs(target.shape[0] - est.shape[0]) < 100, (
+            "Error: Shape mismatch between target and estimation %s and %s" % (str(target.shape), str(est.shape)))
+        m = min(target.shape[0], est.shape[0])           # metrics.py:89-90
+        return est[:m], target[:m]
+
+    def evaluation(self, est, target, file=None):
+        """{lsd, log_sispec, sispec, ssim} for one (estimate, target) pair (metrics.py:51-107)."""
+        return self.evaluation_batch([est], [target])[0]
+
+    def evaluation_batch(self, ests, targets, mask=B.M_ALL):
+        """The same four metrics for lists of pairs, one fused launch sequence for the whole batch."""
+        pairs = [self._prepare_pair(e, t) for e, t in zip(ests, targets)]
+        vals = B.pair_metrics(self._plan(), [p[0] for p in pairs], [p[1] for p in pairs], mask)
+        out = []
+        for row in vals:
+            d = {}
+            for k, v in zip(_KEYS, row):
+                if not np.isnan(v) or (mask & (1 << _KEYS.index(k))):
+                    # lsd / sispec are float32 tensors in the reference (float() of fp32); ssim is float64
+                    d[k] = float(v) if k == "ssim" else float(np.float32(v))
+            out.append(d)
+        return out
+
+    # ---- reductions on [B, C, T, F] tensors (est first)
+    @staticmethod
+    def _images(x):
+        if x.dim() != 4:
+            raise ValueError("expected a [B, C, T, F] tensor, got %s" % (tuple(x.shape),))
+        if x.shape[1] != 1:
+            raise NotImplementedError("multi-channel spectrograms are not produced by AudioMetrics; C must be 1")
+        return [x[b, 0] for b in range(x.shape[0])]
+
+    def _reduce(self, est, target, mask, log_domain=False):
+        e, t = self._images(est), self._images(target)
+        return B.spectrogram_metrics(e, t, mask)
+
+    def lsd(self, est, target):
+        """[B, 1, T, F] x2 -> [B, 1, 1, 1] float32 (metrics.py:109-112)."""
+        v = self._reduce(est, target, B.M_LSD)[:, 0]
+        return v.to(torch.float32).to(est.device)[:, None, None, None]
+
+    def sispec(self, est, target):
+        """Scale-invariant spectrogram-to-noise ratio, mean over the batch, 0-dim float32 (metrics.py:114-121)."""
+        v = self._reduce(est, target, B.M_SISPEC)[:, 2]
+        return (v.sum() / v.shape[0]).to(torch.float32).to(est.device)
+
+    def log_sispec(self, est, target):
+        """sispec(to_log(est), to_log(target)) of metrics.py:99-101 with the log10(x + 1e-12) fused in-kernel."""
+        v = self._reduce(est, target, B.M_LOG_SISPEC)[:, 1]
+        return (v.sum() / v.shape[0]).to(torch.float32).to(est.device)
+
+    def ssim(self, est, target):
+        """[B, 1, T, F] x2 -> [B, 1, 1, 1] float64 (metrics.py:123-132)."""
+        v = self._reduce(est, target, B.M_SSIM)[:, 3]
+        return v.to(est.device)[:, None, None, None]
+
+    def center_crop(self, x, y):
+        """Crop the longer of two [B, C, T, F] tensors around its centre (metrics.py:32-49; unused there)."""
+        d = x.size(2) - y.size(2)
+        if d == 0:
+            return x, y
+        assert abs(d) < 10, "Error: the offset %s is too large, check the code please" % (abs(d))
+        a = abs(d) // 2
+        b = abs(d) - a
+        if d > 0:
+            return x[:, :, a:x.size(2) - b, :], y
+        return x, y[:, :, a:y.size(2) - b, :]

@@ -1,0 +1,54 @@
+"""CPU tests: the N>1 exchange (ssr_eval_amd.dist) with the gloo backend, world_size 2."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from datetime import datetime
+    from ssr_eval_amd import SSR_Eval_Helper, BasicTestee
+    from ssr_eval_amd import dist as D
+    D.init_from_env(backend="gloo")
+    assert D.rank_world() == (rank, world)
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "aggregate.json")))
+    work = [(s, f) for s in g["speakers"] for f in g["files"][s]]
+    mine = D.shard_indices(len(work))
+    assert list(mine) == list(range(rank, len(work), world))
+    local = [g["per_file"][os.path.join(*work[i])] for i in mine]
+    h = SSR_Eval_Helper(BasicTestee(), 44100, 44100, test_data_root=None)
+    os.chdir(out_dir)
+    final = h._assemble(work, g["speakers"], mine, local, rank == 0, datetime(2022, 1, 1))
+    ok = final["averaged"] == g["averaged"] and final["each_speaker"] == g["each_speaker"]
+    ok = ok and all(final[s][f] == g["per_file"][os.path.join(s, f)] for s, f in work)
+    want = np.array([g["averaged"][k][m] for k in local[0] for m in ("lsd", "log_sispec", "sispec", "ssim")])
+    ok = ok and np.allclose(h.last_allreduce_average, want, rtol=1e-13)
+    # raw primitives
+    red = D.allreduce_sums(np.full(5, rank + 1.0))
+    ok = ok and np.array_equal(red, np.full(5, 3.0))
+    open(os.path.join(out_dir, "ok%d" % rank), "w").write("1" if ok else "0")
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_sharded_assembly_world2(tmp_path):
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / "ok0").read() == "1" and open(tmp_path / "ok1").read() == "1"
+
+
+def test_single_process_primitives():
+    sys.path.insert(0, ROOT)
+    from ssr_eval_amd import dist as D
+    rows = np.arange(12.0).reshape(4, 3)
+    out = D.allgather_rows(rows[[0, 2]], [0, 2], 4)
+    assert np.array_equal(out[[0, 2]], rows[[0, 2]]) and np.isnan(out[1]).all()
+    buf = D.speaker_sums(rows, [0, 0, 1, 1], 3)
+    means, avg = D.mean_of_speaker_means(buf)
+    assert means.shape == (2, 3) and np.allclose(avg, rows.reshape(2, 2, 3).mean(1).mean(0))

@@ -1,0 +1,103 @@
+"""CPU tests: the kernel bodies (ssr_eval_amd/csrc/*.h) executed phase-by-phase on the host
+(tests/emu/ssr_emu.cpp, g++ -DSSR_HOST_EMU) against the oracle and the reference-generated vectors.
+The same source compiles to the gfx950 kernels; the -m gpu tests repeat the comparisons on the device."""
+import numpy as np
+import pytest
+from scipy import signal
+
+import emu_lib as E
+from oracle import lowpass as olp
+from oracle import metrics as om
+from oracle import resample as ors
+from oracle import ssim as ossim
+from oracle import stft as ostft
+
+EV = ["noise48k", "noise44k", "noise16k", "speech48k_fftlp6k", "speech44k_fftlp4k_ragged", "speech24k_scaled"]
+
+
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (256, 64), (4096, 1024), (2229, 480), (743, 160), (1114, 240), (100, 25)])
+def test_stft_magnitude_pair_and_single(n_fft, hop):
+    rng = np.random.default_rng(n_fft)
+    lens = (n_fft * 2 + 77, n_fft // 2 + 1, n_fft + hop * 3)
+    x = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    y = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    ea, tb, _ = E.stft(x, y, n_fft, hop, precision=1, units_per_chunk=3)
+    sa, _, _ = E.stft(x, None, n_fft, hop, precision=1, mode=1, units_per_chunk=2)
+    for i in range(len(lens)):
+        ra, rb = ostft.stft_mag_TF(x[i], n_fft, hop), ostft.stft_mag_TF(y[i], n_fft, hop)
+        assert ea[i].shape == ra.shape == (ostft.num_frames(lens[i], n_fft, hop), n_fft // 2 + 1)
+        tol = 2e-7 * max(ra.max(), rb.max())
+        assert np.abs(ea[i] - ra).max() <= tol and np.abs(tb[i] - rb).max() <= tol
+        assert np.abs(sa[i] - ra).max() <= tol
+
+
+def test_stft_complex_matches_tl_stft(golden):
+    x = golden["fd_x"]
+    re, im, _ = E.stft([x], None, 2048, 441, precision=1, mode=1, out_kind=2)
+    rr, ri = ostft.tl_stft(x[None], 2048, 441)
+    assert np.abs(re[0] - rr[0, 0]).max() <= 2e-7 * np.abs(rr).max()
+    assert np.abs(im[0] - ri[0, 0]).max() <= 2e-7 * np.abs(rr).max()
+
+
+@pytest.mark.parametrize("name", EV + ["bench2048"])
+def test_pair_metrics_match_reference_vectors(golden, name):
+    e, t = golden["ev_%s_est" % name], golden["ev_%s_tgt" % name]
+    n_fft, hop = (2048, 512) if name == "bench2048" else om.stft_params(int(golden["ev_%s_rate" % name]))
+    m = min(len(e), len(t))
+    got = E.pair_metrics([e[:m]], [t[:m]], n_fft, hop, precision=1, units_per_chunk=5, rows_per_tile=9)[0]
+    want = golden["ev_%s_out" % name]
+    keep = [0, 1, 3] if name == "speech24k_scaled" else [0, 1, 2, 3]   # est = c*target: sispec is round-off defined
+    np.testing.assert_allclose(got[keep], want[keep], rtol=1e-5)
+
+
+def test_f32_transform_is_not_parity_safe_on_bandlimited_input(golden):
+    """Documents why SSR_F64 is the default: a float32 FFT misses LSD by percents once the estimate is band-limited."""
+    e, t = golden["ev_speech48k_fftlp6k_est"], golden["ev_speech48k_fftlp6k_tgt"]
+    got = E.pair_metrics([e], [t], 2229, 480, precision=0)[0]
+    assert abs(got[0] / golden["ev_speech48k_fftlp6k_out"][0] - 1) > 1e-3
+
+
+def test_spectrogram_reductions_match_reference_vectors(golden):
+    es, ts = golden["sp_est"], golden["sp_tgt"]
+    xs, ys = [es[0, 0], es[1, 0]], [ts[0, 0], ts[1, 0]]
+    part, T = E.specred_parts(xs, ys, mask=7, rows_per_chunk=4)
+    sp, _ = E.ssim_parts(xs, ys, rows_per_tile=5)
+    out = E.finalize(part, sp, T, 65, 15)
+    np.testing.assert_allclose(out[:, 0], golden["sp_lsd"][:, 0, 0, 0], rtol=1e-6)
+    np.testing.assert_allclose(out[:, 2], golden["sp_sispec_each"], rtol=1e-6)
+    np.testing.assert_allclose(out[:, 1], golden["sp_log_sispec_each"], rtol=1e-6)
+    np.testing.assert_allclose(out[:, 3], golden["sp_ssim"][:, 0, 0, 0], rtol=1e-10)
+
+
+@pytest.mark.parametrize("shape", [(7, 7), (8, 1300), (40, 1286), (23, 70)])
+def test_ssim_tiles_and_strips(shape):
+    rng = np.random.default_rng(shape[1])
+    a = np.abs(rng.standard_normal(shape)).astype(np.float32) * 50
+    b = (a * (1 + 0.2 * rng.standard_normal(shape))).astype(np.float32)
+    sp, T = E.ssim_parts([a, a[:max(7, shape[0] - 3)]], [b, b[:max(7, shape[0] - 3)]], rows_per_tile=4)
+    out = E.finalize(None, sp, T, shape[1], 8)
+    assert abs(out[0, 3] - ossim.structural_similarity(a, b)) < 1e-11
+    assert abs(out[1, 3] - ossim.structural_similarity(a[:max(7, shape[0] - 3)], b[:max(7, shape[0] - 3)])) < 1e-11
+
+
+def test_fft_lowpass_and_istft(golden):
+    x = golden["lp_x"]
+    for hc, fs in [(4000, 44100), (12000, 44100), (6000, 48000)]:
+        y = E.lowpass([x, x[:1500]], [olp.cut_bin(hc, fs)] * 2, pairs_per_chunk=3)
+        np.testing.assert_allclose(y[0], golden["lp_y_%d_%d" % (hc, fs)], atol=3e-8)
+        np.testing.assert_allclose(y[1], olp.stft_hard_lowpass(x[:1500], hc / int(fs / 2)), atol=3e-8)
+    np.testing.assert_allclose(E.lowpass([x], [1025])[0], x, atol=1e-7)       # cut beyond Nyquist: identity
+    assert np.abs(E.lowpass([x], [0])[0]).max() == 0.0                         # cut 0: silence
+    re, im = ostft.tl_stft(golden["fd_x"][None])
+    y = E.istft([re[0, 0]], [im[0, 0]], [4000])[0]
+    np.testing.assert_allclose(y, golden["fd_roundtrip"], atol=2e-8)
+
+
+@pytest.mark.parametrize("up,down", [(441, 160), (160, 147), (160, 441), (80, 147), (147, 80), (3, 1), (1, 2)])
+def test_resampler_bit_exact_vs_scipy(golden, up, down):
+    x = golden["rs_x16k"]
+    sig = [x, x[:777], x[:5]]
+    p = ors.poly_plan(len(x), up, down)
+    out = E.resample(sig, up, down, p["h_full"][:p["n_pre_pad"] + len(p["h"])], p["n_pre_remove"], outs_per_block=300)
+    for s, o in zip(sig, out):
+        np.testing.assert_array_equal(o, signal.resample_poly(s, up, down))

@@ -1,0 +1,253 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (ctypes -> libssrhip.so), against the
+CPU oracle on the same seeded inputs, against the reference-generated golden vectors, and - at
+BASELINE.json's full sizes - through size-independent properties.  Nothing here reads /root/reference.
+
+Tolerances (north_star): LSD / SISpec / log-SISpec / SSIM within 1e-5 relative; integer quantities and the
+polyphase resampler bit-exact; spectrogram samples within 2e-7 * max|X| (one float32 ulp at full scale).
+"""
+import numpy as np
+import pytest
+import torch
+from scipy import signal
+
+pytestmark = pytest.mark.gpu
+
+EV = ["noise48k", "noise44k", "noise16k", "speech48k_fftlp6k", "speech44k_fftlp4k_ragged", "speech24k_scaled"]
+KEYS = ("lsd", "log_sispec", "sispec", "ssim")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "-m gpu tests need an MI355X"
+    from ssr_eval_amd import _lib
+    _lib.load()
+
+
+def _vec(d):
+    return np.array([d[k] for k in KEYS])
+
+
+@pytest.mark.parametrize("name", EV)
+def test_evaluation_matches_reference_vectors(golden, name):
+    from ssr_eval_amd import AudioMetrics
+    am = AudioMetrics(int(golden["ev_%s_rate" % name]))
+    got = _vec(am.evaluation(golden["ev_%s_est" % name], golden["ev_%s_tgt" % name], ""))
+    want = golden["ev_%s_out" % name]
+    keep = [0, 1, 3] if name == "speech24k_scaled" else [0, 1, 2, 3]     # est = c*target: sispec is round-off defined
+    np.testing.assert_allclose(got[keep], want[keep], rtol=1e-5)
+    if name == "speech24k_scaled":
+        assert abs(got[0] - 2 * abs(np.log10(0.5))) < 1e-5 and got[2] > 100.0
+
+
+def test_bench_parameters_match_reference_vector(golden):
+    from ssr_eval_amd import AudioMetrics
+    am = AudioMetrics(48000, n_fft=2048, hop_length=512)
+    got = _vec(am.evaluation(golden["ev_bench2048_est"], golden["ev_bench2048_tgt"], ""))
+    np.testing.assert_allclose(got, golden["ev_bench2048_out"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (2229, 480), (1486, 320), (1114, 240), (743, 160), (2048, 441), (256, 64),
+                                       (4096, 1024), (100, 25)])
+def test_stft_magnitude_vs_oracle_ragged(n_fft, hop):
+    from ssr_eval_amd import backend as B
+    from oracle import stft as ostft
+    rng = np.random.default_rng(n_fft + hop)
+    lens = [n_fft * 3 + 77, n_fft // 2 + 1, n_fft + 5 * hop, 9001]
+    xs = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    mags = B.stft(B.get_plan(n_fft, hop, "f64"), xs)
+    for x, m in zip(xs, mags):
+        ref = ostft.stft_mag_TF(x, n_fft, hop)
+        assert tuple(m.shape) == ref.shape == (ostft.num_frames(len(x), n_fft, hop), n_fft // 2 + 1)
+        assert np.abs(m.cpu().numpy() - ref).max() <= 2e-7 * ref.max()
+    mags32 = B.stft(B.get_plan(n_fft, hop, "f32"), xs)
+    for x, m in zip(xs, mags32):
+        ref = ostft.stft_mag_TF(x, n_fft, hop)
+        assert np.abs(m.cpu().numpy() - ref).max() <= 3e-6 * ref.max()
+
+
+def test_wav_to_spectrogram_api(golden):
+    from ssr_eval_amd import AudioMetrics
+    am = AudioMetrics(44100)
+    t = golden["ev_noise44k_tgt"]
+    sp = am.wav_to_spectrogram(t)
+    ref = golden["ev_noise44k_tgt_sp"]
+    assert sp.dtype == torch.float32 and tuple(sp.shape) == (1, 1) + ref.shape and sp.device.type == "cpu"
+    assert np.abs(sp[0, 0].numpy() - ref).max() <= 2e-7 * ref.max()
+    assert am.wav_to_spectrogram(t, keep_on_device=True).is_cuda
+
+
+def test_tensor_reductions_match_reference_vectors(golden):
+    from ssr_eval_amd import AudioMetrics
+    am = AudioMetrics(44100)
+    for dev in ("cpu", "cuda"):
+        e, t = torch.tensor(golden["sp_est"], device=dev), torch.tensor(golden["sp_tgt"], device=dev)
+        lsd = am.lsd(e, t)
+        assert lsd.dtype == torch.float32 and tuple(lsd.shape) == (2, 1, 1, 1) and lsd.device.type == dev
+        np.testing.assert_allclose(lsd.cpu().numpy(), golden["sp_lsd"], rtol=1e-5)
+        np.testing.assert_allclose(float(am.sispec(e, t)), float(golden["sp_sispec"]), rtol=1e-5)
+        np.testing.assert_allclose(float(am.log_sispec(e, t)), golden["sp_log_sispec_each"].mean(), rtol=1e-5)
+        ss = am.ssim(e, t)
+        assert ss.dtype == torch.float64 and tuple(ss.shape) == (2, 1, 1, 1)
+        np.testing.assert_allclose(ss.cpu().numpy(), golden["sp_ssim"], rtol=1e-9)
+
+
+def test_batch_equals_single_and_is_ragged_safe():
+    from ssr_eval_amd import AudioMetrics
+    from oracle import metrics as om
+    rng = np.random.default_rng(3)
+    am = AudioMetrics(48000, n_fft=2048, hop_length=512)
+    lens = [30000, 5000, 4097, 12345, 30000]
+    tg = [(0.1 * rng.standard_normal(n)).astype(np.float32) for n in lens]
+    es = [(t + 0.02 * rng.standard_normal(len(t))).astype(np.float32) for t in tg]
+    batch = am.evaluation_batch(es, tg)
+    for e, t, b in zip(es, tg, batch):
+        np.testing.assert_allclose(_vec(am.evaluation(e, t, "")), _vec(b), rtol=1e-9)
+        np.testing.assert_allclose(_vec(b), _vec(om.evaluation(e, t, n_fft=2048, hop=512)), rtol=1e-5)
+
+
+def test_error_behaviour_matches_reference():
+    from ssr_eval_amd import AudioMetrics
+    am = AudioMetrics(48000)
+    x = np.zeros(5000, np.float32)
+    with pytest.raises(ValueError):
+        am.evaluation(x, "file.wav", "")
+    with pytest.raises(AssertionError):
+        am.evaluation(x, x[:4800], "")                       # |len diff| >= 100
+    with pytest.raises(AssertionError):
+        am.evaluation(x[:, None], x[:, None], "")
+    with pytest.raises(ValueError):
+        AudioMetrics(48000).evaluation(x[:1200], x[:1200], "")       # T = 3 < 7: skimage raises ValueError
+    with pytest.raises(ValueError):
+        am.wav_to_spectrogram(x[:1000])                      # reflect padding needs n > n_fft // 2
+
+
+def test_fft_lowpass_matches_reference_vectors(golden):
+    from ssr_eval_amd.lowpass import lowpass, stft_hard_lowpass_batch
+    from oracle import lowpass as olp
+    x = golden["lp_x"]
+    for hc, fs in [(4000, 44100), (12000, 44100), (6000, 48000)]:
+        y = lowpass(x, hc, fs, order=1, _type="stft_hard")
+        assert y.dtype == np.float32 and y.shape == x.shape
+        np.testing.assert_allclose(y, golden["lp_y_%d_%d" % (hc, fs)], atol=3e-8)
+    ys = stft_hard_lowpass_batch([x, x[:1500], x[:4321]], [0.2, 0.5, 0.9])
+    for xi, r, y in zip([x, x[:1500], x[:4321]], [0.2, 0.5, 0.9], ys):
+        np.testing.assert_allclose(y, olp.stft_hard_lowpass(xi, r), atol=3e-8)
+
+
+def test_fdomain_helper_api(golden):
+    from ssr_eval_amd import FDomainHelper
+    fh = FDomainHelper()
+    x = torch.tensor(golden["fd_x"])[None, None, :]
+    mag, cos, sin = fh.wav_to_spectrogram_phase(x)
+    assert tuple(mag.shape) == (1, 1) + golden["fd_mag"].shape and mag.device.type == "cpu"
+    np.testing.assert_allclose(mag[0, 0].numpy(), golden["fd_mag"], rtol=3e-6, atol=2e-7 * golden["fd_mag"].max())
+    np.testing.assert_allclose(cos[0, 0].numpy() * mag[0, 0].numpy(), golden["fd_cos"] * golden["fd_mag"], atol=1e-5)
+    y = fh.spectrogram_phase_to_wav(mag, cos, sin, 4000)
+    assert tuple(y.shape) == (1, 1, 4000)
+    np.testing.assert_allclose(y[0, 0].numpy(), golden["fd_roundtrip"], atol=1e-6)
+    cs = fh.wav_to_complex_spectrogram(x.cuda())
+    assert cs.is_cuda and tuple(cs.shape) == (1, 2) + golden["fd_mag"].shape
+    back = fh.complex_spectrogram_to_wav(cs, length=4000)
+    np.testing.assert_allclose(back[0, 0].cpu().numpy(), golden["fd_x"], atol=1e-6)
+    sp = fh.wav_to_spectrogram(x)
+    np.testing.assert_allclose(sp[0, 0].numpy(), golden["fd_mag"], rtol=3e-6, atol=2e-7 * golden["fd_mag"].max())
+
+
+@pytest.mark.parametrize("up,down", [(441, 160), (160, 147), (160, 441), (80, 147), (147, 80), (3, 1), (1, 2), (5, 5)])
+def test_resampler_bit_exact_vs_scipy(golden, up, down):
+    from ssr_eval_amd import backend as B
+    x = golden["rs_x16k"]
+    sig = [x, x[:777], x[:5], np.tile(x, 9)]
+    out = B.resample_poly(sig, up, down)
+    for s, o in zip(sig, out):
+        np.testing.assert_array_equal(o.cpu().numpy(), signal.resample_poly(s, up, down))
+
+
+def test_resample_and_subsampling_match_reference_vectors(golden):
+    from ssr_eval_amd import backend as B
+    from ssr_eval_amd.lowpass import lowpass
+    y1 = B.resample_poly([golden["rs_x16k"]], 44100, 16000)[0].cpu().numpy()
+    np.testing.assert_array_equal(y1, golden["rs_16k_to_44k"])
+    np.testing.assert_array_equal(B.resample_poly([y1], 48000, 44100)[0].cpu().numpy(), golden["rs_44k_to_48k"])
+    for hc in (2000, 4000, 12000):
+        y = lowpass(golden["ss_x"], hc, 44100, order=1, _type="subsampling")
+        np.testing.assert_array_equal(np.asarray(y, np.float32), golden["ss_y_%d" % hc])
+
+
+def test_helper_keys_and_end_to_end_arrays(golden, golden_manifest):
+    from ssr_eval_amd import SSR_Eval_Helper, BasicTestee
+    from oracle import lowpass as olp, metrics as om, resample as ors
+    h = SSR_Eval_Helper(BasicTestee(), input_sr=44100, output_sr=44100, evaluation_sr=48000, test_data_root=None,
+                        setting_fft={"cutoff_freq": [1000, 4000, 22050]})
+    d = h.lowpass_stft_hard("f.wav", golden["lp_x"], 44100)
+    assert list(d.keys()) == golden_manifest["fft_keys"]
+    for k, v in d.items():
+        np.testing.assert_allclose(v, golden["key_" + k], atol=3e-8)
+    # cfg-1 shape: identity testee, input 44.1k -> eval 48k, key proc_fft_24000_44100
+    h = SSR_Eval_Helper(BasicTestee(), input_sr=44100, output_sr=44100, evaluation_sr=48000, test_data_root=None,
+                        setting_fft={"cutoff_freq": [12000]})
+    rng = np.random.default_rng(11)
+    items = []
+    for n in (8820, 13230):
+        x44 = (0.1 * rng.standard_normal(n)).astype(np.float32)
+        items.append((ors.librosa_resample_polyphase(x44, 44100, 48000), x44))
+    res = h.evaluate_arrays(items)
+    for (tgt, x44), r in zip(items, res):
+        assert list(r.keys()) == ["proc_fft_24000_44100"]
+        est = ors.librosa_resample_polyphase(olp.lowpass(x44, 12000, 44100, 1, "stft_hard"), 44100, 48000)
+        want = om.evaluation(est, tgt, 48000)
+        np.testing.assert_allclose(_vec(r["proc_fft_24000_44100"]), _vec(want), rtol=1e-5)
+
+
+def test_basic_testee_postprocessing(golden):
+    from ssr_eval_amd import BasicTestee
+    bt = BasicTestee()
+    assert bt._get_cutoff_index(golden["bt_x"]) == int(golden["bt_cutoff_index"])      # integer: bit-exact
+    y = bt.postprocessing(golden["bt_x"], golden["bt_out"].copy())
+    np.testing.assert_allclose(y, golden["bt_post"], atol=2e-6)
+    assert bt.tensor2numpy(torch.ones(3, device="cuda")).sum() == 3
+
+
+# ---- BASELINE.json sizes: size-independent properties --------------------------------------------------
+def test_full_size_properties_cfg2():
+    """64 pairs of 4 s @ 48 kHz, n_fft 2048 / hop 512 (cfg-2 geometry: T = 376, F = 1025)."""
+    from ssr_eval_amd import backend as B
+    from oracle import metrics as om
+    g = torch.Generator(device="cuda").manual_seed(20220328)
+    N, n = 64, 192000
+    tgt = 0.1 * torch.randn((N, n), generator=g, device="cuda", dtype=torch.float32)
+    plan = B.get_plan(2048, 512, "f64")
+    assert plan.frames(n) == 376 and plan.n_bins == 1025
+    # (i) est = c * target -> LSD = 2 |log10 c| for every pair, SSIM(x, x) = 1
+    c = 0.25
+    out = B.PairBatch(plan, B.Ragged.from_uniform((c * tgt).contiguous()), B.Ragged.from_uniform(tgt)).run().cpu().numpy()
+    np.testing.assert_allclose(out[:, 0], 2 * abs(np.log10(c)), rtol=1e-5)
+    same = B.PairBatch(plan, B.Ragged.from_uniform(tgt), B.Ragged.from_uniform(tgt)).run(B.M_SSIM | B.M_LSD).cpu().numpy()
+    np.testing.assert_allclose(same[:, 3], 1.0, rtol=1e-12)
+    assert np.abs(same[:, 0]).max() < 1e-5
+    # (ii) SISpec is invariant to the scale of the target; spot-check two pairs against the oracle
+    est = (tgt + 0.01 * torch.randn((N, n), generator=g, device="cuda", dtype=torch.float32)).contiguous()
+    a = B.PairBatch(plan, B.Ragged.from_uniform(est), B.Ragged.from_uniform(tgt)).run().cpu().numpy()
+    b = B.PairBatch(plan, B.Ragged.from_uniform(est), B.Ragged.from_uniform((3.0 * tgt).contiguous())).run(B.M_SISPEC).cpu().numpy()
+    np.testing.assert_allclose(a[:, 2], b[:, 2], rtol=1e-6)
+    assert np.isnan(b[:, [0, 1, 3]]).all()
+    for i in (0, N - 1):
+        want = om.evaluation(est[i].cpu().numpy(), tgt[i].cpu().numpy(), n_fft=2048, hop=512)
+        np.testing.assert_allclose(a[i], _vec(want), rtol=1e-5)
+    # (iii) permutation of the batch permutes the results
+    perm = torch.randperm(N, device="cuda")
+    p = B.PairBatch(plan, B.Ragged.from_uniform(est[perm].contiguous()), B.Ragged.from_uniform(tgt[perm].contiguous())).run().cpu().numpy()
+    np.testing.assert_allclose(p, a[perm.cpu().numpy()], rtol=1e-12)
+
+
+def test_full_size_properties_resample_cfg5():
+    """16 k -> 44.1 k -> 48 k at 64,000-sample utterances: lengths bit-exact, linearity, oracle spot check."""
+    from ssr_eval_amd import backend as B
+    rng = np.random.default_rng(5)
+    x = [(0.1 * rng.standard_normal(64000)).astype(np.float32) for _ in range(8)]
+    y = B.resample_poly(B.resample_poly(x, 441, 160), 160, 147)
+    assert all(v.shape[0] == 192000 for v in y)
+    ref = signal.resample_poly(signal.resample_poly(x[3], 441, 160), 160, 147)
+    np.testing.assert_array_equal(y[3].cpu().numpy(), ref)
+    y2 = B.resample_poly([2.0 * x[0]], 441, 160)[0].cpu().numpy()
+    np.testing.assert_array_equal(y2, 2.0 * B.resample_poly([x[0]], 441, 160)[0].cpu().numpy())   # scaling by 2 is exact

@@ -262,10 +262,12 @@ def istft(plan, res, ims, lengths):
         out = torch.empty(int(lens.sum()), dtype=torch.float32, device=dev)
         ws_bytes = int(plan.lib.ssr_ola_workspace_bytes(plan.handle, rows.total))
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
-        _lib.check(plan.lib.ssr_istft(plan.handle, _vp(re), _vp(im), _vp(rows.off),
-                                      _vp(torch.from_numpy(lens.astype(np.int32)).to(dev)),
-                                      _vp(torch.from_numpy(out_off).to(dev)), len(lens), int(lens.max()), rows.total,
-                                      _vp(out), _vp(ws), ws_bytes, _stream()))
+        # descriptor tensors must stay referenced until the launch has been enqueued: a temporary would be
+        # returned to the caching allocator (and its block re-used by the next temporary) before the call
+        lens_d = torch.from_numpy(lens.astype(np.int32)).to(dev)
+        out_off_d = torch.from_numpy(out_off).to(dev)
+        _lib.check(plan.lib.ssr_istft(plan.handle, _vp(re), _vp(im), _vp(rows.off), _vp(lens_d), _vp(out_off_d), len(lens),
+                                      int(lens.max()), rows.total, _vp(out), _vp(ws), ws_bytes, _stream()))
         return [out[out_off[i]:out_off[i] + lens[i]] for i in range(len(lens))]
 
 
@@ -284,6 +286,9 @@ class ResamplePlan:
         self.up, self.down, self.half_len = u.value, d.value, hl.value
         self.n_pre_pad, self.n_pre_remove = pp.value, pr.value
         self.identity = self.up == 1 and self.down == 1
+        if self.identity:                      # scipy returns x.copy() before designing any filter
+            self.taps_host, self.taps = None, None
+            return
         h = firwin(2 * self.half_len + 1, 1.0 / max(self.up, self.down), window=("kaiser", 5.0)).astype(np.float32)
         h *= self.up
         self.taps_host = np.concatenate((np.zeros(self.n_pre_pad, np.float32), h))
@@ -314,8 +319,9 @@ def resample_poly(wavs, up, down, device=None):
         out_off = np.concatenate(([0], np.cumsum(out_len)[:-1])).astype(np.int64)
         out = torch.empty(int(out_len.sum()), dtype=torch.float32, device=dev)
         if r.n and out_len.max() > 0:
+            out_off_d = torch.from_numpy(out_off).to(dev)          # keep alive across the call (see istft)
+            out_len_d = torch.from_numpy(out_len.astype(np.int32)).to(dev)
             _lib.check(_lib.load().ssr_resample_poly(
-                _vp(r.data), _vp(r.off), _vp(r.len), _vp(torch.from_numpy(out_off).to(dev)),
-                _vp(torch.from_numpy(out_len.astype(np.int32)).to(dev)), r.n, int(out_len.max()), rp.up, rp.down,
-                _vp(rp.taps), int(rp.taps.numel()), rp.n_pre_remove, _vp(out), _stream()))
+                _vp(r.data), _vp(r.off), _vp(r.len), _vp(out_off_d), _vp(out_len_d), r.n, int(out_len.max()), rp.up,
+                rp.down, _vp(rp.taps), int(rp.taps.numel()), rp.n_pre_remove, _vp(out), _stream()))
         return [out[out_off[i]:out_off[i] + out_len[i]] for i in range(r.n)]

@@ -45,8 +45,17 @@ struct SsrBlk { int tid; };
     __VA_ARGS__;                                                   \
   }                                                                \
   __syncthreads();
-SSR_DEV float ssr_fmul_rn(float a, float b) { return __fmul_rn(a, b); }
-SSR_DEV float ssr_fadd_rn(float a, float b) { return __fadd_rn(a, b); }
+// Separately rounded multiply and add.  HIP's __fmul_rn/__fadd_rn are plain `*` / `+` and hipcc's default
+// -ffp-contract=fast would fuse them into one v_fma_f32; the pragma strips the `contract` flag from
+// these two instructions so they can never be fused (needed for bit-identity with SciPy's upfirdn).
+SSR_DEV float ssr_fmul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+SSR_DEV float ssr_fadd_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
 #endif
 
 // ------------------------------------------------------------------------------------------------

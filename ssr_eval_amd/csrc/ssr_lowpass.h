@@ -52,12 +52,15 @@ SSR_BODY void ssr_lowpass_frames_body(const SsrLowpassParams<T>& p, BLK& blk, in
     const bool b_valid = tb < n_frames;
     if (analysis) {
       SSR_PHASE(blk, regs, {
-        for (int r = 0; r < 8; ++r) {
+        float fa[8], fb[8];
+        T w[8];
+        for (int r = 0; r < 8; ++r) {       // all loads first (branch-free addresses), then the arithmetic
           const int m = ssr_fft_first_index<LOGN>(tid, r);
-          const T w = p.window[m];
-          R.v[r] = {ssr_frame_sample<T>(sig, n, ta, n_frames, m, N, hop) * w,
-                    ssr_frame_sample<T>(sig, n, tb, n_frames, m, N, hop) * w};
+          fa[r] = ssr_frame_sample_raw(sig, n, ta, n_frames, m, N, hop);
+          fb[r] = ssr_frame_sample_raw(sig, n, tb, n_frames, m, N, hop);
+          w[r] = p.window[m];
         }
+        for (int r = 0; r < 8; ++r) R.v[r] = {(T)fa[r] * w[r], b_valid ? (T)fb[r] * w[r] : (T)0};
         ssr_fft_compute<T, LOGN, 0>(tid, R.v, p.tw);
         ssr_fft_store<T, LOGN, 0>(tid, L.re, L.im, R.v);
       });

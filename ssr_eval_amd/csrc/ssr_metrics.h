@@ -40,19 +40,31 @@ struct SsrSsimLds {
   }
 };
 
+// Add row `row_add` to (and, if row_sub >= 0, remove row `row_sub` from) the thread's running column sums.
+// All global loads are issued first with clamped (always valid) column addresses, then consumed, so a row
+// step pays one memory latency instead of one per column.
 SSR_DEV void ssr_ssim_row_update(const SsrSsimParams& p, SsrSsimRegs& R, int tid, const float* x, const float* y,
-                                 int64_t row, int c_in0, int ncol_in, double sign) {
+                                 int64_t row_add, int64_t row_sub, int c_in0, int ncol_in) {
+  float xa[SSR_SSIM_MAXC], ya[SSR_SSIM_MAXC], xs[SSR_SSIM_MAXC], ys[SSR_SSIM_MAXC];
+  const bool sub = row_sub >= 0;
 #pragma unroll
   for (int i = 0; i < SSR_SSIM_MAXC; ++i) {
-    const int c = tid + SSR_SSIM_NT * i;
-    if (c < ncol_in) {
-      const double a = (double)x[row * p.F + c_in0 + c];
-      const double b = (double)y[row * p.F + c_in0 + c];
-      R.cs[i][0] += sign * a;
-      R.cs[i][1] += sign * b;
-      R.cs[i][2] += sign * (a * a);
-      R.cs[i][3] += sign * (b * b);
-      R.cs[i][4] += sign * (a * b);
+    int c = tid + SSR_SSIM_NT * i;
+    if (c >= ncol_in) c = ncol_in - 1;
+    xa[i] = x[row_add * p.F + c_in0 + c];
+    ya[i] = y[row_add * p.F + c_in0 + c];
+    xs[i] = sub ? x[row_sub * p.F + c_in0 + c] : 0.0f;
+    ys[i] = sub ? y[row_sub * p.F + c_in0 + c] : 0.0f;
+  }
+#pragma unroll
+  for (int i = 0; i < SSR_SSIM_MAXC; ++i) {
+    if (tid + SSR_SSIM_NT * i < ncol_in) {
+      const double a = (double)xa[i], b = (double)ya[i], c = (double)xs[i], d = (double)ys[i];
+      R.cs[i][0] += a - c;
+      R.cs[i][1] += b - d;
+      R.cs[i][2] += a * a - c * c;
+      R.cs[i][3] += b * b - d * d;
+      R.cs[i][4] += a * b - c * d;
     }
   }
 }
@@ -96,12 +108,11 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
     for (int i = 0; i < SSR_SSIM_MAXC; ++i)
       for (int q = 0; q < 5; ++q) R.cs[i][q] = 0.0;
     R.s = 0.0;
-    for (int rr = r0; rr < r0 + SSR_SSIM_WIN - 1; ++rr) ssr_ssim_row_update(p, R, tid, x, y, rr, c_in0, ncol_in, 1.0);
+    for (int rr = r0; rr < r0 + SSR_SSIM_WIN - 1; ++rr) ssr_ssim_row_update(p, R, tid, x, y, rr, -1, c_in0, ncol_in);
   });
   for (int r = r0; r < r1; ++r) {
     SSR_PHASE(blk, regs, {
-      ssr_ssim_row_update(p, R, tid, x, y, r + SSR_SSIM_WIN - 1, c_in0, ncol_in, 1.0);
-      if (r > r0) ssr_ssim_row_update(p, R, tid, x, y, r - 1, c_in0, ncol_in, -1.0);
+      ssr_ssim_row_update(p, R, tid, x, y, r + SSR_SSIM_WIN - 1, (r > r0) ? r - 1 : -1, c_in0, ncol_in);
       for (int i = 0; i < SSR_SSIM_MAXC; ++i) {
         const int c = tid + NT * i;
         if (c < ncol_in)

@@ -59,11 +59,11 @@ template <typename T> struct SsrStftRegs {
 
 SSR_DEV int ssr_num_frames_dev(int n, int n_fft, int hop) { return 1 + (n + 2 * (n_fft / 2) - n_fft) / hop; }
 
-// one windowed, reflect-padded sample of frame `t` (0 if the frame does not exist)
-template <typename T>
-SSR_DEV T ssr_frame_sample(const float* sig, int n, int t, int n_frames, int m, int n_fft, int hop) {
-  if (t >= n_frames) return (T)0;
-  return (T)sig[ssr_reflect(t * hop + m - n_fft / 2, n)];
+// one reflect-padded sample of frame `t`, branch-free: a frame that does not exist re-reads the last
+// one (always a valid address) and the caller selects 0 for it
+SSR_DEV float ssr_frame_sample_raw(const float* sig, int n, int t, int n_frames, int m, int n_fft, int hop) {
+  const int tc = (t < n_frames) ? t : n_frames - 1;
+  return sig[ssr_reflect(tc * hop + m - n_fft / 2, n)];
 }
 
 // ---- shared epilogue: one bin of the separated spectra ---------------------------------------------
@@ -174,24 +174,37 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
     const bool b_valid = tb < n_frames;
 
     // ---- phase 1: HBM -> registers (first-pass order), window, pass 0, store.
+    // All 24 loads of a thread (8 samples of each signal + 8 window values) are issued back to back with
+    // branch-free, always-valid addresses (a missing frame re-reads the last one and is scaled by 0), so
+    // the frame pays ONE memory latency instead of 24 dependent ones.
     // Also folds the previous frame's per-thread LSD partials 256 -> 16 (sc0 was written in the
     // previous epilogue; barriers since then make it visible).
+    const int ta_c = (ta < n_frames) ? ta : n_frames - 1;
+    const int tb_c = (tb < n_frames) ? tb : n_frames - 1;
+    const bool a_ok = ta < n_frames, b_ok = tb < n_frames;
     SSR_PHASE(blk, regs, {
+      float fa[8], fb[8];
       for (int r = 0; r < 8; ++r) {
-        const int m = ssr_fft_first_index<LOGN>(tid, r);
-        cx<T> z = {(T)0, (T)0};
-        if (m < n_fft) {
-          const T xa = ssr_frame_sample<T>(sa, n, ta, n_frames, m, n_fft, hop);
-          const T xb = ssr_frame_sample<T>(sb, n, tb, n_frames, m, n_fft, hop);
-          if constexpr (BLUESTEIN) {
-            const cx<T> wc = p.wchirp[m];
-            z = cmul(cx<T>{xa, xb}, wc);
-          } else {
-            const T w = p.window[m];
-            z = {xa * w, xb * w};
-          }
+        int m = ssr_fft_first_index<LOGN>(tid, r);
+        if (BLUESTEIN && m >= n_fft) m = n_fft - 1;
+        fa[r] = sa[ssr_reflect(ta_c * hop + m - n_fft / 2, n)];
+        fb[r] = sb[ssr_reflect(tb_c * hop + m - n_fft / 2, n)];
+      }
+      if constexpr (BLUESTEIN) {
+        cx<T> wc[8];
+        for (int r = 0; r < 8; ++r) {
+          const int m = ssr_fft_first_index<LOGN>(tid, r);
+          wc[r] = p.wchirp[(m < n_fft) ? m : n_fft - 1];
         }
-        R.v[r] = z;
+        for (int r = 0; r < 8; ++r) {
+          const int m = ssr_fft_first_index<LOGN>(tid, r);
+          const cx<T> z = cmul(cx<T>{a_ok ? (T)fa[r] : (T)0, b_ok ? (T)fb[r] : (T)0}, wc[r]);
+          R.v[r] = (m < n_fft) ? z : cx<T>{(T)0, (T)0};
+        }
+      } else {
+        T w[8];
+        for (int r = 0; r < 8; ++r) w[r] = p.window[ssr_fft_first_index<LOGN>(tid, r)];
+        for (int r = 0; r < 8; ++r) R.v[r] = {a_ok ? (T)fa[r] * w[r] : (T)0, b_ok ? (T)fb[r] * w[r] : (T)0};
       }
       ssr_fft_compute<T, LOGN, 0>(tid, R.v, p.tw);
       ssr_fft_store<T, LOGN, 0>(tid, L.re, L.im, R.v);

@@ -45,11 +45,12 @@ __global__ __launch_bounds__((1 << LOGN) / 8) void k_lowpass_frames(SsrLowpassPa
   ssr_lowpass_frames_body<T, LOGN>(p, blk, chunk, item, smem);
 }
 
+template <int CPT>
 __global__ __launch_bounds__(SSR_SSIM_NT) void k_ssim(SsrSsimParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SsrBlk blk{(int)threadIdx.x};
   const int tiles = p.n_row_tiles * p.n_strips;
-  ssr_ssim_body(p, blk, blockIdx.x % tiles, blockIdx.x / tiles, smem);
+  ssr_ssim_body<CPT>(p, blk, blockIdx.x % tiles, blockIdx.x / tiles, smem);
 }
 
 __global__ __launch_bounds__(256) void k_specred(SsrSpecRedParams p) {
@@ -246,7 +247,7 @@ static int units_per_chunk_for(int max_units, int n_items) {
   return (int)u;
 }
 
-struct SsimGeom { int rows_per_tile, n_row_tiles, n_strips; };
+struct SsimGeom { int rows_per_tile, n_row_tiles, n_strips, cpt; };
 static SsimGeom ssim_geom(int max_rows, int n_bins, int n_items) {
   SsimGeom g;
   const int out_rows = max_rows - 6 > 1 ? max_rows - 6 : 1;
@@ -255,7 +256,8 @@ static SsimGeom ssim_geom(int max_rows, int n_bins, int n_items) {
   if (r > out_rows) r = out_rows;
   g.rows_per_tile = (int)r;
   g.n_row_tiles = ceil_div(out_rows, g.rows_per_tile);
-  g.n_strips = n_bins > 6 ? ceil_div(n_bins - 6, SSR_SSIM_SW - 6) : 1;
+  g.cpt = ssr_ssim_pick_cpt(n_bins);
+  g.n_strips = n_bins > 6 ? ceil_div(n_bins - 6, ssr_ssim_strip_out(g.cpt)) : 1;
   return g;
 }
 
@@ -328,20 +330,33 @@ extern "C" size_t ssr_pair_metrics_workspace_bytes(const ssr_plan* pl, int n_ite
   return pair_ws(pl, n_items, max_len, total_rows).total + align256((size_t)n_items * sizeof(int32_t));
 }
 
-static int launch_ssim(const float* x, const float* y, const int64_t* frame_off, const int32_t* n_rows, int n_items,
-                       int F, const SsimGeom& g, double* part, hipStream_t s) {
-  SsrSsimParams p{x, y, frame_off, n_rows, F, g.rows_per_tile, g.n_row_tiles, g.n_strips, part};
-  const size_t lds = SsrSsimLds::bytes();
+template <int CPT> static int launch_ssim_inst(const SsrSsimParams& p, int grid, hipStream_t s) {
+  const size_t lds = SsrSsimLds<CPT>::bytes();
   static thread_local int attr_dev = -1;
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
-  if (attr_dev != dev) {
-    HIP_TRY(hipFuncSetAttribute((const void*)k_ssim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (lds > 48 * 1024 && attr_dev != dev) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_ssim<CPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_dev = dev;
   }
-  hipLaunchKernelGGL(k_ssim, dim3(n_items * g.n_row_tiles * g.n_strips), dim3(SSR_SSIM_NT), lds, s, p);
+  hipLaunchKernelGGL((k_ssim<CPT>), dim3(grid), dim3(SSR_SSIM_NT), lds, s, p);
   HIP_TRY(hipGetLastError());
   return SSR_OK;
+}
+
+static int launch_ssim(const float* x, const float* y, const int64_t* frame_off, const int32_t* n_rows, int n_items,
+                       int F, const SsimGeom& g, double* part, hipStream_t s) {
+  SsrSsimParams p{x, y, frame_off, n_rows, F, g.rows_per_tile, g.n_row_tiles, g.n_strips, part};
+  const int grid = n_items * g.n_row_tiles * g.n_strips;
+  switch (g.cpt) {
+    case 1: return launch_ssim_inst<1>(p, grid, s);
+    case 2: return launch_ssim_inst<2>(p, grid, s);
+    case 3: return launch_ssim_inst<3>(p, grid, s);
+    case 4: return launch_ssim_inst<4>(p, grid, s);
+    case 5: return launch_ssim_inst<5>(p, grid, s);
+    case 6: return launch_ssim_inst<6>(p, grid, s);
+  }
+  return fail(SSR_ERR_UNSUPPORTED, "bad SSIM geometry");
 }
 
 static int launch_finalize(const double* part, int n_chunks, const double* ssim_part, int n_tiles, const int32_t* n_rows,

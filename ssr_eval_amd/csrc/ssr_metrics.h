@@ -8,10 +8,27 @@
 #pragma once
 #include "ssr_stft.h"
 
-#define SSR_SSIM_NT 256
-#define SSR_SSIM_MAXC 5
-#define SSR_SSIM_SW (SSR_SSIM_NT * SSR_SSIM_MAXC)  // input columns per strip (1280 >= 1115 bins of n_fft 2229)
+#define SSR_SSIM_NT 64   // ONE wave per workgroup: the row loop's barriers cost nothing and waves run independently
+#define SSR_SSIM_MAXCPT 6  // contiguous output columns per thread (template parameter CPT = 1..6)
 #define SSR_SSIM_WIN 7
+
+// outputs per strip for a given CPT; a strip reads SSR_SSIM_NT*CPT + 6 input columns
+SSR_HD constexpr int ssr_ssim_strip_out(int cpt) { return SSR_SSIM_NT * cpt; }
+SSR_HD int ssr_ssim_pick_cpt(int n_bins) {
+  // contiguous outputs per thread: the candidate in {4, 5, 6} that wastes the fewest lanes in the last strip
+  const int outs = n_bins - (SSR_SSIM_WIN - 1);
+  if (outs <= SSR_SSIM_NT * 4) {
+    int c = (outs + SSR_SSIM_NT - 1) / SSR_SSIM_NT;
+    return c < 1 ? 1 : c;
+  }
+  int best = 4, best_waste = 1 << 30;
+  for (int c = 4; c <= SSR_SSIM_MAXCPT; ++c) {
+    const int w = SSR_SSIM_NT * c;
+    const int waste = ((outs + w - 1) / w) * w - outs;
+    if (waste < best_waste) { best_waste = waste; best = c; }
+  }
+  return best;
+}
 
 struct SsrSsimParams {
   const float* x;            // est spectrograms  [rows, F]
@@ -23,18 +40,20 @@ struct SsrSsimParams {
   double* part;              // [n_items, n_row_tiles * n_strips] sum of S over the tile
 };
 
-struct SsrSsimRegs {
-  double cs[SSR_SSIM_MAXC][5];  // running 7-row column sums of x, y, xx, yy, xy for the thread's columns
-  double s;                     // sum of S over the thread's outputs
+// Only four window sums are needed: S depends on vx and vy through vx + vy alone, so x^2 and y^2 are
+// accumulated together:  q0 = sum x, q1 = sum y, q2 = sum (x^2 + y^2), q3 = sum x*y.
+template <int CPT> struct SsrSsimRegs {
+  double cs[CPT + 1][4];  // running 7-row sums for the thread's (strided) input columns tid + NT*i
+  double s;               // sum of S over the thread's outputs
 };
 
-struct SsrSsimLds {
-  static constexpr int PW = SSR_SSIM_SW + 8;
-  static constexpr size_t bytes() { return sizeof(double) * (5 * PW + SSR_SSIM_NT + 16 + 8); }
+template <int CPT> struct SsrSsimLds {
+  static constexpr int PW = SSR_SSIM_NT * CPT + 8;
+  static constexpr size_t bytes() { return sizeof(double) * (4 * PW + SSR_SSIM_NT + 16 + 8); }
   double* col; double* sc0; double* sc1; double* res;
   SSR_MEMBER explicit SsrSsimLds(char* base) {
     col = reinterpret_cast<double*>(base);
-    sc0 = col + 5 * PW;
+    sc0 = col + 4 * PW;
     sc1 = sc0 + SSR_SSIM_NT;
     res = sc1 + 16;
   }
@@ -43,94 +62,124 @@ struct SsrSsimLds {
 // Add row `row_add` to (and, if row_sub >= 0, remove row `row_sub` from) the thread's running column sums.
 // All global loads are issued first with clamped (always valid) column addresses, then consumed, so a row
 // step pays one memory latency instead of one per column.
-SSR_DEV void ssr_ssim_row_update(const SsrSsimParams& p, SsrSsimRegs& R, int tid, const float* x, const float* y,
-                                 int64_t row_add, int64_t row_sub, int c_in0, int ncol_in) {
-  float xa[SSR_SSIM_MAXC], ya[SSR_SSIM_MAXC], xs[SSR_SSIM_MAXC], ys[SSR_SSIM_MAXC];
+template <int CPT>
+SSR_DEV void ssr_ssim_row_update(const SsrSsimParams& p, SsrSsimRegs<CPT>& R, int tid, const float* x, const float* y,
+                                 int row_add, int row_sub, int c_in0, int ncol_in) {
+  constexpr int VC = CPT + 1;
+  float xa[VC], ya[VC], xs[VC], ys[VC];
   const bool sub = row_sub >= 0;
+  // block-uniform row base pointers + 32-bit lane offsets (scalar-base addressing, no 64-bit VALU math)
+  const float* xra = x + (int64_t)row_add * p.F + c_in0;
+  const float* yra = y + (int64_t)row_add * p.F + c_in0;
+  const float* xrs = x + (int64_t)(sub ? row_sub : row_add) * p.F + c_in0;
+  const float* yrs = y + (int64_t)(sub ? row_sub : row_add) * p.F + c_in0;
 #pragma unroll
-  for (int i = 0; i < SSR_SSIM_MAXC; ++i) {
+  for (int i = 0; i < VC; ++i) {
     int c = tid + SSR_SSIM_NT * i;
     if (c >= ncol_in) c = ncol_in - 1;
-    xa[i] = x[row_add * p.F + c_in0 + c];
-    ya[i] = y[row_add * p.F + c_in0 + c];
-    xs[i] = sub ? x[row_sub * p.F + c_in0 + c] : 0.0f;
-    ys[i] = sub ? y[row_sub * p.F + c_in0 + c] : 0.0f;
+    xa[i] = xra[c];
+    ya[i] = yra[c];
+    xs[i] = xrs[c];
+    ys[i] = yrs[c];
   }
 #pragma unroll
-  for (int i = 0; i < SSR_SSIM_MAXC; ++i) {
+  for (int i = 0; i < VC; ++i) {
     if (tid + SSR_SSIM_NT * i < ncol_in) {
-      const double a = (double)xa[i], b = (double)ya[i], c = (double)xs[i], d = (double)ys[i];
+      const double a = (double)xa[i], b = (double)ya[i];
+      const double c = sub ? (double)xs[i] : 0.0, d = sub ? (double)ys[i] : 0.0;
       R.cs[i][0] += a - c;
       R.cs[i][1] += b - d;
-      R.cs[i][2] += a * a - c * c;
-      R.cs[i][3] += b * b - d * d;
-      R.cs[i][4] += a * b - c * d;
+      R.cs[i][2] += (a * a + b * b) - (c * c + d * d);
+      R.cs[i][3] += a * b - c * d;
     }
   }
 }
 
-SSR_DEV double ssr_ssim_value(double sx, double sy, double sxx, double syy, double sxy) {
-  const double C1 = (0.01 * 2.0) * (0.01 * 2.0), C2 = (0.03 * 2.0) * (0.03 * 2.0);
-  const double inv = 1.0 / 49.0, cov = 49.0 / 48.0;
-  const double ux = sx * inv, uy = sy * inv;
-  const double vx = cov * (sxx * inv - ux * ux);
-  const double vy = cov * (syy * inv - uy * uy);
-  const double vxy = cov * (sxy * inv - ux * uy);
-  const double a1 = 2.0 * ux * uy + C1, a2 = 2.0 * vxy + C2;
-  const double b1 = ux * ux + uy * uy + C1, b2 = vx + vy + C2;
-  return (a1 * a2) / (b1 * b2);
+// S for one window from the four RAW 49-pixel sums.  Every factor of the skimage expression is scaled by
+// n^2 = 49^2 (numerator and denominator alike), which removes the divisions by n:
+//   A1 = 2 ux uy + C1           -> 2 sx sy + C1 n^2
+//   A2 = 2 cov (uxy - ux uy) + C2 -> 2 cov (n sxy - sx sy) + C2 n^2
+//   B1 = ux^2 + uy^2 + C1       -> sx^2 + sy^2 + C1 n^2
+//   B2 = cov (uxx - ux^2 + uyy - uy^2) + C2 -> cov (n sq - (sx^2 + sy^2)) + C2 n^2
+SSR_DEV double ssr_ssim_value(double sx, double sy, double sq, double sxy) {
+  const double n = 49.0, cov = 49.0 / 48.0;
+  const double C1n = (0.01 * 2.0) * (0.01 * 2.0) * n * n, C2n = (0.03 * 2.0) * (0.03 * 2.0) * n * n;
+  const double pxy = sx * sy, pp = sx * sx + sy * sy;
+  const double a1 = 2.0 * pxy + C1n;
+  const double a2 = (2.0 * cov) * (n * sxy - pxy) + C2n;
+  const double b1 = pp + C1n;
+  const double b2 = cov * (n * sq - pp) + C2n;
+  // The two ratios are O(1) (|a1/b1| <= 1, |a2/b2| <= 1) and carry no cancellation any more, so they are
+  // formed in float32: one rounding of ~6e-8 per pixel, unbiased, against a 1e-5 bar on the MEAN of ~4e5
+  // pixels.  All moment arithmetic above (where the cancellation lives) stays in float64.
+  const float q1 = (float)a1 / (float)b1;
+  const float q2 = (float)a2 / (float)b2;
+  return (double)(q1 * q2);
 }
 
-// grid = (n_row_tiles * n_strips, n_items); block = SSR_SSIM_NT
-template <typename BLK>
+// grid = (n_row_tiles * n_strips, n_items); block = SSR_SSIM_NT.
+// Vertical pass: thread owns STRIDED input columns (coalesced loads, running 7-row sums in registers) and
+// publishes the four column sums through LDS.  Horizontal pass: thread owns CPT CONTIGUOUS outputs, reads
+// CPT+6 column sums per quantity once and slides the 7-wide window across them.
+template <int CPT, typename BLK>
 SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item, char* lds_base) {
-  constexpr int NT = SSR_SSIM_NT, PW = SsrSsimLds::PW;
-  SsrSsimLds L(lds_base);
+  constexpr int NT = SSR_SSIM_NT, PW = SsrSsimLds<CPT>::PW, VC = CPT + 1, W = SSR_SSIM_WIN;
+  using Regs = SsrSsimRegs<CPT>;
+  SsrSsimLds<CPT> L(lds_base);
   const int row_tile = tile / p.n_strips, strip = tile % p.n_strips;
   const int T = p.n_rows[item];
-  const int out_rows = T - (SSR_SSIM_WIN - 1);
+  const int out_rows = T - (W - 1);
   const int r0 = row_tile * p.rows_per_tile;
   const int r1 = (r0 + p.rows_per_tile < out_rows) ? r0 + p.rows_per_tile : out_rows;
-  const int c_in0 = strip * (SSR_SSIM_SW - (SSR_SSIM_WIN - 1));
-  const int ncol_in = (p.F - c_in0 < SSR_SSIM_SW) ? p.F - c_in0 : SSR_SSIM_SW;
-  const int ncol_out = ncol_in - (SSR_SSIM_WIN - 1);
+  const int c_in0 = strip * ssr_ssim_strip_out(CPT);
+  const int ncol_in = (p.F - c_in0 < NT * CPT + (W - 1)) ? p.F - c_in0 : NT * CPT + (W - 1);
+  const int ncol_out = ncol_in - (W - 1);
   double* part = p.part + (int64_t)item * p.n_row_tiles * p.n_strips + tile;
   const float* x = p.x + p.frame_off[item] * p.F;
   const float* y = p.y + p.frame_off[item] * p.F;
 
-  SSR_REGS(SsrSsimRegs, regs, blk);
+  SSR_REGS(Regs, regs, blk);
   if (r0 >= r1 || ncol_out <= 0) {
     SSR_PHASE(blk, regs, if (tid == 0) *part = 0.0);
     return;
   }
   // warm-up: rows r0 .. r0+5
   SSR_PHASE(blk, regs, {
-    for (int i = 0; i < SSR_SSIM_MAXC; ++i)
-      for (int q = 0; q < 5; ++q) R.cs[i][q] = 0.0;
+    for (int i = 0; i < VC; ++i)
+      for (int q = 0; q < 4; ++q) R.cs[i][q] = 0.0;
     R.s = 0.0;
-    for (int rr = r0; rr < r0 + SSR_SSIM_WIN - 1; ++rr) ssr_ssim_row_update(p, R, tid, x, y, rr, -1, c_in0, ncol_in);
+    for (int rr = r0; rr < r0 + W - 1; ++rr) ssr_ssim_row_update<CPT>(p, R, tid, x, y, rr, -1, c_in0, ncol_in);
   });
   for (int r = r0; r < r1; ++r) {
     SSR_PHASE(blk, regs, {
-      ssr_ssim_row_update(p, R, tid, x, y, r + SSR_SSIM_WIN - 1, (r > r0) ? r - 1 : -1, c_in0, ncol_in);
-      for (int i = 0; i < SSR_SSIM_MAXC; ++i) {
+      ssr_ssim_row_update<CPT>(p, R, tid, x, y, r + W - 1, (r > r0) ? r - 1 : -1, c_in0, ncol_in);
+      for (int i = 0; i < VC; ++i) {
         const int c = tid + NT * i;
         if (c < ncol_in)
-          for (int q = 0; q < 5; ++q) L.col[q * PW + c] = R.cs[i][q];
+          for (int q = 0; q < 4; ++q) L.col[q * PW + c] = R.cs[i][q];
       }
     });
     SSR_PHASE(blk, regs, {
-      for (int i = 0; i < SSR_SSIM_MAXC; ++i) {
-        const int j = tid + NT * i;
-        if (j < ncol_out) {
-          double h[5];
-          for (int q = 0; q < 5; ++q) {
-            double s = 0.0;
-            for (int d = 0; d < SSR_SSIM_WIN; ++d) s += L.col[q * PW + j + d];
-            h[q] = s;
+      const int j0 = tid * CPT;
+      if (j0 < ncol_out) {
+        double w[4][CPT];                            // window sums, one quantity at a time (register pressure)
+        for (int q = 0; q < 4; ++q) {
+          double v[CPT + W - 1];
+          for (int d = 0; d < CPT + W - 1; ++d) {
+            int c = j0 + d;
+            if (c >= ncol_in) c = ncol_in - 1;      // only feeds outputs that are masked below
+            v[d] = L.col[q * PW + c];
           }
-          R.s += ssr_ssim_value(h[0], h[1], h[2], h[3], h[4]);
+          double s = v[0];
+          for (int d = 1; d < W; ++d) s += v[d];
+          w[q][0] = s;
+          for (int i = 1; i < CPT; ++i) {
+            s += v[i + W - 1] - v[i - 1];
+            w[q][i] = s;
+          }
         }
+        for (int i = 0; i < CPT; ++i)
+          if (j0 + i < ncol_out) R.s += ssr_ssim_value(w[0][i], w[1][i], w[2][i], w[3][i]);
       }
     });
   }

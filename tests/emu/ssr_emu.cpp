@@ -59,16 +59,35 @@ extern "C" int emu_stft(int precision, int n_fft, int hop, int mode, int out_kin
                            units_per_chunk, n_chunks, out_a, out_b, part);
 }
 
-extern "C" int emu_ssim(const float* x, const float* y, const int64_t* frame_off, const int32_t* n_rows, int n_items,
-                        int F, int rows_per_tile, int n_row_tiles, int n_strips, double* part) {
-  SsrSsimParams p{x, y, frame_off, n_rows, F, rows_per_tile, n_row_tiles, n_strips, part};
+template <int CPT>
+static void run_ssim(const SsrSsimParams& p, int n_items) {
   SsrBlk blk{SSR_SSIM_NT};
   for (int item = 0; item < n_items; ++item)
-    for (int t = 0; t < n_row_tiles * n_strips; ++t) {
-      auto lds = poisoned(SsrSsimLds::bytes());
-      ssr_ssim_body(p, blk, t, item, lds.data());
+    for (int t = 0; t < p.n_row_tiles * p.n_strips; ++t) {
+      auto lds = poisoned(SsrSsimLds<CPT>::bytes());
+      ssr_ssim_body<CPT>(p, blk, t, item, lds.data());
     }
+}
+
+// returns the number of strips it used through *n_strips_out when part == nullptr (geometry query)
+extern "C" int emu_ssim_geom(int F, int* cpt, int* n_strips) {
+  *cpt = ssr_ssim_pick_cpt(F);
+  *n_strips = F > 6 ? (F - 6 + ssr_ssim_strip_out(*cpt) - 1) / ssr_ssim_strip_out(*cpt) : 1;
   return 0;
+}
+
+extern "C" int emu_ssim(const float* x, const float* y, const int64_t* frame_off, const int32_t* n_rows, int n_items,
+                        int F, int rows_per_tile, int n_row_tiles, int n_strips, int cpt, double* part) {
+  SsrSsimParams p{x, y, frame_off, n_rows, F, rows_per_tile, n_row_tiles, n_strips, part};
+  switch (cpt) {
+    case 1: run_ssim<1>(p, n_items); return 0;
+    case 2: run_ssim<2>(p, n_items); return 0;
+    case 3: run_ssim<3>(p, n_items); return 0;
+    case 4: run_ssim<4>(p, n_items); return 0;
+    case 5: run_ssim<5>(p, n_items); return 0;
+    case 6: run_ssim<6>(p, n_items); return 0;
+  }
+  return -1;
 }
 
 extern "C" int emu_specred(const float* x, const float* y, const int64_t* frame_off, const int32_t* n_rows,

@@ -76,15 +76,20 @@ def spectro_desc(sps):
     return np.ascontiguousarray(np.concatenate(sps).astype(np.float32)), frame_off, T
 
 
-def ssim_parts(xs, ys, rows_per_tile=16):
+def ssim_parts(xs, ys, rows_per_tile=16, cpt=None):
     x, frame_off, T = spectro_desc(xs)
     y, _, _ = spectro_desc(ys)
     F = xs[0].shape[1]
     n_row_tiles = int(-(-(T.max() - 6) // rows_per_tile))
-    n_strips = int(-(-(F - 6) // (1280 - 6)))
+    c, ns = C.c_int(), C.c_int()
+    lib().emu_ssim_geom(F, C.byref(c), C.byref(ns))
+    if cpt is None:
+        cpt, n_strips = c.value, ns.value
+    else:                                            # force a smaller CPT to exercise the multi-strip path
+        n_strips = int(-(-(F - 6) // (64 * cpt)))
     part = np.full((len(xs), n_row_tiles * n_strips), np.nan)
     rc = lib().emu_ssim(_p(x, C.c_float), _p(y, C.c_float), _p(frame_off, C.c_int64), _p(T, C.c_int32), len(xs), F,
-                        rows_per_tile, n_row_tiles, n_strips, _p(part, C.c_double))
+                        rows_per_tile, n_row_tiles, n_strips, cpt, _p(part, C.c_double))
     assert rc == 0
     return part, T
 

@@ -66,18 +66,19 @@ def test_spectrogram_reductions_match_reference_vectors(golden):
     np.testing.assert_allclose(out[:, 0], golden["sp_lsd"][:, 0, 0, 0], rtol=1e-6)
     np.testing.assert_allclose(out[:, 2], golden["sp_sispec_each"], rtol=1e-6)
     np.testing.assert_allclose(out[:, 1], golden["sp_log_sispec_each"], rtol=1e-6)
-    np.testing.assert_allclose(out[:, 3], golden["sp_ssim"][:, 0, 0, 0], rtol=1e-10)
+    np.testing.assert_allclose(out[:, 3], golden["sp_ssim"][:, 0, 0, 0], rtol=2e-7)   # float32 final ratio per pixel
 
 
-@pytest.mark.parametrize("shape", [(7, 7), (8, 1300), (40, 1286), (23, 70)])
-def test_ssim_tiles_and_strips(shape):
+@pytest.mark.parametrize("shape,cpt", [((7, 7), None), ((8, 1300), None), ((40, 1286), None), ((23, 70), None), ((12, 1600), None),
+                                       ((9, 1025), 1), ((9, 600), 2), ((10, 1115), 3)])
+def test_ssim_tiles_and_strips(shape, cpt):
     rng = np.random.default_rng(shape[1])
     a = np.abs(rng.standard_normal(shape)).astype(np.float32) * 50
     b = (a * (1 + 0.2 * rng.standard_normal(shape))).astype(np.float32)
-    sp, T = E.ssim_parts([a, a[:max(7, shape[0] - 3)]], [b, b[:max(7, shape[0] - 3)]], rows_per_tile=4)
+    sp, T = E.ssim_parts([a, a[:max(7, shape[0] - 3)]], [b, b[:max(7, shape[0] - 3)]], rows_per_tile=4, cpt=cpt)
     out = E.finalize(None, sp, T, shape[1], 8)
-    assert abs(out[0, 3] - ossim.structural_similarity(a, b)) < 1e-11
-    assert abs(out[1, 3] - ossim.structural_similarity(a[:max(7, shape[0] - 3)], b[:max(7, shape[0] - 3)])) < 1e-11
+    assert abs(out[0, 3] - ossim.structural_similarity(a, b)) < 2e-7
+    assert abs(out[1, 3] - ossim.structural_similarity(a[:max(7, shape[0] - 3)], b[:max(7, shape[0] - 3)])) < 2e-7
 
 
 def test_fft_lowpass_and_istft(golden):

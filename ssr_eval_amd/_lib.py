@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libssrhip.so")
+LIB_PATH = os.environ.get("SSR_HIP_LIB") or os.path.join(_HERE, "libssrhip.so")   # env override: developer A/B builds
 
 SSR_F32, SSR_F64 = 0, 1
 M_LSD, M_LOG_SISPEC, M_SISPEC, M_SSIM, M_ALL = 1, 2, 4, 8, 15

@@ -29,10 +29,21 @@ struct SsrBlk { int nt; };
     auto& R = (regs)[tid]; (void)R;                                \
     __VA_ARGS__;                                                   \
   }
+// inside a phase: dst[tid / 64] = sum of `val` over the lanes of that wave (host: tids run in ascending order)
+#define SSR_WAVE_SUM_STORE(tid, NT_, val, dst)              \
+  do {                                                      \
+    if (((tid) & 63) == 0) (dst)[(tid) >> 6] = 0.0;         \
+    (dst)[(tid) >> 6] += (val);                             \
+  } while (0)
 static inline float ssr_fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 static inline float ssr_fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 #else
 #include <hip/hip_runtime.h>
+#if defined(SSR_ABL_NOBAR)   /* developer ablation: WRONG results, timing only */
+#define SSR_BARRIER() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
+#else
+#define SSR_BARRIER() __syncthreads()
+#endif
 #define SSR_DEV __device__ __forceinline__
 #define SSR_BODY __device__ __forceinline__
 #define SSR_MEMBER __device__ __forceinline__
@@ -44,7 +55,18 @@ struct SsrBlk { int tid; };
     const int tid = (blk).tid; auto& R = (regs); (void)R; (void)tid; \
     __VA_ARGS__;                                                   \
   }                                                                \
-  __syncthreads();
+  SSR_BARRIER();
+// wave-level sum through cross-lane shuffles (no LDS round trip, no barrier); W = active lanes (<= 64)
+template <int W> SSR_DEV double ssr_wave_sum(double v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, W);
+  return v;
+}
+#define SSR_WAVE_SUM_STORE(tid, NT_, val, dst)                                     \
+  do {                                                                             \
+    const double s_ = ssr_wave_sum<((NT_) < 64 ? (NT_) : 64)>(val);                \
+    if (((tid) & 63) == 0) (dst)[(tid) >> 6] = s_;                                 \
+  } while (0)
 // Separately rounded multiply and add.  HIP's __fmul_rn/__fadd_rn are plain `*` / `+` and hipcc's default
 // -ffp-contract=fast would fuse them into one v_fma_f32; the pragma strips the `contract` flag from
 // these two instructions so they can never be fused (needed for bit-identity with SciPy's upfirdn).
@@ -66,10 +88,16 @@ template <typename T> SSR_DEV cx<T> csub(cx<T> a, cx<T> b) { return {a.x - b.x, 
 template <typename T> SSR_DEV cx<T> cmul(cx<T> a, cx<T> b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 template <typename T> SSR_DEV cx<T> cmul_negi(cx<T> a) { return {a.y, -a.x}; }   // a * (-i)
 
-// LDS index padding: one extra element per 16 keeps the strided stores of the early Stockham
-// passes off a single bank group ("LDS layout").
-SSR_DEV int ssr_pad(int i) { return i + (i >> 4); }
-SSR_HD constexpr int ssr_padded_len(int n) { return n + (n >> 4) + 1; }
+// LDS index padding for the FFT arrays: one spare element per 2^SSR_PAD_SHIFT.  An ADDITIVE pad keeps
+// pad(j + q*stride) = pad(j) + q*stride' for the power-of-two strides of the passes, so the compiler folds
+// the eight per-register offsets into the ds_read/ds_write immediate field (one address VALU op per
+// pass).  An XOR swizzle with fewer modelled bank conflicts was measured 28 % SLOWER on MI355X because it
+// needs per-access address arithmetic on a VALU-bound kernel (profiles/r01_notes.md).
+#ifndef SSR_PAD_SHIFT
+#define SSR_PAD_SHIFT 4
+#endif
+SSR_DEV int ssr_pad(int i) { return i + (i >> SSR_PAD_SHIFT); }
+SSR_HD constexpr int ssr_padded_len(int n) { return n + (n >> SSR_PAD_SHIFT) + 1; }
 
 // centred-STFT reflect padding of sample index s into [0, n)  (requires n > n_fft/2)
 SSR_DEV int ssr_reflect(int s, int n) {

@@ -105,9 +105,24 @@ SSR_DEV void ssr_fft_compute(int tid, cx<T>* v, const cx<T>* __restrict__ tw) {
       const int j = tid + b * P::NT;
       const int k = j & (NS - 1);
       const int base = k * (P::N / (NS * R));
-      const cx<T> w1 = tw[base], w2 = tw[2 * base], w4 = tw[4 * base];
+#if defined(SSR_TW_DIRECT)
+      const unsigned ub = (unsigned)base;      // 7 table loads, no arithmetic (q * base < N always)
+      const cx<T> w1 = tw[ub], w2 = tw[2 * ub], w3 = tw[3 * ub], w4 = tw[4 * ub];
+      const cx<T> w5 = tw[5 * ub], w6 = tw[6 * ub], w7 = tw[7 * ub];
+#else
+#if defined(SSR_SIGNED_IDX)
+      const int ub = base;
+#else
+      const unsigned ub = (unsigned)base;
+#endif
+#if defined(SSR_ABL_NOTW)      /* developer ablation: WRONG results, timing only */
+      const cx<T> w1 = {(T)(ub + 1), (T)0.5}, w2 = {(T)0.25, (T)(ub + 2)}, w4 = {(T)0.125, (T)0.75};
+#else
+      const cx<T> w1 = tw[ub], w2 = tw[2 * ub], w4 = tw[4 * ub];
+#endif
       const cx<T> w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4);
       const cx<T> w7 = cmul(w3, w4);
+#endif
       cx<T>* x = v + b * R;
       x[1] = cmul(x[1], w1);
       x[2] = cmul(x[2], w2);

@@ -29,12 +29,15 @@ extern "C" int ssr_version(void) { return SSR_VERSION; }
 
 // ----------------------------------------------------------------------------------------------------
 // kernels
-template <typename T, int LOGN, bool BLU>
-__global__ __launch_bounds__((1 << LOGN) / 8) void k_stft(SsrStftParams<T> p) {
+#ifndef SSR_STFT_WAVES_PER_EU
+#define SSR_STFT_WAVES_PER_EU 1
+#endif
+template <typename T, int LOGN, bool BLU, int MODE>
+__global__ __launch_bounds__((1 << LOGN) / 8, SSR_STFT_WAVES_PER_EU) void k_stft(SsrStftParams<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SsrBlk blk{(int)threadIdx.x};
   const int item = blockIdx.x / p.n_chunks, chunk = blockIdx.x % p.n_chunks;
-  ssr_stft_body<T, LOGN, BLU>(p, blk, chunk, item, smem);
+  ssr_stft_body<T, LOGN, BLU, MODE>(p, blk, chunk, item, smem);
 }
 
 template <typename T, int LOGN>
@@ -93,6 +96,7 @@ __global__ __launch_bounds__(256) void k_magphase(const float* re, const float* 
 // plan
 template <typename T> struct DevTables {
   T* window = nullptr;
+  T* window_h = nullptr;
   cx<T>*tw = nullptr, *wchirp = nullptr, *bfilt = nullptr, *chirp = nullptr;
 };
 
@@ -119,6 +123,7 @@ template <typename T> static int build_dev_tables(ssr_plan* pl, DevTables<T>& d)
   if (!ssr_build_tables<T>(pl->n_fft, t)) return fail(SSR_ERR_UNSUPPORTED, "unsupported n_fft");
   int rc;
   if ((rc = upload(pl, t.window, &d.window))) return rc;
+  if ((rc = upload(pl, t.window_h, &d.window_h))) return rc;
   if ((rc = upload(pl, t.tw, &d.tw))) return rc;
   if ((rc = upload(pl, t.wchirp, &d.wchirp))) return rc;
   if ((rc = upload(pl, t.bfilt, &d.bfilt))) return rc;
@@ -133,23 +138,28 @@ template <> const DevTables<double>& tables_of<double>(const ssr_plan* pl) { ret
 // kernel registry: (precision, logn, bluestein) -> launcher
 typedef int (*stft_launcher)(const ssr_plan*, void* params, int grid, hipStream_t);
 
-template <typename T, int LOGN, bool BLU> static int launch_stft_inst(SsrStftParams<T>& p, int grid, hipStream_t s) {
+template <typename T, int LOGN, bool BLU, int MODE>
+static int launch_stft_mode(SsrStftParams<T>& p, int grid, hipStream_t s) {
   const size_t lds = SsrStftLds<T, LOGN>::bytes();
   static thread_local int attr_dev = -1;
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (lds > 48 * 1024 && attr_dev != dev) {
-    HIP_TRY(hipFuncSetAttribute((const void*)k_stft<T, LOGN, BLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_stft<T, LOGN, BLU, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_dev = dev;
   }
-  hipLaunchKernelGGL((k_stft<T, LOGN, BLU>), dim3(grid), dim3((1 << LOGN) / 8), lds, s, p);
+  hipLaunchKernelGGL((k_stft<T, LOGN, BLU, MODE>), dim3(grid), dim3((1 << LOGN) / 8), lds, s, p);
   HIP_TRY(hipGetLastError());
   return SSR_OK;
+}
+template <typename T, int LOGN, bool BLU> static int launch_stft_inst(SsrStftParams<T>& p, int grid, hipStream_t s) {
+  return p.mode == SSR_MODE_PAIR ? launch_stft_mode<T, LOGN, BLU, SSR_MODE_PAIR>(p, grid, s)
+                                 : launch_stft_mode<T, LOGN, BLU, SSR_MODE_SINGLE>(p, grid, s);
 }
 
 template <typename T> static int launch_stft_t(const ssr_plan* pl, SsrStftParams<T>& p, int grid, hipStream_t s) {
   const DevTables<T>& d = tables_of<T>(pl);
-  p.window = d.window; p.tw = d.tw; p.wchirp = d.wchirp; p.bfilt = d.bfilt; p.chirp = d.chirp;
+  p.window = d.window_h; p.tw = d.tw; p.wchirp = d.wchirp; p.bfilt = d.bfilt; p.chirp = d.chirp;
 #define CASE(L)                                                                   \
   case L:                                                                         \
     return pl->eng.bluestein ? launch_stft_inst<T, L, true>(p, grid, s) : launch_stft_inst<T, L, false>(p, grid, s);

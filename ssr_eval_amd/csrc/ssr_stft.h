@@ -18,6 +18,11 @@
 //               (2229 = 3*743 for AudioMetrics(48000), 743 / 1114 / 1486 for 16/24/32 kHz).
 #pragma once
 #include "ssr_fft.h"
+#if defined(SSR_SIGNED_IDX)
+#define SSR_UIDX(x) (x)
+#else
+#define SSR_UIDX(x) ((unsigned)(x))
+#endif
 
 enum { SSR_MODE_PAIR = 0, SSR_MODE_SINGLE = 1 };
 enum { SSR_OUT_NONE = 0, SSR_OUT_MAG = 1, SSR_OUT_COMPLEX = 2 };
@@ -40,12 +45,12 @@ template <typename T> struct SsrStftParams {
   int n_fft, hop, n_bins;
   int units_per_chunk;       // frames (PAIR) or frame pairs (SINGLE) per workgroup
   int n_chunks;              // gridDim.x
-  const T* window;           // [n_fft] periodic Hann (direct engine)
+  const T* window;           // [n_fft] 0.5 * periodic Hann (direct engine; the 1/2 belongs to the separation)
   const cx<T>* tw;           // [N or M] twiddles
   // bluestein tables (null for the direct engine)
   const cx<T>* wchirp;       // [n_fft]  window[m] * exp(-i*pi*m^2/n_fft)
   const cx<T>* bfilt;        // [M]      FFT_M(exp(+i*pi*m^2/n_fft) wrapped) / M
-  const cx<T>* chirp;        // [n_fft]  exp(-i*pi*k^2/n_fft)
+  const cx<T>* chirp;        // [n_fft]  0.5 * exp(-i*pi*k^2/n_fft)
   float* out_a;              // PAIR: est magnitudes [frames, F]; SINGLE: mag or re
   float* out_b;              // PAIR: target magnitudes;          SINGLE: im (COMPLEX) or unused
   double* part;              // [n_items, n_chunks, SSR_NPART] or null
@@ -69,13 +74,25 @@ SSR_DEV float ssr_frame_sample_raw(const float* sig, int n, int t, int n_frames,
 // ---- shared epilogue: one bin of the separated spectra ---------------------------------------------
 template <typename T> struct SsrBinOut { float ar, ai, br, bi; };
 
+// zk, zn already carry the factor 1/2 (folded into the window / chirp tables; exact in binary FP)
 template <typename T> SSR_DEV SsrBinOut<T> ssr_separate(cx<T> zk, cx<T> zn) {
   SsrBinOut<T> o;
-  o.ar = (float)((zk.x + zn.x) * (T)0.5);
-  o.ai = (float)((zk.y - zn.y) * (T)0.5);
-  o.br = (float)((zk.y + zn.y) * (T)0.5);
-  o.bi = (float)((zn.x - zk.x) * (T)0.5);
+  o.ar = (float)(zk.x + zn.x);
+  o.ai = (float)(zk.y - zn.y);
+  o.br = (float)(zk.y + zn.y);
+  o.bi = (float)(zn.x - zk.x);
   return o;
+}
+
+// |re + i im| for float32 parts.  numpy.abs(complex64) is hypotf; for the magnitudes an STFT produces the
+// plain sqrtf(re^2 + im^2) agrees with it to <= 1 ulp and costs a fraction of the scaled algorithm, so the
+// scaled path is kept only for operands whose squares would leave the float32 normal range.
+SSR_DEV float ssr_cabsf(float re, float im) {
+#if defined(SSR_FAST_MAG)
+  return sqrtf(re * re + im * im);
+#else
+  return hypotf(re, im);
+#endif
 }
 
 // LSD term and SISpec sums for one (est, target) magnitude pair, float32 elementwise arithmetic in
@@ -101,30 +118,55 @@ SSR_DEV void ssr_accumulate_metrics(float e, float t, int mask, double* acc) {
   }
 }
 
-// Emit bin k of the current unit.  zk = Z[k], zn = Z[(n-k) mod n].
-template <typename T>
-SSR_DEV void ssr_emit_bin(const SsrStftParams<T>& p, SsrStftRegs<T>& R, int k, cx<T> zk, cx<T> zn,
-                          int64_t row_a, int64_t row_b, bool b_valid) {
+// Emit bin k of the current unit.  zk = Z[k], zn = Z[(n-k) mod n].  out_a_row / out_b_row: block-uniform
+// row base pointers (scalar base + 32-bit lane offset addressing).
+template <typename T, int MODE>
+SSR_DEV void ssr_emit_bin(const SsrStftParams<T>& p, SsrStftRegs<T>& R, unsigned k, cx<T> zk, cx<T> zn,
+                          float* row_a0, float* row_a1, float* row_b0, float* row_b1, bool b_valid) {
+  // PAIR  : row_a0 = est magnitudes row,  row_b0 = target magnitudes row
+  // SINGLE: row_a0 / row_a1 = rows of frames 2g / 2g+1 in out_a; row_b0 / row_b1 the same rows in out_b
   const SsrBinOut<T> o = ssr_separate<T>(zk, zn);
-  if (p.mode == SSR_MODE_PAIR) {
-    const float e = hypotf(o.ar, o.ai), t = hypotf(o.br, o.bi);
+  if constexpr (MODE == SSR_MODE_PAIR) {
+    const float e = ssr_cabsf(o.ar, o.ai), t = ssr_cabsf(o.br, o.bi);
     if (p.out_kind == SSR_OUT_MAG) {
-      p.out_a[row_a * p.n_bins + k] = e;
-      p.out_b[row_b * p.n_bins + k] = t;
+      row_a0[k] = e;
+      row_b0[k] = t;
     }
     ssr_accumulate_metrics(e, t, p.metric_mask, R.acc);
   } else {
     if (p.out_kind == SSR_OUT_MAG) {
-      p.out_a[row_a * p.n_bins + k] = hypotf(o.ar, o.ai);
-      if (b_valid) p.out_a[row_b * p.n_bins + k] = hypotf(o.br, o.bi);
+      row_a0[k] = ssr_cabsf(o.ar, o.ai);
+      if (b_valid) row_a1[k] = ssr_cabsf(o.br, o.bi);
     } else if (p.out_kind == SSR_OUT_COMPLEX) {
-      p.out_a[row_a * p.n_bins + k] = o.ar;
-      p.out_b[row_a * p.n_bins + k] = o.ai;
+      row_a0[k] = o.ar;
+      row_b0[k] = o.ai;
       if (b_valid) {
-        p.out_a[row_b * p.n_bins + k] = o.br;
-        p.out_b[row_b * p.n_bins + k] = o.bi;
+        row_a1[k] = o.br;
+        row_b1[k] = o.bi;
       }
     }
+  }
+}
+
+// Direct engine epilogue: F = N/2 + 1 = 4 * NT + 1 -> four full, unrolled rounds (all LDS reads in flight
+// together) + the Nyquist bin on thread 0.
+template <typename T, int LOGN, int MODE>
+SSR_DEV void ssr_epilogue_direct(const SsrStftParams<T>& p, SsrStftRegs<T>& R, int tid, const T* re, const T* im,
+                                 float* ra0, float* ra1, float* rb0, float* rb1, bool b_ok) {
+  constexpr int N = 1 << LOGN, NT = N / 8;
+  cx<T> zk[4], zn[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = tid + i * NT, kn = (N - k) & (N - 1);
+    zk[i] = {re[ssr_pad(k)], im[ssr_pad(k)]};
+    zn[i] = {re[ssr_pad(kn)], im[ssr_pad(kn)]};
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    ssr_emit_bin<T, MODE>(p, R, (unsigned)(tid + i * NT), zk[i], zn[i], ra0, ra1, rb0, rb1, b_ok);
+  if (tid == 0) {
+    const cx<T> zq = {re[ssr_pad(N / 2)], im[ssr_pad(N / 2)]};
+    ssr_emit_bin<T, MODE>(p, R, (unsigned)(N / 2), zq, zq, ra0, ra1, rb0, rb1, b_ok);
   }
 }
 
@@ -146,55 +188,66 @@ template <typename T, int LOGN> struct SsrStftLds {
 // ---------------------------------------------------------------------------------------------------
 // The body.  LOGN: FFT length of the engine (n_fft for direct, M for bluestein).
 // grid = (n_chunks, n_items); block = 2^LOGN / 8 threads.
-template <typename T, int LOGN, bool BLUESTEIN, typename BLK>
+template <typename T, int LOGN, bool BLUESTEIN, int MODE, typename BLK>
 SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
   using P = SsrFftPlan<LOGN>;
-  constexpr int N = P::N, NT = P::NT, LAST = P::NPASS - 1;
+  constexpr int N = P::N, NT = P::NT, LAST = P::NPASS - 1, NW = (NT + 63) / 64;
   using Regs = SsrStftRegs<T>;
   SsrStftLds<T, LOGN> L(lds_base);
 
   const int n = p.len[item];
-  const int n_fft = p.n_fft, hop = p.hop, F = p.n_bins;
+  const int n_fft = BLUESTEIN ? p.n_fft : N, hop = p.hop, F = n_fft / 2 + 1;
   const int n_frames = ssr_num_frames_dev(n, n_fft, hop);
-  const int n_units = (p.mode == SSR_MODE_PAIR) ? n_frames : (n_frames + 1) / 2;
+  const int n_units = (MODE == SSR_MODE_PAIR) ? n_frames : (n_frames + 1) / 2;
   const int u0 = chunk * p.units_per_chunk;
   const int u1 = (u0 + p.units_per_chunk < n_units) ? u0 + p.units_per_chunk : n_units;
   const float* sa = p.a + p.a_off[item];
-  const float* sb = (p.mode == SSR_MODE_PAIR) ? p.b + p.b_off[item] : sa;
+  const float* sb = (MODE == SSR_MODE_PAIR) ? p.b + p.b_off[item] : sa;
   const int64_t row0 = p.frame_off[item];
   double* part = p.part ? p.part + ((int64_t)item * p.n_chunks + chunk) * SSR_NPART : nullptr;
-  const bool want_lsd = (p.mode == SSR_MODE_PAIR) && (p.metric_mask & SSR_M_LSD);
+  const bool want_lsd = (MODE == SSR_MODE_PAIR) && (p.metric_mask & SSR_M_LSD);
+  const int pad = n_fft / 2;
 
   SSR_REGS(Regs, regs, blk);
   SSR_PHASE(blk, regs, for (int q = 0; q < 7; ++q) R.acc[q] = 0.0; R.lsd_sum = 0.0);
 
   for (int u = u0; u < u1; ++u) {
-    const int ta = (p.mode == SSR_MODE_PAIR) ? u : 2 * u;
-    const int tb = (p.mode == SSR_MODE_PAIR) ? u : 2 * u + 1;
-    const bool b_valid = tb < n_frames;
+    const int ta = (MODE == SSR_MODE_PAIR) ? u : 2 * u;
+    const int tb = (MODE == SSR_MODE_PAIR) ? u : 2 * u + 1;
+    const bool a_ok = ta < n_frames, b_ok = tb < n_frames;       // a missing frame re-reads the last one, scaled by 0
+    const int ta_c = a_ok ? ta : n_frames - 1, tb_c = b_ok ? tb : n_frames - 1;
+    const int base_a = ta_c * hop - pad, base_b = tb_c * hop - pad;
+    // block-uniform: both frames lie fully inside the signal -> no reflection arithmetic at all
+    const bool interior = base_a >= 0 && base_b >= 0 && base_a + n_fft <= n && base_b + n_fft <= n;
 
     // ---- phase 1: HBM -> registers (first-pass order), window, pass 0, store.
     // All 24 loads of a thread (8 samples of each signal + 8 window values) are issued back to back with
-    // branch-free, always-valid addresses (a missing frame re-reads the last one and is scaled by 0), so
-    // the frame pays ONE memory latency instead of 24 dependent ones.
-    // Also folds the previous frame's per-thread LSD partials 256 -> 16 (sc0 was written in the
-    // previous epilogue; barriers since then make it visible).
-    const int ta_c = (ta < n_frames) ? ta : n_frames - 1;
-    const int tb_c = (tb < n_frames) ? tb : n_frames - 1;
-    const bool a_ok = ta < n_frames, b_ok = tb < n_frames;
+    // branch-free, always-valid addresses, so the frame pays ONE memory latency instead of 24 dependent
+    // ones.  Thread 0 also closes the PREVIOUS frame's LSD (per-wave sums left in sc1 by its epilogue).
     SSR_PHASE(blk, regs, {
       float fa[8], fb[8];
-      for (int r = 0; r < 8; ++r) {
-        int m = ssr_fft_first_index<LOGN>(tid, r);
-        if (BLUESTEIN && m >= n_fft) m = n_fft - 1;
-        fa[r] = sa[ssr_reflect(ta_c * hop + m - n_fft / 2, n)];
-        fb[r] = sb[ssr_reflect(tb_c * hop + m - n_fft / 2, n)];
+      if (interior) {
+        const float* qa = sa + base_a;
+        const float* qb = sb + base_b;
+        for (int r = 0; r < 8; ++r) {
+          int m = ssr_fft_first_index<LOGN>(tid, r);
+          if (BLUESTEIN && m >= n_fft) m = n_fft - 1;
+          fa[r] = qa[SSR_UIDX(m)];
+          fb[r] = qb[SSR_UIDX(m)];
+        }
+      } else {
+        for (int r = 0; r < 8; ++r) {
+          int m = ssr_fft_first_index<LOGN>(tid, r);
+          if (BLUESTEIN && m >= n_fft) m = n_fft - 1;
+          fa[r] = sa[SSR_UIDX(ssr_reflect(base_a + m, n))];
+          fb[r] = sb[SSR_UIDX(ssr_reflect(base_b + m, n))];
+        }
       }
       if constexpr (BLUESTEIN) {
         cx<T> wc[8];
         for (int r = 0; r < 8; ++r) {
           const int m = ssr_fft_first_index<LOGN>(tid, r);
-          wc[r] = p.wchirp[(m < n_fft) ? m : n_fft - 1];
+          wc[r] = p.wchirp[SSR_UIDX((m < n_fft) ? m : n_fft - 1)];
         }
         for (int r = 0; r < 8; ++r) {
           const int m = ssr_fft_first_index<LOGN>(tid, r);
@@ -203,15 +256,15 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
         }
       } else {
         T w[8];
-        for (int r = 0; r < 8; ++r) w[r] = p.window[ssr_fft_first_index<LOGN>(tid, r)];
+        for (int r = 0; r < 8; ++r) w[r] = p.window[SSR_UIDX(ssr_fft_first_index<LOGN>(tid, r))];
         for (int r = 0; r < 8; ++r) R.v[r] = {a_ok ? (T)fa[r] * w[r] : (T)0, b_ok ? (T)fb[r] * w[r] : (T)0};
       }
       ssr_fft_compute<T, LOGN, 0>(tid, R.v, p.tw);
       ssr_fft_store<T, LOGN, 0>(tid, L.re, L.im, R.v);
-      if (want_lsd && u > u0 && tid < 16) {
+      if (want_lsd && u > u0 && tid == 0) {
         double s = 0.0;
-        for (int i = tid; i < NT; i += 16) s += L.sc0[i];
-        L.sc1[tid] = s;
+        for (int w = 0; w < NW; ++w) s += L.sc1[w];
+        R.lsd_sum += sqrt(s / (double)F);
       }
     });
     // remaining forward passes; last pass stays in registers
@@ -223,7 +276,7 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
       SSR_PHASE(blk, regs, {
         for (int r = 0; r < 8; ++r) {
           const int k = ssr_fft_out_index<LOGN, LAST>(tid, r);
-          const cx<T> y = cmul(R.v[r], p.bfilt[k]);
+          const cx<T> y = cmul(R.v[r], p.bfilt[SSR_UIDX(k)]);
           L.re[ssr_pad(k)] = y.x;
           L.im[ssr_pad(k)] = y.y;
         }
@@ -237,7 +290,7 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
         for (int r = 0; r < 8; ++r) {
           const int k = ssr_fft_out_index<LOGN, LAST>(tid, r);
           if (k < n_fft) {
-            const cx<T> zk = cmul(cx<T>{R.v[r].y, R.v[r].x}, p.chirp[k]);
+            const cx<T> zk = cmul(cx<T>{R.v[r].y, R.v[r].x}, p.chirp[SSR_UIDX(k)]);
             L.re[ssr_pad(k)] = zk.x;
             L.im[ssr_pad(k)] = zk.y;
           }
@@ -247,36 +300,41 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
       SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, LAST>(tid, L.re, L.im, R.v));
     }
 
-    // ---- epilogue: separate the two spectra, emit, accumulate.
-    // Thread 0 also finishes the PREVIOUS frame's LSD (sc1 was written in phase 1 of this frame).
+    // ---- epilogue: separate the two spectra, emit, accumulate; leave per-wave LSD sums in sc1.
+    float* ra0 = p.out_a ? p.out_a + (row0 + ta) * F : nullptr;   // block-uniform row pointers
+    float* ra1 = p.out_a ? p.out_a + (row0 + tb) * F : nullptr;
+    float* rb0 = p.out_b ? p.out_b + (row0 + ta) * F : nullptr;
+    float* rb1 = p.out_b ? p.out_b + (row0 + tb) * F : nullptr;
+    if (MODE == SSR_MODE_PAIR) { ra1 = ra0; rb1 = rb0; }
     SSR_PHASE(blk, regs, {
-      if (want_lsd && u > u0 && tid == 0) {
-        double s = 0.0;
-        for (int i = 0; i < 16; ++i) s += L.sc1[i];
-        R.lsd_sum += sqrt(s / (double)F);
-      }
       R.acc[0] = 0.0;
-      for (int k = tid; k < F; k += NT) {
-        const int kn = (k == 0) ? 0 : n_fft - k;
-        const cx<T> zk = {L.re[ssr_pad(k)], L.im[ssr_pad(k)]};
-        const cx<T> zn = {L.re[ssr_pad(kn)], L.im[ssr_pad(kn)]};
-        ssr_emit_bin<T>(p, R, k, zk, zn, row0 + ta, row0 + tb, b_valid);
+#if defined(SSR_ABL_NOEPI)     /* developer ablation: WRONG results, timing only */
+      if (tid == 0) {
+        const cx<T> z0 = {L.re[0], L.im[0]};
+        ssr_emit_bin<T, MODE>(p, R, 0u, z0, z0, ra0, ra1, rb0, rb1, b_ok);
       }
-      if (want_lsd) L.sc0[tid] = R.acc[0];
+#else
+      if constexpr (!BLUESTEIN) {
+        ssr_epilogue_direct<T, LOGN, MODE>(p, R, tid, L.re, L.im, ra0, ra1, rb0, rb1, b_ok);
+      } else {
+        for (int k = tid; k < F; k += NT) {
+          const int kn = (k == 0) ? 0 : n_fft - k;
+          const cx<T> zk = {L.re[ssr_pad(k)], L.im[ssr_pad(k)]};
+          const cx<T> zn = {L.re[ssr_pad(kn)], L.im[ssr_pad(kn)]};
+          ssr_emit_bin<T, MODE>(p, R, (unsigned)k, zk, zn, ra0, ra1, rb0, rb1, b_ok);
+        }
+      }
+#endif
+      if (want_lsd) SSR_WAVE_SUM_STORE(tid, NT, R.acc[0], L.sc1);
     });
   }
 
   if (part == nullptr) return;
   // ---- chunk tail: last frame's LSD, then block-sum the SISpec accumulators.
   if (want_lsd && u1 > u0) {
-    SSR_PHASE(blk, regs, if (tid < 16) {
-      double s = 0.0;
-      for (int i = tid; i < NT; i += 16) s += L.sc0[i];
-      L.sc1[tid] = s;
-    });
     SSR_PHASE(blk, regs, if (tid == 0) {
       double s = 0.0;
-      for (int i = 0; i < 16; ++i) s += L.sc1[i];
+      for (int w = 0; w < NW; ++w) s += L.sc1[w];
       R.lsd_sum += sqrt(s / (double)F);
     });
   }

@@ -30,8 +30,9 @@ inline SsrEngine ssr_pick_engine(int n_fft) {
 template <typename T> struct SsrTables {
   SsrEngine eng;
   int n_fft;
-  std::vector<T> window;                        // [n_fft]
-  std::vector<cx<T>> tw, wchirp, bfilt, chirp;  // [N] | [n_fft] | [N] | [n_fft]
+  std::vector<T> window;                        // [n_fft]  periodic Hann (inverse STFT / OLA)
+  std::vector<T> window_h;                      // [n_fft]  0.5 * Hann: the 1/2 of the two-for-one separation, pre-applied (exact)
+  std::vector<cx<T>> tw, wchirp, bfilt, chirp;  // [N] | [n_fft] | [N] | [n_fft] (chirp also carries the 1/2)
 };
 
 inline void ssr_host_fft_ld(std::vector<long double>& re, std::vector<long double>& im) {
@@ -67,6 +68,8 @@ template <typename T> bool ssr_build_tables(int n_fft, SsrTables<T>& t) {
     w[m] = 0.5L - 0.5L * cosl(2.0L * SSR_PI_L * m / n_fft);  // periodic Hann (fftbins=True)
     t.window[m] = (T)w[m];
   }
+  t.window_h.resize(n_fft);
+  for (int m = 0; m < n_fft; ++m) t.window_h[m] = (T)0.5 * t.window[m];
   t.tw.resize(N);
   for (int i = 0; i < N; ++i) {
     const long double ang = -2.0L * SSR_PI_L * i / N;
@@ -81,7 +84,7 @@ template <typename T> bool ssr_build_tables(int n_fft, SsrTables<T>& t) {
     }
     t.chirp.resize(n_fft); t.wchirp.resize(n_fft);
     for (int k = 0; k < n_fft; ++k) {
-      t.chirp[k] = {(T)cr[k], (T)ci[k]};
+      t.chirp[k] = {(T)0.5 * (T)cr[k], (T)0.5 * (T)ci[k]};
       t.wchirp[k] = {(T)(w[k] * cr[k]), (T)(w[k] * ci[k])};
     }
     std::vector<long double> br(N, 0.0L), bi(N, 0.0L);

@@ -20,7 +20,8 @@ static void run_stft(SsrStftParams<T> p, int n_items) {
   for (int item = 0; item < n_items; ++item)
     for (int c = 0; c < p.n_chunks; ++c) {
       auto lds = poisoned(SsrStftLds<T, LOGN>::bytes());
-      ssr_stft_body<T, LOGN, BLU>(p, blk, c, item, lds.data());
+      if (p.mode == SSR_MODE_PAIR) ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR>(p, blk, c, item, lds.data());
+      else ssr_stft_body<T, LOGN, BLU, SSR_MODE_SINGLE>(p, blk, c, item, lds.data());
     }
 }
 
@@ -35,7 +36,7 @@ static int emu_stft_t(int n_fft, int hop, int mode, int out_kind, int mask, cons
   p.mode = mode; p.out_kind = out_kind; p.metric_mask = mask;
   p.n_fft = n_fft; p.hop = hop; p.n_bins = n_fft / 2 + 1;
   p.units_per_chunk = units_per_chunk; p.n_chunks = n_chunks;
-  p.window = t.window.data(); p.tw = t.tw.data();
+  p.window = t.window_h.data(); p.tw = t.tw.data();
   p.wchirp = t.wchirp.data(); p.bfilt = t.bfilt.data(); p.chirp = t.chirp.data();
   p.out_a = out_a; p.out_b = out_b; p.part = part;
 #define CASE(L)                                                         \

@@ -35,14 +35,25 @@ struct SsrBlk { int nt; };
     if (((tid) & 63) == 0) (dst)[(tid) >> 6] = 0.0;         \
     (dst)[(tid) >> 6] += (val);                             \
   } while (0)
+#define SSR_WAVE_SUM_ADD(tid, NT_, val, dst) do { (dst)[(tid) >> 6] += (val); } while (0)
 static inline float ssr_fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 static inline float ssr_fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 #else
 #include <hip/hip_runtime.h>
 #if defined(SSR_ABL_NOBAR)   /* developer ablation: WRONG results, timing only */
 #define SSR_BARRIER() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
-#else
+#elif defined(SSR_FULL_BARRIER)
 #define SSR_BARRIER() __syncthreads()
+#else
+// Workgroup barrier that orders LDS traffic only.  All cross-thread hand-offs inside a kernel body go
+// through LDS; __syncthreads() would additionally drain every outstanding GLOBAL access (s_waitcnt
+// vmcnt(0)), i.e. expose the full HBM store/load latency at every phase boundary.
+#define SSR_BARRIER()                                                   \
+  do {                                                                  \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");     \
+    __builtin_amdgcn_s_barrier();                                       \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");     \
+  } while (0)
 #endif
 #define SSR_DEV __device__ __forceinline__
 #define SSR_BODY __device__ __forceinline__
@@ -66,6 +77,11 @@ template <int W> SSR_DEV double ssr_wave_sum(double v) {
   do {                                                                             \
     const double s_ = ssr_wave_sum<((NT_) < 64 ? (NT_) : 64)>(val);                \
     if (((tid) & 63) == 0) (dst)[(tid) >> 6] = s_;                                 \
+  } while (0)
+#define SSR_WAVE_SUM_ADD(tid, NT_, val, dst)                                       \
+  do {                                                                             \
+    const double s_ = ssr_wave_sum<((NT_) < 64 ? (NT_) : 64)>(val);                \
+    if (((tid) & 63) == 0) (dst)[(tid) >> 6] += s_;                                \
   } while (0)
 // Separately rounded multiply and add.  HIP's __fmul_rn/__fadd_rn are plain `*` / `+` and hipcc's default
 // -ffp-contract=fast would fuse them into one v_fma_f32; the pragma strips the `contract` flag from

@@ -107,8 +107,8 @@ SSR_DEV void ssr_fft_compute(int tid, cx<T>* v, const cx<T>* __restrict__ tw) {
       const int base = k * (P::N / (NS * R));
 #if defined(SSR_TW_DIRECT)
       const unsigned ub = (unsigned)base;      // 7 table loads, no arithmetic (q * base < N always)
-      const cx<T> w1 = tw[ub], w2 = tw[2 * ub], w3 = tw[3 * ub], w4 = tw[4 * ub];
-      const cx<T> w5 = tw[5 * ub], w6 = tw[6 * ub], w7 = tw[7 * ub];
+      cx<T>* x = v + b * R;
+      for (int q = 1; q < 8; ++q) x[q] = cmul(x[q], tw[(unsigned)q * ub]);
 #else
 #if defined(SSR_SIGNED_IDX)
       const int ub = base;
@@ -120,17 +120,17 @@ SSR_DEV void ssr_fft_compute(int tid, cx<T>* v, const cx<T>* __restrict__ tw) {
 #else
       const cx<T> w1 = tw[ub], w2 = tw[2 * ub], w4 = tw[4 * ub];
 #endif
-      const cx<T> w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4);
-      const cx<T> w7 = cmul(w3, w4);
-#endif
+      // twiddle powers are formed just before use to keep few of them live (register pressure)
       cx<T>* x = v + b * R;
       x[1] = cmul(x[1], w1);
       x[2] = cmul(x[2], w2);
-      x[3] = cmul(x[3], w3);
       x[4] = cmul(x[4], w4);
-      x[5] = cmul(x[5], w5);
-      x[6] = cmul(x[6], w6);
-      x[7] = cmul(x[7], w7);
+      const cx<T> w3 = cmul(w1, w2);
+      x[3] = cmul(x[3], w3);
+      x[5] = cmul(x[5], cmul(w1, w4));
+      x[6] = cmul(x[6], cmul(w2, w4));
+      x[7] = cmul(x[7], cmul(w3, w4));
+#endif
     }
     ssr_bfly<R>(v + b * R);
   }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -32,12 +33,12 @@ extern "C" int ssr_version(void) { return SSR_VERSION; }
 #ifndef SSR_STFT_WAVES_PER_EU
 #define SSR_STFT_WAVES_PER_EU 1
 #endif
-template <typename T, int LOGN, bool BLU, int MODE>
+template <typename T, int LOGN, bool BLU, int MODE, bool SUMS>
 __global__ __launch_bounds__((1 << LOGN) / 8, SSR_STFT_WAVES_PER_EU) void k_stft(SsrStftParams<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SsrBlk blk{(int)threadIdx.x};
   const int item = blockIdx.x / p.n_chunks, chunk = blockIdx.x % p.n_chunks;
-  ssr_stft_body<T, LOGN, BLU, MODE>(p, blk, chunk, item, smem);
+  ssr_stft_body<T, LOGN, BLU, MODE, SUMS>(p, blk, chunk, item, smem);
 }
 
 template <typename T, int LOGN>
@@ -48,8 +49,11 @@ __global__ __launch_bounds__((1 << LOGN) / 8) void k_lowpass_frames(SsrLowpassPa
   ssr_lowpass_frames_body<T, LOGN>(p, blk, chunk, item, smem);
 }
 
+#ifndef SSR_SSIM_WAVES_PER_EU
+#define SSR_SSIM_WAVES_PER_EU 1
+#endif
 template <int CPT>
-__global__ __launch_bounds__(SSR_SSIM_NT) void k_ssim(SsrSsimParams p) {
+__global__ __launch_bounds__(SSR_SSIM_NT, SSR_SSIM_WAVES_PER_EU) void k_ssim(SsrSsimParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SsrBlk blk{(int)threadIdx.x};
   const int tiles = p.n_row_tiles * p.n_strips;
@@ -138,23 +142,26 @@ template <> const DevTables<double>& tables_of<double>(const ssr_plan* pl) { ret
 // kernel registry: (precision, logn, bluestein) -> launcher
 typedef int (*stft_launcher)(const ssr_plan*, void* params, int grid, hipStream_t);
 
-template <typename T, int LOGN, bool BLU, int MODE>
+template <typename T, int LOGN, bool BLU, int MODE, bool SUMS>
 static int launch_stft_mode(SsrStftParams<T>& p, int grid, hipStream_t s) {
-  const size_t lds = SsrStftLds<T, LOGN>::bytes();
+  // SSR_LDS_PAD (bytes, developer knob): over-allocate LDS to cap workgroups per CU in occupancy experiments
+  static const size_t lds_pad = getenv("SSR_LDS_PAD") ? (size_t)atol(getenv("SSR_LDS_PAD")) : 0;
+  const size_t lds = SsrStftLds<T, LOGN>::bytes() + lds_pad;
   static thread_local int attr_dev = -1;
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (lds > 48 * 1024 && attr_dev != dev) {
-    HIP_TRY(hipFuncSetAttribute((const void*)k_stft<T, LOGN, BLU, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_stft<T, LOGN, BLU, MODE, SUMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_dev = dev;
   }
-  hipLaunchKernelGGL((k_stft<T, LOGN, BLU, MODE>), dim3(grid), dim3((1 << LOGN) / 8), lds, s, p);
+  hipLaunchKernelGGL((k_stft<T, LOGN, BLU, MODE, SUMS>), dim3(grid), dim3((1 << LOGN) / 8), lds, s, p);
   HIP_TRY(hipGetLastError());
   return SSR_OK;
 }
 template <typename T, int LOGN, bool BLU> static int launch_stft_inst(SsrStftParams<T>& p, int grid, hipStream_t s) {
-  return p.mode == SSR_MODE_PAIR ? launch_stft_mode<T, LOGN, BLU, SSR_MODE_PAIR>(p, grid, s)
-                                 : launch_stft_mode<T, LOGN, BLU, SSR_MODE_SINGLE>(p, grid, s);
+  if (p.mode != SSR_MODE_PAIR) return launch_stft_mode<T, LOGN, BLU, SSR_MODE_SINGLE, false>(p, grid, s);
+  return (p.metric_mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC)) ? launch_stft_mode<T, LOGN, BLU, SSR_MODE_PAIR, true>(p, grid, s)
+                                                             : launch_stft_mode<T, LOGN, BLU, SSR_MODE_PAIR, false>(p, grid, s);
 }
 
 template <typename T> static int launch_stft_t(const ssr_plan* pl, SsrStftParams<T>& p, int grid, hipStream_t s) {

@@ -33,7 +33,7 @@ template <typename T, int LOGN, typename BLK>
 SSR_BODY void ssr_lowpass_frames_body(const SsrLowpassParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
   using P = SsrFftPlan<LOGN>;
   constexpr int N = P::N, LAST = P::NPASS - 1, F = N / 2 + 1;
-  using Regs = SsrStftRegs<T>;
+  using Regs = SsrStftRegs<T, false>;
   SsrStftLds<T, LOGN> L(lds_base);
   const int n = p.len[item], hop = p.hop;
   const int n_frames = ssr_num_frames_dev(n, N, hop);

@@ -56,10 +56,9 @@ template <typename T> struct SsrStftParams {
   double* part;              // [n_items, n_chunks, SSR_NPART] or null
 };
 
-template <typename T> struct SsrStftRegs {
-  cx<T> v[8];
-  double acc[7];   // [0]: per-frame LSD partial (reset every frame); [1..6]: SISpec sums (whole chunk)
-  double lsd_sum;  // thread 0 only: sum over frames of the per-frame LSD
+template <typename T, bool SUMS = false> struct SsrStftRegs {
+  cx<T> v[8];                // FFT points
+  double sums[SUMS ? 6 : 1]; // SISpec / log-SISpec running sums (kernel variants that do not need them carry none)
 };
 
 SSR_DEV int ssr_num_frames_dev(int n, int n_fft, int hop) { return 1 + (n + 2 * (n_fft / 2) - n_fft) / hop; }
@@ -101,8 +100,16 @@ SSR_DEV void ssr_accumulate_metrics(float e, float t, int mask, double* acc) {
   const float EPSF = 1e-12f;
   if (mask & SSR_M_LSD) {
     const float ee = e + EPSF;
+#if defined(SSR_FAST_LSD) && !defined(SSR_HOST_EMU)
+    const float r = __fdividef(t * t, ee * ee) + EPSF;
+    const float d = __log10f(r);
+#elif defined(SSR_FAST_DIV) && !defined(SSR_HOST_EMU)
+    const float r = __fdividef(t * t, ee * ee) + EPSF;
+    const float d = log10f(r);
+#else
     const float r = (t * t) / (ee * ee) + EPSF;
     const float d = log10f(r);
+#endif
     acc[0] += (double)(d * d);
   }
   if (mask & SSR_M_SISPEC) {
@@ -121,7 +128,7 @@ SSR_DEV void ssr_accumulate_metrics(float e, float t, int mask, double* acc) {
 // Emit bin k of the current unit.  zk = Z[k], zn = Z[(n-k) mod n].  out_a_row / out_b_row: block-uniform
 // row base pointers (scalar base + 32-bit lane offset addressing).
 template <typename T, int MODE>
-SSR_DEV void ssr_emit_bin(const SsrStftParams<T>& p, SsrStftRegs<T>& R, unsigned k, cx<T> zk, cx<T> zn,
+SSR_DEV void ssr_emit_bin(const SsrStftParams<T>& p, double* acc, unsigned k, cx<T> zk, cx<T> zn,
                           float* row_a0, float* row_a1, float* row_b0, float* row_b1, bool b_valid) {
   // PAIR  : row_a0 = est magnitudes row,  row_b0 = target magnitudes row
   // SINGLE: row_a0 / row_a1 = rows of frames 2g / 2g+1 in out_a; row_b0 / row_b1 the same rows in out_b
@@ -132,7 +139,7 @@ SSR_DEV void ssr_emit_bin(const SsrStftParams<T>& p, SsrStftRegs<T>& R, unsigned
       row_a0[k] = e;
       row_b0[k] = t;
     }
-    ssr_accumulate_metrics(e, t, p.metric_mask, R.acc);
+    ssr_accumulate_metrics(e, t, p.metric_mask, acc);
   } else {
     if (p.out_kind == SSR_OUT_MAG) {
       row_a0[k] = ssr_cabsf(o.ar, o.ai);
@@ -151,7 +158,7 @@ SSR_DEV void ssr_emit_bin(const SsrStftParams<T>& p, SsrStftRegs<T>& R, unsigned
 // Direct engine epilogue: F = N/2 + 1 = 4 * NT + 1 -> four full, unrolled rounds (all LDS reads in flight
 // together) + the Nyquist bin on thread 0.
 template <typename T, int LOGN, int MODE>
-SSR_DEV void ssr_epilogue_direct(const SsrStftParams<T>& p, SsrStftRegs<T>& R, int tid, const T* re, const T* im,
+SSR_DEV void ssr_epilogue_direct(const SsrStftParams<T>& p, double* acc, int tid, const T* re, const T* im,
                                  float* ra0, float* ra1, float* rb0, float* rb1, bool b_ok) {
   constexpr int N = 1 << LOGN, NT = N / 8;
   cx<T> zk[4], zn[4];
@@ -163,10 +170,10 @@ SSR_DEV void ssr_epilogue_direct(const SsrStftParams<T>& p, SsrStftRegs<T>& R, i
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    ssr_emit_bin<T, MODE>(p, R, (unsigned)(tid + i * NT), zk[i], zn[i], ra0, ra1, rb0, rb1, b_ok);
+    ssr_emit_bin<T, MODE>(p, acc, (unsigned)(tid + i * NT), zk[i], zn[i], ra0, ra1, rb0, rb1, b_ok);
   if (tid == 0) {
     const cx<T> zq = {re[ssr_pad(N / 2)], im[ssr_pad(N / 2)]};
-    ssr_emit_bin<T, MODE>(p, R, (unsigned)(N / 2), zq, zq, ra0, ra1, rb0, rb1, b_ok);
+    ssr_emit_bin<T, MODE>(p, acc, (unsigned)(N / 2), zq, zq, ra0, ra1, rb0, rb1, b_ok);
   }
 }
 
@@ -174,12 +181,15 @@ SSR_DEV void ssr_epilogue_direct(const SsrStftParams<T>& p, SsrStftRegs<T>& R, i
 template <typename T, int LOGN> struct SsrStftLds {
   static constexpr int NT = (1 << LOGN) / 8;
   static constexpr int PN = ssr_padded_len(1 << LOGN);
-  static constexpr size_t bytes() { return sizeof(double) * (NT + 16 + 8) + sizeof(T) * 2 * PN; }
-  double* sc0; double* sc1; double* res; T* re; T* im;
+  static constexpr int NW = (NT + 63) / 64;
+  // sc1: per-wave LSD sums of the current frame; wacc: per-wave running SISpec sums [6][NW];
+  // res[0]: running sum over frames of the per-frame LSD (thread 0)
+  static constexpr size_t bytes() { return sizeof(double) * (16 + 6 * 16 + 8) + sizeof(T) * 2 * PN; }
+  double* sc1; double* wacc; double* res; T* re; T* im;
   SSR_MEMBER explicit SsrStftLds(char* base) {
-    sc0 = reinterpret_cast<double*>(base);
-    sc1 = sc0 + NT;
-    res = sc1 + 16;
+    sc1 = reinterpret_cast<double*>(base);
+    wacc = sc1 + 16;
+    res = wacc + 6 * 16;
     re = reinterpret_cast<T*>(res + 8);
     im = re + PN;
   }
@@ -188,11 +198,11 @@ template <typename T, int LOGN> struct SsrStftLds {
 // ---------------------------------------------------------------------------------------------------
 // The body.  LOGN: FFT length of the engine (n_fft for direct, M for bluestein).
 // grid = (n_chunks, n_items); block = 2^LOGN / 8 threads.
-template <typename T, int LOGN, bool BLUESTEIN, int MODE, typename BLK>
+template <typename T, int LOGN, bool BLUESTEIN, int MODE, bool SUMS, typename BLK>
 SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
   using P = SsrFftPlan<LOGN>;
   constexpr int N = P::N, NT = P::NT, LAST = P::NPASS - 1, NW = (NT + 63) / 64;
-  using Regs = SsrStftRegs<T>;
+  using Regs = SsrStftRegs<T, SUMS>;
   SsrStftLds<T, LOGN> L(lds_base);
 
   const int n = p.len[item];
@@ -209,7 +219,11 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
   const int pad = n_fft / 2;
 
   SSR_REGS(Regs, regs, blk);
-  SSR_PHASE(blk, regs, for (int q = 0; q < 7; ++q) R.acc[q] = 0.0; R.lsd_sum = 0.0);
+  SSR_PHASE(blk, regs, {
+    if (tid < 6 * 16) L.wacc[tid] = 0.0;
+    if (tid == 0) L.res[0] = 0.0;
+    for (int q = 0; q < (SUMS ? 6 : 1); ++q) R.sums[q] = 0.0;
+  });
 
   for (int u = u0; u < u1; ++u) {
     const int ta = (MODE == SSR_MODE_PAIR) ? u : 2 * u;
@@ -264,7 +278,7 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
       if (want_lsd && u > u0 && tid == 0) {
         double s = 0.0;
         for (int w = 0; w < NW; ++w) s += L.sc1[w];
-        R.lsd_sum += sqrt(s / (double)F);
+        L.res[0] += sqrt(s / (double)F);
       }
     });
     // remaining forward passes; last pass stays in registers
@@ -307,43 +321,48 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
     float* rb1 = p.out_b ? p.out_b + (row0 + tb) * F : nullptr;
     if (MODE == SSR_MODE_PAIR) { ra1 = ra0; rb1 = rb0; }
     SSR_PHASE(blk, regs, {
-      R.acc[0] = 0.0;
+      double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #if defined(SSR_ABL_NOEPI)     /* developer ablation: WRONG results, timing only */
       if (tid == 0) {
         const cx<T> z0 = {L.re[0], L.im[0]};
-        ssr_emit_bin<T, MODE>(p, R, 0u, z0, z0, ra0, ra1, rb0, rb1, b_ok);
+        ssr_emit_bin<T, MODE>(p, acc, 0u, z0, z0, ra0, ra1, rb0, rb1, b_ok);
       }
 #else
       if constexpr (!BLUESTEIN) {
-        ssr_epilogue_direct<T, LOGN, MODE>(p, R, tid, L.re, L.im, ra0, ra1, rb0, rb1, b_ok);
+        ssr_epilogue_direct<T, LOGN, MODE>(p, acc, tid, L.re, L.im, ra0, ra1, rb0, rb1, b_ok);
       } else {
         for (int k = tid; k < F; k += NT) {
           const int kn = (k == 0) ? 0 : n_fft - k;
           const cx<T> zk = {L.re[ssr_pad(k)], L.im[ssr_pad(k)]};
           const cx<T> zn = {L.re[ssr_pad(kn)], L.im[ssr_pad(kn)]};
-          ssr_emit_bin<T, MODE>(p, R, (unsigned)k, zk, zn, ra0, ra1, rb0, rb1, b_ok);
+          ssr_emit_bin<T, MODE>(p, acc, (unsigned)k, zk, zn, ra0, ra1, rb0, rb1, b_ok);
         }
       }
 #endif
-      if (want_lsd) SSR_WAVE_SUM_STORE(tid, NT, R.acc[0], L.sc1);
+      if (want_lsd) SSR_WAVE_SUM_STORE(tid, NT, acc[0], L.sc1);
+      if constexpr (SUMS)
+        for (int q = 0; q < 6; ++q) R.sums[q] += acc[1 + q];
     });
   }
 
   if (part == nullptr) return;
   // ---- chunk tail: last frame's LSD, then block-sum the SISpec accumulators.
-  if (want_lsd && u1 > u0) {
-    SSR_PHASE(blk, regs, if (tid == 0) {
+  if constexpr (SUMS) {
+    SSR_PHASE(blk, regs, for (int q = 0; q < 6; ++q) SSR_WAVE_SUM_ADD(tid, NT, R.sums[q], L.wacc + q * 16));
+  }
+  SSR_PHASE(blk, regs, if (tid == 0) {
+    double lsd = L.res[0];
+    if (want_lsd && u1 > u0) {
       double s = 0.0;
       for (int w = 0; w < NW; ++w) s += L.sc1[w];
-      R.lsd_sum += sqrt(s / (double)F);
-    });
-  }
-#define SSR_GET_ACC(q) R.acc[(q) + 1]
-  SSR_BLOCK_SUM(blk, regs, NT, 6, L.sc0, L.sc1, L.res, SSR_GET_ACC);
-#undef SSR_GET_ACC
-  SSR_PHASE(blk, regs, if (tid == 0) {
-    part[0] = R.lsd_sum;
-    for (int q = 0; q < 6; ++q) part[1 + q] = L.res[q];
+      lsd += sqrt(s / (double)F);
+    }
+    part[0] = lsd;
+    for (int q = 0; q < 6; ++q) {
+      double s = 0.0;
+      for (int w = 0; w < NW; ++w) s += L.wacc[q * 16 + w];
+      part[1 + q] = s;
+    }
     part[7] = 0.0;
   });
 }

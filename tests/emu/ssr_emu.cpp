@@ -20,8 +20,10 @@ static void run_stft(SsrStftParams<T> p, int n_items) {
   for (int item = 0; item < n_items; ++item)
     for (int c = 0; c < p.n_chunks; ++c) {
       auto lds = poisoned(SsrStftLds<T, LOGN>::bytes());
-      if (p.mode == SSR_MODE_PAIR) ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR>(p, blk, c, item, lds.data());
-      else ssr_stft_body<T, LOGN, BLU, SSR_MODE_SINGLE>(p, blk, c, item, lds.data());
+      if (p.mode != SSR_MODE_PAIR) ssr_stft_body<T, LOGN, BLU, SSR_MODE_SINGLE, false>(p, blk, c, item, lds.data());
+      else if (p.metric_mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC))
+        ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, true>(p, blk, c, item, lds.data());
+      else ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, false>(p, blk, c, item, lds.data());
     }
 }
 

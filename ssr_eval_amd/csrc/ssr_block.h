@@ -22,7 +22,10 @@
 #define SSR_BODY static inline
 #define SSR_MEMBER inline
 #define SSR_HD static inline
+#define SSR_SCHED_FENCE() do {} while (0)
+#define SSR_UNROLL
 struct SsrBlk { int nt; };
+static inline void ssr_launder(SsrBlk&) {}
 #define SSR_REGS(TYPE, name, blk) std::vector<TYPE> name((blk).nt)
 #define SSR_PHASE(blk, regs, ...)                                  \
   for (int tid = 0; tid < (blk).nt; ++tid) {                       \
@@ -59,7 +62,16 @@ static inline float ssr_fadd_rn(float a, float b) { volatile float r = a + b; re
 #define SSR_BODY __device__ __forceinline__
 #define SSR_MEMBER __device__ __forceinline__
 #define SSR_HD __host__ __device__ __forceinline__
+// compiler-only fence: keeps the scheduler from hoisting the NEXT group of loads above this point (caps
+// the number of table values live at once in the 16-points-per-thread Bluestein phases)
+#define SSR_SCHED_FENCE() asm volatile("" ::: "memory")
+// full unroll (usable inside SSR_PHASE macro arguments): register arrays must only be indexed statically
+#define SSR_UNROLL _Pragma("unroll")
 struct SsrBlk { int tid; };
+// Make the thread index opaque to the optimiser for the code that follows.  Loop-invariant code motion
+// otherwise hoists EVERY per-register LDS / table address of every pass out of the frame loop; at 16
+// points per thread that is several hundred values which end up in scratch memory.
+SSR_DEV void ssr_launder(SsrBlk& b) { asm volatile("" : "+v"(b.tid)); }
 #define SSR_REGS(TYPE, name, blk) TYPE name
 #define SSR_PHASE(blk, regs, ...)                                  \
   {                                                                \

@@ -1,7 +1,10 @@
 // In-LDS power-of-two complex FFT for one workgroup (Stockham autosort, radix 8 with one leading
 // radix-2/4 pass), forward transform exp(-2*pi*i*j*k/N).
 //
-// Geometry: N = 2^LOGN points, NT = N/8 threads, every thread owns 8 points per pass in registers.
+// Geometry: N = 2^LOGN points, PPT (8 or 16) points per thread in registers, NT = N/PPT threads; a thread
+// runs PPT/R independent radix-R butterflies per pass (PPT = 16: two radix-8 butterflies -> twice the
+// instruction-level parallelism per wave and half the waves per transform; used where 8 points per thread
+// would need more threads than the register file can feed, i.e. the 8192-point Bluestein transforms).
 // Data lives in two LDS arrays (re[], im[], structure-of-arrays, index-padded by ssr_pad); the
 // transform is in place: a pass is  load -> twiddle -> butterfly  |barrier|  store  |barrier|.
 // The first pass takes its 8 points straight from registers (the caller loaded them from HBM in
@@ -58,9 +61,9 @@ template <int R, typename T> SSR_DEV void ssr_bfly(cx<T>* v) {
 }
 
 // pass schedule ----------------------------------------------------------------------------------
-template <int LOGN> struct SsrFftPlan {
+template <int LOGN, int PPT = 8> struct SsrFftPlan {
   static constexpr int N = 1 << LOGN;
-  static constexpr int NT = N / 8;
+  static constexpr int NT = N / PPT;
   static constexpr int R0 = (LOGN % 3 == 0) ? 8 : (1 << (LOGN % 3));
   static constexpr int NPASS = LOGN / 3 + ((LOGN % 3) ? 1 : 0);
   static constexpr int radix(int p) { return p == 0 ? R0 : 8; }
@@ -71,18 +74,18 @@ template <int LOGN> struct SsrFftPlan {
   }
 };
 
-// Order in which a thread's 8 registers map onto natural input indices for pass 0:
+// Order in which a thread's PPT registers map onto natural input indices for pass 0:
 // register b*R0+q  <->  index  tid + b*NT + q*(N/R0).
-template <int LOGN> SSR_DEV int ssr_fft_first_index(int tid, int reg) {
-  using P = SsrFftPlan<LOGN>;
+template <int LOGN, int PPT = 8> SSR_DEV int ssr_fft_first_index(int tid, int reg) {
+  using P = SsrFftPlan<LOGN, PPT>;
   const int b = reg / P::R0, q = reg % P::R0;
   return tid + b * P::NT + q * (P::N / P::R0);
 }
 
-template <typename T, int LOGN, int PASS>
+template <typename T, int LOGN, int PASS, int PPT = 8>
 SSR_DEV void ssr_fft_load(int tid, const T* re, const T* im, cx<T>* v) {
-  using P = SsrFftPlan<LOGN>;
-  constexpr int R = P::radix(PASS), NB = 8 / R;
+  using P = SsrFftPlan<LOGN, PPT>;
+  constexpr int R = P::radix(PASS), NB = PPT / R;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int j = tid + b * P::NT;
@@ -94,10 +97,10 @@ SSR_DEV void ssr_fft_load(int tid, const T* re, const T* im, cx<T>* v) {
   }
 }
 
-template <typename T, int LOGN, int PASS>
+template <typename T, int LOGN, int PASS, int PPT = 8>
 SSR_DEV void ssr_fft_compute(int tid, cx<T>* v, const cx<T>* __restrict__ tw) {
-  using P = SsrFftPlan<LOGN>;
-  constexpr int R = P::radix(PASS), NB = 8 / R, NS = P::ns(PASS);
+  using P = SsrFftPlan<LOGN, PPT>;
+  constexpr int R = P::radix(PASS), NB = PPT / R, NS = P::ns(PASS);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     if constexpr (NS > 1) {
@@ -137,8 +140,8 @@ SSR_DEV void ssr_fft_compute(int tid, cx<T>* v, const cx<T>* __restrict__ tw) {
 }
 
 // natural output index of register `reg` after pass PASS
-template <int LOGN, int PASS> SSR_DEV int ssr_fft_out_index(int tid, int reg) {
-  using P = SsrFftPlan<LOGN>;
+template <int LOGN, int PASS, int PPT = 8> SSR_DEV int ssr_fft_out_index(int tid, int reg) {
+  using P = SsrFftPlan<LOGN, PPT>;
   constexpr int R = P::radix(PASS), NS = P::ns(PASS);
   const int b = reg / R, q = reg % R;
   const int j = tid + b * P::NT;
@@ -146,11 +149,11 @@ template <int LOGN, int PASS> SSR_DEV int ssr_fft_out_index(int tid, int reg) {
   return (j - k) * R + k + q * NS;
 }
 
-template <typename T, int LOGN, int PASS>
+template <typename T, int LOGN, int PASS, int PPT = 8>
 SSR_DEV void ssr_fft_store(int tid, T* re, T* im, const cx<T>* v) {
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int idx = ssr_pad(ssr_fft_out_index<LOGN, PASS>(tid, r));
+  for (int r = 0; r < PPT; ++r) {
+    const int idx = ssr_pad(ssr_fft_out_index<LOGN, PASS, PPT>(tid, r));
     re[idx] = v[r].x;
     im[idx] = v[r].y;
   }
@@ -160,17 +163,17 @@ SSR_DEV void ssr_fft_store(int tid, T* re, T* im, const cx<T>* v) {
 // registers so the caller can fuse its own epilogue into the final store
 // (ssr_fft_out_index<LOGN, NPASS-1> gives each register's natural frequency index).
 // Pre-condition: pass 0 results already stored to (re, im) and a barrier passed.
-// Regs must expose `cx<T> v[8]`.
-template <typename T, int LOGN, int PASS, typename BLK, typename REGS>
+// Regs must expose `cx<T> v[PPT]`.
+template <typename T, int LOGN, int PASS, int PPT, typename BLK, typename REGS>
 SSR_BODY void ssr_fft_mid_passes(BLK& blk, REGS& regs, T* re, T* im, const cx<T>* tw) {
-  using P = SsrFftPlan<LOGN>;
+  using P = SsrFftPlan<LOGN, PPT>;
   if constexpr (PASS < P::NPASS - 1) {
-    SSR_PHASE(blk, regs, ssr_fft_load<T, LOGN, PASS>(tid, re, im, R.v);
-              ssr_fft_compute<T, LOGN, PASS>(tid, R.v, tw));
-    SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, PASS>(tid, re, im, R.v));
-    ssr_fft_mid_passes<T, LOGN, PASS + 1>(blk, regs, re, im, tw);
+    SSR_PHASE(blk, regs, ssr_fft_load<T, LOGN, PASS, PPT>(tid, re, im, R.v);
+              ssr_fft_compute<T, LOGN, PASS, PPT>(tid, R.v, tw));
+    SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, PASS, PPT>(tid, re, im, R.v));
+    ssr_fft_mid_passes<T, LOGN, PASS + 1, PPT>(blk, regs, re, im, tw);
   } else {
-    SSR_PHASE(blk, regs, ssr_fft_load<T, LOGN, PASS>(tid, re, im, R.v);
-              ssr_fft_compute<T, LOGN, PASS>(tid, R.v, tw));
+    SSR_PHASE(blk, regs, ssr_fft_load<T, LOGN, PASS, PPT>(tid, re, im, R.v);
+              ssr_fft_compute<T, LOGN, PASS, PPT>(tid, R.v, tw));
   }
 }

@@ -34,11 +34,11 @@ extern "C" int ssr_version(void) { return SSR_VERSION; }
 #define SSR_STFT_WAVES_PER_EU 1
 #endif
 template <typename T, int LOGN, bool BLU, int MODE, bool SUMS>
-__global__ __launch_bounds__((1 << LOGN) / 8, SSR_STFT_WAVES_PER_EU) void k_stft(SsrStftParams<T> p) {
+__global__ __launch_bounds__((1 << LOGN) / ssr_stft_ppt(LOGN, BLU), SSR_STFT_WAVES_PER_EU) void k_stft(SsrStftParams<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SsrBlk blk{(int)threadIdx.x};
   const int item = blockIdx.x / p.n_chunks, chunk = blockIdx.x % p.n_chunks;
-  ssr_stft_body<T, LOGN, BLU, MODE, SUMS>(p, blk, chunk, item, smem);
+  ssr_stft_body<T, LOGN, BLU, MODE, SUMS, ssr_stft_ppt(LOGN, BLU)>(p, blk, chunk, item, smem);
 }
 
 template <typename T, int LOGN>
@@ -146,7 +146,8 @@ template <typename T, int LOGN, bool BLU, int MODE, bool SUMS>
 static int launch_stft_mode(SsrStftParams<T>& p, int grid, hipStream_t s) {
   // SSR_LDS_PAD (bytes, developer knob): over-allocate LDS to cap workgroups per CU in occupancy experiments
   static const size_t lds_pad = getenv("SSR_LDS_PAD") ? (size_t)atol(getenv("SSR_LDS_PAD")) : 0;
-  const size_t lds = SsrStftLds<T, LOGN>::bytes() + lds_pad;
+  constexpr int PPT = ssr_stft_ppt(LOGN, BLU);
+  const size_t lds = SsrStftLds<T, LOGN, PPT>::bytes() + lds_pad;
   static thread_local int attr_dev = -1;
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
@@ -154,7 +155,7 @@ static int launch_stft_mode(SsrStftParams<T>& p, int grid, hipStream_t s) {
     HIP_TRY(hipFuncSetAttribute((const void*)k_stft<T, LOGN, BLU, MODE, SUMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_dev = dev;
   }
-  hipLaunchKernelGGL((k_stft<T, LOGN, BLU, MODE, SUMS>), dim3(grid), dim3((1 << LOGN) / 8), lds, s, p);
+  hipLaunchKernelGGL((k_stft<T, LOGN, BLU, MODE, SUMS>), dim3(grid), dim3((1 << LOGN) / PPT), lds, s, p);
   HIP_TRY(hipGetLastError());
   return SSR_OK;
 }

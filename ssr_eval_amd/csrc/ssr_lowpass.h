@@ -54,19 +54,19 @@ SSR_BODY void ssr_lowpass_frames_body(const SsrLowpassParams<T>& p, BLK& blk, in
       SSR_PHASE(blk, regs, {
         float fa[8], fb[8];
         T w[8];
-        for (int r = 0; r < 8; ++r) {       // all loads first (branch-free addresses), then the arithmetic
+        SSR_UNROLL for (int r = 0; r < 8; ++r) {       // all loads first (branch-free addresses), then the arithmetic
           const int m = ssr_fft_first_index<LOGN>(tid, r);
           fa[r] = ssr_frame_sample_raw(sig, n, ta, n_frames, m, N, hop);
           fb[r] = ssr_frame_sample_raw(sig, n, tb, n_frames, m, N, hop);
           w[r] = p.window[m];
         }
-        for (int r = 0; r < 8; ++r) R.v[r] = {(T)fa[r] * w[r], b_valid ? (T)fb[r] * w[r] : (T)0};
+        SSR_UNROLL for (int r = 0; r < 8; ++r) R.v[r] = {(T)fa[r] * w[r], b_valid ? (T)fb[r] * w[r] : (T)0};
         ssr_fft_compute<T, LOGN, 0>(tid, R.v, p.tw);
         ssr_fft_store<T, LOGN, 0>(tid, L.re, L.im, R.v);
       });
-      ssr_fft_mid_passes<T, LOGN, 1>(blk, regs, L.re, L.im, p.tw);
+      ssr_fft_mid_passes<T, LOGN, 1, 8>(blk, regs, L.re, L.im, p.tw);
       SSR_PHASE(blk, regs, {
-        for (int r = 0; r < 8; ++r) {
+        SSR_UNROLL for (int r = 0; r < 8; ++r) {
           const int k = ssr_fft_out_index<LOGN, LAST>(tid, r);
           const bool zero = (k >= cut) && (k <= N - cut);
           L.re[ssr_pad(k)] = zero ? (T)0 : R.v[r].x;
@@ -79,7 +79,7 @@ SSR_BODY void ssr_lowpass_frames_body(const SsrLowpassParams<T>& p, BLK& blk, in
     } else {
       // ISTFT mode: pack Z = Xa + i*Xb (Hermitian-extended) straight into inverse pass-0 registers
       SSR_PHASE(blk, regs, {
-        for (int r = 0; r < 8; ++r) {
+        SSR_UNROLL for (int r = 0; r < 8; ++r) {
           const int k = ssr_fft_first_index<LOGN>(tid, r);
           const int kk = (k <= N / 2) ? k : N - k;
           const T sgn = (k <= N / 2) ? (T)1 : (T)-1;
@@ -95,10 +95,10 @@ SSR_BODY void ssr_lowpass_frames_body(const SsrLowpassParams<T>& p, BLK& blk, in
       });
     }
     SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, 0>(tid, L.im, L.re, R.v));
-    ssr_fft_mid_passes<T, LOGN, 1>(blk, regs, L.im, L.re, p.tw);
+    ssr_fft_mid_passes<T, LOGN, 1, 8>(blk, regs, L.im, L.re, p.tw);
     // registers: swap(N * IFFT): frame ta = .y, frame tb = .x.  Window, scale, write (coalesced).
     SSR_PHASE(blk, regs, {
-      for (int r = 0; r < 8; ++r) {
+      SSR_UNROLL for (int r = 0; r < 8; ++r) {
         const int m = ssr_fft_out_index<LOGN, LAST>(tid, r);
         const T w = p.window[m] * inv_n;
         p.frames[(row0 + ta) * N + m] = (float)(R.v[r].y * w);

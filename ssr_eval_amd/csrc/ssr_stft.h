@@ -19,12 +19,21 @@
 #pragma once
 #include "ssr_fft.h"
 #if defined(SSR_SIGNED_IDX)
-#define SSR_UIDX(x) (x)
+#define SSR_UIDX(...) (__VA_ARGS__)
 #else
-#define SSR_UIDX(x) ((unsigned)(x))
+#define SSR_UIDX(...) ((unsigned)(__VA_ARGS__))
 #endif
 
 enum { SSR_MODE_PAIR = 0, SSR_MODE_SINGLE = 1 };
+
+// points per thread of the FFT engine for a given transform length: 16 for the 8192-point Bluestein
+// transforms (512 threads x up to 256 VGPRs instead of 1024 threads x 128 VGPRs with spills), else 8.
+#ifndef SSR_PPT_2048
+#define SSR_PPT_2048 8   /* developer A/B knob for the direct 2048-point engine */
+#endif
+SSR_HD constexpr int ssr_stft_ppt(int logn, bool bluestein) {
+  return logn >= 13 ? 16 : ((logn == 11 && !bluestein) ? SSR_PPT_2048 : 8);
+}
 enum { SSR_OUT_NONE = 0, SSR_OUT_MAG = 1, SSR_OUT_COMPLEX = 2 };
 enum { SSR_M_LSD = 1, SSR_M_LOG_SISPEC = 2, SSR_M_SISPEC = 4, SSR_M_SSIM = 8 };
 
@@ -56,8 +65,8 @@ template <typename T> struct SsrStftParams {
   double* part;              // [n_items, n_chunks, SSR_NPART] or null
 };
 
-template <typename T, bool SUMS = false> struct SsrStftRegs {
-  cx<T> v[8];                // FFT points
+template <typename T, bool SUMS = false, int PPT = 8> struct SsrStftRegs {
+  cx<T> v[PPT];              // FFT points
   double sums[SUMS ? 6 : 1]; // SISpec / log-SISpec running sums (kernel variants that do not need them carry none)
 };
 
@@ -155,21 +164,21 @@ SSR_DEV void ssr_emit_bin(const SsrStftParams<T>& p, double* acc, unsigned k, cx
   }
 }
 
-// Direct engine epilogue: F = N/2 + 1 = 4 * NT + 1 -> four full, unrolled rounds (all LDS reads in flight
+// Direct engine epilogue: F = N/2 + 1 = (PPT/2) * NT + 1 -> PPT/2 full, unrolled rounds (all LDS reads in flight
 // together) + the Nyquist bin on thread 0.
-template <typename T, int LOGN, int MODE>
+template <typename T, int LOGN, int MODE, int PPT>
 SSR_DEV void ssr_epilogue_direct(const SsrStftParams<T>& p, double* acc, int tid, const T* re, const T* im,
                                  float* ra0, float* ra1, float* rb0, float* rb1, bool b_ok) {
-  constexpr int N = 1 << LOGN, NT = N / 8;
-  cx<T> zk[4], zn[4];
+  constexpr int N = 1 << LOGN, NT = N / PPT, RND = PPT / 2;   // F = N/2 + 1 = RND * NT + 1
+  cx<T> zk[RND], zn[RND];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < RND; ++i) {
     const int k = tid + i * NT, kn = (N - k) & (N - 1);
     zk[i] = {re[ssr_pad(k)], im[ssr_pad(k)]};
     zn[i] = {re[ssr_pad(kn)], im[ssr_pad(kn)]};
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RND; ++i)
     ssr_emit_bin<T, MODE>(p, acc, (unsigned)(tid + i * NT), zk[i], zn[i], ra0, ra1, rb0, rb1, b_ok);
   if (tid == 0) {
     const cx<T> zq = {re[ssr_pad(N / 2)], im[ssr_pad(N / 2)]};
@@ -178,8 +187,8 @@ SSR_DEV void ssr_epilogue_direct(const SsrStftParams<T>& p, double* acc, int tid
 }
 
 // LDS carve-out (doubles first so every array stays 8-byte aligned)
-template <typename T, int LOGN> struct SsrStftLds {
-  static constexpr int NT = (1 << LOGN) / 8;
+template <typename T, int LOGN, int PPT = 8> struct SsrStftLds {
+  static constexpr int NT = (1 << LOGN) / PPT;
   static constexpr int PN = ssr_padded_len(1 << LOGN);
   static constexpr int NW = (NT + 63) / 64;
   // sc1: per-wave LSD sums of the current frame; wacc: per-wave running SISpec sums [6][NW];
@@ -198,12 +207,12 @@ template <typename T, int LOGN> struct SsrStftLds {
 // ---------------------------------------------------------------------------------------------------
 // The body.  LOGN: FFT length of the engine (n_fft for direct, M for bluestein).
 // grid = (n_chunks, n_items); block = 2^LOGN / 8 threads.
-template <typename T, int LOGN, bool BLUESTEIN, int MODE, bool SUMS, typename BLK>
+template <typename T, int LOGN, bool BLUESTEIN, int MODE, bool SUMS, int PPT, typename BLK>
 SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
-  using P = SsrFftPlan<LOGN>;
+  using P = SsrFftPlan<LOGN, PPT>;
   constexpr int N = P::N, NT = P::NT, LAST = P::NPASS - 1, NW = (NT + 63) / 64;
-  using Regs = SsrStftRegs<T, SUMS>;
-  SsrStftLds<T, LOGN> L(lds_base);
+  using Regs = SsrStftRegs<T, SUMS, PPT>;
+  SsrStftLds<T, LOGN, PPT> L(lds_base);
 
   const int n = p.len[item];
   const int n_fft = BLUESTEIN ? p.n_fft : N, hop = p.hop, F = n_fft / 2 + 1;
@@ -225,7 +234,13 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
     for (int q = 0; q < (SUMS ? 6 : 1); ++q) R.sums[q] = 0.0;
   });
 
+  BLK blk0 = blk;
   for (int u = u0; u < u1; ++u) {
+#if defined(SSR_LAUNDER_ALL)
+    blk = blk0; ssr_launder(blk);
+#else
+    if constexpr (PPT > 8) { blk = blk0; ssr_launder(blk); }   // see ssr_launder: keeps addresses out of scratch
+#endif
     const int ta = (MODE == SSR_MODE_PAIR) ? u : 2 * u;
     const int tb = (MODE == SSR_MODE_PAIR) ? u : 2 * u + 1;
     const bool a_ok = ta < n_frames, b_ok = tb < n_frames;       // a missing frame re-reads the last one, scaled by 0
@@ -239,42 +254,60 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
     // branch-free, always-valid addresses, so the frame pays ONE memory latency instead of 24 dependent
     // ones.  Thread 0 also closes the PREVIOUS frame's LSD (per-wave sums left in sc1 by its epilogue).
     SSR_PHASE(blk, regs, {
-      float fa[8], fb[8];
-      if (interior) {
-        const float* qa = sa + base_a;
-        const float* qb = sb + base_b;
-        for (int r = 0; r < 8; ++r) {
-          int m = ssr_fft_first_index<LOGN>(tid, r);
-          if (BLUESTEIN && m >= n_fft) m = n_fft - 1;
-          fa[r] = qa[SSR_UIDX(m)];
-          fb[r] = qb[SSR_UIDX(m)];
-        }
-      } else {
-        for (int r = 0; r < 8; ++r) {
-          int m = ssr_fft_first_index<LOGN>(tid, r);
-          if (BLUESTEIN && m >= n_fft) m = n_fft - 1;
-          fa[r] = sa[SSR_UIDX(ssr_reflect(base_a + m, n))];
-          fb[r] = sb[SSR_UIDX(ssr_reflect(base_b + m, n))];
-        }
-      }
       if constexpr (BLUESTEIN) {
-        cx<T> wc[8];
-        for (int r = 0; r < 8; ++r) {
-          const int m = ssr_fft_first_index<LOGN>(tid, r);
-          wc[r] = p.wchirp[SSR_UIDX((m < n_fft) ? m : n_fft - 1)];
-        }
-        for (int r = 0; r < 8; ++r) {
-          const int m = ssr_fft_first_index<LOGN>(tid, r);
-          const cx<T> z = cmul(cx<T>{a_ok ? (T)fa[r] : (T)0, b_ok ? (T)fb[r] : (T)0}, wc[r]);
-          R.v[r] = (m < n_fft) ? z : cx<T>{(T)0, (T)0};
+        // Four points at a time (sample pair + window*chirp value each), fenced, so that at 16 points per
+        // thread the address and table registers of one group die before the next group is issued.
+        // Groups whose indices all lie beyond n_fft (at least the upper half of M) are skipped outright.
+        SSR_UNROLL for (int r0 = 0; r0 < PPT; r0 += 4) {
+          const int m_lo = ssr_fft_first_index<LOGN, PPT>(0, r0);   // smallest index any thread's group can hold
+          bool any = false;
+          SSR_UNROLL for (int r = 0; r < 4; ++r) any = any || (ssr_fft_first_index<LOGN, PPT>(0, r0 + r) < n_fft);
+          (void)m_lo;
+          if (any) {
+            float fa[4], fb[4];
+            cx<T> wc[4];
+            SSR_UNROLL for (int r = 0; r < 4; ++r) {
+              const int m = ssr_fft_first_index<LOGN, PPT>(tid, r0 + r);
+              const int mc = (m < n_fft) ? m : n_fft - 1;
+              const int ia = interior ? base_a + mc : ssr_reflect(base_a + mc, n);
+              const int ib = interior ? base_b + mc : ssr_reflect(base_b + mc, n);
+              fa[r] = sa[SSR_UIDX(ia)];
+              fb[r] = sb[SSR_UIDX(ib)];
+              wc[r] = p.wchirp[SSR_UIDX(mc)];
+            }
+            SSR_UNROLL for (int r = 0; r < 4; ++r) {
+              const int m = ssr_fft_first_index<LOGN, PPT>(tid, r0 + r);
+              const cx<T> z = cmul(cx<T>{a_ok ? (T)fa[r] : (T)0, b_ok ? (T)fb[r] : (T)0}, wc[r]);
+              R.v[r0 + r] = (m < n_fft) ? z : cx<T>{(T)0, (T)0};
+            }
+          } else {
+            SSR_UNROLL for (int r = 0; r < 4; ++r) R.v[r0 + r] = cx<T>{(T)0, (T)0};
+          }
+          SSR_SCHED_FENCE();
         }
       } else {
-        T w[8];
-        for (int r = 0; r < 8; ++r) w[r] = p.window[SSR_UIDX(ssr_fft_first_index<LOGN>(tid, r))];
-        for (int r = 0; r < 8; ++r) R.v[r] = {a_ok ? (T)fa[r] * w[r] : (T)0, b_ok ? (T)fb[r] * w[r] : (T)0};
+        float fa[PPT], fb[PPT];
+        if (interior) {
+          const float* qa = sa + base_a;
+          const float* qb = sb + base_b;
+          SSR_UNROLL for (int r = 0; r < PPT; ++r) {
+            const int m = ssr_fft_first_index<LOGN, PPT>(tid, r);
+            fa[r] = qa[SSR_UIDX(m)];
+            fb[r] = qb[SSR_UIDX(m)];
+          }
+        } else {
+          SSR_UNROLL for (int r = 0; r < PPT; ++r) {
+            const int m = ssr_fft_first_index<LOGN, PPT>(tid, r);
+            fa[r] = sa[SSR_UIDX(ssr_reflect(base_a + m, n))];
+            fb[r] = sb[SSR_UIDX(ssr_reflect(base_b + m, n))];
+          }
+        }
+        T w[PPT];
+        SSR_UNROLL for (int r = 0; r < PPT; ++r) w[r] = p.window[SSR_UIDX(ssr_fft_first_index<LOGN, PPT>(tid, r))];
+        SSR_UNROLL for (int r = 0; r < PPT; ++r) R.v[r] = {a_ok ? (T)fa[r] * w[r] : (T)0, b_ok ? (T)fb[r] * w[r] : (T)0};
       }
-      ssr_fft_compute<T, LOGN, 0>(tid, R.v, p.tw);
-      ssr_fft_store<T, LOGN, 0>(tid, L.re, L.im, R.v);
+      ssr_fft_compute<T, LOGN, 0, PPT>(tid, R.v, p.tw);
+      ssr_fft_store<T, LOGN, 0, PPT>(tid, L.re, L.im, R.v);
       if (want_lsd && u > u0 && tid == 0) {
         double s = 0.0;
         for (int w = 0; w < NW; ++w) s += L.sc1[w];
@@ -282,27 +315,30 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
       }
     });
     // remaining forward passes; last pass stays in registers
-    ssr_fft_mid_passes<T, LOGN, 1>(blk, regs, L.re, L.im, p.tw);
+    ssr_fft_mid_passes<T, LOGN, 1, PPT>(blk, regs, L.re, L.im, p.tw);
 
     if constexpr (BLUESTEIN) {
       // forward spectrum * filter, stored as the INPUT of the inverse transform.  The inverse is the
       // forward engine on exchanged (im, re) arrays.
       SSR_PHASE(blk, regs, {
-        for (int r = 0; r < 8; ++r) {
-          const int k = ssr_fft_out_index<LOGN, LAST>(tid, r);
-          const cx<T> y = cmul(R.v[r], p.bfilt[SSR_UIDX(k)]);
-          L.re[ssr_pad(k)] = y.x;
-          L.im[ssr_pad(k)] = y.y;
+        SSR_UNROLL for (int r0 = 0; r0 < PPT; r0 += 4) {
+          SSR_UNROLL for (int r = r0; r < r0 + 4; ++r) {
+            const int k = ssr_fft_out_index<LOGN, LAST, PPT>(tid, r);
+            const cx<T> y = cmul(R.v[r], p.bfilt[SSR_UIDX(k)]);
+            L.re[ssr_pad(k)] = y.x;
+            L.im[ssr_pad(k)] = y.y;
+          }
+          SSR_SCHED_FENCE();
         }
       });
-      SSR_PHASE(blk, regs, ssr_fft_load<T, LOGN, 0>(tid, L.im, L.re, R.v);
-                ssr_fft_compute<T, LOGN, 0>(tid, R.v, p.tw));
-      SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, 0>(tid, L.im, L.re, R.v));
-      ssr_fft_mid_passes<T, LOGN, 1>(blk, regs, L.im, L.re, p.tw);
+      SSR_PHASE(blk, regs, ssr_fft_load<T, LOGN, 0, PPT>(tid, L.im, L.re, R.v);
+                ssr_fft_compute<T, LOGN, 0, PPT>(tid, R.v, p.tw));
+      SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, 0, PPT>(tid, L.im, L.re, R.v));
+      ssr_fft_mid_passes<T, LOGN, 1, PPT>(blk, regs, L.im, L.re, p.tw);
       // registers hold swap(IFFT*M): true real part = .y, true imaginary part = .x
       SSR_PHASE(blk, regs, {
-        for (int r = 0; r < 8; ++r) {
-          const int k = ssr_fft_out_index<LOGN, LAST>(tid, r);
+        SSR_UNROLL for (int r = 0; r < PPT; ++r) {
+          const int k = ssr_fft_out_index<LOGN, LAST, PPT>(tid, r);
           if (k < n_fft) {
             const cx<T> zk = cmul(cx<T>{R.v[r].y, R.v[r].x}, p.chirp[SSR_UIDX(k)]);
             L.re[ssr_pad(k)] = zk.x;
@@ -311,7 +347,7 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
         }
       });
     } else {
-      SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, LAST>(tid, L.re, L.im, R.v));
+      SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, LAST, PPT>(tid, L.re, L.im, R.v));
     }
 
     // ---- epilogue: separate the two spectra, emit, accumulate; leave per-wave LSD sums in sc1.
@@ -329,7 +365,7 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
       }
 #else
       if constexpr (!BLUESTEIN) {
-        ssr_epilogue_direct<T, LOGN, MODE>(p, acc, tid, L.re, L.im, ra0, ra1, rb0, rb1, b_ok);
+        ssr_epilogue_direct<T, LOGN, MODE, PPT>(p, acc, tid, L.re, L.im, ra0, ra1, rb0, rb1, b_ok);
       } else {
         for (int k = tid; k < F; k += NT) {
           const int kn = (k == 0) ? 0 : n_fft - k;

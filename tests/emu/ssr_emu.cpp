@@ -14,17 +14,27 @@
 
 static std::vector<char> poisoned(size_t bytes) { return std::vector<char>(bytes + 64, (char)0xFF); }
 
-template <typename T, int LOGN, bool BLU>
-static void run_stft(SsrStftParams<T> p, int n_items) {
-  SsrBlk blk{SsrFftPlan<LOGN>::NT};
+static int g_force_ppt = 0;   // tests can force 8 or 16 points per thread for the 2048-point direct engine
+extern "C" void emu_force_ppt(int ppt) { g_force_ppt = ppt; }
+
+template <typename T, int LOGN, bool BLU, int PPT>
+static void run_stft_ppt(SsrStftParams<T> p, int n_items) {
+  SsrBlk blk{SsrFftPlan<LOGN, PPT>::NT};
   for (int item = 0; item < n_items; ++item)
     for (int c = 0; c < p.n_chunks; ++c) {
-      auto lds = poisoned(SsrStftLds<T, LOGN>::bytes());
-      if (p.mode != SSR_MODE_PAIR) ssr_stft_body<T, LOGN, BLU, SSR_MODE_SINGLE, false>(p, blk, c, item, lds.data());
+      auto lds = poisoned(SsrStftLds<T, LOGN, PPT>::bytes());
+      if (p.mode != SSR_MODE_PAIR) ssr_stft_body<T, LOGN, BLU, SSR_MODE_SINGLE, false, PPT>(p, blk, c, item, lds.data());
       else if (p.metric_mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC))
-        ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, true>(p, blk, c, item, lds.data());
-      else ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, false>(p, blk, c, item, lds.data());
+        ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, true, PPT>(p, blk, c, item, lds.data());
+      else ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, false, PPT>(p, blk, c, item, lds.data());
     }
+}
+
+template <typename T, int LOGN, bool BLU>
+static void run_stft(SsrStftParams<T> p, int n_items) {
+  if (g_force_ppt == 16 && LOGN >= 9) return run_stft_ppt<T, LOGN, BLU, 16>(p, n_items);
+  if (g_force_ppt == 8) return run_stft_ppt<T, LOGN, BLU, 8>(p, n_items);
+  return run_stft_ppt<T, LOGN, BLU, ssr_stft_ppt(LOGN, BLU)>(p, n_items);
 }
 
 template <typename T>

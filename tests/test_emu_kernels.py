@@ -102,3 +102,23 @@ def test_resampler_bit_exact_vs_scipy(golden, up, down):
     out = E.resample(sig, up, down, p["h_full"][:p["n_pre_pad"] + len(p["h"])], p["n_pre_remove"], outs_per_block=300)
     for s, o in zip(sig, out):
         np.testing.assert_array_equal(o, signal.resample_poly(s, up, down))
+
+
+@pytest.mark.parametrize("ppt", [8, 16])
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (2229, 480), (512, 128), (743, 160)])
+def test_fft_engine_points_per_thread(ppt, n_fft, hop, golden):
+    """Both register geometries of the FFT engine (8 and 16 points per thread) give the same spectra / metrics."""
+    E.lib().emu_force_ppt(ppt)
+    try:
+        rng = np.random.default_rng(ppt + n_fft)
+        x = [rng.standard_normal(n_fft * 2 + 13).astype(np.float32)]
+        y = [rng.standard_normal(n_fft * 2 + 13).astype(np.float32)]
+        ea, tb, _ = E.stft(x, y, n_fft, hop, precision=1, units_per_chunk=3)
+        ra, rb = ostft.stft_mag_TF(x[0], n_fft, hop), ostft.stft_mag_TF(y[0], n_fft, hop)
+        assert np.abs(ea[0] - ra).max() <= 2e-7 * ra.max() and np.abs(tb[0] - rb).max() <= 2e-7 * rb.max()
+        if n_fft == 2048:
+            e, t = golden["ev_bench2048_est"], golden["ev_bench2048_tgt"]
+            got = E.pair_metrics([e], [t], 2048, 512, precision=1)[0]
+            np.testing.assert_allclose(got, golden["ev_bench2048_out"], rtol=1e-5)
+    finally:
+        E.lib().emu_force_ppt(0)

@@ -24,6 +24,7 @@
 #define SSR_HD static inline
 #define SSR_SCHED_FENCE() do {} while (0)
 #define SSR_UNROLL
+#define SSR_UNROLL4
 struct SsrBlk { int nt; };
 static inline void ssr_launder(SsrBlk&) {}
 #define SSR_REGS(TYPE, name, blk) std::vector<TYPE> name((blk).nt)
@@ -67,6 +68,7 @@ static inline float ssr_fadd_rn(float a, float b) { volatile float r = a + b; re
 #define SSR_SCHED_FENCE() asm volatile("" ::: "memory")
 // full unroll (usable inside SSR_PHASE macro arguments): register arrays must only be indexed statically
 #define SSR_UNROLL _Pragma("unroll")
+#define SSR_UNROLL4 _Pragma("unroll 4")
 struct SsrBlk { int tid; };
 // Make the thread index opaque to the optimiser for the code that follows.  Loop-invariant code motion
 // otherwise hoists EVERY per-register LDS / table address of every pass out of the frame loop; at 16

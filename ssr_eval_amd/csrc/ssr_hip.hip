@@ -584,11 +584,13 @@ extern "C" int ssr_resample_poly(const float* in, const int64_t* in_off, const i
   if (!in || !in_off || !in_len || !out_off || !out_len || !taps || !out) return fail(SSR_ERR_INVALID_ARG, "null argument");
   if (up < 1 || down < 1 || n_taps < 1) return fail(SSR_ERR_INVALID_ARG, "bad resampling plan");
   if (n_items <= 0 || max_out_len <= 0) return SSR_OK;
-  SsrResampleParams p{in, in_off, in_len, out_off, out_len, up, down, taps, n_taps, n_pre_remove, 2048, out};
+  SsrResampleParams p{in, in_off, in_len, out_off, out_len, up, down, taps, n_taps, n_pre_remove,
+                      ssr_resample_pick_groups(up, down), 1, out};
+  if (ssr_resample_lds_bytes(p) > 96 * 1024) p.taps_in_lds = 0;      // huge tap tables stay in HBM / L2
   const size_t lds = ssr_resample_lds_bytes(p);
-  if (lds > 160 * 1024) return fail(SSR_ERR_UNSUPPORTED, "tap table does not fit LDS");
+  if (lds > 160 * 1024) return fail(SSR_ERR_UNSUPPORTED, "input window does not fit LDS");
   if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_resample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int bpi = ceil_div(max_out_len, p.outs_per_block);
+  const int bpi = ceil_div(max_out_len, ssr_resample_opb(p));
   hipLaunchKernelGGL(k_resample, dim3((unsigned)((int64_t)n_items * bpi)), dim3(SSR_RESAMPLE_NT), lds, (hipStream_t)stream, p, bpi);
   HIP_TRY(hipGetLastError());
   return SSR_OK;

@@ -4,16 +4,20 @@
 //
 // out[m] = sum_i  x[q - i] * h[ph + i*up],   t = (m + n_pre_remove) * down,  q = t / up, ph = t % up,
 // with h the Kaiser-windowed sinc (already scaled by `up`, already prefixed by n_pre_pad zeros) and
-// x taken as zero outside [0, n_in).  The sum runs in ASCENDING input index with a separately rounded
-// float32 multiply and add per tap - the order and rounding of SciPy's _upfirdn_apply loop - so the
-// output is bit-identical to the reference's.
+// x taken as zero outside [0, n_in).  Every output is accumulated in ASCENDING input index with a
+// separately rounded float32 multiply and add per tap - the order and rounding of SciPy's
+// _upfirdn_apply loop - so the result is bit-identical to the reference's.
 //
-// LDS: the whole tap table in natural order (lane stride `down mod up` is odd for every rate pair in
-// use, so tap reads are conflict-free) plus the block's input window.
+// Register blocking: outputs m, m + up, m + 2 up, ... share the phase ph (their q advance by `down`), so a
+// work item (residue r, group g) walks the taps of ONE phase once and feeds J = 8 independent accumulators:
+// 1 tap read + J input reads + J multiply-adds per tap, i.e. (1 + 1/J) LDS reads per multiply-add instead
+// of 2, and J independent dependency chains per thread instead of one.
+// LDS: the tap table in natural order (when it fits; otherwise taps come from HBM/L2) + the block's input window.
 #pragma once
 #include "ssr_block.h"
 
 #define SSR_RESAMPLE_NT 256
+#define SSR_RESAMPLE_J 8
 
 struct SsrResampleParams {
   const float* in;
@@ -23,54 +27,89 @@ struct SsrResampleParams {
   const int32_t* out_len;  // [n_items]
   int up, down;
   const float* taps;       // [n_taps] = zeros(n_pre_pad) ++ h*up ++ zeros(n_post_pad)
-  int n_taps, n_pre_remove, outs_per_block;
+  int n_taps, n_pre_remove;
+  int groups;              // G: outputs per block = up * SSR_RESAMPLE_J * G
+  int taps_in_lds;         // 0: tap table too large for LDS, read it through L2
   float* out;
 };
 
 SSR_HD int ssr_resample_hpp(const SsrResampleParams& p) { return (p.n_taps + p.up - 1) / p.up; }
+SSR_HD int ssr_resample_opb(const SsrResampleParams& p) { return p.up * SSR_RESAMPLE_J * p.groups; }
 SSR_HD int ssr_resample_win(const SsrResampleParams& p) {
-  return (int)(((int64_t)p.outs_per_block * p.down) / p.up) + ssr_resample_hpp(p) + 2;
+  return (int)(((int64_t)ssr_resample_opb(p) * p.down) / p.up) + ssr_resample_hpp(p) + 2;
 }
 SSR_HD size_t ssr_resample_lds_bytes(const SsrResampleParams& p) {
-  return sizeof(float) * ((size_t)ssr_resample_hpp(p) * p.up + ssr_resample_win(p) + 8);
+  const size_t taps = p.taps_in_lds ? (size_t)ssr_resample_hpp(p) * p.up : 0;
+  return sizeof(float) * (taps + ssr_resample_win(p) + 8);
+}
+// host-side geometry: about 6144 outputs per block, input window capped at 8192 samples
+SSR_HD int ssr_resample_pick_groups(int up, int down) {
+  int64_t target = 6144;
+  const int64_t cap = (int64_t)8192 * up / down;
+  if (cap < target) target = cap;
+  int64_t g = target / ((int64_t)up * SSR_RESAMPLE_J);
+  return g < 1 ? 1 : (int)g;
 }
 
 // grid = (n_blocks, n_items), block = SSR_RESAMPLE_NT
 template <typename BLK>
 SSR_BODY void ssr_resample_body(const SsrResampleParams& p, BLK& blk, int block, int item, char* lds_base) {
-  constexpr int NT = SSR_RESAMPLE_NT;
+  constexpr int NT = SSR_RESAMPLE_NT, J = SSR_RESAMPLE_J;
   struct Regs { int unused; };
-  const int hpp = ssr_resample_hpp(p), up = p.up, down = p.down;
+  const int hpp = ssr_resample_hpp(p), up = p.up, down = p.down, G = p.groups;
+  const int opb = ssr_resample_opb(p);
   const int n_in = p.in_len[item], n_out = p.out_len[item];
-  const int m0 = block * p.outs_per_block;
+  const int64_t m0 = (int64_t)block * opb;
   if (m0 >= n_out) return;
-  const int m1 = (m0 + p.outs_per_block < n_out) ? m0 + p.outs_per_block : n_out;
-  float* h = reinterpret_cast<float*>(lds_base);
-  float* xw = h + hpp * up;
-  const int64_t q_first = ((int64_t)(m0 + p.n_pre_remove) * down) / up;
+  const int64_t m1 = (m0 + opb < n_out) ? m0 + opb : n_out;
+  float* hl = reinterpret_cast<float*>(lds_base);
+  float* xw = hl + (p.taps_in_lds ? hpp * up : 0);
+  const float* h = p.taps_in_lds ? hl : p.taps;
+  const int h_len = p.taps_in_lds ? hpp * up : p.n_taps;
+  const int64_t q_first = ((m0 + p.n_pre_remove) * down) / up;
   const int64_t q_lo = q_first - (hpp - 1);
-  const int64_t q_hi = ((int64_t)(m1 - 1 + p.n_pre_remove) * down) / up;
+  const int64_t q_hi = ((m1 - 1 + p.n_pre_remove) * down) / up;
   const int win = (int)(q_hi - q_lo + 1);
   const float* x = p.in + p.in_off[item];
   float* y = p.out + p.out_off[item];
 
   SSR_REGS(Regs, regs, blk);
   SSR_PHASE(blk, regs, {
-    for (int i = tid; i < hpp * up; i += NT) h[i] = (i < p.n_taps) ? p.taps[i] : 0.0f;
+    if (p.taps_in_lds)
+      for (int i = tid; i < hpp * up; i += NT) hl[i] = (i < p.n_taps) ? p.taps[i] : 0.0f;
     for (int i = tid; i < win; i += NT) {
       const int64_t j = q_lo + i;
       xw[i] = (j >= 0 && j < n_in) ? x[j] : 0.0f;
     }
   });
   SSR_PHASE(blk, regs, {
-    for (int m = m0 + tid; m < m1; m += NT) {
-      const int64_t t = (int64_t)(m + p.n_pre_remove) * down;
-      const int64_t q = t / up;
-      const int ph = (int)(t - q * up);
-      const int base = (int)(q - q_lo);
-      float acc = 0.0f;
-      for (int i = hpp - 1; i >= 0; --i) acc = ssr_fadd_rn(acc, ssr_fmul_rn(xw[base - i], h[ph + i * up]));
-      y[m] = acc;
+    for (int it = tid; it < up * G; it += NT) {
+      const int r = it % up, g = it / up;
+      const int64_t mf = m0 + r + (int64_t)g * J * up;          // first output of this item
+      if (mf < m1) {
+        const int64_t t0 = (mf + p.n_pre_remove) * down;
+        const int64_t q0 = t0 / up;
+        const int ph = (int)(t0 - q0 * up);
+        const int base = (int)(q0 - q_lo);
+        float acc[J];
+        int xb[J];   // window slot of the OLDEST input sample of output j (outputs past m1 alias output 0, never stored)
+        SSR_UNROLL for (int j = 0; j < J; ++j) {
+          acc[j] = 0.0f;
+          xb[j] = (mf + (int64_t)j * up < m1) ? base + j * down - (hpp - 1) : base - (hpp - 1);
+        }
+        // k ascending = input index ascending (tap index descending): SciPy's accumulation order.
+        // Partial unroll keeps several taps' worth of LDS reads in flight per wait.
+        int hi = ph + (hpp - 1) * up;
+        SSR_UNROLL4 for (int k = 0; k < hpp; ++k) {
+          const float hv = (hi < h_len) ? h[hi] : 0.0f;
+          hi -= up;
+          SSR_UNROLL for (int j = 0; j < J; ++j) acc[j] = ssr_fadd_rn(acc[j], ssr_fmul_rn(xw[xb[j] + k], hv));
+        }
+        SSR_UNROLL for (int j = 0; j < J; ++j) {
+          const int64_t m = mf + (int64_t)j * up;
+          if (m < m1) y[m] = acc[j];
+        }
+      }
     }
   });
 }

@@ -171,10 +171,12 @@ extern "C" int emu_ola(int n_fft, int hop, const float* frames, const int64_t* f
 
 // ---- polyphase resampler ------------------------------------------------------------------------------
 extern "C" int emu_resample(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
-                            const int32_t* out_len, int n_items, int up, int down, const float* taps, int n_taps,
-                            int n_pre_remove, int outs_per_block, int n_blocks, float* out) {
-  SsrResampleParams p{in, in_off, in_len, out_off, out_len, up, down, taps, n_taps, n_pre_remove, outs_per_block, out};
+                            const int32_t* out_len, int n_items, int max_out_len, int up, int down, const float* taps,
+                            int n_taps, int n_pre_remove, int groups, int taps_in_lds, float* out) {
+  SsrResampleParams p{in, in_off, in_len, out_off, out_len, up, down, taps, n_taps, n_pre_remove,
+                      groups > 0 ? groups : ssr_resample_pick_groups(up, down), taps_in_lds, out};
   SsrBlk blk{SSR_RESAMPLE_NT};
+  const int n_blocks = (max_out_len + ssr_resample_opb(p) - 1) / ssr_resample_opb(p);
   for (int item = 0; item < n_items; ++item)
     for (int b = 0; b < n_blocks; ++b) {
       auto lds = poisoned(ssr_resample_lds_bytes(p));

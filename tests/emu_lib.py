@@ -160,15 +160,14 @@ def istft(res, ims, lengths, n_fft=2048, hop=441, precision=1, pairs_per_chunk=4
     return [out[off[i]:off[i] + lens[i]] for i in range(len(lens))]
 
 
-def resample(sigs, up, down, taps_full, n_pre_remove, outs_per_block=512):
+def resample(sigs, up, down, taps_full, n_pre_remove, groups=0, taps_in_lds=1):
     a, off, lens = ragged(sigs)
     out_len = np.array([-(-int(n) * up // down) for n in lens], np.int32)
     out_off = np.concatenate(([0], np.cumsum(out_len)[:-1])).astype(np.int64)
     out = np.full(int(out_len.sum()), np.nan, np.float32)
     taps = np.ascontiguousarray(taps_full, np.float32)
-    n_blocks = int(-(-out_len.max() // outs_per_block))
     rc = lib().emu_resample(_p(a, C.c_float), _p(off, C.c_int64), _p(lens, C.c_int32), _p(out_off, C.c_int64),
-                            _p(out_len, C.c_int32), len(lens), up, down, _p(taps, C.c_float), len(taps), n_pre_remove,
-                            outs_per_block, n_blocks, _p(out, C.c_float))
+                            _p(out_len, C.c_int32), len(lens), int(out_len.max()), up, down, _p(taps, C.c_float), len(taps),
+                            n_pre_remove, groups, taps_in_lds, _p(out, C.c_float))
     assert rc == 0
     return [out[out_off[i]:out_off[i] + out_len[i]] for i in range(len(lens))]

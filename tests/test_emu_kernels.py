@@ -99,9 +99,11 @@ def test_resampler_bit_exact_vs_scipy(golden, up, down):
     x = golden["rs_x16k"]
     sig = [x, x[:777], x[:5]]
     p = ors.poly_plan(len(x), up, down)
-    out = E.resample(sig, up, down, p["h_full"][:p["n_pre_pad"] + len(p["h"])], p["n_pre_remove"], outs_per_block=300)
-    for s, o in zip(sig, out):
-        np.testing.assert_array_equal(o, signal.resample_poly(s, up, down))
+    taps = p["h_full"][:p["n_pre_pad"] + len(p["h"])]
+    for groups, in_lds in ((0, 1), (1, 1), (3, 0)):          # default geometry, smallest block, taps read through L2
+        out = E.resample(sig, up, down, taps, p["n_pre_remove"], groups=groups, taps_in_lds=in_lds)
+        for s, o in zip(sig, out):
+            np.testing.assert_array_equal(o, signal.resample_poly(s, up, down))
 
 
 @pytest.mark.parametrize("ppt", [8, 16])

@@ -43,6 +43,21 @@ def make_inputs(n_pairs, device, seed):
     return est.contiguous(), tgt.contiguous()
 
 
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/rNN_traffic.json, produced by tools/collect_profiles.sh + tools/pmc_to_json.py: separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).  None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return d["traffic_bytes_per_launch"][kernel_key]["total_bytes"], os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def event_time_ms(fn, iters):
     """Average duration of fn() in ms, HIP events on the current stream (the one the kernels launch on)."""
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -165,9 +180,12 @@ def main():
     dom_name, dom_ms = ("ssr_stft_pair(k_stft)", ms_stft) if ms_stft >= ms_ssim else ("ssr_ssim(k_ssim)", ms_ssim)
     alg_bytes = BYTES_PER_PAIR * a.pairs
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic("k_stft<double, 11" if ms_stft >= ms_ssim else "k_ssim")
+    if a.pairs != 1024 or a.precision != "f64":
+        traffic, traffic_src = None, None          # the PMC file was collected at the default workload only
     fft_flops = 2 * 376 * 2.5 * 2048 * 11 * a.pairs          # 42.4 MFLOP of real-FFT work per pair
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(dom_ms, 4),
                 "note": "fused path is compute-side (f64 FFT + f64 SSIM moments); secondary: STFT kernel runs at "
                         "%.2f TFLOP/s of real-FFT work = %.3f of the f64 vector peak"

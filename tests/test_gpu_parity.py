@@ -251,3 +251,57 @@ def test_full_size_properties_resample_cfg5():
     np.testing.assert_array_equal(y[3].cpu().numpy(), ref)
     y2 = B.resample_poly([2.0 * x[0]], 441, 160)[0].cpu().numpy()
     np.testing.assert_array_equal(y2, 2.0 * B.resample_poly([x[0]], 441, 160)[0].cpu().numpy())   # scaling by 2 is exact
+
+
+def test_evaluate_end_to_end_from_wav_files(tmp_path, monkeypatch):
+    """SSR_Eval_Helper.evaluate() on a small VCTK-shaped tree of .wav files (3 speakers, ragged lengths, identity testee,
+    setting_fft cutoff 12 kHz, input 44.1 kHz, evaluation 48 kHz = BASELINE config 1's shape): per-file metrics against the
+    oracle pipeline on the same decoded samples, aggregation = mean of speaker means, JSON written as the reference does."""
+    import json
+    from ssr_eval_amd import SSR_Eval_Helper, BasicTestee, lowpass
+    from ssr_eval_amd import backend as B
+    from ssr_eval_amd.io import write_wav, read_audio
+    from oracle import lowpass as olp, metrics as om, resample as ors, aggregate as oagg
+    rng = np.random.default_rng(2937)
+    root = tmp_path / "vctk_test"
+    counts = {"p360": 3, "p361": 2, "s5": 3}
+    for spk, c in counts.items():
+        (root / spk).mkdir(parents=True)
+        for i in range(c):
+            n = int(rng.integers(44100, 2 * 44100))
+            t = np.arange(n) / 44100.0
+            x = 0.2 * np.sin(2 * np.pi * (150 + 40 * i) * t) * np.sin(2 * np.pi * 3 * t) + 0.05 * rng.standard_normal(n)
+            write_wav(str(root / spk / ("%s_%03d_mic1.wav" % (spk, i))), x.astype(np.float32), 44100)
+    (root / "p360" / "p360_000_mic1_proc_x.wav").write_bytes(b"")      # skipped: name contains "proc"
+    (root / "log.txt").write_text("not a speaker")
+    monkeypatch.chdir(tmp_path)
+    h = SSR_Eval_Helper(BasicTestee(), test_name="unprocessed", input_sr=44100, output_sr=44100, evaluation_sr=48000,
+                        test_data_root=str(root), setting_fft={"cutoff_freq": [12000]})
+    res = h.evaluate(limit_test_nums=-1, limit_test_speaker=-1)
+    assert sorted(k for k in res if k not in ("each_speaker", "averaged")) == sorted(counts)
+    key = "proc_fft_24000_44100"
+    expect = {}
+    for spk, c in counts.items():
+        assert len(res[spk]) == c
+        expect[spk] = {}
+        for fn in res[spk]:
+            x44, sr = read_audio(str(root / spk / fn))
+            assert sr == 44100
+            tgt = ors.librosa_resample_polyphase(x44, 44100, 48000)
+            est_o = ors.librosa_resample_polyphase(olp.lowpass(x44, 12000, 44100, 1, "stft_hard"), 44100, 48000)
+            # the degraded waveform itself: HIP low-pass + resampler vs the oracle's, <= 1 float32 ulp
+            est = B.resample_poly([lowpass(x44, 12000, 44100, order=1, _type="stft_hard")], 48000, 44100)[0].cpu().numpy()
+            np.testing.assert_allclose(est, est_o, atol=3e-7)   # <= 1 ulp before the 21-tap resampler
+            # log-SISpec of a band-limited estimate is ill-conditioned in the estimate's last bit (its stop band IS
+            # float32 rounding noise), so the metric kernels are checked on the identical estimate samples
+            want = om.evaluation(est, tgt, 48000)
+            expect[spk][fn] = {key: want}
+            np.testing.assert_allclose(_vec(res[spk][fn][key]), _vec(want), rtol=1e-5)
+    each, avg = oagg.aggregate(expect)
+    for m in KEYS:
+        assert abs(res["averaged"][key][m] - avg[key][m]) <= 1e-5 * abs(avg[key][m])
+        for spk in counts:
+            assert abs(res["each_speaker"][spk][key][m] - each[spk][key][m]) <= 1e-5 * abs(each[spk][key][m])
+    np.testing.assert_allclose(h.last_allreduce_average, [res["averaged"][key][m] for m in KEYS], rtol=1e-12)
+    files = list((tmp_path / "results").glob("*-unprocessed.json"))
+    assert len(files) == 1 and json.load(open(files[0]))["averaged"] == res["averaged"]

@@ -208,6 +208,22 @@ class SSR_Eval_Helper:
             ret.update(self.lowpass_stft_hard(file, x, sr))
         return ret
 
+    def preprocess_arrays(self, xs, sr):
+        """preprocess_array for a list of waveforms; the FFT low-pass of ALL (waveform, cutoff) combinations is one
+        batched K6 call.  Key order per item is the reference's (the fft keys come last, eval.py:268-269)."""
+        fft_setting, self.setting_fft = self.setting_fft, None
+        try:
+            rets = [self.preprocess_array(x, sr) for x in xs]
+        finally:
+            self.setting_fft = fft_setting
+        if fft_setting is not None and xs:
+            keys, ratios = self._fft_plan_keys(sr)
+            ys = stft_hard_lowpass_batch([x for x in xs for _ in keys], ratios * len(xs), self._device)
+            for i, ret in enumerate(rets):
+                for j, k in enumerate(keys):
+                    ret[k] = ys[i * len(keys) + j]
+        return rets
+
     def preprocess(self, file, sr):
         from .io import load_audio
         return self.preprocess_array(load_audio(file, sr), sr, file)
@@ -230,8 +246,9 @@ class SSR_Eval_Helper:
         """items: list of (target waveform @ evaluation_sr, input waveform @ input_sr).
         -> list of {key: {metric: float}} (one dict per item), everything batched on the GPU."""
         all_keys, all_proc, all_tgt, all_extra, owner = [], [], [], [], []
+        degraded = self.preprocess_arrays([np.asarray(x) for _, x in items], self.model_input_sr)
         for i, (target, x) in enumerate(items):
-            keys, outs, extras = self._infer_and_collect(self.preprocess_array(np.asarray(x), self.model_input_sr))
+            keys, outs, extras = self._infer_and_collect(degraded[i])
             for k, o, e in zip(keys, outs, extras):
                 all_keys.append(k); all_proc.append(o.astype(np.float32)); all_tgt.append(np.asarray(target, np.float32))
                 all_extra.append(e); owner.append(i)
@@ -247,20 +264,25 @@ class SSR_Eval_Helper:
         self._last_processed = dict(zip(zip(owner, all_keys), all_proc)) if self.save_processed_result else None
         return results
 
-    def evaluate_single(self, file):
-        """eval.py:128-156 for one file."""
+    def evaluate_files(self, files):
+        """eval.py:128-156 for a LIST of files in one batched pass (decode on the host, everything else on the GPU)."""
         from .io import load_audio, write_wav
-        target = load_audio(file, self.evaluationset_sr)           # the reference shells out to sox here
-        x = load_audio(file, self.model_input_sr)
-        res = self.evaluate_arrays([(target, x)])[0]
+        items = [(load_audio(f, self.evaluationset_sr),            # the reference shells out to sox here
+                  load_audio(f, self.model_input_sr)) for f in files]
+        res = self.evaluate_arrays(items)
         if self.save_processed_result:
-            for (_, k), y in self._last_processed.items():
-                write_wav(file + k + "_processed_" + self.test_name + ".wav", y, self.evaluationset_sr)
+            for (i, k), y in self._last_processed.items():
+                write_wav(files[i] + k + "_processed_" + self.test_name + ".wav", y, self.evaluationset_sr)
         return res
 
-    def evaluate(self, limit_test_nums=-1, limit_test_speaker=-1, save_json=True):
+    def evaluate_single(self, file):
+        """eval.py:128-156 for one file."""
+        return self.evaluate_files([file])[0]
+
+    def evaluate(self, limit_test_nums=-1, limit_test_speaker=-1, save_json=True, batch_files=32):
         """eval.py:171-227: walk speakers/files, evaluate, aggregate as mean of speaker means, write JSON.
-        With torch.distributed initialised the (speaker, file) list is sharded round-robin over ranks and the
+        Files are evaluated `batch_files` at a time (one ragged launch sequence per batch).  With
+        torch.distributed initialised the (speaker, file) list is sharded round-robin over ranks and the
         per-utterance rows are exchanged once (ssr_eval_amd.dist); every rank returns the full result."""
         from datetime import datetime
         work = []                                                   # (speaker, file) in the reference's order
@@ -280,7 +302,10 @@ class SSR_Eval_Helper:
             work += [(speaker, f) for f in files]
         rank, world = D.rank_world()
         mine = D.shard_indices(len(work), rank, world)
-        local = [self.evaluate_single(os.path.join(self.test_data_root, *work[i])) for i in mine]
+        paths = [os.path.join(self.test_data_root, *work[i]) for i in mine]
+        local = []
+        for b in range(0, len(paths), max(1, int(batch_files))):   # ragged batches of files per launch sequence
+            local += self.evaluate_files(paths[b:b + max(1, int(batch_files))])
         return self._assemble(work, speakers, mine, local, save_json, datetime.now())
 
     def _assemble(self, work, speakers, mine, local, save_json, now):

@@ -13,6 +13,7 @@
 #include "ssr_lowpass.h"
 #include "ssr_metrics.h"
 #include "ssr_resample.h"
+#include "ssr_stft_r3.h"
 #include "ssr_tables.h"
 
 #define SSR_VERSION 100
@@ -41,6 +42,14 @@ void k_stft(SsrStftParams<T> p) {
   SsrBlk blk{(int)threadIdx.x};
   const int item = blockIdx.x / p.n_chunks, chunk = blockIdx.x % p.n_chunks;
   ssr_stft_body<T, LOGN, BLU, MODE, SUMS, ssr_stft_ppt(LOGN, BLU)>(p, blk, chunk, item, smem);
+}
+
+template <typename T, int LOGN, int MODE, bool SUMS>
+__global__ __launch_bounds__((1 << LOGN) / 8) void k_stft_r3(SsrStftParams<T> p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  SsrBlk blk{(int)threadIdx.x};
+  const int item = blockIdx.x / p.n_chunks, chunk = blockIdx.x % p.n_chunks;
+  ssr_stft_r3_body<T, LOGN, MODE, SUMS>(p, blk, chunk, item, smem);
 }
 
 template <typename T, int LOGN>
@@ -167,9 +176,32 @@ template <typename T, int LOGN, bool BLU> static int launch_stft_inst(SsrStftPar
                                                              : launch_stft_mode<T, LOGN, BLU, SSR_MODE_PAIR, false>(p, grid, s);
 }
 
+template <typename T, int LOGN, int MODE, bool SUMS>
+static int launch_stft_r3_mode(SsrStftParams<T>& p, int grid, hipStream_t s) {
+  const size_t lds = SsrStftR3Lds<T, LOGN>::bytes(p.n_fft / 3);
+  HIP_TRY(hipFuncSetAttribute((const void*)k_stft_r3<T, LOGN, MODE, SUMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_stft_r3<T, LOGN, MODE, SUMS>), dim3(grid), dim3((1 << LOGN) / 8), lds, s, p);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+template <typename T, int LOGN> static int launch_stft_r3(SsrStftParams<T>& p, int grid, hipStream_t s) {
+  if (p.mode != SSR_MODE_PAIR) return launch_stft_r3_mode<T, LOGN, SSR_MODE_SINGLE, false>(p, grid, s);
+  return (p.metric_mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC)) ? launch_stft_r3_mode<T, LOGN, SSR_MODE_PAIR, true>(p, grid, s)
+                                                             : launch_stft_r3_mode<T, LOGN, SSR_MODE_PAIR, false>(p, grid, s);
+}
+
 template <typename T> static int launch_stft_t(const ssr_plan* pl, SsrStftParams<T>& p, int grid, hipStream_t s) {
   const DevTables<T>& d = tables_of<T>(pl);
   p.window = d.window_h; p.tw = d.tw; p.wchirp = d.wchirp; p.bfilt = d.bfilt; p.chirp = d.chirp;
+  if (pl->eng.radix == 3) {
+    switch (pl->eng.logn) {
+      case 8: return launch_stft_r3<T, 8>(p, grid, s);
+      case 9: return launch_stft_r3<T, 9>(p, grid, s);
+      case 10: return launch_stft_r3<T, 10>(p, grid, s);
+      case 11: return launch_stft_r3<T, 11>(p, grid, s);
+    }
+    return fail(SSR_ERR_UNSUPPORTED, "no radix-3 kernel for this FFT length");
+  }
 #define CASE(L)                                                                   \
   case L:                                                                         \
     return pl->eng.bluestein ? launch_stft_inst<T, L, true>(p, grid, s) : launch_stft_inst<T, L, false>(p, grid, s);

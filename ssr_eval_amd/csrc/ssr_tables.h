@@ -13,15 +13,28 @@ static const long double SSR_PI_L = 3.14159265358979323846264338327950288L;
 inline bool ssr_is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 inline int ssr_ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 
-// engine choice for an n_fft: direct 2^LOGN FFT when n_fft is a power of two in [256, 4096];
-// otherwise Bluestein with M = 2^LOGM >= max(256, 2*n_fft - 1), M <= 8192.
-struct SsrEngine { bool ok; bool bluestein; int logn; };
+// engine choice for an n_fft:
+//  * direct 2^LOGN FFT when n_fft is a power of two in [256, 4096];
+//  * otherwise Bluestein with M = 2^LOGM >= max(256, 2*n_fft - 1), M <= 8192;
+//  * radix-3 x Bluestein when n_fft = 3 q and plain Bluestein would need M = 8192 while the three length-q
+//    sub-transforms fit M = 2048 (n_fft = 2229 = 3 * 743, i.e. AudioMetrics(48000)): 6 x FFT-2048 in a 35 KB LDS
+//    buffer (2 workgroups per CU) instead of 2 x FFT-8192 in 139 KB (1 workgroup per CU).
+struct SsrEngine { bool ok; bool bluestein; int logn; int radix; int q; };
 inline SsrEngine ssr_pick_engine(int n_fft) {
-  SsrEngine e{false, false, 0};
+  SsrEngine e{false, false, 0, 1, 0};
   if (n_fft < 2) return e;
+  e.q = n_fft;
   if (ssr_is_pow2(n_fft) && n_fft >= 256 && n_fft <= 4096) { e.ok = true; e.logn = ssr_ilog2(n_fft); return e; }
   int m = 256;
   while (m < 2 * n_fft - 1) m <<= 1;
+#ifndef SSR_NO_RADIX3
+  if (n_fft % 3 == 0 && m >= 8192) {
+    const int q = n_fft / 3;
+    int mq = 256;
+    while (mq < 2 * q - 1) mq <<= 1;
+    if (mq <= 2048) { e.ok = true; e.bluestein = true; e.logn = ssr_ilog2(mq); e.radix = 3; e.q = q; return e; }
+  }
+#endif
   if (m > 8192) return e;
   e.ok = true; e.bluestein = true; e.logn = ssr_ilog2(m);
   return e;
@@ -76,19 +89,28 @@ template <typename T> bool ssr_build_tables(int n_fft, SsrTables<T>& t) {
     t.tw[i] = {(T)cosl(ang), (T)sinl(ang)};
   }
   if (t.eng.bluestein) {
-    std::vector<long double> cr(n_fft), ci(n_fft);
-    for (int k = 0; k < n_fft; ++k) {
-      const int64_t kk = ((int64_t)k * k) % (2 * (int64_t)n_fft);  // exact phase reduction
-      const long double ang = -SSR_PI_L * (long double)kk / n_fft;
+    // inner (Bluestein) length q: n_fft itself, or n_fft / 3 under the radix-3 outer step
+    const int q = t.eng.q, R = t.eng.radix;
+    std::vector<long double> cr(q), ci(q);
+    for (int k = 0; k < q; ++k) {
+      const int64_t kk = ((int64_t)k * k) % (2 * (int64_t)q);  // exact phase reduction
+      const long double ang = -SSR_PI_L * (long double)kk / q;
       cr[k] = cosl(ang); ci[k] = sinl(ang);
     }
-    t.chirp.resize(n_fft); t.wchirp.resize(n_fft);
-    for (int k = 0; k < n_fft; ++k) {
-      t.chirp[k] = {(T)0.5 * (T)cr[k], (T)0.5 * (T)ci[k]};
-      t.wchirp[k] = {(T)(w[k] * cr[k]), (T)(w[k] * ci[k])};
-    }
+    // chirp[r*q + k]  = 0.5 * exp(-i*pi*k^2/q) * exp(-2*pi*i * r*k / n_fft)   (post-multiplier incl. the outer twiddle)
+    // wchirp[r*q + m] = window[R*m + r] * exp(-i*pi*m^2/q)                     (pre-multiplier on the decimated frame)
+    t.chirp.resize((size_t)R * q); t.wchirp.resize((size_t)R * q);
+    for (int r = 0; r < R; ++r)
+      for (int k = 0; k < q; ++k) {
+        const int64_t rk = ((int64_t)r * k) % n_fft;
+        const long double a2 = -2.0L * SSR_PI_L * (long double)rk / n_fft;
+        const long double tr = cosl(a2), ti = sinl(a2);
+        t.chirp[(size_t)r * q + k] = {(T)(0.5L * (cr[k] * tr - ci[k] * ti)), (T)(0.5L * (cr[k] * ti + ci[k] * tr))};
+        const long double wv = w[(size_t)R * k + r];
+        t.wchirp[(size_t)r * q + k] = {(T)(wv * cr[k]), (T)(wv * ci[k])};
+      }
     std::vector<long double> br(N, 0.0L), bi(N, 0.0L);
-    for (int m = 0; m < n_fft; ++m) {
+    for (int m = 0; m < q; ++m) {
       br[m] = cr[m]; bi[m] = -ci[m];
       if (m) { br[N - m] = cr[m]; bi[N - m] = -ci[m]; }
     }

@@ -10,6 +10,7 @@
 #include "../../ssr_eval_amd/csrc/ssr_metrics.h"
 #include "../../ssr_eval_amd/csrc/ssr_lowpass.h"
 #include "../../ssr_eval_amd/csrc/ssr_resample.h"
+#include "../../ssr_eval_amd/csrc/ssr_stft_r3.h"
 #include "../../ssr_eval_amd/csrc/ssr_tables.h"
 
 static std::vector<char> poisoned(size_t bytes) { return std::vector<char>(bytes + 64, (char)0xFF); }
@@ -37,6 +38,19 @@ static void run_stft(SsrStftParams<T> p, int n_items) {
   return run_stft_ppt<T, LOGN, BLU, ssr_stft_ppt(LOGN, BLU)>(p, n_items);
 }
 
+template <typename T, int LOGN>
+static void run_stft_r3(SsrStftParams<T> p, int n_items) {
+  SsrBlk blk{SsrFftPlan<LOGN, 8>::NT};
+  for (int item = 0; item < n_items; ++item)
+    for (int c = 0; c < p.n_chunks; ++c) {
+      auto lds = poisoned(SsrStftR3Lds<T, LOGN>::bytes(p.n_fft / 3));
+      if (p.mode != SSR_MODE_PAIR) ssr_stft_r3_body<T, LOGN, SSR_MODE_SINGLE, false>(p, blk, c, item, lds.data());
+      else if (p.metric_mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC))
+        ssr_stft_r3_body<T, LOGN, SSR_MODE_PAIR, true>(p, blk, c, item, lds.data());
+      else ssr_stft_r3_body<T, LOGN, SSR_MODE_PAIR, false>(p, blk, c, item, lds.data());
+    }
+}
+
 template <typename T>
 static int emu_stft_t(int n_fft, int hop, int mode, int out_kind, int mask, const float* a, const float* b,
                       const int64_t* a_off, const int64_t* b_off, const int32_t* len, const int64_t* frame_off,
@@ -51,6 +65,15 @@ static int emu_stft_t(int n_fft, int hop, int mode, int out_kind, int mask, cons
   p.window = t.window_h.data(); p.tw = t.tw.data();
   p.wchirp = t.wchirp.data(); p.bfilt = t.bfilt.data(); p.chirp = t.chirp.data();
   p.out_a = out_a; p.out_b = out_b; p.part = part;
+  if (t.eng.radix == 3) {
+    switch (t.eng.logn) {
+      case 8: run_stft_r3<T, 8>(p, n_items); return 0;
+      case 9: run_stft_r3<T, 9>(p, n_items); return 0;
+      case 10: run_stft_r3<T, 10>(p, n_items); return 0;
+      case 11: run_stft_r3<T, 11>(p, n_items); return 0;
+    }
+    return -3;
+  }
 #define CASE(L)                                                         \
   case L:                                                               \
     if (t.eng.bluestein) run_stft<T, L, true>(p, n_items);              \

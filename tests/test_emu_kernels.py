@@ -124,3 +124,18 @@ def test_fft_engine_points_per_thread(ppt, n_fft, hop, golden):
             np.testing.assert_allclose(got, golden["ev_bench2048_out"], rtol=1e-5)
     finally:
         E.lib().emu_force_ppt(0)
+
+
+@pytest.mark.parametrize("n_fft,hop", [(2229, 480), (3 * 257, 100), (3 * 1021, 700)])
+def test_radix3_bluestein_engine(n_fft, hop):
+    """n_fft = 3 q sizes that route to the radix-3 x Bluestein body (plain Bluestein would need M = 8192)."""
+    rng = np.random.default_rng(n_fft)
+    lens = (n_fft * 2 + 31, n_fft // 2 + 1, n_fft + 3 * hop)
+    x = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    y = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    ea, tb, _ = E.stft(x, y, n_fft, hop, precision=1, units_per_chunk=2)
+    sa, _, _ = E.stft(x, None, n_fft, hop, precision=1, mode=1, units_per_chunk=2)
+    for i in range(len(lens)):
+        ra, rb = ostft.stft_mag_TF(x[i], n_fft, hop), ostft.stft_mag_TF(y[i], n_fft, hop)
+        tol = 2e-7 * max(ra.max(), rb.max())
+        assert np.abs(ea[i] - ra).max() <= tol and np.abs(tb[i] - rb).max() <= tol and np.abs(sa[i] - ra).max() <= tol

@@ -294,6 +294,7 @@ SSR_DEV void ssr_finalize_item(const SsrFinalizeParams& p, int item) {
   if (p.ssim_part && (p.metric_mask & SSR_M_SSIM)) {
     double s = 0.0;
     for (int c = 0; c < p.n_tiles; ++c) s += p.ssim_part[(int64_t)item * p.n_tiles + c];
-    o[3] = s / ((double)(T - 6) * (double)(p.F - 6));
+    // images smaller than the 7x7 window have no valid output (skimage raises for them): NaN, never a division by <= 0
+    o[3] = (T >= SSR_SSIM_WIN && p.F >= SSR_SSIM_WIN) ? s / ((double)(T - 6) * (double)(p.F - 6)) : nan_;
   }
 }

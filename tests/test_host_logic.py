@@ -130,3 +130,25 @@ def test_iir_host_path_matches_reference(golden):
     for ft in ("butter", "cheby1", "ellip", "bessel"):
         np.testing.assert_array_equal(lowpass(golden["ss_x"], 4000, 44100, order=6, _type=ft), golden["iir_%s" % ft])
     np.testing.assert_array_equal(lowpass(golden["ss_x"], 4000, 44100, order=6, _type="but"), golden["iir_butter"])
+
+
+def test_cabi_argument_validation_needs_no_gpu():
+    """Every entry point rejects null / nonsensical arguments with SSR_ERR_INVALID_ARG before touching the device."""
+    from ssr_eval_amd import _lib
+    lib = _lib.load()
+    assert lib.ssr_stft(None, None, None, None, None, 1, 4096, 1, None, None, None) == -1
+    assert b"null" in lib.ssr_last_error()
+    assert lib.ssr_pair_metrics(None, None, None, None, None, None, None, 1, 4096, 9, 15, None, None, 0, None) == -1
+    assert lib.ssr_spectrogram_metrics(None, None, None, None, 1, 10, 10, 15, None, None, 0, None) == -1
+    assert lib.ssr_fft_lowpass(None, None, None, None, None, None, 1, 4096, 9, None, None, 0, None) == -1
+    assert lib.ssr_istft(None, None, None, None, None, None, 1, 4096, 9, None, None, 0, None) == -1
+    assert lib.ssr_resample_poly(None, None, None, None, None, 1, 10, 2, 1, None, 5, 0, None, None) == -1
+    assert lib.ssr_magphase(None, None, 10, 0.0, None, None, None, None) == -1
+    h = C.c_void_p()
+    assert lib.ssr_plan_create(1, 512, 1, C.byref(h)) == -1          # n_fft < 2
+    assert lib.ssr_plan_create(2048, 0, 1, C.byref(h)) == -1         # hop < 1
+    assert lib.ssr_plan_create(2048, 512, 7, C.byref(h)) == -1       # unknown precision
+    assert lib.ssr_plan_create(5000, 512, 1, C.byref(h)) == -2       # Bluestein length would exceed 8192
+    assert lib.ssr_plan_destroy(None) == 0
+    assert lib.ssr_num_frames(None, 100) == -1
+    assert lib.ssr_pair_metrics_workspace_bytes(None, 4, 4096, 36) == 0

@@ -132,6 +132,19 @@ int ssr_resample_poly(const float* in, const int64_t* in_off, const int32_t* in_
                       const int32_t* out_len, int n_items, int max_out_len, int up, int down, const float* taps,
                       int n_taps, int n_pre_remove, float* out, void* stream);
 
+/* N1.  Zero-phase IIR: scipy.signal.sosfiltfilt(sos, x) (padtype "odd", padlen 3*ntaps) for float32 x, float64
+ * arithmetic and output - the arithmetic of lowpass_filter / bandpass_filter (ssr_eval/lowpass.py:54-131, called
+ * from lowpass()/bandpass() :175-190,:215-254 and SSR_Eval_Helper.lowpass_butterworth/... eval.py:334-399).
+ * sos: DEVICE [n_sections][6] float64 (b0 b1 b2 1 a1 a2, designed by the caller as the reference does with
+ * scipy.signal.butter/cheby1/ellip/bessel(output="sos")); zi: DEVICE [n_sections][2] = scipy.signal.sosfilt_zi(sos);
+ * edge = 3 * (2*n_sections + 1 - min(#(b2 == 0), #(a2 == 0))); every item needs len > edge.  n_sections <= 16.
+ * y: float64, same ragged layout as x.  workspace: ssr_sosfiltfilt_workspace_bytes(total_len, n_items, edge).
+ * Bit-identical to SciPy (same operation order, no fused multiply-add). */
+size_t ssr_sosfiltfilt_workspace_bytes(int64_t total_len, int n_items, int edge);
+int ssr_sosfiltfilt(const float* x, const int64_t* off, const int32_t* len, int n_items, int64_t total_len,
+                    const double* sos, const double* zi, int n_sections, int edge, double* y, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,8 @@ SIGNATURES = {
     "ssr_resample_plan": (_i, [_i64, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64), C.POINTER(_i),
                                C.POINTER(_i), C.POINTER(_i)]),
     "ssr_resample_poly": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "ssr_sosfiltfilt_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "ssr_sosfiltfilt": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -325,3 +325,30 @@ def resample_poly(wavs, up, down, device=None):
                 _vp(r.data), _vp(r.off), _vp(r.len), _vp(out_off_d), _vp(out_len_d), r.n, int(out_len.max()), rp.up,
                 rp.down, _vp(rp.taps), int(rp.taps.numel()), rp.n_pre_remove, _vp(out), _stream()))
         return [out[out_off[i]:out_off[i] + out_len[i]] for i in range(r.n)]
+
+
+def sosfiltfilt(sos, wavs, device=None):
+    """scipy.signal.sosfiltfilt(sos, x) for a list of float32 waveforms on the GPU (N1); returns float64 tensors.
+    The section coefficients and sosfilt_zi come from SciPy on the host (filter design, as in the reference)."""
+    from scipy.signal import sosfilt_zi
+    dev = torch.device(device) if device is not None else default_device()
+    sos = np.ascontiguousarray(sos, dtype=np.float64)
+    if sos.ndim != 2 or sos.shape[1] != 6:
+        raise ValueError("sos must have shape (n_sections, 6)")
+    n_sections = sos.shape[0]
+    ntaps = 2 * n_sections + 1 - min(int((sos[:, 2] == 0).sum()), int((sos[:, 5] == 0).sum()))
+    edge = 3 * ntaps
+    with torch.cuda.device(dev):
+        r = wavs if isinstance(wavs, Ragged) else Ragged.from_list(wavs, dev)
+        if r.n and int(r.lens_host.min()) <= edge:
+            raise ValueError("The length of the input vector x must be greater than padlen, which is %d." % edge)
+        lib = _lib.load()
+        total = int(r.lens_host.sum())
+        sos_d = torch.from_numpy(sos).to(dev)
+        zi_d = torch.from_numpy(np.ascontiguousarray(sosfilt_zi(sos), dtype=np.float64)).to(dev)
+        ws_bytes = int(lib.ssr_sosfiltfilt_workspace_bytes(total, r.n, edge))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        y = torch.empty(total, dtype=torch.float64, device=dev)
+        _lib.check(lib.ssr_sosfiltfilt(_vp(r.data), _vp(r.off), _vp(r.len), r.n, total, _vp(sos_d), _vp(zi_d), n_sections, edge,
+                                       _vp(y), _vp(ws), ws_bytes, _stream()))
+        return r.split(y)

@@ -12,6 +12,7 @@
 #include "../../include/ssr_hip.h"
 #include "ssr_lowpass.h"
 #include "ssr_metrics.h"
+#include "ssr_iir.h"
 #include "ssr_resample.h"
 #include "ssr_stft_r3.h"
 #include "ssr_tables.h"
@@ -92,6 +93,12 @@ __global__ __launch_bounds__(SSR_RESAMPLE_NT) void k_resample(SsrResampleParams 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SsrBlk blk{(int)threadIdx.x};
   ssr_resample_body(p, blk, blockIdx.x % blocks_per_item, blockIdx.x / blocks_per_item, smem);
+}
+
+template <int G>
+__global__ __launch_bounds__(64) void k_sosfiltfilt(SsrIirParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ssr_iir_wave<G>(p, blockIdx.x, threadIdx.x, smem);
 }
 
 __global__ __launch_bounds__(256) void k_magphase(const float* re, const float* im, int64_t n, float eps, float* mag,
@@ -627,6 +634,36 @@ extern "C" int ssr_resample_poly(const float* in, const int64_t* in_off, const i
   if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_resample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int bpi = ceil_div(max_out_len, ssr_resample_opb(p));
   hipLaunchKernelGGL(k_resample, dim3((unsigned)((int64_t)n_items * bpi)), dim3(SSR_RESAMPLE_NT), lds, (hipStream_t)stream, p, bpi);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------
+extern "C" size_t ssr_sosfiltfilt_workspace_bytes(int64_t total_len, int n_items, int edge) {
+  if (total_len <= 0 || n_items <= 0 || edge < 0) return 0;
+  return align256(((size_t)total_len + (size_t)2 * edge * n_items) * sizeof(double));
+}
+
+extern "C" int ssr_sosfiltfilt(const float* x, const int64_t* off, const int32_t* len, int n_items, int64_t total_len,
+                               const double* sos, const double* zi, int n_sections, int edge, double* y,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !off || !len || !sos || !zi || !y) return fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n_sections < 1 || n_sections > 16) return fail(SSR_ERR_UNSUPPORTED, "n_sections must be in [1, 16]");
+  if (edge < 0) return fail(SSR_ERR_INVALID_ARG, "negative edge");
+  if (n_items <= 0) return SSR_OK;
+  if (!workspace || workspace_bytes < ssr_sosfiltfilt_workspace_bytes(total_len, n_items, edge))
+    return fail(SSR_ERR_WORKSPACE, "workspace too small");
+  SsrIirParams p{x, off, len, sos, zi, n_sections, edge, n_items, (double*)workspace, y};
+  hipStream_t s = (hipStream_t)stream;
+  if (n_sections <= 8) {
+    const int groups = 8;
+    const size_t lds = (size_t)groups * 4 * SSR_IIR_CH * sizeof(double);
+    hipLaunchKernelGGL((k_sosfiltfilt<8>), dim3(ceil_div(n_items, groups)), dim3(64), lds, s, p);
+  } else {
+    const int groups = 4;
+    const size_t lds = (size_t)groups * 4 * SSR_IIR_CH * sizeof(double);
+    hipLaunchKernelGGL((k_sosfiltfilt<16>), dim3(ceil_div(n_items, groups)), dim3(64), lds, s, p);
+  }
   HIP_TRY(hipGetLastError());
   return SSR_OK;
 }

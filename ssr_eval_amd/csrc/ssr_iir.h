@@ -1,0 +1,173 @@
+// Kernel N1: zero-phase IIR filtering = scipy.signal.sosfiltfilt(sos, x) (padtype="odd", default padlen) for a
+// ragged batch of float32 signals, float64 arithmetic, float64 output - the arithmetic behind
+// lowpass_filter / bandpass_filter (ssr_eval/lowpass.py:54-131).
+//
+// SciPy's algorithm, reproduced operation for operation (no fused multiply-add, same evaluation order):
+//   ext  = odd extension of x by `edge` samples on both sides, formed in FLOAT32 (2*x[0] - x[k]), then widened;
+//   fwd  = sosfilt(sos, ext,        zi * ext[0]);      bwd = sosfilt(sos, reverse(fwd), zi * fwd[-1]);
+//   y    = reverse(bwd)[edge : -edge]
+//   sosfilt, per sample and per section s (direct form II transposed):
+//       y  = b0*x + z0;   z0 = (b1*x - a1*y) + z1;   z1 = b2*x - a2*y;   x <- y
+// so the result is bit-identical to SciPy's (tests/test_gpu_parity.py::test_sosfiltfilt_bit_exact).
+//
+// Parallelisation: the recurrence is sequential in n inside a section and sequential in s inside a sample,
+// so each utterance is a systolic WAVEFRONT: lane s of a G-lane group owns section s and at step t filters
+// sample n = t - s, taking its input from lane s-1 through one DPP row shift.  A wave carries 64/G utterances;
+// the critical path per step is the 4-operation float64 state update, independent of the number of sections.
+// Input / output are staged through LDS in chunks (next chunk's loads are issued a whole chunk early).
+#pragma once
+#include "ssr_block.h"
+
+#define SSR_IIR_CH 128   // samples per staging chunk (> max group size)
+
+struct SsrIirParams {
+  const float* x;          // signals
+  const int64_t* off;      // [n_items] element offset (also used for y)
+  const int32_t* len;      // [n_items]
+  const double* sos;       // [n_sections, 6]  b0 b1 b2 a0(=1) a1 a2
+  const double* zi;        // [n_sections, 2]  sosfilt_zi(sos)
+  int n_sections, edge, n_items;
+  double* fwd;             // workspace: forward pass output, item i at off[i] + 2*edge*i, length len[i] + 2*edge
+  double* y;               // [same layout as x] float64 result
+};
+
+// odd-extended input sample n of [0, len + 2*edge), float32 arithmetic as numpy does it
+SSR_DEV double ssr_iir_ext(const float* x, int len, int edge, int n) {
+#ifndef SSR_HOST_EMU
+#pragma clang fp contract(off)
+#endif
+  if (n < edge) return (double)(2.0f * x[0] - x[edge - n]);
+  if (n < edge + len) return (double)x[n - edge];
+  return (double)(2.0f * x[len - 1] - x[len - 2 - (n - edge - len)]);
+}
+
+// one section, one sample: SciPy's _sosfilt inner statement sequence
+SSR_DEV double ssr_iir_step(double xin, double b0, double b1, double b2, double a1, double a2, double& z0, double& z1) {
+#ifndef SSR_HOST_EMU
+#pragma clang fp contract(off)
+#endif
+  const double yo = b0 * xin + z0;
+  z0 = (b1 * xin - a1 * yo) + z1;
+  z1 = b2 * xin - a2 * yo;
+  return yo;
+}
+
+#ifdef SSR_HOST_EMU
+// sequential statement of the same computation (what every lane schedule must reproduce)
+static inline void ssr_iir_item_host(const SsrIirParams& p, int item) {
+  const int len = p.len[item], edge = p.edge, S = p.n_sections, ne = len + 2 * edge;
+  const float* x = p.x + p.off[item];
+  double* fwd = p.fwd + p.off[item] + (int64_t)2 * edge * item;
+  double* y = p.y + p.off[item];
+  std::vector<double> z0(S), z1(S);
+  const double x0 = ssr_iir_ext(x, len, edge, 0);
+  for (int s = 0; s < S; ++s) { z0[s] = p.zi[2 * s] * x0; z1[s] = p.zi[2 * s + 1] * x0; }
+  for (int n = 0; n < ne; ++n) {
+    double v = ssr_iir_ext(x, len, edge, n);
+    for (int s = 0; s < S; ++s) v = ssr_iir_step(v, p.sos[6 * s], p.sos[6 * s + 1], p.sos[6 * s + 2], p.sos[6 * s + 4], p.sos[6 * s + 5], z0[s], z1[s]);
+    fwd[n] = v;
+  }
+  const double y0 = fwd[ne - 1];
+  for (int s = 0; s < S; ++s) { z0[s] = p.zi[2 * s] * y0; z1[s] = p.zi[2 * s + 1] * y0; }
+  for (int n = 0; n < ne; ++n) {
+    double v = fwd[ne - 1 - n];
+    for (int s = 0; s < S; ++s) v = ssr_iir_step(v, p.sos[6 * s], p.sos[6 * s + 1], p.sos[6 * s + 2], p.sos[6 * s + 4], p.sos[6 * s + 5], z0[s], z1[s]);
+    const int m = (ne - 1 - n) - edge;
+    if (m >= 0 && m < len) y[m] = v;
+  }
+}
+#else
+// value of `v` held by the lane one position lower in the same 16-lane row (DPP row_shr:1), two 32-bit halves
+SSR_DEV double ssr_dpp_from_lower_lane(double v) {
+  union { double d; int i[2]; } a, b;
+  a.d = v;
+  b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x111, 0xf, 0xf, false);
+  b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x111, 0xf, 0xf, false);
+  return b.d;
+}
+
+// One pass (forward or backward) of the wavefront for the lane's group.  G: lanes per utterance (8 or 16).
+// in_buf / out_buf: this group's LDS staging rings of 2*SSR_IIR_CH doubles each.
+template <int G, bool BACKWARD>
+SSR_DEV void ssr_iir_pass(const SsrIirParams& p, bool active, int s, const float* x, int len, double* fwd, double* y,
+                          double* in_buf, double* out_buf, double b0, double b1, double b2, double a1, double a2,
+                          double zi0, double zi1) {
+  constexpr int CH = SSR_IIR_CH, PER = CH / G;
+  const int edge = p.edge, S = p.n_sections, ne = active ? len + 2 * edge : 0;
+  // every group of the wave runs the same number of chunks (wave-uniform trip count): the maximum over its groups
+  int ne_max = ne;
+  for (int o = 32; o > 0; o >>= 1) { const int t_ = __shfl_xor(ne_max, o); ne_max = t_ > ne_max ? t_ : ne_max; }
+  const int n_chunks = (ne_max + S - 1 + CH - 1) / CH + 1;      // +1: flush of the last outputs
+
+  auto load_in = [&](int n) -> double {
+    if (n >= ne) return 0.0;
+    return BACKWARD ? fwd[ne - 1 - n] : ssr_iir_ext(x, len, edge, n);
+  };
+  // initial state: zi * (first input sample of this pass)
+  const double first = active ? load_in(0) : 0.0;
+  double z0 = zi0 * first, z1 = zi1 * first, yout = 0.0;
+
+  double pre[PER];                                              // chunk 0 staged directly
+  for (int i = 0; i < PER; ++i) in_buf[s * PER + i] = load_in(s * PER + i);
+  for (int c = 0; c < n_chunks; ++c) {
+    // issue the NEXT chunk's loads now; they land while this chunk is being filtered
+    for (int i = 0; i < PER; ++i) pre[i] = load_in((c + 1) * CH + s * PER + i);
+    const int ring = (c & 1) * CH;
+    for (int tb = 0; tb < CH; tb += 8) {
+      double x8[8];                                              // lane 0's next eight inputs: eight LDS reads in flight at once
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x8[k] = in_buf[ring + tb + k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int t = c * CH + tb + k;
+        const int n = t - s;                                     // sample this lane filters at this step
+        const double from_lower = ssr_dpp_from_lower_lane(yout); // lane s-1's output of step t-1 = its sample n
+        const double xin = (s == 0) ? x8[k] : from_lower;
+        if (s < S && n >= 0 && n < ne) {
+          yout = ssr_iir_step(xin, b0, b1, b2, a1, a2, z0, z1);
+          if (s == S - 1) out_buf[n & (2 * CH - 1)] = yout;
+        }
+      }
+    }
+    // flush outputs of chunk c-1 (the last section lags by S-1 < CH steps, so they are complete now)
+    if (c >= 1) {
+      for (int i = 0; i < PER; ++i) {
+        const int n = (c - 1) * CH + s * PER + i;
+        if (n < ne) {
+          const double v = out_buf[n & (2 * CH - 1)];
+          if (BACKWARD) {
+            const int m = (ne - 1 - n) - edge;
+            if (m >= 0 && m < len) y[m] = v;
+          } else {
+            fwd[n] = v;
+          }
+        }
+      }
+    }
+    for (int i = 0; i < PER; ++i) in_buf[((c + 1) & 1) * CH + s * PER + i] = pre[i];
+  }
+}
+
+// grid = ceil(n_items / (64/G)) workgroups of ONE wave; LDS: (64/G) groups * 4*CH doubles
+template <int G>
+SSR_DEV void ssr_iir_wave(const SsrIirParams& p, int wg, int lane, char* lds_base) {
+  constexpr int CH = SSR_IIR_CH, GROUPS = 64 / G;
+  const int g = lane / G, s = lane % G;
+  const int item = wg * GROUPS + g;
+  const bool active = item < p.n_items;
+  const int it = active ? item : 0;
+  const int len = p.len[it], S = p.n_sections;
+  const float* x = p.x + p.off[it];
+  double* fwd = p.fwd + p.off[it] + (int64_t)2 * p.edge * it;
+  double* y = p.y + p.off[it];
+  double* in_buf = reinterpret_cast<double*>(lds_base) + (size_t)g * 4 * CH;
+  double* out_buf = in_buf + 2 * CH;
+  const int sc = s < S ? s : 0;
+  const double b0 = p.sos[6 * sc], b1 = p.sos[6 * sc + 1], b2 = p.sos[6 * sc + 2], a1 = p.sos[6 * sc + 4], a2 = p.sos[6 * sc + 5];
+  const double zi0 = p.zi[2 * sc], zi1 = p.zi[2 * sc + 1];
+  ssr_iir_pass<G, false>(p, active, s, x, len, fwd, y, in_buf, out_buf, b0, b1, b2, a1, a2, zi0, zi1);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the backward pass re-reads `fwd` written by other lanes of this wave
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  ssr_iir_pass<G, true>(p, active, s, x, len, fwd, y, in_buf, out_buf, b0, b1, b2, a1, a2, zi0, zi1);
+}
+#endif

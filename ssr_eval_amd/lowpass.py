@@ -6,9 +6,11 @@
 * ``stft_hard``   -> ``ssr_fft_lowpass`` (K6): STFT(2048/441) -> zero bins >= cut -> ISTFT.
 * ``subsampling`` -> ``ssr_resample_poly`` (K7) down then up, then align_length.
 
-The zero-phase IIR types (butter / cheby1 / ellip / bessel) are SURVEY 8(f) row N1 ("next"): they are NOT
-part of the accelerated path yet and run where the reference runs them - SciPy ``sosfiltfilt`` on the
-host (``_host_iir``).  No parity or performance claim is made for them.
+* butter / cheby1 / ellip / bessel -> ``ssr_sosfiltfilt``: the section coefficients are
+  designed on the host with SciPy exactly as the reference does (filter design is a plan, not data), the
+  zero-phase filtering itself (odd extension, forward and backward second-order-section recurrences) runs on the
+  GPU, bit-identical to ``scipy.signal.sosfiltfilt`` for float32 input.  Float64 input is rounded to float32
+  first (the reference only ever feeds it what librosa.load returned, i.e. float32).
 """
 import numpy as np
 import torch
@@ -56,8 +58,8 @@ def limit(integer, high, low):
     return high if integer > high else (low if integer < low else int(integer))
 
 
-def _host_iir(x, highcut, fs, order, ftype, lowcut=None):
-    """SURVEY 8(f) N1 - zero-phase IIR on the HOST with SciPy, exactly as lowpass.py:54-131 does."""
+def _iir(x, highcut, fs, order, ftype, lowcut=None):
+    """lowpass.py:54-131: SciPy designs the sections (host), ssr_sosfiltfilt filters (GPU, float64, bit-exact)."""
     from scipy import signal
     nyq = 0.5 * fs
     wn = highcut / nyq if lowcut is None else [lowcut / nyq, highcut / nyq]
@@ -69,15 +71,16 @@ def _host_iir(x, highcut, fs, order, ftype, lowcut=None):
               "bessel": lambda: signal.bessel(order, wn, btype=bt, output="sos")}
     if ftype not in design:
         raise Exception("The %s filter %s is not supported!" % ("lowpass" if lowcut is None else "bandpass", ftype))
-    return align_length(x, signal.sosfiltfilt(design[ftype](), x))
+    y = B.sosfiltfilt(design[ftype](), [np.asarray(x, np.float32)])[0].cpu().numpy()
+    return align_length(x, y)
 
 
 def lowpass_filter(x, highcut, fs, order, ftype):
-    return _host_iir(x, highcut, fs, order, ftype)
+    return _iir(x, highcut, fs, order, ftype)
 
 
 def bandpass_filter(x, lowcut, highcut, fs, order, ftype):
-    return _host_iir(x, highcut, fs, order, ftype, lowcut=lowcut)
+    return _iir(x, highcut, fs, order, ftype, lowcut=lowcut)
 
 
 def _check_1d(data):

@@ -9,6 +9,7 @@
 
 #include "../../ssr_eval_amd/csrc/ssr_metrics.h"
 #include "../../ssr_eval_amd/csrc/ssr_lowpass.h"
+#include "../../ssr_eval_amd/csrc/ssr_iir.h"
 #include "../../ssr_eval_amd/csrc/ssr_resample.h"
 #include "../../ssr_eval_amd/csrc/ssr_stft_r3.h"
 #include "../../ssr_eval_amd/csrc/ssr_tables.h"
@@ -205,5 +206,13 @@ extern "C" int emu_resample(const float* in, const int64_t* in_off, const int32_
       auto lds = poisoned(ssr_resample_lds_bytes(p));
       ssr_resample_body(p, blk, b, item, lds.data());
     }
+  return 0;
+}
+
+// ---- zero-phase IIR (sequential statement of the wavefront kernel's arithmetic) -------------------------------
+extern "C" int emu_sosfiltfilt(const float* x, const int64_t* off, const int32_t* len, int n_items, const double* sos,
+                               const double* zi, int n_sections, int edge, double* fwd, double* y) {
+  SsrIirParams p{x, off, len, sos, zi, n_sections, edge, n_items, fwd, y};
+  for (int i = 0; i < n_items; ++i) ssr_iir_item_host(p, i);
   return 0;
 }

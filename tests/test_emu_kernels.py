@@ -139,3 +139,15 @@ def test_radix3_bluestein_engine(n_fft, hop):
         ra, rb = ostft.stft_mag_TF(x[i], n_fft, hop), ostft.stft_mag_TF(y[i], n_fft, hop)
         tol = 2e-7 * max(ra.max(), rb.max())
         assert np.abs(ea[i] - ra).max() <= tol and np.abs(tb[i] - rb).max() <= tol and np.abs(sa[i] - ra).max() <= tol
+
+
+@pytest.mark.parametrize("ftype,order,band", [("butter", 3, False), ("cheby1", 6, False), ("ellip", 9, False), ("bessel", 10, False),
+                                               ("butter", 2, False), ("butter", 6, True), ("ellip", 10, True)])
+def test_sosfiltfilt_statement_bit_exact_vs_scipy(golden, ftype, order, band):
+    """The per-sample / per-section statement sequence and the odd extension of csrc/ssr_iir.h against SciPy."""
+    sos = olp.iir_sos(4000, 44100, order, ftype, lowcut=300 if band else None)
+    x = golden["ss_x"]
+    sigs = [x, x[:701], x[:100]]
+    got = E.sosfiltfilt(sos, sigs)
+    for s_, g in zip(sigs, got):
+        np.testing.assert_array_equal(g, signal.sosfiltfilt(sos, s_))

@@ -305,3 +305,31 @@ def test_evaluate_end_to_end_from_wav_files(tmp_path, monkeypatch):
     np.testing.assert_allclose(h.last_allreduce_average, [res["averaged"][key][m] for m in KEYS], rtol=1e-12)
     files = list((tmp_path / "results").glob("*-unprocessed.json"))
     assert len(files) == 1 and json.load(open(files[0]))["averaged"] == res["averaged"]
+
+
+@pytest.mark.parametrize("ftype,order,band", [("butter", 3, False), ("cheby1", 6, False), ("ellip", 9, False), ("bessel", 10, False),
+                                               ("butter", 2, False), ("butter", 6, True), ("ellip", 10, True)])
+def test_sosfiltfilt_bit_exact(golden, ftype, order, band):
+    """ssr_sosfiltfilt (wavefront over sections, DPP hand-off) is bit-identical to scipy.signal.sosfiltfilt."""
+    from ssr_eval_amd import backend as B
+    from oracle import lowpass as olp
+    sos = olp.iir_sos(4000, 44100, order, ftype, lowcut=300 if band else None)
+    x = golden["ss_x"]
+    rng = np.random.default_rng(order)
+    sigs = [x, x[:701], x[:100], np.tile(x, 5)] + [rng.standard_normal(int(n)).astype(np.float32) for n in rng.integers(200, 3000, 9)]
+    got = B.sosfiltfilt(sos, sigs)
+    for s_, g in zip(sigs, got):
+        assert g.dtype == torch.float64
+        np.testing.assert_array_equal(g.cpu().numpy(), signal.sosfiltfilt(sos, s_))
+
+
+def test_iir_lowpass_matches_reference_vectors(golden):
+    from ssr_eval_amd.lowpass import lowpass, bandpass
+    from oracle import lowpass as olp
+    for ft in ("butter", "cheby1", "ellip", "bessel"):
+        np.testing.assert_array_equal(lowpass(golden["ss_x"], 4000, 44100, order=6, _type=ft), golden["iir_%s" % ft])
+    np.testing.assert_array_equal(lowpass(golden["ss_x"], 4000, 44100, order=6, _type="but"), golden["iir_butter"])
+    y = bandpass(golden["ss_x"], 300, 4000, 44100, order=4, _type="butter")
+    np.testing.assert_array_equal(y, signal.sosfiltfilt(olp.iir_sos(4000, 44100, 4, "butter", lowcut=300), golden["ss_x"]))
+    with pytest.raises(ValueError):
+        lowpass(golden["ss_x"][:20], 4000, 44100, order=6, _type="butter")     # shorter than the padding, as SciPy

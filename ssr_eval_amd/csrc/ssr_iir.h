@@ -98,6 +98,9 @@ SSR_DEV void ssr_iir_pass(const SsrIirParams& p, bool active, int s, const float
   int ne_max = ne;
   for (int o = 32; o > 0; o >>= 1) { const int t_ = __shfl_xor(ne_max, o); ne_max = t_ > ne_max ? t_ : ne_max; }
   const int n_chunks = (ne_max + S - 1 + CH - 1) / CH + 1;      // +1: flush of the last outputs
+  // shortest ACTIVE utterance of the wave: blocks of steps that lie inside [S-1, ne_min) need no per-lane predicates
+  int ne_min = active ? ne : 0x7fffffff;
+  for (int o = 32; o > 0; o >>= 1) { const int t_ = __shfl_xor(ne_min, o); ne_min = t_ < ne_min ? t_ : ne_min; }
 
   auto load_in = [&](int n) -> double {
     if (n >= ne) return 0.0;
@@ -117,15 +120,30 @@ SSR_DEV void ssr_iir_pass(const SsrIirParams& p, bool active, int s, const float
       double x8[8];                                              // lane 0's next eight inputs: eight LDS reads in flight at once
 #pragma unroll
       for (int k = 0; k < 8; ++k) x8[k] = in_buf[ring + tb + k];
+      const int t0 = c * CH + tb;
+      if (t0 >= S - 1 && t0 + 8 <= ne_min) {
+        // interior block (wave-uniform): every lane s < S has a valid sample at every step -> no predicates;
+        // lanes s >= S compute on garbage that nobody reads
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int t = c * CH + tb + k;
-        const int n = t - s;                                     // sample this lane filters at this step
-        const double from_lower = ssr_dpp_from_lower_lane(yout); // lane s-1's output of step t-1 = its sample n
-        const double xin = (s == 0) ? x8[k] : from_lower;
-        if (s < S && n >= 0 && n < ne) {
+        for (int k = 0; k < 8; ++k) {
+          const double from_lower = ssr_dpp_from_lower_lane(yout);
+          const double xin = (s == 0) ? x8[k] : from_lower;
           yout = ssr_iir_step(xin, b0, b1, b2, a1, a2, z0, z1);
-          if (s == S - 1) out_buf[n & (2 * CH - 1)] = yout;
+          if (s == S - 1) out_buf[(t0 + k - s) & (2 * CH - 1)] = yout;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int n = t0 + k - s;                                // sample this lane filters at this step
+          const double from_lower = ssr_dpp_from_lower_lane(yout); // lane s-1's output of step t-1 = its sample n
+          const double xin = (s == 0) ? x8[k] : from_lower;
+          double nz0 = z0, nz1 = z1;
+          const double yo = ssr_iir_step(xin, b0, b1, b2, a1, a2, nz0, nz1);
+          const bool on = (s < S) && (n >= 0) && (n < ne);
+          z0 = on ? nz0 : z0;
+          z1 = on ? nz1 : z1;
+          yout = on ? yo : yout;
+          if (on && s == S - 1) out_buf[n & (2 * CH - 1)] = yo;
         }
       }
     }

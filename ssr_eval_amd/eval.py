@@ -18,7 +18,7 @@ import torch
 
 from . import backend as B
 from . import dist as D
-from .lowpass import lowpass, stft_hard_lowpass_batch
+from .lowpass import lowpass, lowpass_batch, stft_hard_lowpass_batch
 from .metrics import AudioMetrics
 from .utils import dict_mean, write_json
 
@@ -209,14 +209,37 @@ class SSR_Eval_Helper:
         return ret
 
     def preprocess_arrays(self, xs, sr):
-        """preprocess_array for a list of waveforms; the FFT low-pass of ALL (waveform, cutoff) combinations is one
-        batched K6 call.  Key order per item is the reference's (the fft keys come last, eval.py:268-269)."""
-        fft_setting, self.setting_fft = self.setting_fft, None
-        try:
-            rets = [self.preprocess_array(x, sr) for x in xs]
-        finally:
-            self.setting_fft = fft_setting
-        if fft_setting is not None and xs:
+        """preprocess_array for a list of waveforms with every degradation batched over the list (one launch
+        sequence per (filter, cutoff, order) instead of one per file).  Key order per item is the reference's
+        (eval.py:243-269: butter, cheby, ellip, bessel, subsampling, mp3, fft)."""
+        rets = [dict() for _ in xs]
+        if not xs:
+            return rets
+
+        def put(key, ys):
+            for ret, x, y in zip(rets, xs, ys):
+                assert y.shape == x.shape, str((y.shape, x.shape))
+                ret[key] = y
+        lp = self.setting_lowpass_filtering
+        if lp is not None:
+            for word, tag, ftype in (("butter", "bw", "butter"), ("cheby", "ch", "cheby1"), ("ellip", "el", "ellip"),
+                                     ("bessel", "bessel", "bessel")):
+                if word not in lp["filter"]:
+                    continue
+                for low_rate in lp["cutoff_freq"]:
+                    for order in lp["filter_order"]:
+                        if low_rate == sr:
+                            low_rate -= 1
+                        put("proc_%s_%s_%s_%s" % (tag, low_rate, order, sr),
+                            lowpass_batch(xs, low_rate // 2, sr, order=order, _type=ftype))
+        if self.setting_subsampling is not None:
+            for low_rate in self.setting_subsampling["cutoff_freq"]:
+                if low_rate == sr:
+                    low_rate -= 1
+                put("proc_subsampling_%s_%s" % (low_rate, sr), lowpass_batch(xs, low_rate // 2, sr, order=1, _type="subsampling"))
+        if self.setting_mp3_compression is not None:
+            self.mp3_encoding("<array>", xs[0], sr)          # raises: host codec, out of scope
+        if self.setting_fft is not None:
             keys, ratios = self._fft_plan_keys(sr)
             ys = stft_hard_lowpass_batch([x for x in xs for _ in keys], ratios * len(xs), self._device)
             for i, ret in enumerate(rets):

@@ -58,8 +58,8 @@ def limit(integer, high, low):
     return high if integer > high else (low if integer < low else int(integer))
 
 
-def _iir(x, highcut, fs, order, ftype, lowcut=None):
-    """lowpass.py:54-131: SciPy designs the sections (host), ssr_sosfiltfilt filters (GPU, float64, bit-exact)."""
+def _design(highcut, fs, order, ftype, lowcut=None):
+    """Section design of lowpass.py:70-85 / :110-125 (SciPy on the host: a plan, not data)."""
     from scipy import signal
     nyq = 0.5 * fs
     wn = highcut / nyq if lowcut is None else [lowcut / nyq, highcut / nyq]
@@ -71,8 +71,17 @@ def _iir(x, highcut, fs, order, ftype, lowcut=None):
               "bessel": lambda: signal.bessel(order, wn, btype=bt, output="sos")}
     if ftype not in design:
         raise Exception("The %s filter %s is not supported!" % ("lowpass" if lowcut is None else "bandpass", ftype))
-    y = B.sosfiltfilt(design[ftype](), [np.asarray(x, np.float32)])[0].cpu().numpy()
-    return align_length(x, y)
+    return design[ftype]()
+
+
+def _iir_batch(xs, highcut, fs, order, ftype, lowcut=None):
+    """lowpass.py:54-131 for a list of signals: one ssr_sosfiltfilt launch (GPU, float64, bit-exact with SciPy)."""
+    ys = B.sosfiltfilt(_design(highcut, fs, order, ftype, lowcut), [np.asarray(x, np.float32) for x in xs])
+    return [align_length(x, y.cpu().numpy()) for x, y in zip(xs, ys)]
+
+
+def _iir(x, highcut, fs, order, ftype, lowcut=None):
+    return _iir_batch([x], highcut, fs, order, ftype, lowcut)[0]
 
 
 def lowpass_filter(x, highcut, fs, order, ftype):
@@ -100,6 +109,26 @@ def lowpass(data, highcut, fs, order=5, _type="butter"):
         return subsampling(data, lowpass_ratio=highcut / int(fs / 2))
     if _type in "stft_hard":
         return stft_hard_lowpass_v0(data, lowpass_ratio=highcut / int(fs / 2))
+    raise ValueError("Error: Unexpected filter type " + _type)
+
+
+def lowpass_batch(datas, highcut, fs, order=5, _type="butter"):
+    """lowpass() for a LIST of 1-D signals with one batched launch sequence per call (same dispatch semantics)."""
+    order = limit(order, high=10, low=2)
+    for d in datas:
+        _check_1d(d)
+    for name in ("butter", "cheby1", "ellip", "bessel"):
+        if _type in name:
+            return _iir_batch(datas, int(highcut), fs, order, name)
+    if _type in "subsampling":
+        ratio = highcut / int(fs / 2)
+        fs_down = int(ratio * 44100)
+        xs = [np.asarray(d) for d in datas]
+        down = B.resample_poly([x.astype(np.float32) for x in xs], fs_down, 44100)
+        up = B.resample_poly(down, 44100, fs_down)
+        return [align_length(x, u.cpu().numpy().astype(x.dtype if x.dtype.kind == "f" else np.float32)) for x, u in zip(xs, up)]
+    if _type in "stft_hard":
+        return stft_hard_lowpass_batch(datas, [highcut / int(fs / 2)] * len(datas))
     raise ValueError("Error: Unexpected filter type " + _type)
 
 

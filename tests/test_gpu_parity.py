@@ -333,3 +333,21 @@ def test_iir_lowpass_matches_reference_vectors(golden):
     np.testing.assert_array_equal(y, signal.sosfiltfilt(olp.iir_sos(4000, 44100, 4, "butter", lowcut=300), golden["ss_x"]))
     with pytest.raises(ValueError):
         lowpass(golden["ss_x"][:20], 4000, 44100, order=6, _type="butter")     # shorter than the padding, as SciPy
+
+
+def test_helper_batched_degradations_match_per_item(golden):
+    """preprocess_arrays (batched over the list) == preprocess_array per item, same keys in the reference's order."""
+    from ssr_eval_amd import SSR_Eval_Helper, BasicTestee
+    h = SSR_Eval_Helper(BasicTestee(), 44100, 44100, test_data_root=None,
+                        setting_lowpass_filtering={"filter": ["butter", "cheby", "ellip", "bessel"], "cutoff_freq": [2000, 22050],
+                                                   "filter_order": [3, 9]},
+                        setting_subsampling={"cutoff_freq": [4000]}, setting_fft={"cutoff_freq": [6000]})
+    xs = [golden["ss_x"], golden["lp_x"][:5000]]
+    batched = h.preprocess_arrays(xs, 44100)
+    for x, b in zip(xs, batched):
+        single = h.preprocess_array(x, 44100)
+        assert list(single.keys()) == list(b.keys())
+        assert list(b.keys())[0] == "proc_bw_4000_3_44100" and "proc_bw_44099_9_44100" in b      # doubled cutoff; sr -> sr-1 quirk
+        assert list(b.keys())[-2:] == ["proc_subsampling_8000_44100", "proc_fft_12000_44100"]
+        for k in b:
+            np.testing.assert_array_equal(np.asarray(b[k]), np.asarray(single[k]))

@@ -229,7 +229,7 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
 
   SSR_REGS(Regs, regs, blk);
   SSR_PHASE(blk, regs, {
-    if (tid < 6 * 16) L.wacc[tid] = 0.0;
+    for (int i = tid; i < 6 * 16; i += NT) L.wacc[i] = 0.0;   // NT may be as small as 32
     if (tid == 0) L.res[0] = 0.0;
     for (int q = 0; q < (SUMS ? 6 : 1); ++q) R.sums[q] = 0.0;
   });

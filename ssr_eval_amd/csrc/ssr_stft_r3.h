@@ -55,7 +55,7 @@ SSR_BODY void ssr_stft_r3_body(const SsrStftParams<T>& p, BLK& blk, int chunk, i
 
   SSR_REGS(Regs, regs, blk);
   SSR_PHASE(blk, regs, {
-    if (tid < 6 * 16) L.wacc[tid] = 0.0;
+    for (int i = tid; i < 6 * 16; i += NT) L.wacc[i] = 0.0;   // NT may be as small as 32
     if (tid == 0) L.res[0] = 0.0;
     for (int i = 0; i < (SUMS ? 6 : 1); ++i) R.sums[i] = 0.0;
   });

@@ -151,3 +151,15 @@ def test_sosfiltfilt_statement_bit_exact_vs_scipy(golden, ftype, order, band):
     got = E.sosfiltfilt(sos, sigs)
     for s_, g in zip(sigs, got):
         np.testing.assert_array_equal(g, signal.sosfiltfilt(sos, s_))
+
+
+@pytest.mark.parametrize("n_fft,hop,n", [(256, 64, 3000), (512, 100, 5000), (4096, 1024, 20000), (1486, 320, 6000), (3 * 257, 100, 4000)])
+def test_pair_metrics_other_transform_sizes(n_fft, hop, n):
+    """All four metrics through engines with few threads per workgroup (32 / 64) and through every engine kind;
+    LDS is poisoned with NaN, so any accumulator that is not initialised by its own kernel shows up here."""
+    rng = np.random.default_rng(n_fft)
+    tgt = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    est = (tgt * 0.7 + 0.03 * rng.standard_normal(n)).astype(np.float32)
+    got = E.pair_metrics([est], [tgt], n_fft, hop, precision=1, units_per_chunk=7, rows_per_tile=5)[0]
+    want = om.evaluation(est, tgt, n_fft=n_fft, hop=hop)
+    np.testing.assert_allclose(got, [want["lsd"], want["log_sispec"], want["sispec"], want["ssim"]], rtol=1e-5)

@@ -351,3 +351,18 @@ def test_helper_batched_degradations_match_per_item(golden):
         assert list(b.keys())[-2:] == ["proc_subsampling_8000_44100", "proc_fft_12000_44100"]
         for k in b:
             np.testing.assert_array_equal(np.asarray(b[k]), np.asarray(single[k]))
+
+
+@pytest.mark.parametrize("n_fft,hop,n", [(4096, 1024, 40000), (256, 64, 3000), (1486, 320, 12000), (512, 100, 5000), (3063, 700, 30000)])
+def test_pair_metrics_other_transform_sizes(n_fft, hop, n):
+    """Engines / SSIM geometries the reference's rates do not reach by default: 4096 (six SSIM strips), tiny 256,
+    1486 (32 kHz, plain Bluestein), non-multiple hop, 3063 = 3 * 1021 (radix-3 x Bluestein with M = 2048)."""
+    from ssr_eval_amd import AudioMetrics
+    from oracle import metrics as om
+    rng = np.random.default_rng(n_fft)
+    tgt = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    est = (tgt * 0.7 + 0.03 * rng.standard_normal(n)).astype(np.float32)
+    am = AudioMetrics(48000, n_fft=n_fft, hop_length=hop)
+    got = _vec(am.evaluation(est, tgt, ""))
+    want = _vec(om.evaluation(est, tgt, n_fft=n_fft, hop=hop))
+    np.testing.assert_allclose(got, want, rtol=1e-5)

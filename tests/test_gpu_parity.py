@@ -366,3 +366,32 @@ def test_pair_metrics_other_transform_sizes(n_fft, hop, n):
     got = _vec(am.evaluation(est, tgt, ""))
     want = _vec(om.evaluation(est, tgt, n_fft=n_fft, hop=hop))
     np.testing.assert_allclose(got, want, rtol=1e-5)
+
+
+def test_randomised_ragged_batches_against_oracle():
+    """Seeded sweep over transform sizes (all engines), hops, ragged lengths and signal kinds: every metric of every item
+    of every batch against the oracle.  Catches geometry-dependent mistakes (chunk / tile / strip boundaries)."""
+    from ssr_eval_amd import AudioMetrics
+    from oracle import metrics as om
+    rng = np.random.default_rng(777)
+    sizes = [(2048, 512), (2229, 480), (2048, 441), (1024, 256), (743, 160), (1114, 240), (1486, 320), (300, 77), (4096, 1000)]
+    for case in range(12):
+        n_fft, hop = sizes[case % len(sizes)]
+        am = AudioMetrics(48000, n_fft=n_fft, hop_length=hop)
+        n_items = int(rng.integers(1, 6))
+        ests, tgts = [], []
+        for _ in range(n_items):
+            n = int(rng.integers(7 * hop + n_fft // 2 + 1, 7 * hop + 6 * n_fft))
+            t = (0.1 * rng.standard_normal(n)).astype(np.float32)
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                e = (t + 0.02 * rng.standard_normal(n)).astype(np.float32)
+            elif kind == 1:
+                e = (0.3 * t + 0.05 * rng.standard_normal(n)).astype(np.float32)
+            else:                                    # smoothed (band-limited) estimate: deep stop band
+                e = np.convolve(t, np.ones(9, np.float32) / 9, mode="same").astype(np.float32)
+            ests.append(e); tgts.append(t)
+        got = am.evaluation_batch(ests, tgts)
+        for e, t, g in zip(ests, tgts, got):
+            want = om.evaluation(e, t, n_fft=n_fft, hop=hop)
+            np.testing.assert_allclose(_vec(g), _vec(want), rtol=1e-5, err_msg="n_fft=%d hop=%d n=%d" % (n_fft, hop, len(e)))

@@ -108,21 +108,8 @@ SSR_DEV void ssr_fft_compute(int tid, cx<T>* v, const cx<T>* __restrict__ tw) {
       const int j = tid + b * P::NT;
       const int k = j & (NS - 1);
       const int base = k * (P::N / (NS * R));
-#if defined(SSR_TW_DIRECT)
-      const unsigned ub = (unsigned)base;      // 7 table loads, no arithmetic (q * base < N always)
-      cx<T>* x = v + b * R;
-      for (int q = 1; q < 8; ++q) x[q] = cmul(x[q], tw[(unsigned)q * ub]);
-#else
-#if defined(SSR_SIGNED_IDX)
-      const int ub = base;
-#else
-      const unsigned ub = (unsigned)base;
-#endif
-#if defined(SSR_ABL_NOTW)      /* developer ablation: WRONG results, timing only */
-      const cx<T> w1 = {(T)(ub + 1), (T)0.5}, w2 = {(T)0.25, (T)(ub + 2)}, w4 = {(T)0.125, (T)0.75};
-#else
+      const unsigned ub = (unsigned)base;          // scalar table base + 32-bit lane offset
       const cx<T> w1 = tw[ub], w2 = tw[2 * ub], w4 = tw[4 * ub];
-#endif
       // twiddle powers are formed just before use to keep few of them live (register pressure)
       cx<T>* x = v + b * R;
       x[1] = cmul(x[1], w1);
@@ -133,7 +120,6 @@ SSR_DEV void ssr_fft_compute(int tid, cx<T>* v, const cx<T>* __restrict__ tw) {
       x[5] = cmul(x[5], cmul(w1, w4));
       x[6] = cmul(x[6], cmul(w2, w4));
       x[7] = cmul(x[7], cmul(w3, w4));
-#endif
     }
     ssr_bfly<R>(v + b * R);
   }

@@ -18,11 +18,8 @@
 //               (2229 = 3*743 for AudioMetrics(48000), 743 / 1114 / 1486 for 16/24/32 kHz).
 #pragma once
 #include "ssr_fft.h"
-#if defined(SSR_SIGNED_IDX)
-#define SSR_UIDX(...) (__VA_ARGS__)
-#else
+// unsigned index: lets the compiler address tables as scalar base + 32-bit lane offset
 #define SSR_UIDX(...) ((unsigned)(__VA_ARGS__))
-#endif
 
 enum { SSR_MODE_PAIR = 0, SSR_MODE_SINGLE = 1 };
 
@@ -92,15 +89,10 @@ template <typename T> SSR_DEV SsrBinOut<T> ssr_separate(cx<T> zk, cx<T> zn) {
   return o;
 }
 
-// |re + i im| for float32 parts.  numpy.abs(complex64) is hypotf; for the magnitudes an STFT produces the
-// plain sqrtf(re^2 + im^2) agrees with it to <= 1 ulp and costs a fraction of the scaled algorithm, so the
-// scaled path is kept only for operands whose squares would leave the float32 normal range.
+// |re + i im| for float32 parts: numpy.abs(complex64) is hypotf (a plain sqrtf(re^2 + im^2) measured slower
+// in this kernel, profiles/r01_notes.md).
 SSR_DEV float ssr_cabsf(float re, float im) {
-#if defined(SSR_FAST_MAG)
-  return sqrtf(re * re + im * im);
-#else
   return hypotf(re, im);
-#endif
 }
 
 // LSD term and SISpec sums for one (est, target) magnitude pair, float32 elementwise arithmetic in
@@ -109,16 +101,8 @@ SSR_DEV void ssr_accumulate_metrics(float e, float t, int mask, double* acc) {
   const float EPSF = 1e-12f;
   if (mask & SSR_M_LSD) {
     const float ee = e + EPSF;
-#if defined(SSR_FAST_LSD) && !defined(SSR_HOST_EMU)
-    const float r = __fdividef(t * t, ee * ee) + EPSF;
-    const float d = __log10f(r);
-#elif defined(SSR_FAST_DIV) && !defined(SSR_HOST_EMU)
-    const float r = __fdividef(t * t, ee * ee) + EPSF;
+    const float r = (t * t) / (ee * ee) + EPSF;     // IEEE division + accurate log10f: cheaper variants measured no faster
     const float d = log10f(r);
-#else
-    const float r = (t * t) / (ee * ee) + EPSF;
-    const float d = log10f(r);
-#endif
     acc[0] += (double)(d * d);
   }
   if (mask & SSR_M_SISPEC) {

@@ -13,6 +13,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The shared objects are git-ignored build products: make sure libssrhip.so exists (hipcc cross-compiles for
+    gfx950 without a GPU).  Only a MISSING library is built here; __graft_entry__.build() is the real build step."""
+    lib = os.path.join(ROOT, "ssr_eval_amd", "libssrhip.so")
+    if not os.path.exists(lib):
+        from ssr_eval_amd import build as b
+        try:
+            b.build(force=True)
+        except Exception as e:          # no hipcc: the tests that need the library will say so themselves
+            sys.stderr.write("could not build libssrhip.so: %r\n" % (e,))
+
+
 @pytest.fixture(scope="session")
 def golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz"))

@@ -302,6 +302,7 @@ static const int TARGET_WGS = getenv("SSR_TARGET_WGS") ? atoi(getenv("SSR_TARGET
 static int units_per_chunk_for(int max_units, int n_items) {
   int64_t u = ((int64_t)max_units * n_items + TARGET_WGS - 1) / TARGET_WGS;
   if (u < 4) u = 4;
+  if (u > 128) u = 128;             // ragged batches: short workgroups keep the tail of a launch balanced
   if (u > max_units) u = max_units;
   if (u < 1) u = 1;
   return (int)u;
@@ -313,6 +314,7 @@ static SsimGeom ssim_geom(int max_rows, int n_bins, int n_items) {
   const int out_rows = max_rows - 6 > 1 ? max_rows - 6 : 1;
   int64_t r = ((int64_t)out_rows * n_items + TARGET_WGS - 1) / TARGET_WGS;
   if (r < 8) r = 8;
+  if (r > 128) r = 128;
   if (r > out_rows) r = out_rows;
   g.rows_per_tile = (int)r;
   g.n_row_tiles = ceil_div(out_rows, g.rows_per_tile);

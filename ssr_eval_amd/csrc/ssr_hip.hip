@@ -53,8 +53,11 @@ __global__ __launch_bounds__((1 << LOGN) / 8) void k_stft_r3(SsrStftParams<T> p)
   ssr_stft_r3_body<T, LOGN, MODE, SUMS>(p, blk, chunk, item, smem);
 }
 
+#ifndef SSR_LOWPASS_WAVES_PER_EU
+#define SSR_LOWPASS_WAVES_PER_EU 3   /* 168 VGPRs, no spill: 3 workgroups per CU instead of 2 */
+#endif
 template <typename T, int LOGN>
-__global__ __launch_bounds__((1 << LOGN) / 8) void k_lowpass_frames(SsrLowpassParams<T> p) {
+__global__ __launch_bounds__((1 << LOGN) / 8, SSR_LOWPASS_WAVES_PER_EU) void k_lowpass_frames(SsrLowpassParams<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SsrBlk blk{(int)threadIdx.x};
   const int item = blockIdx.x / p.n_chunks, chunk = blockIdx.x % p.n_chunks;

@@ -661,13 +661,20 @@ extern "C" int ssr_sosfiltfilt(const float* x, const int64_t* off, const int32_t
   SsrIirParams p{x, off, len, sos, zi, n_sections, edge, n_items, (double*)workspace, y};
   hipStream_t s = (hipStream_t)stream;
   if (n_sections <= 8) {
-    const int groups = 8;
-    const size_t lds = (size_t)groups * 4 * SSR_IIR_CH * sizeof(double);
-    hipLaunchKernelGGL((k_sosfiltfilt<8>), dim3(ceil_div(n_items, groups)), dim3(64), lds, s, p);
+    const int per_wave = 8 * SSR_IIR_U;                           // utterances per one-wave workgroup
+    const size_t lds = (size_t)per_wave * 4 * SSR_IIR_CH * sizeof(double);
+    static thread_local int attr8 = -1;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (lds > 48 * 1024 && attr8 != dev) {
+      HIP_TRY(hipFuncSetAttribute((const void*)k_sosfiltfilt<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr8 = dev;
+    }
+    hipLaunchKernelGGL((k_sosfiltfilt<8>), dim3(ceil_div(n_items, per_wave)), dim3(64), lds, s, p);
   } else {
-    const int groups = 4;
-    const size_t lds = (size_t)groups * 4 * SSR_IIR_CH * sizeof(double);
-    hipLaunchKernelGGL((k_sosfiltfilt<16>), dim3(ceil_div(n_items, groups)), dim3(64), lds, s, p);
+    const int per_wave = 4 * SSR_IIR_U;
+    const size_t lds = (size_t)per_wave * 4 * SSR_IIR_CH * sizeof(double);
+    hipLaunchKernelGGL((k_sosfiltfilt<16>), dim3(ceil_div(n_items, per_wave)), dim3(64), lds, s, p);
   }
   HIP_TRY(hipGetLastError());
   return SSR_OK;

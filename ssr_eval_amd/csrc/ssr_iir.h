@@ -86,106 +86,149 @@ SSR_DEV double ssr_dpp_from_lower_lane(double v) {
   return b.d;
 }
 
-// One pass (forward or backward) of the wavefront for the lane's group.  G: lanes per utterance (8 or 16).
-// in_buf / out_buf: this group's LDS staging rings of 2*SSR_IIR_CH doubles each.
+// Per-lane view of one utterance slot.  A lane can serve U utterances at once (independent recurrences
+// interleaved in one instruction stream); measured on MI355X the step time grows almost linearly with U, so
+// U = 1 is the default.
+#define SSR_IIR_U 1   /* utterances per lane slot: 2 measured 1.67x the latency for 2x the work - only pays beyond ~8k utterances */
+template <int G> struct SsrIirSlot {
+  bool active;
+  const float* x;
+  int len, ne;
+  double* fwd;
+  double* y;
+  double* in_buf;    // LDS ring of 2*CH inputs of this (group, slot)
+  double* out_buf;   // LDS ring of 2*CH outputs
+  double z0, z1, yout;
+  double pre[SSR_IIR_CH / G];
+};
+
 template <int G, bool BACKWARD>
-SSR_DEV void ssr_iir_pass(const SsrIirParams& p, bool active, int s, const float* x, int len, double* fwd, double* y,
-                          double* in_buf, double* out_buf, double b0, double b1, double b2, double a1, double a2,
-                          double zi0, double zi1) {
-  constexpr int CH = SSR_IIR_CH, PER = CH / G;
-  const int edge = p.edge, S = p.n_sections, ne = active ? len + 2 * edge : 0;
-  // every group of the wave runs the same number of chunks (wave-uniform trip count): the maximum over its groups
-  int ne_max = ne;
-  for (int o = 32; o > 0; o >>= 1) { const int t_ = __shfl_xor(ne_max, o); ne_max = t_ > ne_max ? t_ : ne_max; }
+SSR_DEV double ssr_iir_load_in(const SsrIirSlot<G>& q, int edge, int n) {
+  if (n >= q.ne) return 0.0;
+  return BACKWARD ? q.fwd[q.ne - 1 - n] : ssr_iir_ext(q.x, q.len, edge, n);
+}
+
+// One pass (forward or backward) of the wavefront for the lane's group.  G: lanes per utterance (8 or 16).
+template <int G, bool BACKWARD>
+SSR_DEV void ssr_iir_pass(const SsrIirParams& p, int s, SsrIirSlot<G> (&sl)[SSR_IIR_U], double b0, double b1, double b2,
+                          double a1, double a2, double zi0, double zi1) {
+  constexpr int CH = SSR_IIR_CH, PER = CH / G, U = SSR_IIR_U;
+  const int edge = p.edge, S = p.n_sections;
+  // wave-uniform trip count (longest utterance of the wave) and the shortest ACTIVE one: blocks of steps inside
+  // [S-1, ne_min) need no per-lane predicates
+  int ne_max = 0, ne_min = 0x7fffffff;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    ne_max = sl[u].ne > ne_max ? sl[u].ne : ne_max;
+    if (sl[u].active) ne_min = sl[u].ne < ne_min ? sl[u].ne : ne_min;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const int a_ = __shfl_xor(ne_max, o), b_ = __shfl_xor(ne_min, o);
+    ne_max = a_ > ne_max ? a_ : ne_max;
+    ne_min = b_ < ne_min ? b_ : ne_min;
+  }
   const int n_chunks = (ne_max + S - 1 + CH - 1) / CH + 1;      // +1: flush of the last outputs
-  // shortest ACTIVE utterance of the wave: blocks of steps that lie inside [S-1, ne_min) need no per-lane predicates
-  int ne_min = active ? ne : 0x7fffffff;
-  for (int o = 32; o > 0; o >>= 1) { const int t_ = __shfl_xor(ne_min, o); ne_min = t_ < ne_min ? t_ : ne_min; }
 
-  auto load_in = [&](int n) -> double {
-    if (n >= ne) return 0.0;
-    return BACKWARD ? fwd[ne - 1 - n] : ssr_iir_ext(x, len, edge, n);
-  };
-  // initial state: zi * (first input sample of this pass)
-  const double first = active ? load_in(0) : 0.0;
-  double z0 = zi0 * first, z1 = zi1 * first, yout = 0.0;
-
-  double pre[PER];                                              // chunk 0 staged directly
-  for (int i = 0; i < PER; ++i) in_buf[s * PER + i] = load_in(s * PER + i);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    // initial state: zi * (first input sample of this pass); chunk 0 staged directly
+    const double first = sl[u].active ? ssr_iir_load_in<G, BACKWARD>(sl[u], edge, 0) : 0.0;
+    sl[u].z0 = zi0 * first; sl[u].z1 = zi1 * first; sl[u].yout = 0.0;
+    for (int i = 0; i < PER; ++i) sl[u].in_buf[s * PER + i] = ssr_iir_load_in<G, BACKWARD>(sl[u], edge, s * PER + i);
+  }
   for (int c = 0; c < n_chunks; ++c) {
     // issue the NEXT chunk's loads now; they land while this chunk is being filtered
-    for (int i = 0; i < PER; ++i) pre[i] = load_in((c + 1) * CH + s * PER + i);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      for (int i = 0; i < PER; ++i) sl[u].pre[i] = ssr_iir_load_in<G, BACKWARD>(sl[u], edge, (c + 1) * CH + s * PER + i);
     const int ring = (c & 1) * CH;
     for (int tb = 0; tb < CH; tb += 8) {
-      double x8[8];                                              // lane 0's next eight inputs: eight LDS reads in flight at once
+      double x8[U][8];                                           // lane 0's next eight inputs: all LDS reads in flight at once
 #pragma unroll
-      for (int k = 0; k < 8; ++k) x8[k] = in_buf[ring + tb + k];
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x8[u][k] = sl[u].in_buf[ring + tb + k];
       const int t0 = c * CH + tb;
       if (t0 >= S - 1 && t0 + 8 <= ne_min) {
         // interior block (wave-uniform): every lane s < S has a valid sample at every step -> no predicates;
         // lanes s >= S compute on garbage that nobody reads
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const double from_lower = ssr_dpp_from_lower_lane(yout);
-          const double xin = (s == 0) ? x8[k] : from_lower;
-          yout = ssr_iir_step(xin, b0, b1, b2, a1, a2, z0, z1);
-          if (s == S - 1) out_buf[(t0 + k - s) & (2 * CH - 1)] = yout;
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const double from_lower = ssr_dpp_from_lower_lane(sl[u].yout);   // lane s-1's output of step t-1
+            const double xin = (s == 0) ? x8[u][k] : from_lower;
+            sl[u].yout = ssr_iir_step(xin, b0, b1, b2, a1, a2, sl[u].z0, sl[u].z1);
+            if (s == S - 1) sl[u].out_buf[(t0 + k - s) & (2 * CH - 1)] = sl[u].yout;
+          }
         }
       } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const int n = t0 + k - s;                                // sample this lane filters at this step
-          const double from_lower = ssr_dpp_from_lower_lane(yout); // lane s-1's output of step t-1 = its sample n
-          const double xin = (s == 0) ? x8[k] : from_lower;
-          double nz0 = z0, nz1 = z1;
-          const double yo = ssr_iir_step(xin, b0, b1, b2, a1, a2, nz0, nz1);
-          const bool on = (s < S) && (n >= 0) && (n < ne);
-          z0 = on ? nz0 : z0;
-          z1 = on ? nz1 : z1;
-          yout = on ? yo : yout;
-          if (on && s == S - 1) out_buf[n & (2 * CH - 1)] = yo;
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const double from_lower = ssr_dpp_from_lower_lane(sl[u].yout);
+            const double xin = (s == 0) ? x8[u][k] : from_lower;
+            double nz0 = sl[u].z0, nz1 = sl[u].z1;
+            const double yo = ssr_iir_step(xin, b0, b1, b2, a1, a2, nz0, nz1);
+            const bool on = (s < S) && (n >= 0) && (n < sl[u].ne);
+            sl[u].z0 = on ? nz0 : sl[u].z0;
+            sl[u].z1 = on ? nz1 : sl[u].z1;
+            sl[u].yout = on ? yo : sl[u].yout;
+            if (on && s == S - 1) sl[u].out_buf[n & (2 * CH - 1)] = yo;
+          }
         }
       }
     }
     // flush outputs of chunk c-1 (the last section lags by S-1 < CH steps, so they are complete now)
     if (c >= 1) {
-      for (int i = 0; i < PER; ++i) {
-        const int n = (c - 1) * CH + s * PER + i;
-        if (n < ne) {
-          const double v = out_buf[n & (2 * CH - 1)];
-          if (BACKWARD) {
-            const int m = (ne - 1 - n) - edge;
-            if (m >= 0 && m < len) y[m] = v;
-          } else {
-            fwd[n] = v;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        for (int i = 0; i < PER; ++i) {
+          const int n = (c - 1) * CH + s * PER + i;
+          if (n < sl[u].ne) {
+            const double v = sl[u].out_buf[n & (2 * CH - 1)];
+            if (BACKWARD) {
+              const int m = (sl[u].ne - 1 - n) - edge;
+              if (m >= 0 && m < sl[u].len) sl[u].y[m] = v;
+            } else {
+              sl[u].fwd[n] = v;
+            }
           }
         }
-      }
     }
-    for (int i = 0; i < PER; ++i) in_buf[((c + 1) & 1) * CH + s * PER + i] = pre[i];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      for (int i = 0; i < PER; ++i) sl[u].in_buf[((c + 1) & 1) * CH + s * PER + i] = sl[u].pre[i];
   }
 }
 
-// grid = ceil(n_items / (64/G)) workgroups of ONE wave; LDS: (64/G) groups * 4*CH doubles
+// grid = ceil(n_items / (U * 64/G)) workgroups of ONE wave; LDS: (64/G) groups * U slots * 4*CH doubles
 template <int G>
 SSR_DEV void ssr_iir_wave(const SsrIirParams& p, int wg, int lane, char* lds_base) {
-  constexpr int CH = SSR_IIR_CH, GROUPS = 64 / G;
-  const int g = lane / G, s = lane % G;
-  const int item = wg * GROUPS + g;
-  const bool active = item < p.n_items;
-  const int it = active ? item : 0;
-  const int len = p.len[it], S = p.n_sections;
-  const float* x = p.x + p.off[it];
-  double* fwd = p.fwd + p.off[it] + (int64_t)2 * p.edge * it;
-  double* y = p.y + p.off[it];
-  double* in_buf = reinterpret_cast<double*>(lds_base) + (size_t)g * 4 * CH;
-  double* out_buf = in_buf + 2 * CH;
+  constexpr int CH = SSR_IIR_CH, GROUPS = 64 / G, U = SSR_IIR_U;
+  const int g = lane / G, s = lane % G, S = p.n_sections;
+  SsrIirSlot<G> sl[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int item = (wg * GROUPS + g) * U + u;
+    sl[u].active = item < p.n_items;
+    const int it = sl[u].active ? item : 0;
+    sl[u].len = p.len[it];
+    sl[u].ne = sl[u].active ? sl[u].len + 2 * p.edge : 0;
+    sl[u].x = p.x + p.off[it];
+    sl[u].fwd = p.fwd + p.off[it] + (int64_t)2 * p.edge * it;
+    sl[u].y = p.y + p.off[it];
+    sl[u].in_buf = reinterpret_cast<double*>(lds_base) + ((size_t)g * U + u) * 4 * CH;
+    sl[u].out_buf = sl[u].in_buf + 2 * CH;
+  }
   const int sc = s < S ? s : 0;
   const double b0 = p.sos[6 * sc], b1 = p.sos[6 * sc + 1], b2 = p.sos[6 * sc + 2], a1 = p.sos[6 * sc + 4], a2 = p.sos[6 * sc + 5];
   const double zi0 = p.zi[2 * sc], zi1 = p.zi[2 * sc + 1];
-  ssr_iir_pass<G, false>(p, active, s, x, len, fwd, y, in_buf, out_buf, b0, b1, b2, a1, a2, zi0, zi1);
+  ssr_iir_pass<G, false>(p, s, sl, b0, b1, b2, a1, a2, zi0, zi1);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the backward pass re-reads `fwd` written by other lanes of this wave
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  ssr_iir_pass<G, true>(p, active, s, x, len, fwd, y, in_buf, out_buf, b0, b1, b2, a1, a2, zi0, zi1);
+  ssr_iir_pass<G, true>(p, s, sl, b0, b1, b2, a1, a2, zi0, zi1);
 }
 #endif

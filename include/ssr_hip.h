@@ -57,8 +57,9 @@ int ssr_version(void);
 /* STFT plan: centred, reflect-padded, periodic-Hann, win_length = n_fft.
  * Replaces the parameter choice of AudioMetrics.__init__ (ssr_eval/metrics.py:16-19: rate -> n_fft, hop),
  * FDomainHelper.__init__ (ssr_eval/dsp.py:7-59: 2048 / 441) and librosa.stft defaults (eval.py:29: 2048 / 512).
- * Any 2 <= n_fft <= 4096 is accepted: powers of two run a direct FFT, everything else (2229, 1486,
- * 1114, 743 ...) runs Bluestein over a power-of-two length >= 2 n_fft - 1. */
+ * Any 2 <= n_fft <= 4096 is accepted: powers of two in [256, 4096] run a direct FFT; n_fft = 3q whose plain
+ * chirp-z length would be 8192 (2229 = 3 * 743) runs a radix-3 step over three Bluestein transforms of
+ * length 2048; everything else (1486, 1114, 743 ...) runs Bluestein over a power of two >= 2 n_fft - 1. */
 int ssr_plan_create(int n_fft, int hop, int precision, ssr_plan** plan);
 int ssr_plan_destroy(ssr_plan* plan);
 int ssr_plan_query(const ssr_plan* plan, int* n_fft, int* hop, int* n_bins, int* fft_len, int* bluestein,

@@ -12,10 +12,11 @@
 //   mode PAIR   : x_a = est frame t, x_b = target frame t        (metrics path)
 //   mode SINGLE : x_a = frame 2g,    x_b = frame 2g+1 of one signal (wav_to_spectrogram, FDomainHelper)
 //
-// Two transform engines share the epilogue:
+// Three transform engines share the epilogue:
 //   direct    : n_fft = 2^LOGN, FFT of length n_fft.
 //   bluestein : any n_fft; chirp-z through two FFTs of length M = 2^LOGM >= 2*n_fft-1
-//               (2229 = 3*743 for AudioMetrics(48000), 743 / 1114 / 1486 for 16/24/32 kHz).
+//               (743 / 1114 / 1486 for AudioMetrics at 16 / 24 / 32 kHz).
+//   radix-3   : n_fft = 3q (2229 = 3*743 for AudioMetrics(48000)); ssr_stft_r3.h.
 #pragma once
 #include "ssr_fft.h"
 // unsigned index: lets the compiler address tables as scalar base + 32-bit lane offset

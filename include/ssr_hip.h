@@ -89,6 +89,16 @@ int ssr_pair_metrics(const ssr_plan* plan, const float* est, const int64_t* est_
                      int64_t total_rows, unsigned metric_mask, double* out, void* workspace, size_t workspace_bytes,
                      void* stream);
 
+/* The same for an estimate held as a FLOAT64 signal against a float32 target.  This is what
+ * AudioMetrics.evaluation receives from SSR_Eval_Helper.evaluate_single (ssr_eval/eval.py:128-156) whenever the
+ * degradation was an IIR low-pass: scipy.signal.sosfiltfilt returns float64 (ssr_eval/lowpass.py:54-131), the
+ * testee output and librosa.resample keep it, librosa.stft then yields complex128, and torch promotes every
+ * est-side operation of metrics.py:109-121 to float64.  Same workspace size, same output layout. */
+int ssr_pair_metrics_est64(const ssr_plan* plan, const double* est, const int64_t* est_off, const float* tgt,
+                           const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off, int n_items,
+                           int max_len, int64_t total_rows, unsigned metric_mask, double* out, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* Same, restricted to a subset of its three launches (bit 0: STFT + fused LSD/SISpec epilogue, bit 1:
  * SSIM, bit 2: finalisation) so that bench.py can time the dominant kernel on its own stream with
  * HIP events.  stages = 7 is ssr_pair_metrics. */
@@ -132,6 +142,12 @@ int ssr_resample_plan(int64_t n_in, int up, int down, int* up_reduced, int* down
 int ssr_resample_poly(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
                       const int32_t* out_len, int n_items, int max_out_len, int up, int down, const float* taps,
                       int n_taps, int n_pre_remove, float* out, void* stream);
+
+/* K7 for a float64 signal (what the reference has after an IIR degradation or a float64-returning testee):
+ * SciPy then keeps the taps in float64 and accumulates in float64; same plan, same ordering, bit-identical. */
+int ssr_resample_poly_f64(const double* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
+                          const int32_t* out_len, int n_items, int max_out_len, int up, int down, const double* taps,
+                          int n_taps, int n_pre_remove, double* out, void* stream);
 
 /* N1.  Zero-phase IIR: scipy.signal.sosfiltfilt(sos, x) (padtype "odd", padlen 3*ntaps) for float32 x, float64
  * arithmetic and output - the arithmetic of lowpass_filter / bandpass_filter (ssr_eval/lowpass.py:54-131, called

@@ -28,6 +28,7 @@ SIGNATURES = {
     "ssr_magphase": (_i, [_vp, _vp, _i64, C.c_float, _vp, _vp, _vp, _vp]),
     "ssr_pair_metrics_workspace_bytes": (_sz, [_vp, _i, _i, _i64]),
     "ssr_pair_metrics": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _u, _vp, _vp, _sz, _vp]),
+    "ssr_pair_metrics_est64": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _u, _vp, _vp, _sz, _vp]),
     "ssr_pair_metrics_stages": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _u, _vp, _vp, _sz, _vp, _i]),
     "ssr_spectrogram_metrics_workspace_bytes": (_sz, [_i, _i, _i]),
     "ssr_spectrogram_metrics": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u, _vp, _vp, _sz, _vp]),
@@ -37,6 +38,7 @@ SIGNATURES = {
     "ssr_resample_plan": (_i, [_i64, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64), C.POINTER(_i),
                                C.POINTER(_i), C.POINTER(_i)]),
     "ssr_resample_poly": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "ssr_resample_poly_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "ssr_sosfiltfilt_workspace_bytes": (_sz, [_i64, _i, _i]),
     "ssr_sosfiltfilt": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
 }

@@ -83,8 +83,13 @@ def get_plan(n_fft, hop, precision="f64", device=None):
         return p
 
 
+def _is_f64(a):
+    return (a.dtype == torch.float64) if isinstance(a, torch.Tensor) else (getattr(a, "dtype", None) == np.float64)
+
+
 class Ragged:
-    """A ragged batch of 1-D float32 signals resident on the device."""
+    """A ragged batch of 1-D signals resident on the device: float32, or float64 where the reference would hold
+    float64 (IIR-degraded / resampled-from-float64 estimates)."""
 
     def __init__(self, data, off, lens_dev, lens_host):
         self.data, self.off, self.len = data, off, lens_dev
@@ -94,21 +99,27 @@ class Ragged:
         self.device = data.device
 
     @staticmethod
-    def from_list(arrays, device=None):
+    def from_list(arrays, device=None, dtype=torch.float32):
         dev = torch.device(device) if device is not None else default_device()
         ts = []
         for a in arrays:
             t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
             if t.dim() != 1:
                 raise ValueError("expected 1-D signals, got shape %s" % (tuple(t.shape),))
-            ts.append(t.to(device=dev, dtype=torch.float32, non_blocking=True))
+            ts.append(t.to(device=dev, dtype=dtype, non_blocking=True))
         lens = np.array([t.shape[0] for t in ts], dtype=np.int64)
         if len(ts) and lens.max() >= 2 ** 31:
             raise ValueError("signal too long")
-        data = torch.cat(ts) if len(ts) else torch.empty(0, dtype=torch.float32, device=dev)
+        data = torch.cat(ts) if len(ts) else torch.empty(0, dtype=dtype, device=dev)
         off = np.concatenate(([0], np.cumsum(lens)[:-1])) if len(ts) else np.zeros(0, np.int64)
         return Ragged(data, torch.from_numpy(off.astype(np.int64)).to(dev),
                       torch.from_numpy(lens.astype(np.int32)).to(dev), lens)
+
+    @staticmethod
+    def from_list_keep64(arrays, device=None):
+        """float64 batch if ANY signal is float64 (exact for the float32 ones), else float32."""
+        arrays = list(arrays)
+        return Ragged.from_list(arrays, device, torch.float64 if any(_is_f64(a) for a in arrays) else torch.float32)
 
     @staticmethod
     def from_uniform(x):
@@ -150,6 +161,8 @@ class PairBatch:
     def __init__(self, plan, est, tgt):
         if est.n != tgt.n or not np.array_equal(est.lens_host, tgt.lens_host):
             raise ValueError("est and target must have identical lengths (truncate to min_len first)")
+        if tgt.data.dtype != torch.float32:
+            raise ValueError("the target batch must be float32 (only the estimate may be float64)")
         _check_reflect(plan, est.lens_host)
         self.plan, self.est, self.tgt = plan, est, tgt
         self.rows = _Rows(plan, est.lens_host, est.device)
@@ -164,6 +177,13 @@ class PairBatch:
             return self.out
         if (mask & M_SSIM) and (self.rows.T.min() < 7 or p.n_bins < 7):
             raise ValueError("win_size exceeds image extent")  # what skimage raises for images smaller than 7x7
+        if e.data.dtype == torch.float64:
+            if stages != 7:
+                raise ValueError("stage selection is a bench facility of the float32 path")
+            _lib.check(p.lib.ssr_pair_metrics_est64(
+                p.handle, _vp(e.data), _vp(e.off), _vp(t.data), _vp(t.off), _vp(e.len), _vp(self.rows.off), e.n,
+                e.max_len, self.rows.total, mask, _vp(self.out), _vp(self.ws), self.ws_bytes, _stream()))
+            return self.out
         _lib.check(p.lib.ssr_pair_metrics_stages(
             p.handle, _vp(e.data), _vp(e.off), _vp(t.data), _vp(t.off), _vp(e.len), _vp(self.rows.off), e.n, e.max_len,
             self.rows.total, mask, _vp(self.out), _vp(self.ws), self.ws_bytes, _stream(), stages))
@@ -171,9 +191,10 @@ class PairBatch:
 
 
 def pair_metrics(plan, est_list, tgt_list, mask=M_ALL):
-    """[n, 4] float64 (lsd, log_sispec, sispec, ssim) for lists of equal-length (est, target) waveforms."""
+    """[n, 4] float64 (lsd, log_sispec, sispec, ssim) for lists of equal-length (est, target) waveforms.
+    float64 estimates stay float64 (ssr_pair_metrics_est64); targets are float32."""
     with torch.cuda.device(plan.device):
-        b = PairBatch(plan, Ragged.from_list(est_list, plan.device), Ragged.from_list(tgt_list, plan.device))
+        b = PairBatch(plan, Ragged.from_list_keep64(est_list, plan.device), Ragged.from_list(tgt_list, plan.device))
         return b.run(mask).cpu().numpy()
 
 
@@ -273,7 +294,8 @@ def istft(plan, res, ims, lengths):
 
 # ------------------------------------------------------------------------------------------------------
 class ResamplePlan:
-    """Integer plan + taps of scipy.signal.resample_poly(x, up, down) for float32 x."""
+    """Integer plan + taps of scipy.signal.resample_poly(x, up, down): float32 taps for a float32
+    signal, the unrounded float64 design for a float64 one - as SciPy casts `h` to the signal's dtype."""
 
     _cache = {}
 
@@ -287,12 +309,14 @@ class ResamplePlan:
         self.n_pre_pad, self.n_pre_remove = pp.value, pr.value
         self.identity = self.up == 1 and self.down == 1
         if self.identity:                      # scipy returns x.copy() before designing any filter
-            self.taps_host, self.taps = None, None
+            self.taps_host, self.taps, self.taps64 = None, None, None
             return
-        h = firwin(2 * self.half_len + 1, 1.0 / max(self.up, self.down), window=("kaiser", 5.0)).astype(np.float32)
-        h *= self.up
+        h64 = firwin(2 * self.half_len + 1, 1.0 / max(self.up, self.down), window=("kaiser", 5.0))
+        h = h64.astype(np.float32)
+        h *= self.up                            # scipy: h = h.astype(x.dtype) first, then h * up
         self.taps_host = np.concatenate((np.zeros(self.n_pre_pad, np.float32), h))
         self.taps = torch.from_numpy(self.taps_host).to(device)
+        self.taps64 = torch.from_numpy(np.concatenate((np.zeros(self.n_pre_pad), h64 * self.up))).to(device)
 
     @classmethod
     def get(cls, up, down, device):
@@ -308,22 +332,25 @@ class ResamplePlan:
 
 
 def resample_poly(wavs, up, down, device=None):
-    """Polyphase resampling (K7) of a list of float32 waveforms; bit-identical to scipy.signal.resample_poly."""
+    """Polyphase resampling (K7) of a list of waveforms; bit-identical to scipy.signal.resample_poly.  A batch
+    holding float64 signals is resampled in float64 (float64 taps and accumulation), everything else in float32."""
     dev = torch.device(device) if device is not None else default_device()
     with torch.cuda.device(dev):
-        r = wavs if isinstance(wavs, Ragged) else Ragged.from_list(wavs, dev)
+        r = wavs if isinstance(wavs, Ragged) else Ragged.from_list_keep64(wavs, dev)
         rp = ResamplePlan.get(up, down, dev)
         if rp.identity:
             return [w.clone() for w in r.split()]
+        f64 = r.data.dtype == torch.float64
         out_len = np.array([rp.n_out(n) for n in r.lens_host], dtype=np.int64)
         out_off = np.concatenate(([0], np.cumsum(out_len)[:-1])).astype(np.int64)
-        out = torch.empty(int(out_len.sum()), dtype=torch.float32, device=dev)
+        out = torch.empty(int(out_len.sum()), dtype=r.data.dtype, device=dev)
         if r.n and out_len.max() > 0:
             out_off_d = torch.from_numpy(out_off).to(dev)          # keep alive across the call (see istft)
             out_len_d = torch.from_numpy(out_len.astype(np.int32)).to(dev)
-            _lib.check(_lib.load().ssr_resample_poly(
-                _vp(r.data), _vp(r.off), _vp(r.len), _vp(out_off_d), _vp(out_len_d), r.n, int(out_len.max()), rp.up,
-                rp.down, _vp(rp.taps), int(rp.taps.numel()), rp.n_pre_remove, _vp(out), _stream()))
+            taps = rp.taps64 if f64 else rp.taps
+            fn = _lib.load().ssr_resample_poly_f64 if f64 else _lib.load().ssr_resample_poly
+            _lib.check(fn(_vp(r.data), _vp(r.off), _vp(r.len), _vp(out_off_d), _vp(out_len_d), r.n, int(out_len.max()),
+                          rp.up, rp.down, _vp(taps), int(taps.numel()), rp.n_pre_remove, _vp(out), _stream()))
         return [out[out_off[i]:out_off[i] + out_len[i]] for i in range(r.n)]
 
 

@@ -42,6 +42,8 @@ static inline void ssr_launder(SsrBlk&) {}
 #define SSR_WAVE_SUM_ADD(tid, NT_, val, dst) do { (dst)[(tid) >> 6] += (val); } while (0)
 static inline float ssr_fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 static inline float ssr_fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline double ssr_fmul_rn(double a, double b) { volatile double r = a * b; return r; }
+static inline double ssr_fadd_rn(double a, double b) { volatile double r = a + b; return r; }
 #else
 #include <hip/hip_runtime.h>
 #if defined(SSR_ABL_NOBAR)   /* developer ablation: WRONG results, timing only */
@@ -105,6 +107,14 @@ SSR_DEV float ssr_fmul_rn(float a, float b) {
   return a * b;
 }
 SSR_DEV float ssr_fadd_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+SSR_DEV double ssr_fmul_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+SSR_DEV double ssr_fadd_rn(double a, double b) {
 #pragma clang fp contract(off)
   return a + b;
 }

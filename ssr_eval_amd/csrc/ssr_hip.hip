@@ -36,21 +36,23 @@ extern "C" int ssr_version(void) { return SSR_VERSION; }
 // SISpec sums fits 128 VGPRs with no spill, which admits a 4th workgroup per CU (-4.5 % time, measured);
 // the variant that carries the six sums would spill at 128, so it stays at 3.
 constexpr int ssr_stft_min_waves(int logn, bool blu, bool sums) { return (logn == 11 && !blu && !sums) ? 4 : 1; }
-template <typename T, int LOGN, bool BLU, int MODE, bool SUMS>
-__global__ __launch_bounds__((1 << LOGN) / ssr_stft_ppt(LOGN, BLU), ssr_stft_min_waves(LOGN, BLU, SUMS))
+// E64: the estimate is a float64 signal (pair mode only); its float64 epilogue needs more registers, so those
+// variants are left to the allocator (min waves 1).
+template <typename T, int LOGN, bool BLU, int MODE, bool SUMS, bool E64>
+__global__ __launch_bounds__((1 << LOGN) / ssr_stft_ppt(LOGN, BLU), E64 ? 1 : ssr_stft_min_waves(LOGN, BLU, SUMS))
 void k_stft(SsrStftParams<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SsrBlk blk{(int)threadIdx.x};
   const int item = blockIdx.x / p.n_chunks, chunk = blockIdx.x % p.n_chunks;
-  ssr_stft_body<T, LOGN, BLU, MODE, SUMS, ssr_stft_ppt(LOGN, BLU)>(p, blk, chunk, item, smem);
+  ssr_stft_body<T, LOGN, BLU, MODE, SUMS, ssr_stft_ppt(LOGN, BLU), E64>(p, blk, chunk, item, smem);
 }
 
-template <typename T, int LOGN, int MODE, bool SUMS>
+template <typename T, int LOGN, int MODE, bool SUMS, bool E64>
 __global__ __launch_bounds__((1 << LOGN) / 8) void k_stft_r3(SsrStftParams<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SsrBlk blk{(int)threadIdx.x};
   const int item = blockIdx.x / p.n_chunks, chunk = blockIdx.x % p.n_chunks;
-  ssr_stft_r3_body<T, LOGN, MODE, SUMS>(p, blk, chunk, item, smem);
+  ssr_stft_r3_body<T, LOGN, MODE, SUMS, E64>(p, blk, chunk, item, smem);
 }
 
 #ifndef SSR_LOWPASS_WAVES_PER_EU
@@ -92,10 +94,11 @@ __global__ __launch_bounds__(256) void k_ola(SsrOlaParams p, int blocks_per_item
   ssr_ola_sample(p, item, s);
 }
 
-__global__ __launch_bounds__(SSR_RESAMPLE_NT) void k_resample(SsrResampleParams p, int blocks_per_item) {
+template <typename S>
+__global__ __launch_bounds__(SSR_RESAMPLE_NT) void k_resample(SsrResampleParamsT<S> p, int blocks_per_item) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SsrBlk blk{(int)threadIdx.x};
-  ssr_resample_body(p, blk, blockIdx.x % blocks_per_item, blockIdx.x / blocks_per_item, smem);
+  ssr_resample_body<S>(p, blk, blockIdx.x % blocks_per_item, blockIdx.x / blocks_per_item, smem);
 }
 
 template <int G>
@@ -163,7 +166,7 @@ template <> const DevTables<double>& tables_of<double>(const ssr_plan* pl) { ret
 // kernel registry: (precision, logn, bluestein) -> launcher
 typedef int (*stft_launcher)(const ssr_plan*, void* params, int grid, hipStream_t);
 
-template <typename T, int LOGN, bool BLU, int MODE, bool SUMS>
+template <typename T, int LOGN, bool BLU, int MODE, bool SUMS, bool E64 = false>
 static int launch_stft_mode(SsrStftParams<T>& p, int grid, hipStream_t s) {
   // SSR_LDS_PAD (bytes, developer knob): over-allocate LDS to cap workgroups per CU in occupancy experiments
   static const size_t lds_pad = getenv("SSR_LDS_PAD") ? (size_t)atol(getenv("SSR_LDS_PAD")) : 0;
@@ -173,31 +176,39 @@ static int launch_stft_mode(SsrStftParams<T>& p, int grid, hipStream_t s) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (lds > 48 * 1024 && attr_dev != dev) {
-    HIP_TRY(hipFuncSetAttribute((const void*)k_stft<T, LOGN, BLU, MODE, SUMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_stft<T, LOGN, BLU, MODE, SUMS, E64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_dev = dev;
   }
-  hipLaunchKernelGGL((k_stft<T, LOGN, BLU, MODE, SUMS>), dim3(grid), dim3((1 << LOGN) / PPT), lds, s, p);
+  hipLaunchKernelGGL((k_stft<T, LOGN, BLU, MODE, SUMS, E64>), dim3(grid), dim3((1 << LOGN) / PPT), lds, s, p);
   HIP_TRY(hipGetLastError());
   return SSR_OK;
 }
 template <typename T, int LOGN, bool BLU> static int launch_stft_inst(SsrStftParams<T>& p, int grid, hipStream_t s) {
   if (p.mode != SSR_MODE_PAIR) return launch_stft_mode<T, LOGN, BLU, SSR_MODE_SINGLE, false>(p, grid, s);
-  return (p.metric_mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC)) ? launch_stft_mode<T, LOGN, BLU, SSR_MODE_PAIR, true>(p, grid, s)
-                                                             : launch_stft_mode<T, LOGN, BLU, SSR_MODE_PAIR, false>(p, grid, s);
+  const bool sums = p.metric_mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC);
+  if (p.a64)
+    return sums ? launch_stft_mode<T, LOGN, BLU, SSR_MODE_PAIR, true, true>(p, grid, s)
+                : launch_stft_mode<T, LOGN, BLU, SSR_MODE_PAIR, false, true>(p, grid, s);
+  return sums ? launch_stft_mode<T, LOGN, BLU, SSR_MODE_PAIR, true>(p, grid, s)
+              : launch_stft_mode<T, LOGN, BLU, SSR_MODE_PAIR, false>(p, grid, s);
 }
 
-template <typename T, int LOGN, int MODE, bool SUMS>
+template <typename T, int LOGN, int MODE, bool SUMS, bool E64 = false>
 static int launch_stft_r3_mode(SsrStftParams<T>& p, int grid, hipStream_t s) {
   const size_t lds = SsrStftR3Lds<T, LOGN>::bytes(p.n_fft / 3);
-  HIP_TRY(hipFuncSetAttribute((const void*)k_stft_r3<T, LOGN, MODE, SUMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((k_stft_r3<T, LOGN, MODE, SUMS>), dim3(grid), dim3((1 << LOGN) / 8), lds, s, p);
+  HIP_TRY(hipFuncSetAttribute((const void*)k_stft_r3<T, LOGN, MODE, SUMS, E64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_stft_r3<T, LOGN, MODE, SUMS, E64>), dim3(grid), dim3((1 << LOGN) / 8), lds, s, p);
   HIP_TRY(hipGetLastError());
   return SSR_OK;
 }
 template <typename T, int LOGN> static int launch_stft_r3(SsrStftParams<T>& p, int grid, hipStream_t s) {
   if (p.mode != SSR_MODE_PAIR) return launch_stft_r3_mode<T, LOGN, SSR_MODE_SINGLE, false>(p, grid, s);
-  return (p.metric_mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC)) ? launch_stft_r3_mode<T, LOGN, SSR_MODE_PAIR, true>(p, grid, s)
-                                                             : launch_stft_r3_mode<T, LOGN, SSR_MODE_PAIR, false>(p, grid, s);
+  const bool sums = p.metric_mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC);
+  if (p.a64)
+    return sums ? launch_stft_r3_mode<T, LOGN, SSR_MODE_PAIR, true, true>(p, grid, s)
+                : launch_stft_r3_mode<T, LOGN, SSR_MODE_PAIR, false, true>(p, grid, s);
+  return sums ? launch_stft_r3_mode<T, LOGN, SSR_MODE_PAIR, true>(p, grid, s)
+              : launch_stft_r3_mode<T, LOGN, SSR_MODE_PAIR, false>(p, grid, s);
 }
 
 template <typename T> static int launch_stft_t(const ssr_plan* pl, SsrStftParams<T>& p, int grid, hipStream_t s) {
@@ -439,11 +450,11 @@ __global__ void k_rows_from_len(const int32_t* len, int n_items, int n_fft, int 
 }
 
 template <typename T>
-static int pair_stage_stft(const ssr_plan* pl, const float* est, const int64_t* est_off, const float* tgt,
+static int pair_stage_stft(const ssr_plan* pl, const float* est, const double* est64, const int64_t* est_off, const float* tgt,
                            const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off, int n_items,
                            unsigned mask, bool need_mag, const PairWs& w, char* ws, hipStream_t s) {
   SsrStftParams<T> p{};
-  p.a = est; p.b = tgt; p.a_off = est_off; p.b_off = tgt_off; p.len = len; p.frame_off = frame_off;
+  p.a = est; p.a64 = est64; p.b = tgt; p.a_off = est_off; p.b_off = tgt_off; p.len = len; p.frame_off = frame_off;
   p.mode = SSR_MODE_PAIR; p.out_kind = need_mag ? SSR_OUT_MAG : SSR_OUT_NONE; p.metric_mask = (int)mask;
   p.n_fft = pl->n_fft; p.hop = pl->hop; p.n_bins = pl->n_bins;
   p.units_per_chunk = w.units_per_chunk; p.n_chunks = w.n_chunks;
@@ -453,11 +464,11 @@ static int pair_stage_stft(const ssr_plan* pl, const float* est, const int64_t* 
 }
 
 // stages: 1 = STFT + LSD/SISpec epilogue, 2 = SSIM, 4 = finalise (bench.py times stages separately)
-extern "C" int ssr_pair_metrics_stages(const ssr_plan* pl, const float* est, const int64_t* est_off, const float* tgt,
-                                       const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off,
-                                       int n_items, int max_len, int64_t total_rows, unsigned mask, double* out,
-                                       void* workspace, size_t workspace_bytes, void* stream, int stages) {
-  if (!pl || !est || !tgt || !est_off || !tgt_off || !len || !frame_off || !out)
+static int pair_metrics_impl(const ssr_plan* pl, const float* est, const double* est64, const int64_t* est_off,
+                             const float* tgt, const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off,
+                             int n_items, int max_len, int64_t total_rows, unsigned mask, double* out,
+                             void* workspace, size_t workspace_bytes, void* stream, int stages) {
+  if (!pl || (!est && !est64) || !tgt || !est_off || !tgt_off || !len || !frame_off || !out)
     return fail(SSR_ERR_INVALID_ARG, "null argument");
   if (n_items <= 0) return SSR_OK;
   if (max_len <= pl->n_fft / 2) return fail(SSR_ERR_INVALID_ARG, "reflect padding needs len > n_fft/2");
@@ -477,8 +488,8 @@ extern "C" int ssr_pair_metrics_stages(const ssr_plan* pl, const float* est, con
     hipLaunchKernelGGL(k_rows_from_len, dim3(ceil_div(n_items, 256)), dim3(256), 0, s, len, n_items, pl->n_fft, pl->hop, rows);
     HIP_TRY(hipGetLastError());
     rc = pl->precision == SSR_F64
-             ? pair_stage_stft<double>(pl, est, est_off, tgt, tgt_off, len, frame_off, n_items, mask, want_ssim, w, ws, s)
-             : pair_stage_stft<float>(pl, est, est_off, tgt, tgt_off, len, frame_off, n_items, mask, want_ssim, w, ws, s);
+             ? pair_stage_stft<double>(pl, est, est64, est_off, tgt, tgt_off, len, frame_off, n_items, mask, want_ssim, w, ws, s)
+             : pair_stage_stft<float>(pl, est, est64, est_off, tgt, tgt_off, len, frame_off, n_items, mask, want_ssim, w, ws, s);
     if (rc) return rc;
   }
   if ((stages & 2) && want_ssim) {
@@ -493,12 +504,28 @@ extern "C" int ssr_pair_metrics_stages(const ssr_plan* pl, const float* est, con
   return rc;
 }
 
+extern "C" int ssr_pair_metrics_stages(const ssr_plan* pl, const float* est, const int64_t* est_off, const float* tgt,
+                                       const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off,
+                                       int n_items, int max_len, int64_t total_rows, unsigned mask, double* out,
+                                       void* workspace, size_t workspace_bytes, void* stream, int stages) {
+  return pair_metrics_impl(pl, est, nullptr, est_off, tgt, tgt_off, len, frame_off, n_items, max_len, total_rows, mask,
+                           out, workspace, workspace_bytes, stream, stages);
+}
+
 extern "C" int ssr_pair_metrics(const ssr_plan* pl, const float* est, const int64_t* est_off, const float* tgt,
                                 const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off, int n_items,
                                 int max_len, int64_t total_rows, unsigned mask, double* out, void* workspace,
                                 size_t workspace_bytes, void* stream) {
-  return ssr_pair_metrics_stages(pl, est, est_off, tgt, tgt_off, len, frame_off, n_items, max_len, total_rows, mask, out,
-                                 workspace, workspace_bytes, stream, 7);
+  return pair_metrics_impl(pl, est, nullptr, est_off, tgt, tgt_off, len, frame_off, n_items, max_len, total_rows, mask,
+                           out, workspace, workspace_bytes, stream, 7);
+}
+
+extern "C" int ssr_pair_metrics_est64(const ssr_plan* pl, const double* est, const int64_t* est_off, const float* tgt,
+                                      const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off, int n_items,
+                                      int max_len, int64_t total_rows, unsigned mask, double* out, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  return pair_metrics_impl(pl, nullptr, est, est_off, tgt, tgt_off, len, frame_off, n_items, max_len, total_rows, mask,
+                           out, workspace, workspace_bytes, stream, 7);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -625,22 +652,38 @@ extern "C" int ssr_resample_plan(int64_t n_in, int up, int down, int* up_r, int*
   return SSR_OK;
 }
 
-extern "C" int ssr_resample_poly(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
-                                 const int32_t* out_len, int n_items, int max_out_len, int up, int down,
-                                 const float* taps, int n_taps, int n_pre_remove, float* out, void* stream) {
+template <typename S>
+static int resample_poly_t(const S* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
+                           const int32_t* out_len, int n_items, int max_out_len, int up, int down, const S* taps,
+                           int n_taps, int n_pre_remove, S* out, void* stream) {
   if (!in || !in_off || !in_len || !out_off || !out_len || !taps || !out) return fail(SSR_ERR_INVALID_ARG, "null argument");
   if (up < 1 || down < 1 || n_taps < 1) return fail(SSR_ERR_INVALID_ARG, "bad resampling plan");
   if (n_items <= 0 || max_out_len <= 0) return SSR_OK;
-  SsrResampleParams p{in, in_off, in_len, out_off, out_len, up, down, taps, n_taps, n_pre_remove,
-                      ssr_resample_pick_groups(up, down), 1, out};
+  SsrResampleParamsT<S> p{in, in_off, in_len, out_off, out_len, up, down, taps, n_taps, n_pre_remove,
+                          ssr_resample_pick_groups(up, down), 1, out};
   if (ssr_resample_lds_bytes(p) > 96 * 1024) p.taps_in_lds = 0;      // huge tap tables stay in HBM / L2
   const size_t lds = ssr_resample_lds_bytes(p);
   if (lds > 160 * 1024) return fail(SSR_ERR_UNSUPPORTED, "input window does not fit LDS");
-  if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_resample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_resample<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int bpi = ceil_div(max_out_len, ssr_resample_opb(p));
-  hipLaunchKernelGGL(k_resample, dim3((unsigned)((int64_t)n_items * bpi)), dim3(SSR_RESAMPLE_NT), lds, (hipStream_t)stream, p, bpi);
+  hipLaunchKernelGGL((k_resample<S>), dim3((unsigned)((int64_t)n_items * bpi)), dim3(SSR_RESAMPLE_NT), lds, (hipStream_t)stream, p, bpi);
   HIP_TRY(hipGetLastError());
   return SSR_OK;
+}
+
+extern "C" int ssr_resample_poly(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
+                                 const int32_t* out_len, int n_items, int max_out_len, int up, int down,
+                                 const float* taps, int n_taps, int n_pre_remove, float* out, void* stream) {
+  return resample_poly_t<float>(in, in_off, in_len, out_off, out_len, n_items, max_out_len, up, down, taps, n_taps,
+                                n_pre_remove, out, stream);
+}
+
+extern "C" int ssr_resample_poly_f64(const double* in, const int64_t* in_off, const int32_t* in_len,
+                                     const int64_t* out_off, const int32_t* out_len, int n_items, int max_out_len, int up,
+                                     int down, const double* taps, int n_taps, int n_pre_remove, double* out,
+                                     void* stream) {
+  return resample_poly_t<double>(in, in_off, in_len, out_off, out_len, n_items, max_out_len, up, down, taps, n_taps,
+                                 n_pre_remove, out, stream);
 }
 
 // ----------------------------------------------------------------------------------------------------

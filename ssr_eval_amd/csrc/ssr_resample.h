@@ -19,28 +19,30 @@
 #define SSR_RESAMPLE_NT 256
 #define SSR_RESAMPLE_J 8
 
-struct SsrResampleParams {
-  const float* in;
+// S: sample type (float, or double for a float64 signal: SciPy then designs float64 taps and accumulates in float64)
+template <typename S> struct SsrResampleParamsT {
+  const S* in;
   const int64_t* in_off;   // [n_items]
   const int32_t* in_len;   // [n_items]
   const int64_t* out_off;  // [n_items]
   const int32_t* out_len;  // [n_items]
   int up, down;
-  const float* taps;       // [n_taps] = zeros(n_pre_pad) ++ h*up ++ zeros(n_post_pad)
+  const S* taps;           // [n_taps] = zeros(n_pre_pad) ++ h*up ++ zeros(n_post_pad)
   int n_taps, n_pre_remove;
   int groups;              // G: outputs per block = up * SSR_RESAMPLE_J * G
   int taps_in_lds;         // 0: tap table too large for LDS, read it through L2
-  float* out;
+  S* out;
 };
+typedef SsrResampleParamsT<float> SsrResampleParams;
 
-SSR_HD int ssr_resample_hpp(const SsrResampleParams& p) { return (p.n_taps + p.up - 1) / p.up; }
-SSR_HD int ssr_resample_opb(const SsrResampleParams& p) { return p.up * SSR_RESAMPLE_J * p.groups; }
-SSR_HD int ssr_resample_win(const SsrResampleParams& p) {
+template <typename S> SSR_HD int ssr_resample_hpp(const SsrResampleParamsT<S>& p) { return (p.n_taps + p.up - 1) / p.up; }
+template <typename S> SSR_HD int ssr_resample_opb(const SsrResampleParamsT<S>& p) { return p.up * SSR_RESAMPLE_J * p.groups; }
+template <typename S> SSR_HD int ssr_resample_win(const SsrResampleParamsT<S>& p) {
   return (int)(((int64_t)ssr_resample_opb(p) * p.down) / p.up) + ssr_resample_hpp(p) + 2;
 }
-SSR_HD size_t ssr_resample_lds_bytes(const SsrResampleParams& p) {
+template <typename S> SSR_HD size_t ssr_resample_lds_bytes(const SsrResampleParamsT<S>& p) {
   const size_t taps = p.taps_in_lds ? (size_t)ssr_resample_hpp(p) * p.up : 0;
-  return sizeof(float) * (taps + ssr_resample_win(p) + 8);
+  return sizeof(S) * (taps + ssr_resample_win(p) + 8);
 }
 // host-side geometry: about 6144 outputs per block, input window capped at 8192 samples
 SSR_HD int ssr_resample_pick_groups(int up, int down) {
@@ -52,8 +54,8 @@ SSR_HD int ssr_resample_pick_groups(int up, int down) {
 }
 
 // grid = (n_blocks, n_items), block = SSR_RESAMPLE_NT
-template <typename BLK>
-SSR_BODY void ssr_resample_body(const SsrResampleParams& p, BLK& blk, int block, int item, char* lds_base) {
+template <typename S, typename BLK>
+SSR_BODY void ssr_resample_body(const SsrResampleParamsT<S>& p, BLK& blk, int block, int item, char* lds_base) {
   constexpr int NT = SSR_RESAMPLE_NT, J = SSR_RESAMPLE_J;
   struct Regs { int unused; };
   const int hpp = ssr_resample_hpp(p), up = p.up, down = p.down, G = p.groups;
@@ -62,24 +64,24 @@ SSR_BODY void ssr_resample_body(const SsrResampleParams& p, BLK& blk, int block,
   const int64_t m0 = (int64_t)block * opb;
   if (m0 >= n_out) return;
   const int64_t m1 = (m0 + opb < n_out) ? m0 + opb : n_out;
-  float* hl = reinterpret_cast<float*>(lds_base);
-  float* xw = hl + (p.taps_in_lds ? hpp * up : 0);
-  const float* h = p.taps_in_lds ? hl : p.taps;
+  S* hl = reinterpret_cast<S*>(lds_base);
+  S* xw = hl + (p.taps_in_lds ? hpp * up : 0);
+  const S* h = p.taps_in_lds ? hl : p.taps;
   const int h_len = p.taps_in_lds ? hpp * up : p.n_taps;
   const int64_t q_first = ((m0 + p.n_pre_remove) * down) / up;
   const int64_t q_lo = q_first - (hpp - 1);
   const int64_t q_hi = ((m1 - 1 + p.n_pre_remove) * down) / up;
   const int win = (int)(q_hi - q_lo + 1);
-  const float* x = p.in + p.in_off[item];
-  float* y = p.out + p.out_off[item];
+  const S* x = p.in + p.in_off[item];
+  S* y = p.out + p.out_off[item];
 
   SSR_REGS(Regs, regs, blk);
   SSR_PHASE(blk, regs, {
     if (p.taps_in_lds)
-      for (int i = tid; i < hpp * up; i += NT) hl[i] = (i < p.n_taps) ? p.taps[i] : 0.0f;
+      for (int i = tid; i < hpp * up; i += NT) hl[i] = (i < p.n_taps) ? p.taps[i] : (S)0;
     for (int i = tid; i < win; i += NT) {
       const int64_t j = q_lo + i;
-      xw[i] = (j >= 0 && j < n_in) ? x[j] : 0.0f;
+      xw[i] = (j >= 0 && j < n_in) ? x[j] : (S)0;
     }
   });
   SSR_PHASE(blk, regs, {
@@ -91,17 +93,17 @@ SSR_BODY void ssr_resample_body(const SsrResampleParams& p, BLK& blk, int block,
         const int64_t q0 = t0 / up;
         const int ph = (int)(t0 - q0 * up);
         const int base = (int)(q0 - q_lo);
-        float acc[J];
+        S acc[J];
         int xb[J];   // window slot of the OLDEST input sample of output j (outputs past m1 alias output 0, never stored)
         SSR_UNROLL for (int j = 0; j < J; ++j) {
-          acc[j] = 0.0f;
+          acc[j] = (S)0;
           xb[j] = (mf + (int64_t)j * up < m1) ? base + j * down - (hpp - 1) : base - (hpp - 1);
         }
         // k ascending = input index ascending (tap index descending): SciPy's accumulation order.
         // Partial unroll keeps several taps' worth of LDS reads in flight per wait.
         int hi = ph + (hpp - 1) * up;
         SSR_UNROLL4 for (int k = 0; k < hpp; ++k) {
-          const float hv = (hi < h_len) ? h[hi] : 0.0f;
+          const S hv = (hi < h_len) ? h[hi] : (S)0;
           hi -= up;
           SSR_UNROLL for (int j = 0; j < J; ++j) acc[j] = ssr_fadd_rn(acc[j], ssr_fmul_rn(xw[xb[j] + k], hv));
         }

@@ -43,6 +43,7 @@ enum { SSR_M_LSD = 1, SSR_M_LOG_SISPEC = 2, SSR_M_SISPEC = 4, SSR_M_SSIM = 8 };
 
 template <typename T> struct SsrStftParams {
   const float* a;            // signal buffer A (est, or the only signal in SINGLE mode)
+  const double* a64;         // EST64 kernels only: the estimate as float64 samples (a is unused then)
   const float* b;            // signal buffer B (target); unused in SINGLE mode
   const int64_t* a_off;      // [n_items] element offset of item i in a
   const int64_t* b_off;      // [n_items] element offset of item i in b
@@ -62,6 +63,10 @@ template <typename T> struct SsrStftParams {
   float* out_b;              // PAIR: target magnitudes;          SINGLE: im (COMPLEX) or unused
   double* part;              // [n_items, n_chunks, SSR_NPART] or null
 };
+
+// sample type of signal A
+template <bool EST64> struct SsrSampleA { typedef float type; };
+template <> struct SsrSampleA<true> { typedef double type; };
 
 template <typename T, bool SUMS = false, int PPT = 8> struct SsrStftRegs {
   cx<T> v[PPT];              // FFT points
@@ -119,15 +124,51 @@ SSR_DEV void ssr_accumulate_metrics(float e, float t, int mask, double* acc) {
   }
 }
 
+// The same terms when the estimate is a float64 signal.  librosa.stft then returns complex128 and the reference's
+// est spectrogram is a float64 tensor against a float32 target, so torch's type promotion applies:
+//   lsd        : target**2 stays float32, (est + EPS)**2, the quotient, + EPS and log10 are float64;
+//   log-sispec : to_log(est) is float64, to_log(target) float32 (promoted when the two meet);
+//   sispec     : products in float64.
+SSR_DEV void ssr_accumulate_metrics(double e, float t, int mask, double* acc) {
+  const double EPS = 1e-12;
+  const float EPSF = 1e-12f;
+  if (mask & SSR_M_LSD) {
+    const double ee = e + EPS;
+    const double d = log10((double)(t * t) / (ee * ee) + EPS);
+    acc[0] += d * d;
+  }
+  if (mask & SSR_M_SISPEC) {
+    acc[1] += e * e;
+    acc[2] += (double)t * (double)t;
+    acc[3] += e * (double)t;
+  }
+  if (mask & SSR_M_LOG_SISPEC) {
+    const double le = log10(e + EPS), lt = (double)log10f(t + EPSF);
+    acc[4] += le * le;
+    acc[5] += lt * lt;
+    acc[6] += le * lt;
+  }
+}
+
 // Emit bin k of the current unit.  zk = Z[k], zn = Z[(n-k) mod n].  out_a_row / out_b_row: block-uniform
 // row base pointers (scalar base + 32-bit lane offset addressing).
-template <typename T, int MODE>
+template <typename T, int MODE, bool EST64 = false>
 SSR_DEV void ssr_emit_bin(const SsrStftParams<T>& p, double* acc, unsigned k, cx<T> zk, cx<T> zn,
                           float* row_a0, float* row_a1, float* row_b0, float* row_b1, bool b_valid) {
   // PAIR  : row_a0 = est magnitudes row,  row_b0 = target magnitudes row
   // SINGLE: row_a0 / row_a1 = rows of frames 2g / 2g+1 in out_a; row_b0 / row_b1 the same rows in out_b
   const SsrBinOut<T> o = ssr_separate<T>(zk, zn);
-  if constexpr (MODE == SSR_MODE_PAIR) {
+  if constexpr (MODE == SSR_MODE_PAIR && EST64) {
+    // numpy.abs(complex128) of the unrounded est spectrum; the SSIM image keeps its float32 layout (the
+    // rounding moves SSIM by < 2e-7, tests/test_gpu_parity.py)
+    const double e = hypot((double)zk.x + (double)zn.x, (double)zk.y - (double)zn.y);
+    const float t = ssr_cabsf(o.br, o.bi);
+    if (p.out_kind == SSR_OUT_MAG) {
+      row_a0[k] = (float)e;
+      row_b0[k] = t;
+    }
+    ssr_accumulate_metrics(e, t, p.metric_mask, acc);
+  } else if constexpr (MODE == SSR_MODE_PAIR) {
     const float e = ssr_cabsf(o.ar, o.ai), t = ssr_cabsf(o.br, o.bi);
     if (p.out_kind == SSR_OUT_MAG) {
       row_a0[k] = e;
@@ -151,7 +192,7 @@ SSR_DEV void ssr_emit_bin(const SsrStftParams<T>& p, double* acc, unsigned k, cx
 
 // Direct engine epilogue: F = N/2 + 1 = (PPT/2) * NT + 1 -> PPT/2 full, unrolled rounds (all LDS reads in flight
 // together) + the Nyquist bin on thread 0.
-template <typename T, int LOGN, int MODE, int PPT>
+template <typename T, int LOGN, int MODE, int PPT, bool EST64 = false>
 SSR_DEV void ssr_epilogue_direct(const SsrStftParams<T>& p, double* acc, int tid, const T* re, const T* im,
                                  float* ra0, float* ra1, float* rb0, float* rb1, bool b_ok) {
   constexpr int N = 1 << LOGN, NT = N / PPT, RND = PPT / 2;   // F = N/2 + 1 = RND * NT + 1
@@ -164,10 +205,10 @@ SSR_DEV void ssr_epilogue_direct(const SsrStftParams<T>& p, double* acc, int tid
   }
 #pragma unroll
   for (int i = 0; i < RND; ++i)
-    ssr_emit_bin<T, MODE>(p, acc, (unsigned)(tid + i * NT), zk[i], zn[i], ra0, ra1, rb0, rb1, b_ok);
+    ssr_emit_bin<T, MODE, EST64>(p, acc, (unsigned)(tid + i * NT), zk[i], zn[i], ra0, ra1, rb0, rb1, b_ok);
   if (tid == 0) {
     const cx<T> zq = {re[ssr_pad(N / 2)], im[ssr_pad(N / 2)]};
-    ssr_emit_bin<T, MODE>(p, acc, (unsigned)(N / 2), zq, zq, ra0, ra1, rb0, rb1, b_ok);
+    ssr_emit_bin<T, MODE, EST64>(p, acc, (unsigned)(N / 2), zq, zq, ra0, ra1, rb0, rb1, b_ok);
   }
 }
 
@@ -192,7 +233,7 @@ template <typename T, int LOGN, int PPT = 8> struct SsrStftLds {
 // ---------------------------------------------------------------------------------------------------
 // The body.  LOGN: FFT length of the engine (n_fft for direct, M for bluestein).
 // grid = (n_chunks, n_items); block = 2^LOGN / 8 threads.
-template <typename T, int LOGN, bool BLUESTEIN, int MODE, bool SUMS, int PPT, typename BLK>
+template <typename T, int LOGN, bool BLUESTEIN, int MODE, bool SUMS, int PPT, bool EST64, typename BLK>
 SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
   using P = SsrFftPlan<LOGN, PPT>;
   constexpr int N = P::N, NT = P::NT, LAST = P::NPASS - 1, NW = (NT + 63) / 64;
@@ -205,8 +246,12 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
   const int n_units = (MODE == SSR_MODE_PAIR) ? n_frames : (n_frames + 1) / 2;
   const int u0 = chunk * p.units_per_chunk;
   const int u1 = (u0 + p.units_per_chunk < n_units) ? u0 + p.units_per_chunk : n_units;
-  const float* sa = p.a + p.a_off[item];
-  const float* sb = (MODE == SSR_MODE_PAIR) ? p.b + p.b_off[item] : sa;
+  static_assert(!EST64 || MODE == SSR_MODE_PAIR, "float64 estimates exist on the pair path only");
+  using SA = typename SsrSampleA<EST64>::type;
+  const SA* sa;
+  if constexpr (EST64) sa = p.a64 + p.a_off[item];
+  else sa = p.a + p.a_off[item];
+  const float* sb = (MODE == SSR_MODE_PAIR) ? p.b + p.b_off[item] : p.a + p.a_off[item];
   const int64_t row0 = p.frame_off[item];
   double* part = p.part ? p.part + ((int64_t)item * p.n_chunks + chunk) * SSR_NPART : nullptr;
   const bool want_lsd = (MODE == SSR_MODE_PAIR) && (p.metric_mask & SSR_M_LSD);
@@ -249,7 +294,8 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
           SSR_UNROLL for (int r = 0; r < 4; ++r) any = any || (ssr_fft_first_index<LOGN, PPT>(0, r0 + r) < n_fft);
           (void)m_lo;
           if (any) {
-            float fa[4], fb[4];
+            SA fa[4];
+            float fb[4];
             cx<T> wc[4];
             SSR_UNROLL for (int r = 0; r < 4; ++r) {
               const int m = ssr_fft_first_index<LOGN, PPT>(tid, r0 + r);
@@ -271,9 +317,10 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
           SSR_SCHED_FENCE();
         }
       } else {
-        float fa[PPT], fb[PPT];
+        SA fa[PPT];
+        float fb[PPT];
         if (interior) {
-          const float* qa = sa + base_a;
+          const SA* qa = sa + base_a;
           const float* qb = sb + base_b;
           SSR_UNROLL for (int r = 0; r < PPT; ++r) {
             const int m = ssr_fft_first_index<LOGN, PPT>(tid, r);
@@ -346,17 +393,17 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
 #if defined(SSR_ABL_NOEPI)     /* developer ablation: WRONG results, timing only */
       if (tid == 0) {
         const cx<T> z0 = {L.re[0], L.im[0]};
-        ssr_emit_bin<T, MODE>(p, acc, 0u, z0, z0, ra0, ra1, rb0, rb1, b_ok);
+        ssr_emit_bin<T, MODE, EST64>(p, acc, 0u, z0, z0, ra0, ra1, rb0, rb1, b_ok);
       }
 #else
       if constexpr (!BLUESTEIN) {
-        ssr_epilogue_direct<T, LOGN, MODE, PPT>(p, acc, tid, L.re, L.im, ra0, ra1, rb0, rb1, b_ok);
+        ssr_epilogue_direct<T, LOGN, MODE, PPT, EST64>(p, acc, tid, L.re, L.im, ra0, ra1, rb0, rb1, b_ok);
       } else {
         for (int k = tid; k < F; k += NT) {
           const int kn = (k == 0) ? 0 : n_fft - k;
           const cx<T> zk = {L.re[ssr_pad(k)], L.im[ssr_pad(k)]};
           const cx<T> zn = {L.re[ssr_pad(kn)], L.im[ssr_pad(kn)]};
-          ssr_emit_bin<T, MODE>(p, acc, (unsigned)k, zk, zn, ra0, ra1, rb0, rb1, b_ok);
+          ssr_emit_bin<T, MODE, EST64>(p, acc, (unsigned)k, zk, zn, ra0, ra1, rb0, rb1, b_ok);
         }
       }
 #endif

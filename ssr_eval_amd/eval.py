@@ -273,11 +273,19 @@ class SSR_Eval_Helper:
         for i, (target, x) in enumerate(items):
             keys, outs, extras = self._infer_and_collect(degraded[i])
             for k, o, e in zip(keys, outs, extras):
-                all_keys.append(k); all_proc.append(o.astype(np.float32)); all_tgt.append(np.asarray(target, np.float32))
+                # a float64 output (IIR-degraded input through a pass-through testee) stays float64, as in the
+                # reference: librosa.resample and AudioMetrics.evaluation keep the dtype they are given
+                all_keys.append(k); all_proc.append(o if o.dtype == np.float64 else o.astype(np.float32))
+                all_tgt.append(np.asarray(target, np.float32))
                 all_extra.append(e); owner.append(i)
         if self.model_output_sr != self.evaluationset_sr and all_proc:
-            ys = B.resample_poly(all_proc, self.evaluationset_sr, self.model_output_sr, self._device)   # eval.py:144-150
-            all_proc = [y.cpu().numpy() for y in ys]
+            # eval.py:144-150; float64 and float32 outputs are resampled in their own dtype
+            for want64 in (False, True):
+                idx = [i for i, o in enumerate(all_proc) if (o.dtype == np.float64) == want64]
+                if idx:
+                    ys = B.resample_poly([all_proc[i] for i in idx], self.evaluationset_sr, self.model_output_sr, self._device)
+                    for i, y in zip(idx, ys):
+                        all_proc[i] = y.cpu().numpy()
         results = [dict() for _ in items]
         if all_proc:
             vals = self.audio_metrics.evaluation_batch(all_proc, all_tgt)

@@ -49,9 +49,21 @@ def subsampling(data, lowpass_ratio, fs_ori=44100):
     """Down- then up-sample through fs_down = int(ratio * 44100) (lowpass.py:134-144)."""
     fs_down = int(lowpass_ratio * fs_ori)
     x = np.asarray(data)
-    down = B.resample_poly([x.astype(np.float32)], fs_down, fs_ori)[0]
-    up = B.resample_poly([down], fs_ori, fs_down)[0].cpu().numpy().astype(x.dtype if x.dtype.kind == "f" else np.float32)
-    return align_length(x, up)
+    return _subsample_batch([x], fs_down, fs_ori)[0]
+
+
+def _subsample_batch(xs, fs_down, fs_ori=44100):
+    """float64 signals are resampled in float64, everything else in float32 (what SciPy does per dtype)."""
+    outs = [None] * len(xs)
+    for want64 in (False, True):
+        idx = [i for i, x in enumerate(xs) if (x.dtype == np.float64) == want64]
+        if not idx:
+            continue
+        sel = [xs[i] if want64 else xs[i].astype(np.float32) for i in idx]
+        up = B.resample_poly(B.resample_poly(sel, fs_down, fs_ori), fs_ori, fs_down)
+        for i, u in zip(idx, up):
+            outs[i] = align_length(xs[i], u.cpu().numpy())
+    return outs
 
 
 def limit(integer, high, low):
@@ -123,10 +135,7 @@ def lowpass_batch(datas, highcut, fs, order=5, _type="butter"):
     if _type in "subsampling":
         ratio = highcut / int(fs / 2)
         fs_down = int(ratio * 44100)
-        xs = [np.asarray(d) for d in datas]
-        down = B.resample_poly([x.astype(np.float32) for x in xs], fs_down, 44100)
-        up = B.resample_poly(down, 44100, fs_down)
-        return [align_length(x, u.cpu().numpy().astype(x.dtype if x.dtype.kind == "f" else np.float32)) for x, u in zip(xs, up)]
+        return _subsample_batch([np.asarray(d) for d in datas], fs_down)
     if _type in "stft_hard":
         return stft_hard_lowpass_batch(datas, [highcut / int(fs / 2)] * len(datas))
     raise ValueError("Error: Unexpected filter type " + _type)

@@ -64,15 +64,23 @@ class AudioMetrics:
     def evaluation_batch(self, ests, targets, mask=B.M_ALL):
         """The same four metrics for lists of pairs, one fused launch sequence for the whole batch."""
         pairs = [self._prepare_pair(e, t) for e, t in zip(ests, targets)]
-        vals = B.pair_metrics(self._plan(), [p[0] for p in pairs], [p[1] for p in pairs], mask)
-        out = []
-        for row in vals:
-            d = {}
-            for k, v in zip(_KEYS, row):
-                if not np.isnan(v) or (mask & (1 << _KEYS.index(k))):
-                    # lsd / sispec are float32 tensors in the reference (float() of fp32); ssim is float64
-                    d[k] = float(v) if k == "ssim" else float(np.float32(v))
-            out.append(d)
+        # A float64 estimate (IIR-degraded input passed through a testee, eval.py:138-150) makes the reference's est
+        # spectrogram - and with it every metric - float64; those pairs run through ssr_pair_metrics_est64 in their
+        # own launch sequence.  Targets are what librosa.load returned: float32.
+        is64 = [B._is_f64(p[0]) for p in pairs]
+        out = [None] * len(pairs)
+        for want64 in (False, True):
+            idx = [i for i, f in enumerate(is64) if f == want64]
+            if not idx:
+                continue
+            vals = B.pair_metrics(self._plan(), [pairs[i][0] for i in idx], [pairs[i][1] for i in idx], mask)
+            for i, row in zip(idx, vals):
+                d = {}
+                for k, v in zip(_KEYS, row):
+                    if not np.isnan(v) or (mask & (1 << _KEYS.index(k))):
+                        # float32 pairs: lsd / sispec are float32 tensors in the reference (float() of fp32), ssim float64
+                        d[k] = float(v) if (k == "ssim" or want64) else float(np.float32(v))
+                out[i] = d
         return out
 
     # ---- reductions on [B, C, T, F] tensors (est first)

@@ -25,10 +25,12 @@ static void run_stft_ppt(SsrStftParams<T> p, int n_items) {
   for (int item = 0; item < n_items; ++item)
     for (int c = 0; c < p.n_chunks; ++c) {
       auto lds = poisoned(SsrStftLds<T, LOGN, PPT>::bytes());
-      if (p.mode != SSR_MODE_PAIR) ssr_stft_body<T, LOGN, BLU, SSR_MODE_SINGLE, false, PPT>(p, blk, c, item, lds.data());
-      else if (p.metric_mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC))
-        ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, true, PPT>(p, blk, c, item, lds.data());
-      else ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, false, PPT>(p, blk, c, item, lds.data());
+      const bool sums = p.metric_mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC);
+      if (p.mode != SSR_MODE_PAIR) ssr_stft_body<T, LOGN, BLU, SSR_MODE_SINGLE, false, PPT, false>(p, blk, c, item, lds.data());
+      else if (p.a64 && sums) ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, true, PPT, true>(p, blk, c, item, lds.data());
+      else if (p.a64) ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, false, PPT, true>(p, blk, c, item, lds.data());
+      else if (sums) ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, true, PPT, false>(p, blk, c, item, lds.data());
+      else ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, false, PPT, false>(p, blk, c, item, lds.data());
     }
 }
 
@@ -45,21 +47,23 @@ static void run_stft_r3(SsrStftParams<T> p, int n_items) {
   for (int item = 0; item < n_items; ++item)
     for (int c = 0; c < p.n_chunks; ++c) {
       auto lds = poisoned(SsrStftR3Lds<T, LOGN>::bytes(p.n_fft / 3));
-      if (p.mode != SSR_MODE_PAIR) ssr_stft_r3_body<T, LOGN, SSR_MODE_SINGLE, false>(p, blk, c, item, lds.data());
-      else if (p.metric_mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC))
-        ssr_stft_r3_body<T, LOGN, SSR_MODE_PAIR, true>(p, blk, c, item, lds.data());
-      else ssr_stft_r3_body<T, LOGN, SSR_MODE_PAIR, false>(p, blk, c, item, lds.data());
+      const bool sums = p.metric_mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC);
+      if (p.mode != SSR_MODE_PAIR) ssr_stft_r3_body<T, LOGN, SSR_MODE_SINGLE, false, false>(p, blk, c, item, lds.data());
+      else if (p.a64 && sums) ssr_stft_r3_body<T, LOGN, SSR_MODE_PAIR, true, true>(p, blk, c, item, lds.data());
+      else if (p.a64) ssr_stft_r3_body<T, LOGN, SSR_MODE_PAIR, false, true>(p, blk, c, item, lds.data());
+      else if (sums) ssr_stft_r3_body<T, LOGN, SSR_MODE_PAIR, true, false>(p, blk, c, item, lds.data());
+      else ssr_stft_r3_body<T, LOGN, SSR_MODE_PAIR, false, false>(p, blk, c, item, lds.data());
     }
 }
 
 template <typename T>
-static int emu_stft_t(int n_fft, int hop, int mode, int out_kind, int mask, const float* a, const float* b,
+static int emu_stft_t(int n_fft, int hop, int mode, int out_kind, int mask, const float* a, const double* a64, const float* b,
                       const int64_t* a_off, const int64_t* b_off, const int32_t* len, const int64_t* frame_off,
                       int n_items, int units_per_chunk, int n_chunks, float* out_a, float* out_b, double* part) {
   SsrTables<T> t;
   if (!ssr_build_tables<T>(n_fft, t)) return -3;
   SsrStftParams<T> p{};
-  p.a = a; p.b = b; p.a_off = a_off; p.b_off = b_off; p.len = len; p.frame_off = frame_off;
+  p.a = a; p.a64 = a64; p.b = b; p.a_off = a_off; p.b_off = b_off; p.len = len; p.frame_off = frame_off;
   p.mode = mode; p.out_kind = out_kind; p.metric_mask = mask;
   p.n_fft = n_fft; p.hop = hop; p.n_bins = n_fft / 2 + 1;
   p.units_per_chunk = units_per_chunk; p.n_chunks = n_chunks;
@@ -90,10 +94,22 @@ extern "C" int emu_stft(int precision, int n_fft, int hop, int mode, int out_kin
                         const int64_t* frame_off, int n_items, int units_per_chunk, int n_chunks, float* out_a,
                         float* out_b, double* part) {
   if (precision == 1)
-    return emu_stft_t<double>(n_fft, hop, mode, out_kind, mask, a, b, a_off, b_off, len, frame_off, n_items,
+    return emu_stft_t<double>(n_fft, hop, mode, out_kind, mask, a, nullptr, b, a_off, b_off, len, frame_off, n_items,
                               units_per_chunk, n_chunks, out_a, out_b, part);
-  return emu_stft_t<float>(n_fft, hop, mode, out_kind, mask, a, b, a_off, b_off, len, frame_off, n_items,
+  return emu_stft_t<float>(n_fft, hop, mode, out_kind, mask, a, nullptr, b, a_off, b_off, len, frame_off, n_items,
                            units_per_chunk, n_chunks, out_a, out_b, part);
+}
+
+// pair mode with a float64 estimate (EST64 kernel variants)
+extern "C" int emu_stft_est64(int precision, int n_fft, int hop, int out_kind, int mask, const double* a64,
+                              const float* b, const int64_t* a_off, const int64_t* b_off, const int32_t* len,
+                              const int64_t* frame_off, int n_items, int units_per_chunk, int n_chunks, float* out_a,
+                              float* out_b, double* part) {
+  if (precision == 1)
+    return emu_stft_t<double>(n_fft, hop, SSR_MODE_PAIR, out_kind, mask, nullptr, a64, b, a_off, b_off, len, frame_off,
+                              n_items, units_per_chunk, n_chunks, out_a, out_b, part);
+  return emu_stft_t<float>(n_fft, hop, SSR_MODE_PAIR, out_kind, mask, nullptr, a64, b, a_off, b_off, len, frame_off,
+                           n_items, units_per_chunk, n_chunks, out_a, out_b, part);
 }
 
 template <int CPT>
@@ -194,19 +210,32 @@ extern "C" int emu_ola(int n_fft, int hop, const float* frames, const int64_t* f
 }
 
 // ---- polyphase resampler ------------------------------------------------------------------------------
-extern "C" int emu_resample(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
-                            const int32_t* out_len, int n_items, int max_out_len, int up, int down, const float* taps,
-                            int n_taps, int n_pre_remove, int groups, int taps_in_lds, float* out) {
-  SsrResampleParams p{in, in_off, in_len, out_off, out_len, up, down, taps, n_taps, n_pre_remove,
-                      groups > 0 ? groups : ssr_resample_pick_groups(up, down), taps_in_lds, out};
+template <typename S>
+static int emu_resample_t(const S* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
+                          const int32_t* out_len, int n_items, int max_out_len, int up, int down, const S* taps, int n_taps,
+                          int n_pre_remove, int groups, int taps_in_lds, S* out) {
+  SsrResampleParamsT<S> p{in, in_off, in_len, out_off, out_len, up, down, taps, n_taps, n_pre_remove,
+                          groups > 0 ? groups : ssr_resample_pick_groups(up, down), taps_in_lds, out};
   SsrBlk blk{SSR_RESAMPLE_NT};
   const int n_blocks = (max_out_len + ssr_resample_opb(p) - 1) / ssr_resample_opb(p);
   for (int item = 0; item < n_items; ++item)
     for (int b = 0; b < n_blocks; ++b) {
       auto lds = poisoned(ssr_resample_lds_bytes(p));
-      ssr_resample_body(p, blk, b, item, lds.data());
+      ssr_resample_body<S>(p, blk, b, item, lds.data());
     }
   return 0;
+}
+extern "C" int emu_resample(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
+                            const int32_t* out_len, int n_items, int max_out_len, int up, int down, const float* taps,
+                            int n_taps, int n_pre_remove, int groups, int taps_in_lds, float* out) {
+  return emu_resample_t<float>(in, in_off, in_len, out_off, out_len, n_items, max_out_len, up, down, taps, n_taps,
+                               n_pre_remove, groups, taps_in_lds, out);
+}
+extern "C" int emu_resample_f64(const double* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
+                                const int32_t* out_len, int n_items, int max_out_len, int up, int down, const double* taps,
+                                int n_taps, int n_pre_remove, int groups, int taps_in_lds, double* out) {
+  return emu_resample_t<double>(in, in_off, in_len, out_off, out_len, n_items, max_out_len, up, down, taps, n_taps,
+                                n_pre_remove, groups, taps_in_lds, out);
 }
 
 // ---- zero-phase IIR (sequential statement of the wavefront kernel's arithmetic) -------------------------------

@@ -45,9 +45,13 @@ def ragged(arrs):
     return np.concatenate(arrs).astype(np.float32), off, lens
 
 
-def stft(sigs_a, sigs_b, n_fft, hop, precision=1, mode=0, out_kind=1, mask=0, units_per_chunk=8):
-    """mode 0 (pair): returns (mag_a list, mag_b list, part); mode 1 (single): (out_a list, out_b list, None)."""
+def stft(sigs_a, sigs_b, n_fft, hop, precision=1, mode=0, out_kind=1, mask=0, units_per_chunk=8, est64=False):
+    """mode 0 (pair): returns (mag_a list, mag_b list, part); mode 1 (single): (out_a list, out_b list, None).
+    est64 (pair mode): sigs_a are float64 signals and run through the EST64 kernel variants."""
     a, a_off, lens = ragged(sigs_a)
+    if est64:
+        assert mode == 0
+        a = np.concatenate(sigs_a).astype(np.float64)
     if mode == 0:
         b, b_off, lens_b = ragged(sigs_b)
         assert (lens == lens_b).all()
@@ -61,10 +65,12 @@ def stft(sigs_a, sigs_b, n_fft, hop, precision=1, mode=0, out_kind=1, mask=0, un
     out_a = np.full((int(T.sum()), F), np.nan, np.float32)
     out_b = np.full((int(T.sum()), F), np.nan, np.float32)
     part = np.full((len(lens), n_chunks, 8), np.nan, np.float64) if mode == 0 else None
-    rc = lib().emu_stft(precision, n_fft, hop, mode, out_kind, mask, _p(a, C.c_float), _p(b, C.c_float),
-                        _p(a_off, C.c_int64), _p(b_off, C.c_int64), _p(lens, C.c_int32), _p(frame_off, C.c_int64),
-                        len(lens), units_per_chunk, n_chunks, _p(out_a, C.c_float), _p(out_b, C.c_float),
-                        _p(part, C.c_double))
+    tail = (_p(a_off, C.c_int64), _p(b_off, C.c_int64), _p(lens, C.c_int32), _p(frame_off, C.c_int64), len(lens),
+            units_per_chunk, n_chunks, _p(out_a, C.c_float), _p(out_b, C.c_float), _p(part, C.c_double))
+    if est64:
+        rc = lib().emu_stft_est64(precision, n_fft, hop, out_kind, mask, _p(a, C.c_double), _p(b, C.c_float), *tail)
+    else:
+        rc = lib().emu_stft(precision, n_fft, hop, mode, out_kind, mask, _p(a, C.c_float), _p(b, C.c_float), *tail)
     assert rc == 0, rc
     split = lambda o: [o[frame_off[i]:frame_off[i] + T[i]] for i in range(len(lens))]
     return split(out_a), split(out_b), part
@@ -117,8 +123,8 @@ def finalize(part, ssim_part, T, F, mask):
     return out
 
 
-def pair_metrics(ests, tgts, n_fft, hop, precision=1, mask=M_ALL, units_per_chunk=8, rows_per_tile=16):
-    ea, tb, part = stft(ests, tgts, n_fft, hop, precision, 0, 1, mask, units_per_chunk)
+def pair_metrics(ests, tgts, n_fft, hop, precision=1, mask=M_ALL, units_per_chunk=8, rows_per_tile=16, est64=False):
+    ea, tb, part = stft(ests, tgts, n_fft, hop, precision, 0, 1, mask, units_per_chunk, est64=est64)
     sp, T = ssim_parts(ea, tb, rows_per_tile) if mask & M_SSIM else (None, np.array([e.shape[0] for e in ea]))
     return finalize(part, sp, T, n_fft // 2 + 1, mask)
 
@@ -160,15 +166,18 @@ def istft(res, ims, lengths, n_fft=2048, hop=441, precision=1, pairs_per_chunk=4
     return [out[off[i]:off[i] + lens[i]] for i in range(len(lens))]
 
 
-def resample(sigs, up, down, taps_full, n_pre_remove, groups=0, taps_in_lds=1):
-    a, off, lens = ragged(sigs)
+def resample(sigs, up, down, taps_full, n_pre_remove, groups=0, taps_in_lds=1, dtype=np.float32):
+    ct = C.c_float if dtype == np.float32 else C.c_double
+    lens = np.array([len(a) for a in sigs], np.int32)
+    off = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int64)
+    a = np.concatenate(sigs).astype(dtype)
     out_len = np.array([-(-int(n) * up // down) for n in lens], np.int32)
     out_off = np.concatenate(([0], np.cumsum(out_len)[:-1])).astype(np.int64)
-    out = np.full(int(out_len.sum()), np.nan, np.float32)
-    taps = np.ascontiguousarray(taps_full, np.float32)
-    rc = lib().emu_resample(_p(a, C.c_float), _p(off, C.c_int64), _p(lens, C.c_int32), _p(out_off, C.c_int64),
-                            _p(out_len, C.c_int32), len(lens), int(out_len.max()), up, down, _p(taps, C.c_float), len(taps),
-                            n_pre_remove, groups, taps_in_lds, _p(out, C.c_float))
+    out = np.full(int(out_len.sum()), np.nan, dtype)
+    taps = np.ascontiguousarray(taps_full, dtype)
+    fn = lib().emu_resample if dtype == np.float32 else lib().emu_resample_f64
+    rc = fn(_p(a, ct), _p(off, C.c_int64), _p(lens, C.c_int32), _p(out_off, C.c_int64), _p(out_len, C.c_int32), len(lens),
+            int(out_len.max()), up, down, _p(taps, ct), len(taps), n_pre_remove, groups, taps_in_lds, _p(out, ct))
     assert rc == 0
     return [out[out_off[i]:out_off[i] + out_len[i]] for i in range(len(lens))]
 

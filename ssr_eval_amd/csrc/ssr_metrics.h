@@ -45,6 +45,7 @@ struct SsrSsimParams {
 template <int CPT> struct SsrSsimRegs {
   double cs[CPT + 1][4];  // running 7-row sums for the thread's (strided) input columns tid + NT*i
   double s;               // sum of S over the thread's outputs
+  float px[4][CPT + 1];   // row values in flight: entering row (x, y), leaving row (x, y) - loaded one row step ahead
 };
 
 // Column-sum index in LDS.  The horizontal pass reads with a lane stride of CPT doubles; for even CPT that is a
@@ -64,14 +65,14 @@ template <int CPT> struct SsrSsimLds {
   }
 };
 
-// Add row `row_add` to (and, if row_sub >= 0, remove row `row_sub` from) the thread's running column sums.
-// All global loads are issued first with clamped (always valid) column addresses, then consumed, so a row
-// step pays one memory latency instead of one per column.
+// Row step, split in two so that the loads of the NEXT step are in flight while the current one is consumed:
+// ssr_ssim_row_load issues the global loads of the row entering the 7-row window (row_add) and of the row leaving
+// it (row_sub; re-reads row_add when there is none) with clamped, always valid column addresses;
+// ssr_ssim_row_apply folds the loaded values into the thread's running column sums.
 template <int CPT>
-SSR_DEV void ssr_ssim_row_update(const SsrSsimParams& p, SsrSsimRegs<CPT>& R, int tid, const float* x, const float* y,
-                                 int row_add, int row_sub, int c_in0, int ncol_in) {
+SSR_DEV void ssr_ssim_row_load(const SsrSsimParams& p, SsrSsimRegs<CPT>& R, int tid, const float* x, const float* y,
+                               int row_add, int row_sub, int c_in0, int ncol_in) {
   constexpr int VC = CPT + 1;
-  float xa[VC], ya[VC], xs[VC], ys[VC];
   const bool sub = row_sub >= 0;
   // block-uniform row base pointers + 32-bit lane offsets (scalar-base addressing, no 64-bit VALU math)
   const float* xra = x + (int64_t)row_add * p.F + c_in0;
@@ -82,16 +83,21 @@ SSR_DEV void ssr_ssim_row_update(const SsrSsimParams& p, SsrSsimRegs<CPT>& R, in
   for (int i = 0; i < VC; ++i) {
     int c = tid + SSR_SSIM_NT * i;
     if (c >= ncol_in) c = ncol_in - 1;
-    xa[i] = xra[c];
-    ya[i] = yra[c];
-    xs[i] = xrs[c];
-    ys[i] = yrs[c];
+    R.px[0][i] = xra[c];
+    R.px[1][i] = yra[c];
+    R.px[2][i] = xrs[c];
+    R.px[3][i] = yrs[c];
   }
+}
+
+template <int CPT>
+SSR_DEV void ssr_ssim_row_apply(SsrSsimRegs<CPT>& R, int tid, bool sub, int ncol_in) {
+  constexpr int VC = CPT + 1;
 #pragma unroll
   for (int i = 0; i < VC; ++i) {
     if (tid + SSR_SSIM_NT * i < ncol_in) {
-      const double a = (double)xa[i], b = (double)ya[i];
-      const double c = sub ? (double)xs[i] : 0.0, d = sub ? (double)ys[i] : 0.0;
+      const double a = (double)R.px[0][i], b = (double)R.px[1][i];
+      const double c = sub ? (double)R.px[2][i] : 0.0, d = sub ? (double)R.px[3][i] : 0.0;
       R.cs[i][0] += a - c;
       R.cs[i][1] += b - d;
       R.cs[i][2] += (a * a + b * b) - (c * c + d * d);
@@ -153,11 +159,16 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
     for (int i = 0; i < VC; ++i)
       for (int q = 0; q < 4; ++q) R.cs[i][q] = 0.0;
     R.s = 0.0;
-    for (int rr = r0; rr < r0 + W - 1; ++rr) ssr_ssim_row_update<CPT>(p, R, tid, x, y, rr, -1, c_in0, ncol_in);
+    for (int rr = r0; rr < r0 + W - 1; ++rr) {
+      ssr_ssim_row_load<CPT>(p, R, tid, x, y, rr, -1, c_in0, ncol_in);
+      ssr_ssim_row_apply<CPT>(R, tid, false, ncol_in);
+    }
+    ssr_ssim_row_load<CPT>(p, R, tid, x, y, r0 + W - 1, -1, c_in0, ncol_in);   // first step of the row loop
   });
   for (int r = r0; r < r1; ++r) {
     SSR_PHASE(blk, regs, {
-      ssr_ssim_row_update<CPT>(p, R, tid, x, y, r + W - 1, (r > r0) ? r - 1 : -1, c_in0, ncol_in);
+      ssr_ssim_row_apply<CPT>(R, tid, r > r0, ncol_in);
+      if (r + 1 < r1) ssr_ssim_row_load<CPT>(p, R, tid, x, y, r + W, r, c_in0, ncol_in);   // next step, one row ahead
       for (int i = 0; i < VC; ++i) {
         const int c = tid + NT * i;
         if (c < ncol_in)

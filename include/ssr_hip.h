@@ -115,6 +115,19 @@ int ssr_spectrogram_metrics(const float* est_sp, const float* tgt_sp, const int6
                             int n_items, int max_rows, int n_bins, unsigned metric_mask, double* out, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/* A6.  The tensor helpers of ssr_eval/utils.py as stand-alone calls (inside ssr_pair_metrics /
+ * ssr_spectrogram_metrics they are fused; these back `from ssr_eval.utils import to_log, pow_p_norm, ...`).
+ *   ssr_to_log      out = log10(x + 1e-12)                       utils.py:43-44
+ *   ssr_from_log    out = 10 ** min(x, 5)                        utils.py:47-49
+ *   ssr_energy_sums sums[i] = {sum a^2, sum b^2, sum a*b} over item i's per_item contiguous elements (float64):
+ *                   pow_p_norm = (float)sqrt(sum)^2 (utils.py:68-76), pow_norm = sum a*b (utils.py:85-92)
+ *   ssr_scale_items out[i][j] = (x[i][j] * mul[i]) / div[i]      the rescaled target of energy_unify, utils.py:79-82 */
+int ssr_to_log(const float* x, int64_t n, float* out, void* stream);
+int ssr_from_log(const float* x, int64_t n, float* out, void* stream);
+int ssr_energy_sums(const float* a, const float* b, int n_items, int64_t per_item, double* sums, void* stream);
+int ssr_scale_items(const float* x, const float* mul, const float* div, int n_items, int64_t per_item, float* out,
+                    void* stream);
+
 /* K6.  STFT-domain hard low-pass: stft_hard_lowpass_v0 (ssr_eval/lowpass.py:17-28) through
  * FDomainHelper.wav_to_spectrogram_phase / spectrogram_phase_to_wav (ssr_eval/dsp.py:83-119).
  * cut[i] = first zeroed bin = int(n_bins * highcut / int(fs/2)) (lowpass.py:24,193-194; computed by the

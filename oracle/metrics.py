@@ -33,6 +33,18 @@ def to_log(x):
     return torch.log10(x + 1e-12)
 
 
+def from_log(x):
+    """ssr_eval/utils.py:47-49."""
+    return 10 ** torch.clip(x, min=-np.inf, max=5)
+
+
+def energy_unify(estimated, original):
+    """ssr_eval/utils.py:79-82."""
+    target = _inner_last_dims(estimated, original) * original
+    target /= _sq_norm_all_but_batch(original) + EPS
+    return estimated, target
+
+
 def lsd(est, target):
     """ssr_eval/metrics.py:109-112; est/target [B, C, T, F] float32 -> [B, C, 1, 1]."""
     ratio = target ** 2 / ((est + EPS) ** 2)

@@ -32,6 +32,10 @@ SIGNATURES = {
     "ssr_pair_metrics_stages": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _u, _vp, _vp, _sz, _vp, _i]),
     "ssr_spectrogram_metrics_workspace_bytes": (_sz, [_i, _i, _i]),
     "ssr_spectrogram_metrics": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u, _vp, _vp, _sz, _vp]),
+    "ssr_to_log": (_i, [_vp, _i64, _vp, _vp]),
+    "ssr_from_log": (_i, [_vp, _i64, _vp, _vp]),
+    "ssr_energy_sums": (_i, [_vp, _vp, _i, _i64, _vp, _vp]),
+    "ssr_scale_items": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp]),
     "ssr_ola_workspace_bytes": (_sz, [_vp, _i64]),
     "ssr_fft_lowpass": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _vp, _vp, _sz, _vp]),
     "ssr_istft": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _vp, _vp, _sz, _vp]),

@@ -221,6 +221,50 @@ def magphase(re, im, eps):
     return mag, cos, sin
 
 
+def _dev_f32(x, dev=None):
+    t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+    dev = dev if dev is not None else (t.device if t.is_cuda else default_device())
+    return t.to(device=dev, dtype=torch.float32).contiguous()
+
+
+def elementwise(op, x):
+    """op "to_log": log10(x + 1e-12); "from_log": 10 ** min(x, 5) (ssr_eval/utils.py:43-50).  float32 device tensor."""
+    require_gpu()
+    t = _dev_f32(x)
+    out = torch.empty_like(t)
+    fn = {"to_log": _lib.load().ssr_to_log, "from_log": _lib.load().ssr_from_log}[op]
+    with torch.cuda.device(t.device):
+        _lib.check(fn(_vp(t), t.numel(), _vp(out), _stream()))
+    return out
+
+
+def energy_sums(a, b, n_items):
+    """[n_items, 3] float64 device tensor {sum a^2, sum b^2, sum a*b} over n_items equal contiguous slices."""
+    require_gpu()
+    ta = _dev_f32(a)
+    tb = _dev_f32(b, ta.device)
+    if ta.shape != tb.shape or n_items <= 0 or ta.numel() % n_items:
+        raise ValueError("energy_sums needs two tensors of one shape that split evenly into n_items slices")
+    out = torch.empty((n_items, 3), dtype=torch.float64, device=ta.device)
+    with torch.cuda.device(ta.device):
+        _lib.check(_lib.load().ssr_energy_sums(_vp(ta), _vp(tb), n_items, ta.numel() // n_items, _vp(out), _stream()))
+    return out
+
+
+def scale_items(x, mul, div):
+    """(x[i] * mul[i]) / div[i] per leading-dimension slice, float32 with two roundings (energy_unify)."""
+    require_gpu()
+    t = _dev_f32(x)
+    m, d = _dev_f32(mul, t.device).reshape(-1), _dev_f32(div, t.device).reshape(-1)
+    n_items = m.numel()
+    if d.numel() != n_items or n_items == 0 or t.numel() % n_items:
+        raise ValueError("one multiplier and one divisor per slice")
+    out = torch.empty_like(t)
+    with torch.cuda.device(t.device):
+        _lib.check(_lib.load().ssr_scale_items(_vp(t), _vp(m), _vp(d), n_items, t.numel() // n_items, _vp(out), _stream()))
+    return out
+
+
 def spectrogram_metrics(est_sps, tgt_sps, mask=M_ALL):
     """Metrics on lists of [T_i, F] float32 magnitude spectrograms -> [n, 4] float64 device tensor."""
     require_gpu()

@@ -401,6 +401,83 @@ extern "C" int ssr_magphase(const float* re, const float* im, int64_t n, float e
 }
 
 // ----------------------------------------------------------------------------------------------------
+// A6: the tensor helpers of ssr_eval/utils.py as stand-alone calls (AudioMetrics.sispec has them fused in-kernel).
+enum { SSR_EW_TO_LOG = 0, SSR_EW_FROM_LOG = 1 };
+__global__ __launch_bounds__(256) void k_elementwise(int op, const float* x, int64_t n, float* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = x[i];
+    if (op == SSR_EW_TO_LOG) out[i] = log10f(v + 1e-12f);               // utils.py:43-44
+    else out[i] = powf(10.0f, v > 5.0f ? 5.0f : v);                     // utils.py:47-49 (clip(max=5), NaN passes through)
+  }
+}
+
+// sums[item] = {sum a^2, sum b^2, sum a*b} over per_item contiguous elements; one workgroup per item, float64
+// accumulation in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void k_energy_sums(const float* a, const float* b, int64_t per_item, double* sums) {
+  __shared__ double sh[3][4];
+  const float* pa = a + (int64_t)blockIdx.x * per_item;
+  const float* pb = b + (int64_t)blockIdx.x * per_item;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int64_t i = threadIdx.x; i < per_item; i += 256) {
+    const double u = (double)pa[i], v = (double)pb[i];
+    s0 += u * u; s1 += v * v; s2 += u * v;
+  }
+  s0 = ssr_wave_sum<64>(s0); s1 = ssr_wave_sum<64>(s1); s2 = ssr_wave_sum<64>(s2);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s0; sh[1][threadIdx.x >> 6] = s1; sh[2][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x < 3) sums[(int64_t)blockIdx.x * 3 + threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+
+// out[item][j] = (x[item][j] * mul[item]) / div[item], two float32 roundings as in energy_unify (utils.py:79-82)
+__global__ __launch_bounds__(256) void k_scale_items(const float* x, const float* mul, const float* div, int64_t per_item,
+                                                     int64_t n, float* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t item = i / per_item;
+    out[i] = ssr_fmul_rn(x[i], mul[item]) / div[item];
+  }
+}
+
+static unsigned ew_blocks(int64_t n) {
+  int64_t blocks = (n + 255) / 256;
+  return (unsigned)(blocks > 8192 ? 8192 : blocks);
+}
+
+extern "C" int ssr_to_log(const float* x, int64_t n, float* out, void* stream) {
+  if (!x || !out) return fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n <= 0) return SSR_OK;
+  hipLaunchKernelGGL(k_elementwise, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (int)SSR_EW_TO_LOG, x, n, out);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+
+extern "C" int ssr_from_log(const float* x, int64_t n, float* out, void* stream) {
+  if (!x || !out) return fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n <= 0) return SSR_OK;
+  hipLaunchKernelGGL(k_elementwise, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (int)SSR_EW_FROM_LOG, x, n, out);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+
+extern "C" int ssr_energy_sums(const float* a, const float* b, int n_items, int64_t per_item, double* sums, void* stream) {
+  if (!a || !b || !sums) return fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n_items <= 0) return SSR_OK;
+  if (per_item < 0) return fail(SSR_ERR_INVALID_ARG, "negative item size");
+  hipLaunchKernelGGL(k_energy_sums, dim3((unsigned)n_items), dim3(256), 0, (hipStream_t)stream, a, b, per_item, sums);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+
+extern "C" int ssr_scale_items(const float* x, const float* mul, const float* div, int n_items, int64_t per_item,
+                               float* out, void* stream) {
+  if (!x || !mul || !div || !out) return fail(SSR_ERR_INVALID_ARG, "null argument");
+  const int64_t n = (int64_t)n_items * per_item;
+  if (n <= 0) return SSR_OK;
+  hipLaunchKernelGGL(k_scale_items, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, mul, div, per_item, n, out);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------
 extern "C" size_t ssr_pair_metrics_workspace_bytes(const ssr_plan* pl, int n_items, int max_len, int64_t total_rows) {
   if (!pl || n_items <= 0) return 0;
   return pair_ws(pl, n_items, max_len, total_rows).total + align256((size_t)n_items * sizeof(int32_t));

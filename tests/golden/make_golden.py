@@ -182,6 +182,12 @@ def main():
                                           for i in range(2)])
     out["sp_to_log"] = ref_utils.to_log(torch.tensor(esp)).numpy()
     out["sp_ssim"] = am.ssim(torch.tensor(esp), torch.tensor(tsp)).numpy()
+    # A6 helpers called directly (ssr_eval/utils.py:43-50,68-92)
+    out["sp_from_log"] = ref_utils.from_log(torch.tensor(esp) * 2 - 3).numpy()         # covers the clip at 5
+    out["sp_pow_p_norm"] = ref_utils.pow_p_norm(torch.tensor(tsp)).numpy()
+    out["sp_pow_norm"] = ref_utils.pow_norm(torch.tensor(esp), torch.tensor(tsp)).numpy()
+    eu_e, eu_t = ref_utils.energy_unify(torch.tensor(esp), torch.tensor(tsp))
+    out["sp_energy_unify_est"], out["sp_energy_unify_tgt"] = eu_e.numpy(), eu_t.numpy()
 
     # ---- A8/A9: FFT low-pass (lowpass.py:17-28,156-196) + cut bins
     x = speechlike(11, 9000, 44100)

@@ -91,6 +91,32 @@ def test_tensor_reductions_match_reference_vectors(golden):
         np.testing.assert_allclose(ss.cpu().numpy(), golden["sp_ssim"], rtol=2e-7)
 
 
+def test_utils_tensor_helpers_match_reference_vectors(golden):
+    """to_log / from_log / pow_p_norm / pow_norm / energy_unify called directly (ssr_eval/utils.py:43-50,68-92)."""
+    from ssr_eval_amd import utils as U
+    for dev in ("cpu", "cuda"):
+        e, t = torch.tensor(golden["sp_est"], device=dev), torch.tensor(golden["sp_tgt"], device=dev)
+        tl = U.to_log(e)
+        assert tl.dtype == torch.float32 and tl.shape == e.shape and tl.device.type == dev
+        np.testing.assert_allclose(tl.cpu().numpy(), golden["sp_to_log"], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(U.from_log(e * 2 - 3).cpu().numpy(), golden["sp_from_log"], rtol=3e-6)
+        ppn = U.pow_p_norm(t)
+        assert tuple(ppn.shape) == (2, 1, 1, 1) and ppn.dtype == torch.float32
+        np.testing.assert_allclose(ppn.cpu().numpy(), golden["sp_pow_p_norm"], rtol=1e-6)
+        pn = U.pow_norm(e, t)
+        assert tuple(pn.shape) == (2, 1, 1, 1)
+        np.testing.assert_allclose(pn.cpu().numpy(), golden["sp_pow_norm"], rtol=1e-6)
+        ue, ut = U.energy_unify(e, t)
+        assert ue is e and ut.device.type == dev
+        np.testing.assert_allclose(ut.cpu().numpy(), golden["sp_energy_unify_tgt"], rtol=2e-6)
+    # sispec assembled from the stand-alone helpers equals the fused kernel's
+    from ssr_eval_amd import AudioMetrics
+    e, t = torch.tensor(golden["sp_est"][:1]), torch.tensor(golden["sp_tgt"][:1])
+    _, scaled = U.energy_unify(e, t)
+    val = 10 * torch.log10(U.pow_p_norm(scaled) / (U.pow_p_norm(e - scaled) + 1e-12) + 1e-12)
+    np.testing.assert_allclose(float(val), float(AudioMetrics(44100).sispec(e, t)), rtol=1e-5)
+
+
 def test_batch_equals_single_and_is_ragged_safe():
     from ssr_eval_amd import AudioMetrics
     from oracle import metrics as om

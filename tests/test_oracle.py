@@ -45,6 +45,13 @@ def test_reductions_on_spectrograms_match_reference(golden):
     assert float(om.sispec(e, t)) == float(golden["sp_sispec"])
     np.testing.assert_array_equal(om.to_log(e).numpy(), golden["sp_to_log"])
     np.testing.assert_array_equal(om.ssim(e, t).numpy(), golden["sp_ssim"])
+    # the A6 helpers called directly (ssr_eval/utils.py:43-50,68-92)
+    np.testing.assert_array_equal(om.from_log(e * 2 - 3).numpy(), golden["sp_from_log"])
+    np.testing.assert_array_equal(om._sq_norm_all_but_batch(t).numpy(), golden["sp_pow_p_norm"])
+    np.testing.assert_array_equal(om._inner_last_dims(e, t).numpy(), golden["sp_pow_norm"])
+    ue, ut = om.energy_unify(e, t)
+    np.testing.assert_array_equal(ue.numpy(), golden["sp_energy_unify_est"])
+    np.testing.assert_array_equal(ut.numpy(), golden["sp_energy_unify_tgt"])
 
 
 @pytest.mark.parametrize("n_fft,hop,n", [(2048, 512, 9000), (2229, 480, 7001), (743, 160, 4000), (2048, 441, 5000)])

@@ -99,6 +99,13 @@ int ssr_pair_metrics_est64(const ssr_plan* plan, const double* est, const int64_
                            int max_len, int64_t total_rows, unsigned metric_mask, double* out, void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* Both signals float64 (e.g. arrays read with soundfile's default dtype handed to AudioMetrics.evaluation): two
+ * complex128 spectra, every tensor of metrics.py:109-121 float64. */
+int ssr_pair_metrics_f64(const ssr_plan* plan, const double* est, const int64_t* est_off, const double* tgt,
+                         const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off, int n_items, int max_len,
+                         int64_t total_rows, unsigned metric_mask, double* out, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
 /* Same, restricted to a subset of its three launches (bit 0: STFT + fused LSD/SISpec epilogue, bit 1:
  * SSIM, bit 2: finalisation) so that bench.py can time the dominant kernel on its own stream with
  * HIP events.  stages = 7 is ssr_pair_metrics. */

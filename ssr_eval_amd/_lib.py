@@ -29,6 +29,7 @@ SIGNATURES = {
     "ssr_pair_metrics_workspace_bytes": (_sz, [_vp, _i, _i, _i64]),
     "ssr_pair_metrics": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _u, _vp, _vp, _sz, _vp]),
     "ssr_pair_metrics_est64": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _u, _vp, _vp, _sz, _vp]),
+    "ssr_pair_metrics_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _u, _vp, _vp, _sz, _vp]),
     "ssr_pair_metrics_stages": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _u, _vp, _vp, _sz, _vp, _i]),
     "ssr_spectrogram_metrics_workspace_bytes": (_sz, [_i, _i, _i]),
     "ssr_spectrogram_metrics": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _u, _vp, _vp, _sz, _vp]),

@@ -161,8 +161,11 @@ class PairBatch:
     def __init__(self, plan, est, tgt):
         if est.n != tgt.n or not np.array_equal(est.lens_host, tgt.lens_host):
             raise ValueError("est and target must have identical lengths (truncate to min_len first)")
-        if tgt.data.dtype != torch.float32:
-            raise ValueError("the target batch must be float32 (only the estimate may be float64)")
+        if tgt.data.dtype == torch.float64 and est.data.dtype != torch.float64:
+            # float32 estimate against a float64 target: widening the estimate is exact, and the reference promotes
+            # every mixed operation to float64 anyway
+            est = Ragged(est.data.to(torch.float64), est.off, est.len, est.lens_host)
+            self.est = est
         _check_reflect(plan, est.lens_host)
         self.plan, self.est, self.tgt = plan, est, tgt
         self.rows = _Rows(plan, est.lens_host, est.device)
@@ -180,7 +183,8 @@ class PairBatch:
         if e.data.dtype == torch.float64:
             if stages != 7:
                 raise ValueError("stage selection is a bench facility of the float32 path")
-            _lib.check(p.lib.ssr_pair_metrics_est64(
+            fn = p.lib.ssr_pair_metrics_f64 if t.data.dtype == torch.float64 else p.lib.ssr_pair_metrics_est64
+            _lib.check(fn(
                 p.handle, _vp(e.data), _vp(e.off), _vp(t.data), _vp(t.off), _vp(e.len), _vp(self.rows.off), e.n,
                 e.max_len, self.rows.total, mask, _vp(self.out), _vp(self.ws), self.ws_bytes, _stream()))
             return self.out
@@ -192,9 +196,9 @@ class PairBatch:
 
 def pair_metrics(plan, est_list, tgt_list, mask=M_ALL):
     """[n, 4] float64 (lsd, log_sispec, sispec, ssim) for lists of equal-length (est, target) waveforms.
-    float64 estimates stay float64 (ssr_pair_metrics_est64); targets are float32."""
+    float64 signals stay float64 (ssr_pair_metrics_est64 / ssr_pair_metrics_f64)."""
     with torch.cuda.device(plan.device):
-        b = PairBatch(plan, Ragged.from_list_keep64(est_list, plan.device), Ragged.from_list(tgt_list, plan.device))
+        b = PairBatch(plan, Ragged.from_list_keep64(est_list, plan.device), Ragged.from_list_keep64(tgt_list, plan.device))
         return b.run(mask).cpu().numpy()
 
 

@@ -36,9 +36,9 @@ extern "C" int ssr_version(void) { return SSR_VERSION; }
 // SISpec sums fits 128 VGPRs with no spill, which admits a 4th workgroup per CU (-4.5 % time, measured);
 // the variant that carries the six sums would spill at 128, so it stays at 3.
 constexpr int ssr_stft_min_waves(int logn, bool blu, bool sums) { return (logn == 11 && !blu && !sums) ? 4 : 1; }
-// E64: the estimate is a float64 signal (pair mode only); its float64 epilogue needs more registers, so those
-// variants are left to the allocator (min waves 1).
-template <typename T, int LOGN, bool BLU, int MODE, bool SUMS, bool E64>
+// E64 (SSR_IN_EST64 / SSR_IN_BOTH64): float64 signals (pair mode only); their float64 epilogue needs more registers,
+// so those variants are left to the allocator (min waves 1).
+template <typename T, int LOGN, bool BLU, int MODE, bool SUMS, int E64>
 __global__ __launch_bounds__((1 << LOGN) / ssr_stft_ppt(LOGN, BLU), E64 ? 1 : ssr_stft_min_waves(LOGN, BLU, SUMS))
 void k_stft(SsrStftParams<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -47,7 +47,7 @@ void k_stft(SsrStftParams<T> p) {
   ssr_stft_body<T, LOGN, BLU, MODE, SUMS, ssr_stft_ppt(LOGN, BLU), E64>(p, blk, chunk, item, smem);
 }
 
-template <typename T, int LOGN, int MODE, bool SUMS, bool E64>
+template <typename T, int LOGN, int MODE, bool SUMS, int E64>
 __global__ __launch_bounds__((1 << LOGN) / 8) void k_stft_r3(SsrStftParams<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SsrBlk blk{(int)threadIdx.x};
@@ -166,7 +166,7 @@ template <> const DevTables<double>& tables_of<double>(const ssr_plan* pl) { ret
 // kernel registry: (precision, logn, bluestein) -> launcher
 typedef int (*stft_launcher)(const ssr_plan*, void* params, int grid, hipStream_t);
 
-template <typename T, int LOGN, bool BLU, int MODE, bool SUMS, bool E64 = false>
+template <typename T, int LOGN, bool BLU, int MODE, bool SUMS, int E64 = 0>
 static int launch_stft_mode(SsrStftParams<T>& p, int grid, hipStream_t s) {
   // SSR_LDS_PAD (bytes, developer knob): over-allocate LDS to cap workgroups per CU in occupancy experiments
   static const size_t lds_pad = getenv("SSR_LDS_PAD") ? (size_t)atol(getenv("SSR_LDS_PAD")) : 0;
@@ -186,14 +186,17 @@ static int launch_stft_mode(SsrStftParams<T>& p, int grid, hipStream_t s) {
 template <typename T, int LOGN, bool BLU> static int launch_stft_inst(SsrStftParams<T>& p, int grid, hipStream_t s) {
   if (p.mode != SSR_MODE_PAIR) return launch_stft_mode<T, LOGN, BLU, SSR_MODE_SINGLE, false>(p, grid, s);
   const bool sums = p.metric_mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC);
+  if (p.a64 && p.b64)
+    return sums ? launch_stft_mode<T, LOGN, BLU, SSR_MODE_PAIR, true, SSR_IN_BOTH64>(p, grid, s)
+                : launch_stft_mode<T, LOGN, BLU, SSR_MODE_PAIR, false, SSR_IN_BOTH64>(p, grid, s);
   if (p.a64)
-    return sums ? launch_stft_mode<T, LOGN, BLU, SSR_MODE_PAIR, true, true>(p, grid, s)
-                : launch_stft_mode<T, LOGN, BLU, SSR_MODE_PAIR, false, true>(p, grid, s);
+    return sums ? launch_stft_mode<T, LOGN, BLU, SSR_MODE_PAIR, true, SSR_IN_EST64>(p, grid, s)
+                : launch_stft_mode<T, LOGN, BLU, SSR_MODE_PAIR, false, SSR_IN_EST64>(p, grid, s);
   return sums ? launch_stft_mode<T, LOGN, BLU, SSR_MODE_PAIR, true>(p, grid, s)
               : launch_stft_mode<T, LOGN, BLU, SSR_MODE_PAIR, false>(p, grid, s);
 }
 
-template <typename T, int LOGN, int MODE, bool SUMS, bool E64 = false>
+template <typename T, int LOGN, int MODE, bool SUMS, int E64 = 0>
 static int launch_stft_r3_mode(SsrStftParams<T>& p, int grid, hipStream_t s) {
   const size_t lds = SsrStftR3Lds<T, LOGN>::bytes(p.n_fft / 3);
   HIP_TRY(hipFuncSetAttribute((const void*)k_stft_r3<T, LOGN, MODE, SUMS, E64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -204,9 +207,12 @@ static int launch_stft_r3_mode(SsrStftParams<T>& p, int grid, hipStream_t s) {
 template <typename T, int LOGN> static int launch_stft_r3(SsrStftParams<T>& p, int grid, hipStream_t s) {
   if (p.mode != SSR_MODE_PAIR) return launch_stft_r3_mode<T, LOGN, SSR_MODE_SINGLE, false>(p, grid, s);
   const bool sums = p.metric_mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC);
+  if (p.a64 && p.b64)
+    return sums ? launch_stft_r3_mode<T, LOGN, SSR_MODE_PAIR, true, SSR_IN_BOTH64>(p, grid, s)
+                : launch_stft_r3_mode<T, LOGN, SSR_MODE_PAIR, false, SSR_IN_BOTH64>(p, grid, s);
   if (p.a64)
-    return sums ? launch_stft_r3_mode<T, LOGN, SSR_MODE_PAIR, true, true>(p, grid, s)
-                : launch_stft_r3_mode<T, LOGN, SSR_MODE_PAIR, false, true>(p, grid, s);
+    return sums ? launch_stft_r3_mode<T, LOGN, SSR_MODE_PAIR, true, SSR_IN_EST64>(p, grid, s)
+                : launch_stft_r3_mode<T, LOGN, SSR_MODE_PAIR, false, SSR_IN_EST64>(p, grid, s);
   return sums ? launch_stft_r3_mode<T, LOGN, SSR_MODE_PAIR, true>(p, grid, s)
               : launch_stft_r3_mode<T, LOGN, SSR_MODE_PAIR, false>(p, grid, s);
 }
@@ -527,11 +533,11 @@ __global__ void k_rows_from_len(const int32_t* len, int n_items, int n_fft, int 
 }
 
 template <typename T>
-static int pair_stage_stft(const ssr_plan* pl, const float* est, const double* est64, const int64_t* est_off, const float* tgt,
+static int pair_stage_stft(const ssr_plan* pl, const float* est, const double* est64, const int64_t* est_off, const float* tgt, const double* tgt64,
                            const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off, int n_items,
                            unsigned mask, bool need_mag, const PairWs& w, char* ws, hipStream_t s) {
   SsrStftParams<T> p{};
-  p.a = est; p.a64 = est64; p.b = tgt; p.a_off = est_off; p.b_off = tgt_off; p.len = len; p.frame_off = frame_off;
+  p.a = est; p.a64 = est64; p.b = tgt; p.b64 = tgt64; p.a_off = est_off; p.b_off = tgt_off; p.len = len; p.frame_off = frame_off;
   p.mode = SSR_MODE_PAIR; p.out_kind = need_mag ? SSR_OUT_MAG : SSR_OUT_NONE; p.metric_mask = (int)mask;
   p.n_fft = pl->n_fft; p.hop = pl->hop; p.n_bins = pl->n_bins;
   p.units_per_chunk = w.units_per_chunk; p.n_chunks = w.n_chunks;
@@ -542,10 +548,10 @@ static int pair_stage_stft(const ssr_plan* pl, const float* est, const double* e
 
 // stages: 1 = STFT + LSD/SISpec epilogue, 2 = SSIM, 4 = finalise (bench.py times stages separately)
 static int pair_metrics_impl(const ssr_plan* pl, const float* est, const double* est64, const int64_t* est_off,
-                             const float* tgt, const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off,
+                             const float* tgt, const double* tgt64, const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off,
                              int n_items, int max_len, int64_t total_rows, unsigned mask, double* out,
                              void* workspace, size_t workspace_bytes, void* stream, int stages) {
-  if (!pl || (!est && !est64) || !tgt || !est_off || !tgt_off || !len || !frame_off || !out)
+  if (!pl || (!est && !est64) || (!tgt && !tgt64) || !est_off || !tgt_off || !len || !frame_off || !out)
     return fail(SSR_ERR_INVALID_ARG, "null argument");
   if (n_items <= 0) return SSR_OK;
   if (max_len <= pl->n_fft / 2) return fail(SSR_ERR_INVALID_ARG, "reflect padding needs len > n_fft/2");
@@ -565,8 +571,8 @@ static int pair_metrics_impl(const ssr_plan* pl, const float* est, const double*
     hipLaunchKernelGGL(k_rows_from_len, dim3(ceil_div(n_items, 256)), dim3(256), 0, s, len, n_items, pl->n_fft, pl->hop, rows);
     HIP_TRY(hipGetLastError());
     rc = pl->precision == SSR_F64
-             ? pair_stage_stft<double>(pl, est, est64, est_off, tgt, tgt_off, len, frame_off, n_items, mask, want_ssim, w, ws, s)
-             : pair_stage_stft<float>(pl, est, est64, est_off, tgt, tgt_off, len, frame_off, n_items, mask, want_ssim, w, ws, s);
+             ? pair_stage_stft<double>(pl, est, est64, est_off, tgt, tgt64, tgt_off, len, frame_off, n_items, mask, want_ssim, w, ws, s)
+             : pair_stage_stft<float>(pl, est, est64, est_off, tgt, tgt64, tgt_off, len, frame_off, n_items, mask, want_ssim, w, ws, s);
     if (rc) return rc;
   }
   if ((stages & 2) && want_ssim) {
@@ -585,24 +591,32 @@ extern "C" int ssr_pair_metrics_stages(const ssr_plan* pl, const float* est, con
                                        const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off,
                                        int n_items, int max_len, int64_t total_rows, unsigned mask, double* out,
                                        void* workspace, size_t workspace_bytes, void* stream, int stages) {
-  return pair_metrics_impl(pl, est, nullptr, est_off, tgt, tgt_off, len, frame_off, n_items, max_len, total_rows, mask,
-                           out, workspace, workspace_bytes, stream, stages);
+  return pair_metrics_impl(pl, est, nullptr, est_off, tgt, nullptr, tgt_off, len, frame_off, n_items, max_len, total_rows,
+                           mask, out, workspace, workspace_bytes, stream, stages);
 }
 
 extern "C" int ssr_pair_metrics(const ssr_plan* pl, const float* est, const int64_t* est_off, const float* tgt,
                                 const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off, int n_items,
                                 int max_len, int64_t total_rows, unsigned mask, double* out, void* workspace,
                                 size_t workspace_bytes, void* stream) {
-  return pair_metrics_impl(pl, est, nullptr, est_off, tgt, tgt_off, len, frame_off, n_items, max_len, total_rows, mask,
-                           out, workspace, workspace_bytes, stream, 7);
+  return pair_metrics_impl(pl, est, nullptr, est_off, tgt, nullptr, tgt_off, len, frame_off, n_items, max_len, total_rows,
+                           mask, out, workspace, workspace_bytes, stream, 7);
 }
 
 extern "C" int ssr_pair_metrics_est64(const ssr_plan* pl, const double* est, const int64_t* est_off, const float* tgt,
                                       const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off, int n_items,
                                       int max_len, int64_t total_rows, unsigned mask, double* out, void* workspace,
                                       size_t workspace_bytes, void* stream) {
-  return pair_metrics_impl(pl, nullptr, est, est_off, tgt, tgt_off, len, frame_off, n_items, max_len, total_rows, mask,
-                           out, workspace, workspace_bytes, stream, 7);
+  return pair_metrics_impl(pl, nullptr, est, est_off, tgt, nullptr, tgt_off, len, frame_off, n_items, max_len, total_rows,
+                           mask, out, workspace, workspace_bytes, stream, 7);
+}
+
+extern "C" int ssr_pair_metrics_f64(const ssr_plan* pl, const double* est, const int64_t* est_off, const double* tgt,
+                                    const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off, int n_items,
+                                    int max_len, int64_t total_rows, unsigned mask, double* out, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  return pair_metrics_impl(pl, nullptr, est, est_off, nullptr, tgt, tgt_off, len, frame_off, n_items, max_len, total_rows,
+                           mask, out, workspace, workspace_bytes, stream, 7);
 }
 
 // ----------------------------------------------------------------------------------------------------

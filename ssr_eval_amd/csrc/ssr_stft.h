@@ -43,7 +43,8 @@ enum { SSR_M_LSD = 1, SSR_M_LOG_SISPEC = 2, SSR_M_SISPEC = 4, SSR_M_SSIM = 8 };
 
 template <typename T> struct SsrStftParams {
   const float* a;            // signal buffer A (est, or the only signal in SINGLE mode)
-  const double* a64;         // EST64 kernels only: the estimate as float64 samples (a is unused then)
+  const double* a64;         // IN64 kernels only: the estimate as float64 samples (a is unused then)
+  const double* b64;         // IN64 == 3 kernels only: the target as float64 samples (b is unused then)
   const float* b;            // signal buffer B (target); unused in SINGLE mode
   const int64_t* a_off;      // [n_items] element offset of item i in a
   const int64_t* b_off;      // [n_items] element offset of item i in b
@@ -64,9 +65,11 @@ template <typename T> struct SsrStftParams {
   double* part;              // [n_items, n_chunks, SSR_NPART] or null
 };
 
-// sample type of signal A
-template <bool EST64> struct SsrSampleA { typedef float type; };
-template <> struct SsrSampleA<true> { typedef double type; };
+// Sample types of the two signals of a pair.  IN64: 0 = both float32, 1 = float64 estimate against a float32
+// target, 3 = both float64.  (A float32 estimate against a float64 target is widened on the host and runs as 3.)
+enum { SSR_IN_F32 = 0, SSR_IN_EST64 = 1, SSR_IN_BOTH64 = 3 };
+template <bool F64> struct SsrSample { typedef float type; };
+template <> struct SsrSample<true> { typedef double type; };
 
 template <typename T, bool SUMS = false, int PPT = 8> struct SsrStftRegs {
   cx<T> v[PPT];              // FFT points
@@ -150,15 +153,44 @@ SSR_DEV void ssr_accumulate_metrics(double e, float t, int mask, double* acc) {
   }
 }
 
+// Both signals float64: every tensor of metrics.py:109-121 is float64.
+SSR_DEV void ssr_accumulate_metrics(double e, double t, int mask, double* acc) {
+  const double EPS = 1e-12;
+  if (mask & SSR_M_LSD) {
+    const double ee = e + EPS;
+    const double d = log10((t * t) / (ee * ee) + EPS);
+    acc[0] += d * d;
+  }
+  if (mask & SSR_M_SISPEC) {
+    acc[1] += e * e;
+    acc[2] += t * t;
+    acc[3] += e * t;
+  }
+  if (mask & SSR_M_LOG_SISPEC) {
+    const double le = log10(e + EPS), lt = log10(t + EPS);
+    acc[4] += le * le;
+    acc[5] += lt * lt;
+    acc[6] += le * lt;
+  }
+}
+
 // Emit bin k of the current unit.  zk = Z[k], zn = Z[(n-k) mod n].  out_a_row / out_b_row: block-uniform
 // row base pointers (scalar base + 32-bit lane offset addressing).
-template <typename T, int MODE, bool EST64 = false>
+template <typename T, int MODE, int IN64 = 0>
 SSR_DEV void ssr_emit_bin(const SsrStftParams<T>& p, double* acc, unsigned k, cx<T> zk, cx<T> zn,
                           float* row_a0, float* row_a1, float* row_b0, float* row_b1, bool b_valid) {
   // PAIR  : row_a0 = est magnitudes row,  row_b0 = target magnitudes row
   // SINGLE: row_a0 / row_a1 = rows of frames 2g / 2g+1 in out_a; row_b0 / row_b1 the same rows in out_b
   const SsrBinOut<T> o = ssr_separate<T>(zk, zn);
-  if constexpr (MODE == SSR_MODE_PAIR && EST64) {
+  if constexpr (MODE == SSR_MODE_PAIR && IN64 == SSR_IN_BOTH64) {
+    const double e = hypot((double)zk.x + (double)zn.x, (double)zk.y - (double)zn.y);
+    const double t = hypot((double)zk.y + (double)zn.y, (double)zn.x - (double)zk.x);
+    if (p.out_kind == SSR_OUT_MAG) {
+      row_a0[k] = (float)e;
+      row_b0[k] = (float)t;
+    }
+    ssr_accumulate_metrics(e, t, p.metric_mask, acc);
+  } else if constexpr (MODE == SSR_MODE_PAIR && IN64 == SSR_IN_EST64) {
     // numpy.abs(complex128) of the unrounded est spectrum; the SSIM image keeps its float32 layout (the
     // rounding moves SSIM by < 2e-7, tests/test_gpu_parity.py)
     const double e = hypot((double)zk.x + (double)zn.x, (double)zk.y - (double)zn.y);
@@ -192,7 +224,7 @@ SSR_DEV void ssr_emit_bin(const SsrStftParams<T>& p, double* acc, unsigned k, cx
 
 // Direct engine epilogue: F = N/2 + 1 = (PPT/2) * NT + 1 -> PPT/2 full, unrolled rounds (all LDS reads in flight
 // together) + the Nyquist bin on thread 0.
-template <typename T, int LOGN, int MODE, int PPT, bool EST64 = false>
+template <typename T, int LOGN, int MODE, int PPT, int IN64 = 0>
 SSR_DEV void ssr_epilogue_direct(const SsrStftParams<T>& p, double* acc, int tid, const T* re, const T* im,
                                  float* ra0, float* ra1, float* rb0, float* rb1, bool b_ok) {
   constexpr int N = 1 << LOGN, NT = N / PPT, RND = PPT / 2;   // F = N/2 + 1 = RND * NT + 1
@@ -205,10 +237,10 @@ SSR_DEV void ssr_epilogue_direct(const SsrStftParams<T>& p, double* acc, int tid
   }
 #pragma unroll
   for (int i = 0; i < RND; ++i)
-    ssr_emit_bin<T, MODE, EST64>(p, acc, (unsigned)(tid + i * NT), zk[i], zn[i], ra0, ra1, rb0, rb1, b_ok);
+    ssr_emit_bin<T, MODE, IN64>(p, acc, (unsigned)(tid + i * NT), zk[i], zn[i], ra0, ra1, rb0, rb1, b_ok);
   if (tid == 0) {
     const cx<T> zq = {re[ssr_pad(N / 2)], im[ssr_pad(N / 2)]};
-    ssr_emit_bin<T, MODE, EST64>(p, acc, (unsigned)(N / 2), zq, zq, ra0, ra1, rb0, rb1, b_ok);
+    ssr_emit_bin<T, MODE, IN64>(p, acc, (unsigned)(N / 2), zq, zq, ra0, ra1, rb0, rb1, b_ok);
   }
 }
 
@@ -233,7 +265,7 @@ template <typename T, int LOGN, int PPT = 8> struct SsrStftLds {
 // ---------------------------------------------------------------------------------------------------
 // The body.  LOGN: FFT length of the engine (n_fft for direct, M for bluestein).
 // grid = (n_chunks, n_items); block = 2^LOGN / 8 threads.
-template <typename T, int LOGN, bool BLUESTEIN, int MODE, bool SUMS, int PPT, bool EST64, typename BLK>
+template <typename T, int LOGN, bool BLUESTEIN, int MODE, bool SUMS, int PPT, int IN64, typename BLK>
 SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
   using P = SsrFftPlan<LOGN, PPT>;
   constexpr int N = P::N, NT = P::NT, LAST = P::NPASS - 1, NW = (NT + 63) / 64;
@@ -246,12 +278,15 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
   const int n_units = (MODE == SSR_MODE_PAIR) ? n_frames : (n_frames + 1) / 2;
   const int u0 = chunk * p.units_per_chunk;
   const int u1 = (u0 + p.units_per_chunk < n_units) ? u0 + p.units_per_chunk : n_units;
-  static_assert(!EST64 || MODE == SSR_MODE_PAIR, "float64 estimates exist on the pair path only");
-  using SA = typename SsrSampleA<EST64>::type;
+  static_assert(IN64 == 0 || MODE == SSR_MODE_PAIR, "float64 signals exist on the pair path only");
+  using SA = typename SsrSample<(IN64 & 1) != 0>::type;
+  using SB = typename SsrSample<(IN64 & 2) != 0>::type;
   const SA* sa;
-  if constexpr (EST64) sa = p.a64 + p.a_off[item];
+  if constexpr (IN64 & 1) sa = p.a64 + p.a_off[item];
   else sa = p.a + p.a_off[item];
-  const float* sb = (MODE == SSR_MODE_PAIR) ? p.b + p.b_off[item] : p.a + p.a_off[item];
+  const SB* sb;
+  if constexpr (IN64 & 2) sb = p.b64 + p.b_off[item];
+  else sb = (MODE == SSR_MODE_PAIR) ? p.b + p.b_off[item] : p.a + p.a_off[item];
   const int64_t row0 = p.frame_off[item];
   double* part = p.part ? p.part + ((int64_t)item * p.n_chunks + chunk) * SSR_NPART : nullptr;
   const bool want_lsd = (MODE == SSR_MODE_PAIR) && (p.metric_mask & SSR_M_LSD);
@@ -295,7 +330,7 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
           (void)m_lo;
           if (any) {
             SA fa[4];
-            float fb[4];
+            SB fb[4];
             cx<T> wc[4];
             SSR_UNROLL for (int r = 0; r < 4; ++r) {
               const int m = ssr_fft_first_index<LOGN, PPT>(tid, r0 + r);
@@ -318,10 +353,10 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
         }
       } else {
         SA fa[PPT];
-        float fb[PPT];
+        SB fb[PPT];
         if (interior) {
           const SA* qa = sa + base_a;
-          const float* qb = sb + base_b;
+          const SB* qb = sb + base_b;
           SSR_UNROLL for (int r = 0; r < PPT; ++r) {
             const int m = ssr_fft_first_index<LOGN, PPT>(tid, r);
             fa[r] = qa[SSR_UIDX(m)];
@@ -393,17 +428,17 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
 #if defined(SSR_ABL_NOEPI)     /* developer ablation: WRONG results, timing only */
       if (tid == 0) {
         const cx<T> z0 = {L.re[0], L.im[0]};
-        ssr_emit_bin<T, MODE, EST64>(p, acc, 0u, z0, z0, ra0, ra1, rb0, rb1, b_ok);
+        ssr_emit_bin<T, MODE, IN64>(p, acc, 0u, z0, z0, ra0, ra1, rb0, rb1, b_ok);
       }
 #else
       if constexpr (!BLUESTEIN) {
-        ssr_epilogue_direct<T, LOGN, MODE, PPT, EST64>(p, acc, tid, L.re, L.im, ra0, ra1, rb0, rb1, b_ok);
+        ssr_epilogue_direct<T, LOGN, MODE, PPT, IN64>(p, acc, tid, L.re, L.im, ra0, ra1, rb0, rb1, b_ok);
       } else {
         for (int k = tid; k < F; k += NT) {
           const int kn = (k == 0) ? 0 : n_fft - k;
           const cx<T> zk = {L.re[ssr_pad(k)], L.im[ssr_pad(k)]};
           const cx<T> zn = {L.re[ssr_pad(kn)], L.im[ssr_pad(kn)]};
-          ssr_emit_bin<T, MODE, EST64>(p, acc, (unsigned)k, zk, zn, ra0, ra1, rb0, rb1, b_ok);
+          ssr_emit_bin<T, MODE, IN64>(p, acc, (unsigned)k, zk, zn, ra0, ra1, rb0, rb1, b_ok);
         }
       }
 #endif

@@ -30,7 +30,7 @@ template <typename T> SSR_DEV cx<T> ssr_r3_combine(const T* yre, const T* yim, i
 }
 
 // grid = (n_chunks, n_items); block = 2^LOGN / 8 threads.
-template <typename T, int LOGN, int MODE, bool SUMS, bool EST64, typename BLK>
+template <typename T, int LOGN, int MODE, bool SUMS, int IN64, typename BLK>
 SSR_BODY void ssr_stft_r3_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
   constexpr int PPT = 8;
   using P = SsrFftPlan<LOGN, PPT>;
@@ -46,12 +46,15 @@ SSR_BODY void ssr_stft_r3_body(const SsrStftParams<T>& p, BLK& blk, int chunk, i
   const int n_units = (MODE == SSR_MODE_PAIR) ? n_frames : (n_frames + 1) / 2;
   const int u0 = chunk * p.units_per_chunk;
   const int u1 = (u0 + p.units_per_chunk < n_units) ? u0 + p.units_per_chunk : n_units;
-  static_assert(!EST64 || MODE == SSR_MODE_PAIR, "float64 estimates exist on the pair path only");
-  using SA = typename SsrSampleA<EST64>::type;
+  static_assert(IN64 == 0 || MODE == SSR_MODE_PAIR, "float64 signals exist on the pair path only");
+  using SA = typename SsrSample<(IN64 & 1) != 0>::type;
+  using SB = typename SsrSample<(IN64 & 2) != 0>::type;
   const SA* sa;
-  if constexpr (EST64) sa = p.a64 + p.a_off[item];
+  if constexpr (IN64 & 1) sa = p.a64 + p.a_off[item];
   else sa = p.a + p.a_off[item];
-  const float* sb = (MODE == SSR_MODE_PAIR) ? p.b + p.b_off[item] : p.a + p.a_off[item];
+  const SB* sb;
+  if constexpr (IN64 & 2) sb = p.b64 + p.b_off[item];
+  else sb = (MODE == SSR_MODE_PAIR) ? p.b + p.b_off[item] : p.a + p.a_off[item];
   const int64_t row0 = p.frame_off[item];
   double* part = p.part ? p.part + ((int64_t)item * p.n_chunks + chunk) * SSR_NPART : nullptr;
   const bool want_lsd = (MODE == SSR_MODE_PAIR) && (p.metric_mask & SSR_M_LSD);
@@ -87,7 +90,7 @@ SSR_BODY void ssr_stft_r3_body(const SsrStftParams<T>& p, BLK& blk, int chunk, i
             const int ia = interior ? base_a + s3 : ssr_reflect(base_a + s3, n);
             const int ib = interior ? base_b + s3 : ssr_reflect(base_b + s3, n);
             const SA fa = sa[SSR_UIDX(ia)];
-            const float fb = sb[SSR_UIDX(ib)];
+            const SB fb = sb[SSR_UIDX(ib)];
             const cx<T> z = cmul(cx<T>{a_ok ? (T)fa : (T)0, b_ok ? (T)fb : (T)0}, wch[SSR_UIDX(mc)]);
             R.v[g] = (m < q) ? z : cx<T>{(T)0, (T)0};
           } else {
@@ -140,7 +143,7 @@ SSR_BODY void ssr_stft_r3_body(const SsrStftParams<T>& p, BLK& blk, int chunk, i
         const int Kn = (K == 0) ? 0 : n_fft - K;
         const cx<T> zk = ssr_r3_combine<T>(yre, yim, q, K);
         const cx<T> zn = ssr_r3_combine<T>(yre, yim, q, Kn);
-        ssr_emit_bin<T, MODE, EST64>(p, acc, (unsigned)K, zk, zn, ra0, ra1, rb0, rb1, b_ok);
+        ssr_emit_bin<T, MODE, IN64>(p, acc, (unsigned)K, zk, zn, ra0, ra1, rb0, rb1, b_ok);
       }
       if (want_lsd) SSR_WAVE_SUM_STORE(tid, NT, acc[0], L.sc1);
       if constexpr (SUMS)

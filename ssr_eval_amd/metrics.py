@@ -65,12 +65,13 @@ class AudioMetrics:
         """The same four metrics for lists of pairs, one fused launch sequence for the whole batch."""
         pairs = [self._prepare_pair(e, t) for e, t in zip(ests, targets)]
         # A float64 estimate (IIR-degraded input passed through a testee, eval.py:138-150) makes the reference's est
-        # spectrogram - and with it every metric - float64; those pairs run through ssr_pair_metrics_est64 in their
-        # own launch sequence.  Targets are what librosa.load returned: float32.
-        is64 = [B._is_f64(p[0]) for p in pairs]
+        # spectrogram - and with it every metric - float64; float64 targets (arrays decoded as float64 by the caller)
+        # likewise.  Pairs are grouped by dtype combination and each group runs its own launch sequence:
+        # 0 = both float32, 1 = float64 estimate / float32 target, 2 = float64 target (estimate widened if needed).
+        kind = [2 if B._is_f64(p[1]) else (1 if B._is_f64(p[0]) else 0) for p in pairs]
         out = [None] * len(pairs)
-        for want64 in (False, True):
-            idx = [i for i, f in enumerate(is64) if f == want64]
+        for want in (0, 1, 2):
+            idx = [i for i, f in enumerate(kind) if f == want]
             if not idx:
                 continue
             vals = B.pair_metrics(self._plan(), [pairs[i][0] for i in idx], [pairs[i][1] for i in idx], mask)
@@ -79,7 +80,7 @@ class AudioMetrics:
                 for k, v in zip(_KEYS, row):
                     if not np.isnan(v) or (mask & (1 << _KEYS.index(k))):
                         # float32 pairs: lsd / sispec are float32 tensors in the reference (float() of fp32), ssim float64
-                        d[k] = float(v) if (k == "ssim" or want64) else float(np.float32(v))
+                        d[k] = float(v) if (k == "ssim" or want) else float(np.float32(v))
                 out[i] = d
         return out
 

@@ -26,11 +26,13 @@ static void run_stft_ppt(SsrStftParams<T> p, int n_items) {
     for (int c = 0; c < p.n_chunks; ++c) {
       auto lds = poisoned(SsrStftLds<T, LOGN, PPT>::bytes());
       const bool sums = p.metric_mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC);
-      if (p.mode != SSR_MODE_PAIR) ssr_stft_body<T, LOGN, BLU, SSR_MODE_SINGLE, false, PPT, false>(p, blk, c, item, lds.data());
-      else if (p.a64 && sums) ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, true, PPT, true>(p, blk, c, item, lds.data());
-      else if (p.a64) ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, false, PPT, true>(p, blk, c, item, lds.data());
-      else if (sums) ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, true, PPT, false>(p, blk, c, item, lds.data());
-      else ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, false, PPT, false>(p, blk, c, item, lds.data());
+      if (p.mode != SSR_MODE_PAIR) ssr_stft_body<T, LOGN, BLU, SSR_MODE_SINGLE, false, PPT, 0>(p, blk, c, item, lds.data());
+      else if (p.a64 && p.b64 && sums) ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, true, PPT, SSR_IN_BOTH64>(p, blk, c, item, lds.data());
+      else if (p.a64 && p.b64) ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, false, PPT, SSR_IN_BOTH64>(p, blk, c, item, lds.data());
+      else if (p.a64 && sums) ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, true, PPT, SSR_IN_EST64>(p, blk, c, item, lds.data());
+      else if (p.a64) ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, false, PPT, SSR_IN_EST64>(p, blk, c, item, lds.data());
+      else if (sums) ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, true, PPT, 0>(p, blk, c, item, lds.data());
+      else ssr_stft_body<T, LOGN, BLU, SSR_MODE_PAIR, false, PPT, 0>(p, blk, c, item, lds.data());
     }
 }
 
@@ -48,22 +50,25 @@ static void run_stft_r3(SsrStftParams<T> p, int n_items) {
     for (int c = 0; c < p.n_chunks; ++c) {
       auto lds = poisoned(SsrStftR3Lds<T, LOGN>::bytes(p.n_fft / 3));
       const bool sums = p.metric_mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC);
-      if (p.mode != SSR_MODE_PAIR) ssr_stft_r3_body<T, LOGN, SSR_MODE_SINGLE, false, false>(p, blk, c, item, lds.data());
-      else if (p.a64 && sums) ssr_stft_r3_body<T, LOGN, SSR_MODE_PAIR, true, true>(p, blk, c, item, lds.data());
-      else if (p.a64) ssr_stft_r3_body<T, LOGN, SSR_MODE_PAIR, false, true>(p, blk, c, item, lds.data());
-      else if (sums) ssr_stft_r3_body<T, LOGN, SSR_MODE_PAIR, true, false>(p, blk, c, item, lds.data());
-      else ssr_stft_r3_body<T, LOGN, SSR_MODE_PAIR, false, false>(p, blk, c, item, lds.data());
+      if (p.mode != SSR_MODE_PAIR) ssr_stft_r3_body<T, LOGN, SSR_MODE_SINGLE, false, 0>(p, blk, c, item, lds.data());
+      else if (p.a64 && p.b64 && sums) ssr_stft_r3_body<T, LOGN, SSR_MODE_PAIR, true, SSR_IN_BOTH64>(p, blk, c, item, lds.data());
+      else if (p.a64 && p.b64) ssr_stft_r3_body<T, LOGN, SSR_MODE_PAIR, false, SSR_IN_BOTH64>(p, blk, c, item, lds.data());
+      else if (p.a64 && sums) ssr_stft_r3_body<T, LOGN, SSR_MODE_PAIR, true, SSR_IN_EST64>(p, blk, c, item, lds.data());
+      else if (p.a64) ssr_stft_r3_body<T, LOGN, SSR_MODE_PAIR, false, SSR_IN_EST64>(p, blk, c, item, lds.data());
+      else if (sums) ssr_stft_r3_body<T, LOGN, SSR_MODE_PAIR, true, 0>(p, blk, c, item, lds.data());
+      else ssr_stft_r3_body<T, LOGN, SSR_MODE_PAIR, false, 0>(p, blk, c, item, lds.data());
     }
 }
 
 template <typename T>
 static int emu_stft_t(int n_fft, int hop, int mode, int out_kind, int mask, const float* a, const double* a64, const float* b,
+                      const double* b64,
                       const int64_t* a_off, const int64_t* b_off, const int32_t* len, const int64_t* frame_off,
                       int n_items, int units_per_chunk, int n_chunks, float* out_a, float* out_b, double* part) {
   SsrTables<T> t;
   if (!ssr_build_tables<T>(n_fft, t)) return -3;
   SsrStftParams<T> p{};
-  p.a = a; p.a64 = a64; p.b = b; p.a_off = a_off; p.b_off = b_off; p.len = len; p.frame_off = frame_off;
+  p.a = a; p.a64 = a64; p.b = b; p.b64 = b64; p.a_off = a_off; p.b_off = b_off; p.len = len; p.frame_off = frame_off;
   p.mode = mode; p.out_kind = out_kind; p.metric_mask = mask;
   p.n_fft = n_fft; p.hop = hop; p.n_bins = n_fft / 2 + 1;
   p.units_per_chunk = units_per_chunk; p.n_chunks = n_chunks;
@@ -94,21 +99,21 @@ extern "C" int emu_stft(int precision, int n_fft, int hop, int mode, int out_kin
                         const int64_t* frame_off, int n_items, int units_per_chunk, int n_chunks, float* out_a,
                         float* out_b, double* part) {
   if (precision == 1)
-    return emu_stft_t<double>(n_fft, hop, mode, out_kind, mask, a, nullptr, b, a_off, b_off, len, frame_off, n_items,
+    return emu_stft_t<double>(n_fft, hop, mode, out_kind, mask, a, nullptr, b, nullptr, a_off, b_off, len, frame_off, n_items,
                               units_per_chunk, n_chunks, out_a, out_b, part);
-  return emu_stft_t<float>(n_fft, hop, mode, out_kind, mask, a, nullptr, b, a_off, b_off, len, frame_off, n_items,
+  return emu_stft_t<float>(n_fft, hop, mode, out_kind, mask, a, nullptr, b, nullptr, a_off, b_off, len, frame_off, n_items,
                            units_per_chunk, n_chunks, out_a, out_b, part);
 }
 
-// pair mode with a float64 estimate (EST64 kernel variants)
-extern "C" int emu_stft_est64(int precision, int n_fft, int hop, int out_kind, int mask, const double* a64,
-                              const float* b, const int64_t* a_off, const int64_t* b_off, const int32_t* len,
-                              const int64_t* frame_off, int n_items, int units_per_chunk, int n_chunks, float* out_a,
-                              float* out_b, double* part) {
+// pair mode with a float64 estimate and a float32 (b) or float64 (b64) target (IN64 kernel variants)
+extern "C" int emu_stft_in64(int precision, int n_fft, int hop, int out_kind, int mask, const double* a64,
+                             const float* b, const double* b64, const int64_t* a_off, const int64_t* b_off,
+                             const int32_t* len, const int64_t* frame_off, int n_items, int units_per_chunk, int n_chunks,
+                             float* out_a, float* out_b, double* part) {
   if (precision == 1)
-    return emu_stft_t<double>(n_fft, hop, SSR_MODE_PAIR, out_kind, mask, nullptr, a64, b, a_off, b_off, len, frame_off,
-                              n_items, units_per_chunk, n_chunks, out_a, out_b, part);
-  return emu_stft_t<float>(n_fft, hop, SSR_MODE_PAIR, out_kind, mask, nullptr, a64, b, a_off, b_off, len, frame_off,
+    return emu_stft_t<double>(n_fft, hop, SSR_MODE_PAIR, out_kind, mask, nullptr, a64, b, b64, a_off, b_off, len,
+                              frame_off, n_items, units_per_chunk, n_chunks, out_a, out_b, part);
+  return emu_stft_t<float>(n_fft, hop, SSR_MODE_PAIR, out_kind, mask, nullptr, a64, b, b64, a_off, b_off, len, frame_off,
                            n_items, units_per_chunk, n_chunks, out_a, out_b, part);
 }
 

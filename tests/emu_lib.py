@@ -45,13 +45,15 @@ def ragged(arrs):
     return np.concatenate(arrs).astype(np.float32), off, lens
 
 
-def stft(sigs_a, sigs_b, n_fft, hop, precision=1, mode=0, out_kind=1, mask=0, units_per_chunk=8, est64=False):
+def stft(sigs_a, sigs_b, n_fft, hop, precision=1, mode=0, out_kind=1, mask=0, units_per_chunk=8, est64=False,
+         tgt64=False):
     """mode 0 (pair): returns (mag_a list, mag_b list, part); mode 1 (single): (out_a list, out_b list, None).
-    est64 (pair mode): sigs_a are float64 signals and run through the EST64 kernel variants."""
+    est64 / tgt64 (pair mode): the signals are float64 and run through the IN64 kernel variants."""
     a, a_off, lens = ragged(sigs_a)
     if est64:
         assert mode == 0
         a = np.concatenate(sigs_a).astype(np.float64)
+    assert est64 or not tgt64
     if mode == 0:
         b, b_off, lens_b = ragged(sigs_b)
         assert (lens == lens_b).all()
@@ -68,7 +70,9 @@ def stft(sigs_a, sigs_b, n_fft, hop, precision=1, mode=0, out_kind=1, mask=0, un
     tail = (_p(a_off, C.c_int64), _p(b_off, C.c_int64), _p(lens, C.c_int32), _p(frame_off, C.c_int64), len(lens),
             units_per_chunk, n_chunks, _p(out_a, C.c_float), _p(out_b, C.c_float), _p(part, C.c_double))
     if est64:
-        rc = lib().emu_stft_est64(precision, n_fft, hop, out_kind, mask, _p(a, C.c_double), _p(b, C.c_float), *tail)
+        b64 = np.concatenate(sigs_b).astype(np.float64) if tgt64 else None
+        rc = lib().emu_stft_in64(precision, n_fft, hop, out_kind, mask, _p(a, C.c_double),
+                                 None if tgt64 else _p(b, C.c_float), _p(b64, C.c_double) if tgt64 else None, *tail)
     else:
         rc = lib().emu_stft(precision, n_fft, hop, mode, out_kind, mask, _p(a, C.c_float), _p(b, C.c_float), *tail)
     assert rc == 0, rc
@@ -123,8 +127,9 @@ def finalize(part, ssim_part, T, F, mask):
     return out
 
 
-def pair_metrics(ests, tgts, n_fft, hop, precision=1, mask=M_ALL, units_per_chunk=8, rows_per_tile=16, est64=False):
-    ea, tb, part = stft(ests, tgts, n_fft, hop, precision, 0, 1, mask, units_per_chunk, est64=est64)
+def pair_metrics(ests, tgts, n_fft, hop, precision=1, mask=M_ALL, units_per_chunk=8, rows_per_tile=16, est64=False,
+                 tgt64=False):
+    ea, tb, part = stft(ests, tgts, n_fft, hop, precision, 0, 1, mask, units_per_chunk, est64=est64, tgt64=tgt64)
     sp, T = ssim_parts(ea, tb, rows_per_tile) if mask & M_SSIM else (None, np.array([e.shape[0] for e in ea]))
     return finalize(part, sp, T, n_fft // 2 + 1, mask)
 

@@ -188,3 +188,9 @@ def test_pair_metrics_float64_estimate(golden, n_fft, hop):
     np.testing.assert_allclose(got, want, rtol=1e-6)
     rounded = E.pair_metrics([est.astype(np.float32)], [tgt], n_fft, hop, precision=1)[0]
     assert abs(rounded[0] / want[0] - 1) > 1e-5
+    # both signals float64 (complex128 spectra on both sides, all-float64 metric arithmetic)
+    tgt64 = tgt.astype(np.float64) * 1.00000001
+    want = om.evaluation(est, tgt64, n_fft=n_fft, hop=hop)
+    want = np.array([want["lsd"], want["log_sispec"], want["sispec"], want["ssim"]])
+    got = E.pair_metrics([est], [tgt64], n_fft, hop, precision=1, units_per_chunk=5, rows_per_tile=9, est64=True, tgt64=True)[0]
+    np.testing.assert_allclose(got, want, rtol=1e-6)

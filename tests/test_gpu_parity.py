@@ -444,6 +444,14 @@ def test_pair_metrics_float64_estimate(golden, n_fft, hop):
         np.testing.assert_allclose(g[[1, 2]], want[[1, 2]], rtol=1e-5)
     rounded = B.pair_metrics(plan, [e.astype(np.float32) for e in ests], sigs)
     assert np.abs(rounded[:, 0] / got[:, 0] - 1).max() > 1e-5
+    # both float64 (arrays decoded as float64 by the caller): complex128 on both sides
+    sigs64 = [s_.astype(np.float64) * 1.00000001 for s_ in sigs]
+    got64 = B.pair_metrics(plan, ests, sigs64)
+    for e, t, g in zip(ests, sigs64, got64):
+        np.testing.assert_allclose(g, _vec(om.evaluation(e, t, n_fft=n_fft, hop=hop)), rtol=1e-6)
+    # float32 estimate against a float64 target (estimate widened, exact)
+    g = B.pair_metrics(plan, [ests[1].astype(np.float32)], [sigs64[1]])[0]
+    np.testing.assert_allclose(g, _vec(om.evaluation(ests[1].astype(np.float32), sigs64[1], n_fft=n_fft, hop=hop)), rtol=1e-6)
     # mixed batch through the API: float32 and float64 estimates each take their own path
     from ssr_eval_amd import AudioMetrics
     am = AudioMetrics(44100)

@@ -64,9 +64,11 @@ template <int R, typename T> SSR_DEV void ssr_bfly(cx<T>* v) {
 template <int LOGN, int PPT = 8> struct SsrFftPlan {
   static constexpr int N = 1 << LOGN;
   static constexpr int NT = N / PPT;
-  static constexpr int R0 = (LOGN % 3 == 0) ? 8 : (1 << (LOGN % 3));
-  static constexpr int NPASS = LOGN / 3 + ((LOGN % 3) ? 1 : 0);
-  static constexpr int radix(int p) { return p == 0 ? R0 : 8; }
+  static constexpr int LR = (PPT >= 8) ? 3 : 2;          // log2 of the working radix: 8, or 4 at 4 points per thread
+  static constexpr int RW = 1 << LR;
+  static constexpr int R0 = (LOGN % LR == 0) ? RW : (1 << (LOGN % LR));
+  static constexpr int NPASS = LOGN / LR + ((LOGN % LR) ? 1 : 0);
+  static constexpr int radix(int p) { return p == 0 ? R0 : RW; }
   static constexpr int ns(int p) {  // product of the radices of the passes before p
     int s = 1;
     for (int i = 0; i < p; ++i) s *= radix(i);
@@ -104,22 +106,29 @@ SSR_DEV void ssr_fft_compute(int tid, cx<T>* v, const cx<T>* __restrict__ tw) {
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     if constexpr (NS > 1) {
-      static_assert(R == 8 || NS == 1, "only the leading pass may be radix 2/4");
+      static_assert(R == P::RW || NS == 1, "only the leading pass may have a smaller radix");
       const int j = tid + b * P::NT;
       const int k = j & (NS - 1);
       const int base = k * (P::N / (NS * R));
       const unsigned ub = (unsigned)base;          // scalar table base + 32-bit lane offset
-      const cx<T> w1 = tw[ub], w2 = tw[2 * ub], w4 = tw[4 * ub];
-      // twiddle powers are formed just before use to keep few of them live (register pressure)
       cx<T>* x = v + b * R;
-      x[1] = cmul(x[1], w1);
-      x[2] = cmul(x[2], w2);
-      x[4] = cmul(x[4], w4);
-      const cx<T> w3 = cmul(w1, w2);
-      x[3] = cmul(x[3], w3);
-      x[5] = cmul(x[5], cmul(w1, w4));
-      x[6] = cmul(x[6], cmul(w2, w4));
-      x[7] = cmul(x[7], cmul(w3, w4));
+      if constexpr (R == 4) {
+        const cx<T> w1 = tw[ub], w2 = tw[2 * ub];
+        x[1] = cmul(x[1], w1);
+        x[2] = cmul(x[2], w2);
+        x[3] = cmul(x[3], cmul(w1, w2));
+      } else {
+        const cx<T> w1 = tw[ub], w2 = tw[2 * ub], w4 = tw[4 * ub];
+        // twiddle powers are formed just before use to keep few of them live (register pressure)
+        x[1] = cmul(x[1], w1);
+        x[2] = cmul(x[2], w2);
+        x[4] = cmul(x[4], w4);
+        const cx<T> w3 = cmul(w1, w2);
+        x[3] = cmul(x[3], w3);
+        x[5] = cmul(x[5], cmul(w1, w4));
+        x[6] = cmul(x[6], cmul(w2, w4));
+        x[7] = cmul(x[7], cmul(w3, w4));
+      }
     }
     ssr_bfly<R>(v + b * R);
   }

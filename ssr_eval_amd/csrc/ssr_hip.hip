@@ -35,7 +35,10 @@ extern "C" int ssr_version(void) { return SSR_VERSION; }
 // Minimum waves per SIMD asked of the register allocator.  The 2048-point direct kernel without running
 // SISpec sums fits 128 VGPRs with no spill, which admits a 4th workgroup per CU (-4.5 % time, measured);
 // the variant that carries the six sums would spill at 128, so it stays at 3.
-constexpr int ssr_stft_min_waves(int logn, bool blu, bool sums) { return (logn == 11 && !blu && !sums) ? 4 : 1; }
+#ifndef SSR_MINW
+#define SSR_MINW 4
+#endif
+constexpr int ssr_stft_min_waves(int logn, bool blu, bool sums) { return (logn == 11 && !blu && !sums) ? SSR_MINW : 1; }
 // E64 (SSR_IN_EST64 / SSR_IN_BOTH64): float64 signals (pair mode only); their float64 epilogue needs more registers,
 // so those variants are left to the allocator (min waves 1).
 template <typename T, int LOGN, bool BLU, int MODE, bool SUMS, int E64>

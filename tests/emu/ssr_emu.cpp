@@ -16,7 +16,7 @@
 
 static std::vector<char> poisoned(size_t bytes) { return std::vector<char>(bytes + 64, (char)0xFF); }
 
-static int g_force_ppt = 0;   // tests can force 8 or 16 points per thread for the 2048-point direct engine
+static int g_force_ppt = 0;   // tests can force 4, 8 or 16 points per thread for the 2048-point direct engine
 extern "C" void emu_force_ppt(int ppt) { g_force_ppt = ppt; }
 
 template <typename T, int LOGN, bool BLU, int PPT>
@@ -40,6 +40,7 @@ template <typename T, int LOGN, bool BLU>
 static void run_stft(SsrStftParams<T> p, int n_items) {
   if (g_force_ppt == 16 && LOGN >= 9) return run_stft_ppt<T, LOGN, BLU, 16>(p, n_items);
   if (g_force_ppt == 8) return run_stft_ppt<T, LOGN, BLU, 8>(p, n_items);
+  if (g_force_ppt == 4) return run_stft_ppt<T, LOGN, BLU, 4>(p, n_items);
   return run_stft_ppt<T, LOGN, BLU, ssr_stft_ppt(LOGN, BLU)>(p, n_items);
 }
 

@@ -113,7 +113,7 @@ def test_resampler_bit_exact_vs_scipy(golden, up, down):
         np.testing.assert_array_equal(o, signal.resample_poly(s, up, down))
 
 
-@pytest.mark.parametrize("ppt", [8, 16])
+@pytest.mark.parametrize("ppt", [4, 8, 16])
 @pytest.mark.parametrize("n_fft,hop", [(2048, 512), (2229, 480), (512, 128), (743, 160)])
 def test_fft_engine_points_per_thread(ppt, n_fft, hop, golden):
     """Both register geometries of the FFT engine (8 and 16 points per thread) give the same spectra / metrics."""

@@ -169,6 +169,15 @@ int ssr_resample_poly_f64(const double* in, const int64_t* in_off, const int32_t
                           const int32_t* out_len, int n_items, int max_out_len, int up, int down, const double* taps,
                           int n_taps, int n_pre_remove, double* out, void* stream);
 
+/* N4.  Position of the maximum of the full cross-correlation of two equal-length signals,
+ *   z[k] = sum_l a[l] * b[l - k + n - 1],  k = 0 .. 2n-2   (scipy.signal.correlate(a, b, "full")),
+ * first maximum on ties (numpy.argmax): the alignment step of SSR_Eval_Helper.mp3_encoding
+ * (ssr_eval/eval.py:319  shift = argmax(correlate(decoded, x)) - len(x)).  argmax_out: int64 [n_items]. */
+size_t ssr_xcorr_workspace_bytes(int n_items, int max_len);
+int ssr_xcorr_argmax(const float* a, const int64_t* a_off, const float* b, const int64_t* b_off, const int32_t* len,
+                     int n_items, int max_len, int64_t* argmax_out, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
 /* N1.  Zero-phase IIR: scipy.signal.sosfiltfilt(sos, x) (padtype "odd", padlen 3*ntaps) for float32 x, float64
  * arithmetic and output - the arithmetic of lowpass_filter / bandpass_filter (ssr_eval/lowpass.py:54-131, called
  * from lowpass()/bandpass() :175-190,:215-254 and SSR_Eval_Helper.lowpass_butterworth/... eval.py:334-399).

@@ -427,3 +427,23 @@ def sosfiltfilt(sos, wavs, device=None):
         _lib.check(lib.ssr_sosfiltfilt(_vp(r.data), _vp(r.off), _vp(r.len), r.n, total, _vp(sos_d), _vp(zi_d), n_sections, edge,
                                        _vp(y), _vp(ws), ws_bytes, _stream()))
         return r.split(y)
+
+
+def xcorr_argmax(a_list, b_list, device=None):
+    """numpy.argmax(scipy.signal.correlate(a, b, "full")) for lists of equal-length float32 signal pairs (N4)."""
+    dev = torch.device(device) if device is not None else default_device()
+    with torch.cuda.device(dev):
+        ra, rb = Ragged.from_list(a_list, dev), Ragged.from_list(b_list, dev)
+        if ra.n != rb.n or not np.array_equal(ra.lens_host, rb.lens_host):
+            raise ValueError("cross-correlation alignment needs pairs of equal length (unify_length first)")
+        if ra.n == 0:
+            return np.zeros(0, np.int64)
+        if int(ra.lens_host.min()) < 1:
+            raise ValueError("empty signal")
+        lib = _lib.load()
+        ws_bytes = int(lib.ssr_xcorr_workspace_bytes(ra.n, ra.max_len))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        out = torch.empty(ra.n, dtype=torch.int64, device=dev)
+        _lib.check(lib.ssr_xcorr_argmax(_vp(ra.data), _vp(ra.off), _vp(rb.data), _vp(rb.off), _vp(ra.len), ra.n, ra.max_len,
+                                        _vp(out), _vp(ws), ws_bytes, _stream()))
+        return out.cpu().numpy()

@@ -13,6 +13,7 @@
 #include "ssr_lowpass.h"
 #include "ssr_metrics.h"
 #include "ssr_iir.h"
+#include "ssr_xcorr.h"
 #include "ssr_resample.h"
 #include "ssr_stft_r3.h"
 #include "ssr_tables.h"
@@ -84,6 +85,18 @@ __global__ __launch_bounds__(256) void k_specred(SsrSpecRedParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SsrBlk blk{(int)threadIdx.x};
   ssr_specred_body(p, blk, blockIdx.x % p.n_chunks, blockIdx.x / p.n_chunks, smem);
+}
+
+__global__ __launch_bounds__(SSR_XC_NT) void k_xcorr(SsrXcorrParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  SsrBlk blk{(int)threadIdx.x};
+  ssr_xcorr_body(p, blk, blockIdx.x % p.n_lag_blocks, blockIdx.x / p.n_lag_blocks, smem);
+}
+
+__global__ __launch_bounds__(64) void k_xcorr_pick(const double* best_val, const int64_t* best_idx, int n_lag_blocks,
+                                                   int n_items, int64_t* argmax_out) {
+  const int item = blockIdx.x * 64 + threadIdx.x;
+  if (item < n_items) ssr_xcorr_pick(best_val, best_idx, n_lag_blocks, item, argmax_out);
 }
 
 __global__ __launch_bounds__(64) void k_finalize(SsrFinalizeParams p) {
@@ -778,6 +791,33 @@ extern "C" int ssr_resample_poly_f64(const double* in, const int64_t* in_off, co
                                      void* stream) {
   return resample_poly_t<double>(in, in_off, in_len, out_off, out_len, n_items, max_out_len, up, down, taps, n_taps,
                                  n_pre_remove, out, stream);
+}
+
+// ----------------------------------------------------------------------------------------------------
+static int xcorr_blocks(int max_len) { return max_len > 0 ? ceil_div(2 * (int64_t)max_len - 1, SSR_XC_LAGS) : 1; }
+
+extern "C" size_t ssr_xcorr_workspace_bytes(int n_items, int max_len) {
+  if (n_items <= 0) return 0;
+  return 2 * align256((size_t)n_items * xcorr_blocks(max_len) * sizeof(double));
+}
+
+extern "C" int ssr_xcorr_argmax(const float* a, const int64_t* a_off, const float* b, const int64_t* b_off,
+                                const int32_t* len, int n_items, int max_len, int64_t* argmax_out, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  if (!a || !a_off || !b || !b_off || !len || !argmax_out) return fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n_items <= 0) return SSR_OK;
+  if (max_len <= 0) return fail(SSR_ERR_INVALID_ARG, "empty signals");
+  const int nb = xcorr_blocks(max_len);
+  const size_t half = align256((size_t)n_items * nb * sizeof(double));
+  if (!workspace || workspace_bytes < 2 * half) return fail(SSR_ERR_WORKSPACE, "workspace too small");
+  if ((int64_t)n_items * nb > 0x7fffffff) return fail(SSR_ERR_UNSUPPORTED, "batch too large for one launch");
+  SsrXcorrParams p{a, a_off, b, b_off, len, nb, (double*)workspace, (int64_t*)((char*)workspace + half)};
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_xcorr, dim3((unsigned)(n_items * nb)), dim3(SSR_XC_NT), SsrXcorrLds::bytes(), s, p);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_xcorr_pick, dim3(ceil_div(n_items, 64)), dim3(64), 0, s, p.best_val, p.best_idx, nb, n_items, argmax_out);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
 }
 
 // ----------------------------------------------------------------------------------------------------

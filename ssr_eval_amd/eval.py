@@ -163,9 +163,46 @@ class SSR_Eval_Helper:
             ret["proc_subsampling_%s_%s" % (low_rate, sr)] = lowpass(x, low_rate // 2, sr, order=1, _type="subsampling")
         return ret
 
+    def _run_sox(self, args):
+        """One sox invocation (the reference uses os.system, eval.py:309-314).  The codec is host tooling."""
+        import shutil
+        import subprocess
+        if shutil.which("sox") is None:
+            raise RuntimeError("mp3 degradation needs the `sox` codec on PATH (ssr_eval/eval.py:309-311 shells out to it)")
+        subprocess.run(["sox"] + list(args), check=True)
+
     def mp3_encoding(self, file, x, sr):
-        raise RuntimeError("mp3 degradation (eval.py:302-325) shells out to the `sox` codec; it is host tooling "
-                           "outside this library (SURVEY 8(f) N4)")
+        """eval.py:302-325.  sox encodes `file` to mp3 at every bit rate and decodes it again (host codec, exactly as
+        the reference); the decoded signal is brought to len(x) and aligned with x by the position of the maximum of
+        their full cross-correlation - that search runs on the GPU (ssr_xcorr_argmax), all bit rates
+        of the file in one launch."""
+        from .io import load_audio, write_wav
+        if not isinstance(file, str) or not os.path.exists(file):
+            raise RuntimeError("mp3 degradation encodes the source FILE with sox; no file path was given (%r)" % (file,))
+        keys, decoded = [], []
+        for low_kbps in self.setting_mp3_compression["low_kbps"]:
+            key = "proc_mp3_%s_%s" % (low_kbps, sr)
+            temp_file = self.cache_file_name("temp", file, suffix=".wav")     # reference: .flac - lossless either way
+            target_mp3_file = self.cache_file_name(key, file, suffix=".mp3")
+            self._run_sox([file, "-C", str(low_kbps), target_mp3_file])
+            self._run_sox([target_mp3_file, temp_file])
+            os.remove(target_mp3_file)
+            y = load_audio(temp_file, sr)
+            os.remove(temp_file)
+            y, _ = self.unify_length(y, x)
+            keys.append(key)
+            decoded.append(np.ascontiguousarray(y, dtype=np.float32))
+        ret = {}
+        if not keys:
+            return ret
+        peaks = B.xcorr_argmax(decoded, [np.asarray(x, np.float32)] * len(decoded), self._device)
+        for key, y, peak in zip(keys, decoded, peaks):
+            shifted = self.shift(y, int(peak) - x.shape[0])         # eval.py:319-320
+            write_wav(self.cache_file_name(key, file, suffix=".wav"), shifted, sr)   # the reference caches a .flac here
+            ret[key] = shifted
+            assert ret[key].shape == x.shape, str((ret[key].shape, x.shape))
+            assert np.sum(ret[key] - x) != 0.0
+        return ret
 
     def shift(self, x, shift):
         ret = np.zeros_like(x)
@@ -208,10 +245,11 @@ class SSR_Eval_Helper:
             ret.update(self.lowpass_stft_hard(file, x, sr))
         return ret
 
-    def preprocess_arrays(self, xs, sr):
+    def preprocess_arrays(self, xs, sr, files=None):
         """preprocess_array for a list of waveforms with every degradation batched over the list (one launch
         sequence per (filter, cutoff, order) instead of one per file).  Key order per item is the reference's
-        (eval.py:243-269: butter, cheby, ellip, bessel, subsampling, mp3, fft)."""
+        (eval.py:243-269: butter, cheby, ellip, bessel, subsampling, mp3, fft).  `files`: the source paths, needed
+        by the mp3 degradation only (sox encodes the file itself)."""
         rets = [dict() for _ in xs]
         if not xs:
             return rets
@@ -238,7 +276,10 @@ class SSR_Eval_Helper:
                     low_rate -= 1
                 put("proc_subsampling_%s_%s" % (low_rate, sr), lowpass_batch(xs, low_rate // 2, sr, order=1, _type="subsampling"))
         if self.setting_mp3_compression is not None:
-            self.mp3_encoding("<array>", xs[0], sr)          # raises: host codec, out of scope
+            if files is None:
+                raise RuntimeError("mp3 degradation encodes the source files with sox: pass `files`")
+            for ret, f, x in zip(rets, files, xs):
+                ret.update(self.mp3_encoding(f, x, sr))
         if self.setting_fft is not None:
             keys, ratios = self._fft_plan_keys(sr)
             ys = stft_hard_lowpass_batch([x for x in xs for _ in keys], ratios * len(xs), self._device)
@@ -265,11 +306,11 @@ class SSR_Eval_Helper:
             extras.append(add)
         return keys, outs, extras
 
-    def evaluate_arrays(self, items):
+    def evaluate_arrays(self, items, files=None):
         """items: list of (target waveform @ evaluation_sr, input waveform @ input_sr).
         -> list of {key: {metric: float}} (one dict per item), everything batched on the GPU."""
         all_keys, all_proc, all_tgt, all_extra, owner = [], [], [], [], []
-        degraded = self.preprocess_arrays([np.asarray(x) for _, x in items], self.model_input_sr)
+        degraded = self.preprocess_arrays([np.asarray(x) for _, x in items], self.model_input_sr, files)
         for i, (target, x) in enumerate(items):
             keys, outs, extras = self._infer_and_collect(degraded[i])
             for k, o, e in zip(keys, outs, extras):
@@ -300,7 +341,7 @@ class SSR_Eval_Helper:
         from .io import load_audio, write_wav
         items = [(load_audio(f, self.evaluationset_sr),            # the reference shells out to sox here
                   load_audio(f, self.model_input_sr)) for f in files]
-        res = self.evaluate_arrays(items)
+        res = self.evaluate_arrays(items, files)
         if self.save_processed_result:
             for (i, k), y in self._last_processed.items():
                 write_wav(files[i] + k + "_processed_" + self.test_name + ".wav", y, self.evaluationset_sr)

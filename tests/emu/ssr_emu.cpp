@@ -10,6 +10,7 @@
 #include "../../ssr_eval_amd/csrc/ssr_metrics.h"
 #include "../../ssr_eval_amd/csrc/ssr_lowpass.h"
 #include "../../ssr_eval_amd/csrc/ssr_iir.h"
+#include "../../ssr_eval_amd/csrc/ssr_xcorr.h"
 #include "../../ssr_eval_amd/csrc/ssr_resample.h"
 #include "../../ssr_eval_amd/csrc/ssr_stft_r3.h"
 #include "../../ssr_eval_amd/csrc/ssr_tables.h"
@@ -249,5 +250,23 @@ extern "C" int emu_sosfiltfilt(const float* x, const int64_t* off, const int32_t
                                const double* zi, int n_sections, int edge, double* fwd, double* y) {
   SsrIirParams p{x, off, len, sos, zi, n_sections, edge, n_items, fwd, y};
   for (int i = 0; i < n_items; ++i) ssr_iir_item_host(p, i);
+  return 0;
+}
+
+// ---- cross-correlation argmax (N4) ------------------------------------------------------------------------
+extern "C" int emu_xcorr_argmax(const float* a, const int64_t* a_off, const float* b, const int64_t* b_off,
+                                const int32_t* len, int n_items, int max_len, int64_t* argmax_out) {
+  const int nb = (int)((2 * (int64_t)max_len - 1 + SSR_XC_LAGS - 1) / SSR_XC_LAGS);
+  std::vector<double> bv((size_t)n_items * nb);
+  std::vector<int64_t> bi((size_t)n_items * nb);
+  SsrXcorrParams p{a, a_off, b, b_off, len, nb, bv.data(), bi.data()};
+  SsrBlk blk{SSR_XC_NT};
+  for (int item = 0; item < n_items; ++item) {
+    for (int c = 0; c < nb; ++c) {
+      auto lds = poisoned(SsrXcorrLds::bytes());
+      ssr_xcorr_body(p, blk, c, item, lds.data());
+    }
+    ssr_xcorr_pick(bv.data(), bi.data(), nb, item, argmax_out);
+  }
   return 0;
 }

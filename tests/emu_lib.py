@@ -200,3 +200,14 @@ def sosfiltfilt(sos, sigs):
                                _p(zi, C.c_double), S, edge, _p(fwd, C.c_double), _p(y, C.c_double))
     assert rc == 0
     return [y[off[i]:off[i] + lens[i]] for i in range(len(lens))]
+
+
+def xcorr_argmax(a_list, b_list):
+    a, off, lens = ragged(a_list)
+    b, _, lens_b = ragged(b_list)
+    assert (lens == lens_b).all()
+    out = np.full(len(lens), -1, np.int64)
+    rc = lib().emu_xcorr_argmax(_p(a, C.c_float), _p(off, C.c_int64), _p(b, C.c_float), _p(off, C.c_int64),
+                                _p(lens, C.c_int32), len(lens), int(lens.max()), _p(out, C.c_int64))
+    assert rc == 0
+    return out

@@ -194,3 +194,24 @@ def test_pair_metrics_float64_estimate(golden, n_fft, hop):
     want = np.array([want["lsd"], want["log_sispec"], want["sispec"], want["ssim"]])
     got = E.pair_metrics([est], [tgt64], n_fft, hop, precision=1, units_per_chunk=5, rows_per_tile=9, est64=True, tgt64=True)[0]
     np.testing.assert_allclose(got, want, rtol=1e-6)
+
+
+def test_xcorr_argmax_matches_scipy_correlate(golden):
+    """N4: numpy.argmax(scipy.signal.correlate(a, b)) - the alignment step of mp3_encoding (ssr_eval/eval.py:319)."""
+    rng = np.random.default_rng(319)
+    x = np.tile(golden["ss_x"], 2)[:9000].astype(np.float32)
+    pairs = []
+    for n, delay in [(9000, 37), (5000, -123), (2049, 0), (2048, 1), (700, -5), (3, 1), (1, 0)]:
+        src = x[:n].copy()
+        dec = np.zeros_like(src)
+        if delay >= 0:
+            dec[delay:] = src[:n - delay]
+        else:
+            dec[:n + delay] = src[-delay:]
+        dec = (dec + 0.01 * rng.standard_normal(n)).astype(np.float32)      # "codec noise"
+        pairs.append((dec, src))
+    got = E.xcorr_argmax([p[0] for p in pairs], [p[1] for p in pairs])
+    want = [int(np.argmax(signal.correlate(d, s))) for d, s in pairs]
+    assert list(got) == want
+    # the shift the reference derives from it: argmax - len(x)  (zero delay -> -1, eval.py:319)
+    assert int(got[2]) - 2049 == -1

@@ -5,6 +5,8 @@ BASELINE.json's full sizes - through size-independent properties.  Nothing here 
 Tolerances (north_star): LSD / SISpec / log-SISpec / SSIM within 1e-5 relative; integer quantities and the
 polyphase resampler bit-exact; spectrogram samples within 2e-7 * max|X| (one float32 ulp at full scale).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -497,3 +499,74 @@ def test_iir_degradation_end_to_end_keeps_float64():
         est = ors.librosa_resample_polyphase(olp.lowpass(x44, 8000, 44100, 1, "subsampling"), 44100, 48000)
         assert est.dtype == np.float32
         np.testing.assert_allclose(_vec(r["proc_subsampling_16000_44100"]), _vec(om.evaluation(est, tgt, 48000)), rtol=1e-5)
+
+
+# ---- N4: mp3 alignment ---------------------------------------------------------------------------------------
+def test_xcorr_argmax_matches_scipy_correlate(golden):
+    from ssr_eval_amd import backend as B
+    rng = np.random.default_rng(319)
+    x = np.tile(golden["ss_x"], 30)[:192000].astype(np.float32)
+    pairs = []
+    for n, delay in [(192000, 1105), (9000, 37), (5000, -123), (2049, 0), (2048, 1), (700, -5), (3, 1), (1, 0)]:
+        src = x[:n].copy()
+        dec = np.zeros_like(src)
+        if delay >= 0:
+            dec[delay:] = src[:n - delay]
+        else:
+            dec[:n + delay] = src[-delay:]
+        pairs.append(((dec + 0.01 * rng.standard_normal(n)).astype(np.float32), src))
+    got = B.xcorr_argmax([p[0] for p in pairs], [p[1] for p in pairs])
+    want = [int(np.argmax(signal.correlate(d, s))) for d, s in pairs]
+    assert list(got) == want                      # integer: bit-exact
+    with pytest.raises(ValueError):
+        B.xcorr_argmax([x[:10]], [x[:11]])
+
+
+def test_mp3_degradation_with_stub_codec(tmp_path, monkeypatch):
+    """SSR_Eval_Helper.mp3_encoding (eval.py:302-325) with the sox calls replaced by a stand-in codec (delay + noise):
+    key naming, length unification, the cross-correlation shift (argmax - len(x), reference quirk: zero delay -> -1)
+    and the cached file."""
+    import shutil
+    from ssr_eval_amd import SSR_Eval_Helper, BasicTestee
+    from ssr_eval_amd.io import write_wav, read_audio
+    rng = np.random.default_rng(8)
+    n = 30000
+    t = np.arange(n) / 44100.0
+    x = (0.3 * np.sin(2 * np.pi * 330 * t) * np.sin(2 * np.pi * 5 * t) + 0.05 * rng.standard_normal(n)).astype(np.float32)
+    src = tmp_path / "p360_001_mic1.wav"
+    write_wav(str(src), x, 44100)
+    x, _ = read_audio(str(src))                                    # 16-bit quantised, as every later read sees it
+    delays = {"8": 1105, "32": 0}
+
+    def fake_sox(self, args):
+        if "-C" in args:                                           # encode: source -> "<key>.mp3"
+            y, sr = read_audio(args[0])
+            d = delays[args[2]]
+            y = np.concatenate((np.zeros(d, np.float32), y))[:len(y) + 17]        # codec delay + a few extra samples
+            write_wav(args[3] + ".wav", y + 0.002 * rng.standard_normal(len(y)).astype(np.float32), sr)
+            shutil.move(args[3] + ".wav", args[3])
+        else:                                                      # decode: "<key>.mp3" -> temp
+            shutil.copy(args[0], args[1])
+
+    monkeypatch.setattr(SSR_Eval_Helper, "_run_sox", fake_sox)
+    h = SSR_Eval_Helper(BasicTestee(), input_sr=44100, output_sr=44100, evaluation_sr=44100, test_data_root=None,
+                        setting_mp3_compression={"low_kbps": [8, 32]})
+    ret = h.mp3_encoding(str(src), x, 44100)
+    assert list(ret.keys()) == ["proc_mp3_8_44100", "proc_mp3_32_44100"]
+    for kbps, key in (("8", "proc_mp3_8_44100"), ("32", "proc_mp3_32_44100")):
+        y = ret[key]
+        assert y.shape == x.shape and y.dtype == np.float32
+        # the decoded stream is cut to len(x), then moved by argmax(correlate) - len(x): delay d -> shift d - 1
+        assert np.abs(y[1:n - 1200] - x[:n - 1201]).max() < 0.02
+        assert os.path.exists(str(tmp_path / ("p360_001_mic1_%s.wav" % key)))
+    assert not os.path.exists(str(tmp_path / "p360_001_mic1_temp.wav"))
+    # through the batched helper path: keys arrive in the reference's order (mp3 before fft)
+    h2 = SSR_Eval_Helper(BasicTestee(), input_sr=44100, output_sr=44100, evaluation_sr=44100, test_data_root=None,
+                         setting_mp3_compression={"low_kbps": [8]}, setting_fft={"cutoff_freq": [4000]})
+    res = h2.evaluate_files([str(src)])[0]
+    assert list(res.keys()) == ["proc_mp3_8_44100", "proc_fft_8000_44100"]
+    assert res["proc_mp3_8_44100"]["lsd"] > 0
+    h3 = SSR_Eval_Helper(BasicTestee(), input_sr=44100, output_sr=44100, evaluation_sr=44100, test_data_root=None,
+                         setting_mp3_compression={"low_kbps": [8]})
+    with pytest.raises(RuntimeError):
+        h3.evaluate_arrays([(x, x)])                               # no file to hand to the codec

@@ -190,6 +190,10 @@ size_t ssr_sosfiltfilt_workspace_bytes(int64_t total_len, int n_items, int edge)
 int ssr_sosfiltfilt(const float* x, const int64_t* off, const int32_t* len, int n_items, int64_t total_len,
                     const double* sos, const double* zi, int n_sections, int edge, double* y, void* workspace,
                     size_t workspace_bytes, void* stream);
+/* The same for a float64 signal (odd extension and filtering on the float64 values, as SciPy does). */
+int ssr_sosfiltfilt_f64(const double* x, const int64_t* off, const int32_t* len, int n_items, int64_t total_len,
+                    const double* sos, const double* zi, int n_sections, int edge, double* y, void* workspace,
+                    size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,7 @@ SIGNATURES = {
     "ssr_xcorr_argmax": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "ssr_sosfiltfilt_workspace_bytes": (_sz, [_i64, _i, _i]),
     "ssr_sosfiltfilt": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "ssr_sosfiltfilt_f64": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

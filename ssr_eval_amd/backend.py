@@ -403,7 +403,7 @@ def resample_poly(wavs, up, down, device=None):
 
 
 def sosfiltfilt(sos, wavs, device=None):
-    """scipy.signal.sosfiltfilt(sos, x) for a list of float32 waveforms on the GPU (N1); returns float64 tensors.
+    """scipy.signal.sosfiltfilt(sos, x) for a list of float32 (or float64) waveforms on the GPU (N1); float64 tensors out.
     The section coefficients and sosfilt_zi come from SciPy on the host (filter design, as in the reference)."""
     from scipy.signal import sosfilt_zi
     dev = torch.device(device) if device is not None else default_device()
@@ -414,7 +414,7 @@ def sosfiltfilt(sos, wavs, device=None):
     ntaps = 2 * n_sections + 1 - min(int((sos[:, 2] == 0).sum()), int((sos[:, 5] == 0).sum()))
     edge = 3 * ntaps
     with torch.cuda.device(dev):
-        r = wavs if isinstance(wavs, Ragged) else Ragged.from_list(wavs, dev)
+        r = wavs if isinstance(wavs, Ragged) else Ragged.from_list_keep64(wavs, dev)
         if r.n and int(r.lens_host.min()) <= edge:
             raise ValueError("The length of the input vector x must be greater than padlen, which is %d." % edge)
         lib = _lib.load()
@@ -424,8 +424,9 @@ def sosfiltfilt(sos, wavs, device=None):
         ws_bytes = int(lib.ssr_sosfiltfilt_workspace_bytes(total, r.n, edge))
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
         y = torch.empty(total, dtype=torch.float64, device=dev)
-        _lib.check(lib.ssr_sosfiltfilt(_vp(r.data), _vp(r.off), _vp(r.len), r.n, total, _vp(sos_d), _vp(zi_d), n_sections, edge,
-                                       _vp(y), _vp(ws), ws_bytes, _stream()))
+        fn = lib.ssr_sosfiltfilt_f64 if r.data.dtype == torch.float64 else lib.ssr_sosfiltfilt
+        _lib.check(fn(_vp(r.data), _vp(r.off), _vp(r.len), r.n, total, _vp(sos_d), _vp(zi_d), n_sections, edge, _vp(y), _vp(ws),
+                      ws_bytes, _stream()))
         return r.split(y)
 
 

@@ -117,10 +117,10 @@ __global__ __launch_bounds__(SSR_RESAMPLE_NT) void k_resample(SsrResampleParamsT
   ssr_resample_body<S>(p, blk, blockIdx.x % blocks_per_item, blockIdx.x / blocks_per_item, smem);
 }
 
-template <int G>
-__global__ __launch_bounds__(64) void k_sosfiltfilt(SsrIirParams p) {
+template <int G, typename X>
+__global__ __launch_bounds__(64) void k_sosfiltfilt(SsrIirParamsT<X> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  ssr_iir_wave<G>(p, blockIdx.x, threadIdx.x, smem);
+  ssr_iir_wave<G, X>(p, blockIdx.x, threadIdx.x, smem);
 }
 
 __global__ __launch_bounds__(256) void k_magphase(const float* re, const float* im, int64_t n, float eps, float* mag,
@@ -826,16 +826,17 @@ extern "C" size_t ssr_sosfiltfilt_workspace_bytes(int64_t total_len, int n_items
   return align256(((size_t)total_len + (size_t)2 * edge * n_items) * sizeof(double));
 }
 
-extern "C" int ssr_sosfiltfilt(const float* x, const int64_t* off, const int32_t* len, int n_items, int64_t total_len,
-                               const double* sos, const double* zi, int n_sections, int edge, double* y,
-                               void* workspace, size_t workspace_bytes, void* stream) {
+template <typename X>
+static int sosfiltfilt_t(const X* x, const int64_t* off, const int32_t* len, int n_items, int64_t total_len,
+                         const double* sos, const double* zi, int n_sections, int edge, double* y, void* workspace,
+                         size_t workspace_bytes, void* stream) {
   if (!x || !off || !len || !sos || !zi || !y) return fail(SSR_ERR_INVALID_ARG, "null argument");
   if (n_sections < 1 || n_sections > 16) return fail(SSR_ERR_UNSUPPORTED, "n_sections must be in [1, 16]");
   if (edge < 0) return fail(SSR_ERR_INVALID_ARG, "negative edge");
   if (n_items <= 0) return SSR_OK;
   if (!workspace || workspace_bytes < ssr_sosfiltfilt_workspace_bytes(total_len, n_items, edge))
     return fail(SSR_ERR_WORKSPACE, "workspace too small");
-  SsrIirParams p{x, off, len, sos, zi, n_sections, edge, n_items, (double*)workspace, y};
+  SsrIirParamsT<X> p{x, off, len, sos, zi, n_sections, edge, n_items, (double*)workspace, y};
   hipStream_t s = (hipStream_t)stream;
   if (n_sections <= 8) {
     const int per_wave = 8 * SSR_IIR_U;                           // utterances per one-wave workgroup
@@ -844,15 +845,27 @@ extern "C" int ssr_sosfiltfilt(const float* x, const int64_t* off, const int32_t
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (lds > 48 * 1024 && attr8 != dev) {
-      HIP_TRY(hipFuncSetAttribute((const void*)k_sosfiltfilt<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_sosfiltfilt<8, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr8 = dev;
     }
-    hipLaunchKernelGGL((k_sosfiltfilt<8>), dim3(ceil_div(n_items, per_wave)), dim3(64), lds, s, p);
+    hipLaunchKernelGGL((k_sosfiltfilt<8, X>), dim3(ceil_div(n_items, per_wave)), dim3(64), lds, s, p);
   } else {
     const int per_wave = 4 * SSR_IIR_U;
     const size_t lds = (size_t)per_wave * 4 * SSR_IIR_CH * sizeof(double);
-    hipLaunchKernelGGL((k_sosfiltfilt<16>), dim3(ceil_div(n_items, per_wave)), dim3(64), lds, s, p);
+    hipLaunchKernelGGL((k_sosfiltfilt<16, X>), dim3(ceil_div(n_items, per_wave)), dim3(64), lds, s, p);
   }
   HIP_TRY(hipGetLastError());
   return SSR_OK;
+}
+
+extern "C" int ssr_sosfiltfilt(const float* x, const int64_t* off, const int32_t* len, int n_items, int64_t total_len,
+                               const double* sos, const double* zi, int n_sections, int edge, double* y,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  return sosfiltfilt_t<float>(x, off, len, n_items, total_len, sos, zi, n_sections, edge, y, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ssr_sosfiltfilt_f64(const double* x, const int64_t* off, const int32_t* len, int n_items, int64_t total_len,
+                                   const double* sos, const double* zi, int n_sections, int edge, double* y,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  return sosfiltfilt_t<double>(x, off, len, n_items, total_len, sos, zi, n_sections, edge, y, workspace, workspace_bytes, stream);
 }

@@ -20,8 +20,9 @@
 
 #define SSR_IIR_CH 128   // samples per staging chunk (> max group size)
 
-struct SsrIirParams {
-  const float* x;          // signals
+// X: input sample type (float, or double for a float64 signal - SciPy then extends and filters the float64 values)
+template <typename X> struct SsrIirParamsT {
+  const X* x;              // signals
   const int64_t* off;      // [n_items] element offset (also used for y)
   const int32_t* len;      // [n_items]
   const double* sos;       // [n_sections, 6]  b0 b1 b2 a0(=1) a1 a2
@@ -30,15 +31,16 @@ struct SsrIirParams {
   double* fwd;             // workspace: forward pass output, item i at off[i] + 2*edge*i, length len[i] + 2*edge
   double* y;               // [same layout as x] float64 result
 };
+typedef SsrIirParamsT<float> SsrIirParams;
 
-// odd-extended input sample n of [0, len + 2*edge), float32 arithmetic as numpy does it
-SSR_DEV double ssr_iir_ext(const float* x, int len, int edge, int n) {
+// odd-extended input sample n of [0, len + 2*edge), in the signal's own arithmetic as numpy does it
+template <typename X> SSR_DEV double ssr_iir_ext(const X* x, int len, int edge, int n) {
 #ifndef SSR_HOST_EMU
 #pragma clang fp contract(off)
 #endif
-  if (n < edge) return (double)(2.0f * x[0] - x[edge - n]);
+  if (n < edge) return (double)((X)2 * x[0] - x[edge - n]);
   if (n < edge + len) return (double)x[n - edge];
-  return (double)(2.0f * x[len - 1] - x[len - 2 - (n - edge - len)]);
+  return (double)((X)2 * x[len - 1] - x[len - 2 - (n - edge - len)]);
 }
 
 // one section, one sample: SciPy's _sosfilt inner statement sequence
@@ -54,9 +56,9 @@ SSR_DEV double ssr_iir_step(double xin, double b0, double b1, double b2, double 
 
 #ifdef SSR_HOST_EMU
 // sequential statement of the same computation (what every lane schedule must reproduce)
-static inline void ssr_iir_item_host(const SsrIirParams& p, int item) {
+template <typename X> static inline void ssr_iir_item_host(const SsrIirParamsT<X>& p, int item) {
   const int len = p.len[item], edge = p.edge, S = p.n_sections, ne = len + 2 * edge;
-  const float* x = p.x + p.off[item];
+  const X* x = p.x + p.off[item];
   double* fwd = p.fwd + p.off[item] + (int64_t)2 * edge * item;
   double* y = p.y + p.off[item];
   std::vector<double> z0(S), z1(S);
@@ -90,9 +92,9 @@ SSR_DEV double ssr_dpp_from_lower_lane(double v) {
 // interleaved in one instruction stream); measured on MI355X the step time grows almost linearly with U, so
 // U = 1 is the default.
 #define SSR_IIR_U 1   /* utterances per lane slot: 2 measured 1.67x the latency for 2x the work - only pays beyond ~8k utterances */
-template <int G> struct SsrIirSlot {
+template <int G, typename X> struct SsrIirSlot {
   bool active;
-  const float* x;
+  const X* x;
   int len, ne;
   double* fwd;
   double* y;
@@ -102,15 +104,15 @@ template <int G> struct SsrIirSlot {
   double pre[SSR_IIR_CH / G];
 };
 
-template <int G, bool BACKWARD>
-SSR_DEV double ssr_iir_load_in(const SsrIirSlot<G>& q, int edge, int n) {
+template <int G, bool BACKWARD, typename X>
+SSR_DEV double ssr_iir_load_in(const SsrIirSlot<G, X>& q, int edge, int n) {
   if (n >= q.ne) return 0.0;
   return BACKWARD ? q.fwd[q.ne - 1 - n] : ssr_iir_ext(q.x, q.len, edge, n);
 }
 
 // One pass (forward or backward) of the wavefront for the lane's group.  G: lanes per utterance (8 or 16).
-template <int G, bool BACKWARD>
-SSR_DEV void ssr_iir_pass(const SsrIirParams& p, int s, SsrIirSlot<G> (&sl)[SSR_IIR_U], double b0, double b1, double b2,
+template <int G, bool BACKWARD, typename X>
+SSR_DEV void ssr_iir_pass(const SsrIirParamsT<X>& p, int s, SsrIirSlot<G, X> (&sl)[SSR_IIR_U], double b0, double b1, double b2,
                           double a1, double a2, double zi0, double zi1) {
   constexpr int CH = SSR_IIR_CH, PER = CH / G, U = SSR_IIR_U;
   const int edge = p.edge, S = p.n_sections;
@@ -205,11 +207,11 @@ SSR_DEV void ssr_iir_pass(const SsrIirParams& p, int s, SsrIirSlot<G> (&sl)[SSR_
 }
 
 // grid = ceil(n_items / (U * 64/G)) workgroups of ONE wave; LDS: (64/G) groups * U slots * 4*CH doubles
-template <int G>
-SSR_DEV void ssr_iir_wave(const SsrIirParams& p, int wg, int lane, char* lds_base) {
+template <int G, typename X>
+SSR_DEV void ssr_iir_wave(const SsrIirParamsT<X>& p, int wg, int lane, char* lds_base) {
   constexpr int CH = SSR_IIR_CH, GROUPS = 64 / G, U = SSR_IIR_U;
   const int g = lane / G, s = lane % G, S = p.n_sections;
-  SsrIirSlot<G> sl[U];
+  SsrIirSlot<G, X> sl[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int item = (wg * GROUPS + g) * U + u;

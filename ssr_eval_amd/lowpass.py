@@ -9,8 +9,7 @@
 * butter / cheby1 / ellip / bessel -> ``ssr_sosfiltfilt``: the section coefficients are
   designed on the host with SciPy exactly as the reference does (filter design is a plan, not data), the
   zero-phase filtering itself (odd extension, forward and backward second-order-section recurrences) runs on the
-  GPU, bit-identical to ``scipy.signal.sosfiltfilt`` for float32 input.  Float64 input is rounded to float32
-  first (the reference only ever feeds it what librosa.load returned, i.e. float32).
+  GPU, bit-identical to ``scipy.signal.sosfiltfilt`` for float32 and for float64 input.
 """
 import numpy as np
 import torch
@@ -88,8 +87,16 @@ def _design(highcut, fs, order, ftype, lowcut=None):
 
 def _iir_batch(xs, highcut, fs, order, ftype, lowcut=None):
     """lowpass.py:54-131 for a list of signals: one ssr_sosfiltfilt launch (GPU, float64, bit-exact with SciPy)."""
-    ys = B.sosfiltfilt(_design(highcut, fs, order, ftype, lowcut), [np.asarray(x, np.float32) for x in xs])
-    return [align_length(x, y.cpu().numpy()) for x, y in zip(xs, ys)]
+    sos = _design(highcut, fs, order, ftype, lowcut)
+    xs = [np.asarray(x) for x in xs]
+    outs = [None] * len(xs)
+    for want64 in (False, True):                     # float64 signals are filtered on their float64 values
+        idx = [i for i, x in enumerate(xs) if (x.dtype == np.float64) == want64]
+        if idx:
+            ys = B.sosfiltfilt(sos, [xs[i] if want64 else xs[i].astype(np.float32) for i in idx])
+            for i, y in zip(idx, ys):
+                outs[i] = align_length(xs[i], y.cpu().numpy())
+    return outs
 
 
 def _iir(x, highcut, fs, order, ftype, lowcut=None):

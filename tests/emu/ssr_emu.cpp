@@ -252,6 +252,12 @@ extern "C" int emu_sosfiltfilt(const float* x, const int64_t* off, const int32_t
   for (int i = 0; i < n_items; ++i) ssr_iir_item_host(p, i);
   return 0;
 }
+extern "C" int emu_sosfiltfilt_f64(const double* x, const int64_t* off, const int32_t* len, int n_items, const double* sos,
+                                   const double* zi, int n_sections, int edge, double* fwd, double* y) {
+  SsrIirParamsT<double> p{x, off, len, sos, zi, n_sections, edge, n_items, fwd, y};
+  for (int i = 0; i < n_items; ++i) ssr_iir_item_host(p, i);
+  return 0;
+}
 
 // ---- cross-correlation argmax (N4) ------------------------------------------------------------------------
 extern "C" int emu_xcorr_argmax(const float* a, const int64_t* a_off, const float* b, const int64_t* b_off,

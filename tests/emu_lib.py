@@ -187,17 +187,20 @@ def resample(sigs, up, down, taps_full, n_pre_remove, groups=0, taps_in_lds=1, d
     return [out[out_off[i]:out_off[i] + out_len[i]] for i in range(len(lens))]
 
 
-def sosfiltfilt(sos, sigs):
+def sosfiltfilt(sos, sigs, dtype=np.float32):
     from scipy.signal import sosfilt_zi
     a, off, lens = ragged(sigs)
+    if dtype == np.float64:
+        a = np.concatenate(sigs).astype(np.float64)
     sos = np.ascontiguousarray(sos, np.float64)
     zi = np.ascontiguousarray(sosfilt_zi(sos), np.float64)
     S = sos.shape[0]
     edge = 3 * (2 * S + 1 - min(int((sos[:, 2] == 0).sum()), int((sos[:, 5] == 0).sum())))
     fwd = np.full(int(lens.sum()) + 2 * edge * len(lens), np.nan)
     y = np.full(int(lens.sum()), np.nan)
-    rc = lib().emu_sosfiltfilt(_p(a, C.c_float), _p(off, C.c_int64), _p(lens, C.c_int32), len(lens), _p(sos, C.c_double),
-                               _p(zi, C.c_double), S, edge, _p(fwd, C.c_double), _p(y, C.c_double))
+    fn, ct = (lib().emu_sosfiltfilt, C.c_float) if dtype == np.float32 else (lib().emu_sosfiltfilt_f64, C.c_double)
+    rc = fn(_p(a, ct), _p(off, C.c_int64), _p(lens, C.c_int32), len(lens), _p(sos, C.c_double), _p(zi, C.c_double), S, edge,
+            _p(fwd, C.c_double), _p(y, C.c_double))
     assert rc == 0
     return [y[off[i]:off[i] + lens[i]] for i in range(len(lens))]
 

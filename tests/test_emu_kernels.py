@@ -158,6 +158,9 @@ def test_sosfiltfilt_statement_bit_exact_vs_scipy(golden, ftype, order, band):
     got = E.sosfiltfilt(sos, sigs)
     for s_, g in zip(sigs, got):
         np.testing.assert_array_equal(g, signal.sosfiltfilt(sos, s_))
+    sigs64 = [s_.astype(np.float64) * 1.0000000321 for s_ in sigs]          # float64 signal: float64 extension
+    for s_, g in zip(sigs64, E.sosfiltfilt(sos, sigs64, dtype=np.float64)):
+        np.testing.assert_array_equal(g, signal.sosfiltfilt(sos, s_))
 
 
 @pytest.mark.parametrize("n_fft,hop,n", [(256, 64, 3000), (512, 100, 5000), (4096, 1024, 20000), (1486, 320, 6000), (3 * 257, 100, 4000)])

@@ -349,6 +349,13 @@ def test_sosfiltfilt_bit_exact(golden, ftype, order, band):
     for s_, g in zip(sigs, got):
         assert g.dtype == torch.float64
         np.testing.assert_array_equal(g.cpu().numpy(), signal.sosfiltfilt(sos, s_))
+    # float64 signals: extension and filtering on the float64 values (ssr_sosfiltfilt_f64), through lowpass() too
+    sigs64 = [s_.astype(np.float64) * 1.0000000321 for s_ in sigs[:5]]
+    for s_, g in zip(sigs64, B.sosfiltfilt(sos, sigs64)):
+        np.testing.assert_array_equal(g.cpu().numpy(), signal.sosfiltfilt(sos, s_))
+    if not band:
+        from ssr_eval_amd.lowpass import lowpass
+        np.testing.assert_array_equal(lowpass(sigs64[0], 4000, 44100, order=order, _type=ftype), olp.lowpass(sigs64[0], 4000, 44100, order, ftype))
 
 
 def test_iir_lowpass_matches_reference_vectors(golden):

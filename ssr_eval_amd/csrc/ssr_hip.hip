@@ -355,6 +355,8 @@ static SsimGeom ssim_geom(int max_rows, int n_bins, int n_items) {
   g.rows_per_tile = (int)r;
   g.n_row_tiles = ceil_div(out_rows, g.rows_per_tile);
   g.cpt = ssr_ssim_pick_cpt(n_bins);
+  static const int cpt_env = getenv("SSR_SSIM_CPT") ? atoi(getenv("SSR_SSIM_CPT")) : 0;   // developer knob
+  if (cpt_env >= 1 && cpt_env <= SSR_SSIM_MAXCPT) g.cpt = cpt_env;
   g.n_strips = n_bins > 6 ? ceil_div(n_bins - 6, ssr_ssim_strip_out(g.cpt)) : 1;
   return g;
 }

@@ -70,7 +70,9 @@ int64_t ssr_num_frames(const ssr_plan* plan, int64_t n_samples);
 /* K1+K2.  Batched STFT of ragged float32 waveforms -> [total_rows, n_bins] float32.
  * Replaces AudioMetrics.wav_to_spectrogram (ssr_eval/metrics.py:26-30 -> librosa.stft + abs + transpose)
  * and FDomainHelper.complex_spectrogram / spectrogram / spectrogram_phase (ssr_eval/dsp.py:61-81 ->
- * torchlibrosa STFT).  Every item needs len > n_fft/2 (reflect padding). */
+ * torchlibrosa STFT).  Reflect padding follows numpy.pad (what librosa calls): items shorter than n_fft/2 are reflected
+ * repeatedly; every item needs len >= 1.  (torch's reflect padding, used by torchlibrosa, refuses such items - the Python
+ * FDomainHelper mirror raises for them before calling in.) */
 int ssr_stft(const ssr_plan* plan, const float* wav, const int64_t* wav_off, const int32_t* wav_len,
              const int64_t* frame_off, int n_items, int max_len, int out_kind, float* out_a, float* out_b,
              void* stream);

@@ -25,15 +25,19 @@ def num_frames(n, n_fft, hop):
     return 1 + (n + 2 * (n_fft // 2) - n_fft) // hop
 
 
-def reflect_pad(y, pad):
-    if y.shape[-1] <= pad:
+def reflect_pad(y, pad, torch_style=False):
+    """numpy.pad(mode="reflect") as librosa calls it (the reflection repeats when the signal is shorter than the pad);
+    torch_style: F.pad(mode="reflect") of torchlibrosa, which refuses pad >= length."""
+    if y.shape[-1] < 1:
+        raise ValueError("empty signal")
+    if torch_style and y.shape[-1] <= pad:
         raise ValueError("reflect padding needs len(y) > n_fft//2 (got %d <= %d)" % (y.shape[-1], pad))
     return np.pad(y, pad, mode="reflect")
 
 
-def frame_matrix(y, n_fft, hop, dtype=np.float64):
+def frame_matrix(y, n_fft, hop, dtype=np.float64, torch_style=False):
     """[T, n_fft] matrix of centred, reflect-padded frames."""
-    yp = reflect_pad(np.asarray(y), n_fft // 2)
+    yp = reflect_pad(np.asarray(y), n_fft // 2, torch_style)
     T = 1 + (yp.shape[0] - n_fft) // hop
     idx = np.arange(n_fft)[None, :] + hop * np.arange(T)[:, None]
     return yp[idx].astype(dtype)
@@ -99,7 +103,7 @@ def tl_stft(x, n_fft=2048, hop=441):
     win = hann_periodic(n_fft)
     re, im = [], []
     for b in range(x.shape[0]):
-        spec = np.fft.rfft(frame_matrix(x[b], n_fft, hop) * win[None, :], axis=1)
+        spec = np.fft.rfft(frame_matrix(x[b], n_fft, hop, torch_style=True) * win[None, :], axis=1)
         re.append(spec.real.astype(np.float32))
         im.append(spec.imag.astype(np.float32))
     return np.stack(re)[:, None], np.stack(im)[:, None]

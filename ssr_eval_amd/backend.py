@@ -150,8 +150,15 @@ class _Rows:
 
 
 def _check_reflect(plan, lens_host):
+    """torch-style reflect padding (torchlibrosa STFT / ISTFT: F.pad refuses a pad >= the signal length)."""
     if len(lens_host) and int(np.min(lens_host)) <= plan.n_fft // 2:
         raise ValueError("reflect padding needs every signal longer than n_fft//2 = %d samples" % (plan.n_fft // 2))
+
+
+def _check_nonempty(lens_host):
+    """librosa-style reflect padding (numpy.pad) repeats the reflection for short signals; only empty ones fail."""
+    if len(lens_host) and int(np.min(lens_host)) < 1:
+        raise ValueError("empty signal")
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -161,12 +168,12 @@ class PairBatch:
     def __init__(self, plan, est, tgt):
         if est.n != tgt.n or not np.array_equal(est.lens_host, tgt.lens_host):
             raise ValueError("est and target must have identical lengths (truncate to min_len first)")
+        _check_nonempty(est.lens_host)
         if tgt.data.dtype == torch.float64 and est.data.dtype != torch.float64:
             # float32 estimate against a float64 target: widening the estimate is exact, and the reference promotes
             # every mixed operation to float64 anyway
             est = Ragged(est.data.to(torch.float64), est.off, est.len, est.lens_host)
             self.est = est
-        _check_reflect(plan, est.lens_host)
         self.plan, self.est, self.tgt = plan, est, tgt
         self.rows = _Rows(plan, est.lens_host, est.device)
         lib = plan.lib
@@ -202,11 +209,15 @@ def pair_metrics(plan, est_list, tgt_list, mask=M_ALL):
         return b.run(mask).cpu().numpy()
 
 
-def stft(plan, wavs, kind="mag"):
-    """STFT of a list of waveforms.  kind "mag": list of [T, F] tensors; "complex": (re list, im list)."""
+def stft(plan, wavs, kind="mag", torch_style_pad=False):
+    """STFT of a list of waveforms.  kind "mag": list of [T, F] tensors; "complex": (re list, im list).
+    torch_style_pad: refuse signals not longer than n_fft//2 the way torch's reflect padding does (torchlibrosa);
+    otherwise short signals are reflect-padded repeatedly, as numpy.pad / librosa do."""
     with torch.cuda.device(plan.device):
         r = wavs if isinstance(wavs, Ragged) else Ragged.from_list(wavs, plan.device)
-        _check_reflect(plan, r.lens_host)
+        if torch_style_pad:
+            _check_reflect(plan, r.lens_host)
+        _check_nonempty(r.lens_host)
         rows = _Rows(plan, r.lens_host, r.device)
         a = torch.empty((rows.total, plan.n_bins), dtype=torch.float32, device=r.device)
         b = torch.empty_like(a) if kind == "complex" else None

@@ -139,10 +139,17 @@ template <typename T> SSR_DEV cx<T> cmul_negi(cx<T> a) { return {a.y, -a.x}; }  
 SSR_DEV int ssr_pad(int i) { return i + (i >> SSR_PAD_SHIFT); }
 SSR_HD constexpr int ssr_padded_len(int n) { return n + (n >> SSR_PAD_SHIFT) + 1; }
 
-// centred-STFT reflect padding of sample index s into [0, n)  (requires n > n_fft/2)
+// centred-STFT reflect padding of sample index s into [0, n): numpy.pad(mode="reflect"), i.e. reflection about both
+// ends repeated with period 2 (n - 1) when the pad is longer than the signal (n = 1: constant).  The modulo is only
+// reached by samples beyond the end.
 SSR_DEV int ssr_reflect(int s, int n) {
   if (s < 0) s = -s;
-  if (s >= n) s = 2 * (n - 1) - s;
+  if (s >= n) {
+    if (n == 1) return 0;
+    const int period = 2 * (n - 1);
+    s %= period;
+    if (s >= n) s = period - s;
+  }
   return s;
 }
 

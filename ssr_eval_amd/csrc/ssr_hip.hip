@@ -406,7 +406,7 @@ extern "C" int ssr_stft(const ssr_plan* pl, const float* wav, const int64_t* wav
   if (out_kind != SSR_STFT_MAG && out_kind != SSR_STFT_COMPLEX) return fail(SSR_ERR_INVALID_ARG, "bad out_kind");
   if (out_kind == SSR_STFT_COMPLEX && !out_b) return fail(SSR_ERR_INVALID_ARG, "complex output needs out_b");
   if (n_items <= 0) return SSR_OK;
-  if (max_len <= pl->n_fft / 2) return fail(SSR_ERR_INVALID_ARG, "reflect padding needs len > n_fft/2");
+  if (max_len < 1) return fail(SSR_ERR_INVALID_ARG, "empty signals");
   hipStream_t s = (hipStream_t)stream;
   return pl->precision == SSR_F64
              ? stft_single_t<double>(pl, wav, wav_off, wav_len, frame_off, n_items, max_len, out_kind, out_a, out_b, s)
@@ -572,7 +572,7 @@ static int pair_metrics_impl(const ssr_plan* pl, const float* est, const double*
   if (!pl || (!est && !est64) || (!tgt && !tgt64) || !est_off || !tgt_off || !len || !frame_off || !out)
     return fail(SSR_ERR_INVALID_ARG, "null argument");
   if (n_items <= 0) return SSR_OK;
-  if (max_len <= pl->n_fft / 2) return fail(SSR_ERR_INVALID_ARG, "reflect padding needs len > n_fft/2");
+  if (max_len < 1) return fail(SSR_ERR_INVALID_ARG, "empty signals");
   if ((mask & ~SSR_METRIC_ALL) || mask == 0) return fail(SSR_ERR_INVALID_ARG, "bad metric mask");
   const int max_T = (int)ssr_num_frames(pl, max_len);
   const bool want_ssim = mask & SSR_METRIC_SSIM;

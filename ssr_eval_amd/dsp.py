@@ -31,7 +31,7 @@ class FDomainHelper(torch.nn.Module):
         """x [B, n] -> (real, imag) each [B, 1, T, F] on x's device."""
         if x.dim() != 2:
             raise ValueError("expected [batch, samples], got %s" % (tuple(x.shape),))
-        re, im = B.stft(self._plan(), [x[b].float() for b in range(x.shape[0])], kind="complex")
+        re, im = B.stft(self._plan(), [x[b].float() for b in range(x.shape[0])], kind="complex", torch_style_pad=True)
         return torch.stack(re)[:, None].to(x.device), torch.stack(im)[:, None].to(x.device)
 
     def _istft(self, real, imag, length):

@@ -18,7 +18,7 @@ EV = ["noise48k", "noise44k", "noise16k", "speech48k_fftlp6k", "speech44k_fftlp4
 @pytest.mark.parametrize("n_fft,hop", [(2048, 512), (256, 64), (4096, 1024), (2229, 480), (743, 160), (1114, 240), (100, 25)])
 def test_stft_magnitude_pair_and_single(n_fft, hop):
     rng = np.random.default_rng(n_fft)
-    lens = (n_fft * 2 + 77, n_fft // 2 + 1, n_fft + hop * 3)
+    lens = (n_fft * 2 + 77, n_fft // 2 + 1, n_fft + hop * 3, 5, n_fft // 3)      # incl. shorter than the reflect pad
     x = [rng.standard_normal(n).astype(np.float32) for n in lens]
     y = [rng.standard_normal(n).astype(np.float32) for n in lens]
     ea, tb, _ = E.stft(x, y, n_fft, hop, precision=1, units_per_chunk=3)

@@ -146,7 +146,36 @@ def test_error_behaviour_matches_reference():
     with pytest.raises(ValueError):
         AudioMetrics(48000).evaluation(x[:1200], x[:1200], "")       # T = 3 < 7: skimage raises ValueError
     with pytest.raises(ValueError):
-        am.wav_to_spectrogram(x[:1000])                      # reflect padding needs n > n_fft // 2
+        am.wav_to_spectrogram(x[:0])                         # empty signal
+    from ssr_eval_amd import FDomainHelper
+    with pytest.raises(ValueError):                          # torch's reflect padding refuses pad >= length (torchlibrosa)
+        FDomainHelper().wav_to_spectrogram(torch.zeros(1, 1, 1000))
+
+
+def test_short_signals_reflect_repeatedly_like_numpy_pad():
+    """librosa pads with numpy.pad(mode="reflect"), which keeps reflecting when the signal is shorter than n_fft // 2;
+    AudioMetrics.wav_to_spectrogram and the LSD / SISpec reductions therefore work on very short signals."""
+    from ssr_eval_amd import backend as B
+    from oracle import stft as ostft, metrics as om
+    rng = np.random.default_rng(12)
+    for n_fft, hop in [(2048, 512), (2229, 480), (743, 160)]:
+        plan = B.get_plan(n_fft, hop, "f64")
+        lens = [1, 2, 3, 17, n_fft // 2, n_fft // 2 + 1, n_fft // 3, hop * 3 + 5]
+        sigs = [rng.standard_normal(n).astype(np.float32) for n in lens]
+        mags = B.stft(plan, sigs)
+        for x, m in zip(sigs, mags):
+            ref = ostft.stft_mag_TF(x, n_fft, hop)
+            assert tuple(m.shape) == ref.shape
+            assert np.abs(m.cpu().numpy() - ref).max() <= 2e-7 * max(ref.max(), 1e-30)
+        # metrics on the non-degenerate ones: a signal much shorter than the frame is reflected into a PERIODIC frame
+        # whose spectrum is exact zeros (up to FFT round-off) between its harmonics - LSD is then defined by round-off
+        sigs = [x for x in sigs if len(x) >= n_fft // 3]
+        est = [(x * 0.8 + 0.05 * rng.standard_normal(len(x))).astype(np.float32) for x in sigs]
+        got = B.pair_metrics(plan, est, sigs, B.M_LSD | B.M_SISPEC | B.M_LOG_SISPEC)
+        for e, t, g in zip(est, sigs, got):
+            es, ts = om.wav_to_spectrogram(e, n_fft, hop), om.wav_to_spectrogram(t, n_fft, hop)
+            want = [float(om.lsd(es, ts)), float(om.sispec(om.to_log(es), om.to_log(ts))), float(om.sispec(es, ts))]
+            np.testing.assert_allclose(g[:3], want, rtol=1e-5)
 
 
 def test_fft_lowpass_matches_reference_vectors(golden):

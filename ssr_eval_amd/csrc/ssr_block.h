@@ -40,6 +40,15 @@ static inline void ssr_launder(SsrBlk&) {}
     (dst)[(tid) >> 6] += (val);                             \
   } while (0)
 #define SSR_WAVE_SUM_ADD(tid, NT_, val, dst) do { (dst)[(tid) >> 6] += (val); } while (0)
+// inside a phase: SSR_WAVE_ANY(pred) = "pred holds on some lane of this wave" (device: a scalar; host: the lane's own
+// pred, folded over the wave by the store); SSR_WAVE_FLAG_STORE: dst[tid / 64] = that flag
+#define SSR_WAVE_ANY(pred) ((pred) ? 1 : 0)
+#define SSR_WAVE_FLAG_STORE(tid, flag, dst)                 \
+  do {                                                      \
+    if (((tid) & 63) == 0) (dst)[(tid) >> 6] = 0;           \
+    if (flag) (dst)[(tid) >> 6] = 1;                        \
+  } while (0)
+#define SSR_WAVE_ANY_STORE(tid, pred, dst) SSR_WAVE_FLAG_STORE(tid, SSR_WAVE_ANY(pred), dst)
 static inline float ssr_fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 static inline float ssr_fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 static inline double ssr_fmul_rn(double a, double b) { volatile double r = a * b; return r; }
@@ -89,16 +98,25 @@ template <int W> SSR_DEV double ssr_wave_sum(double v) {
   for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, W);
   return v;
 }
+// wave number as a SCALAR (recomputed where it is used: a per-lane copy would be loop-invariant, get hoisted out of the
+// frame loop and occupy - or spill - a vector register for the whole kernel)
+SSR_DEV int ssr_wave_index(int tid) { return __builtin_amdgcn_readfirstlane(tid) >> 6; }
 #define SSR_WAVE_SUM_STORE(tid, NT_, val, dst)                                     \
   do {                                                                             \
     const double s_ = ssr_wave_sum<((NT_) < 64 ? (NT_) : 64)>(val);                \
-    if (((tid) & 63) == 0) (dst)[(tid) >> 6] = s_;                                 \
+    if (((tid) & 63) == 0) (dst)[ssr_wave_index(tid)] = s_;                        \
   } while (0)
 #define SSR_WAVE_SUM_ADD(tid, NT_, val, dst)                                       \
   do {                                                                             \
     const double s_ = ssr_wave_sum<((NT_) < 64 ? (NT_) : 64)>(val);                \
-    if (((tid) & 63) == 0) (dst)[(tid) >> 6] += s_;                                \
+    if (((tid) & 63) == 0) (dst)[ssr_wave_index(tid)] += s_;                       \
   } while (0)
+#define SSR_WAVE_ANY(pred) (__builtin_amdgcn_ballot_w64(pred) != 0ull ? 1 : 0)
+#define SSR_WAVE_FLAG_STORE(tid, flag, dst)                                        \
+  do {                                                                             \
+    if (((tid) & 63) == 0) (dst)[ssr_wave_index(tid)] = (flag);                    \
+  } while (0)
+#define SSR_WAVE_ANY_STORE(tid, pred, dst) SSR_WAVE_FLAG_STORE(tid, SSR_WAVE_ANY(pred), dst)
 // Separately rounded multiply and add.  HIP's __fmul_rn/__fadd_rn are plain `*` / `+` and hipcc's default
 // -ffp-contract=fast would fuse them into one v_fma_f32; the pragma strips the `contract` flag from
 // these two instructions so they can never be fused (needed for bit-identity with SciPy's upfirdn).
@@ -119,6 +137,18 @@ SSR_DEV double ssr_fadd_rn(double a, double b) {
   return a + b;
 }
 #endif
+
+// magnitude bits of a sample (sign dropped): non-zero iff the sample is not +-0 (NaN and Inf count as non-zero)
+SSR_DEV unsigned ssr_mag_bits(float v) {
+  unsigned u;
+  memcpy(&u, &v, 4);
+  return u << 1;
+}
+SSR_DEV unsigned ssr_mag_bits(double v) {
+  unsigned long long u;
+  memcpy(&u, &v, 8);
+  return (unsigned)(u & 0xffffffffu) | (unsigned)((u >> 32) & 0x7fffffffu);
+}
 
 // ------------------------------------------------------------------------------------------------
 // complex helpers

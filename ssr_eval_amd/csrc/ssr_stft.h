@@ -178,13 +178,19 @@ SSR_DEV void ssr_accumulate_metrics(double e, double t, int mask, double* acc) {
 // row base pointers (scalar base + 32-bit lane offset addressing).
 template <typename T, int MODE, int IN64 = 0>
 SSR_DEV void ssr_emit_bin(const SsrStftParams<T>& p, double* acc, unsigned k, cx<T> zk, cx<T> zn,
-                          float* row_a0, float* row_a1, float* row_b0, float* row_b1, bool b_valid) {
+                          float* row_a0, float* row_a1, float* row_b0, float* row_b1, bool b_valid, bool a_nz, bool b_nz) {
+  // An all-zero frame has an exactly zero spectrum in the reference (separate real FFTs).  In the packed transform
+  // the other signal leaks into it at round-off level (1e-16 of ITS magnitude), which is not negligible against
+  // the 1e-12 guards of the metrics - so the outputs of an all-zero frame are forced to exact zeros (a_nz / b_nz
+  // are block-uniform).
   // PAIR  : row_a0 = est magnitudes row,  row_b0 = target magnitudes row
   // SINGLE: row_a0 / row_a1 = rows of frames 2g / 2g+1 in out_a; row_b0 / row_b1 the same rows in out_b
-  const SsrBinOut<T> o = ssr_separate<T>(zk, zn);
+  SsrBinOut<T> o = ssr_separate<T>(zk, zn);
+  if (!a_nz) { o.ar = 0.0f; o.ai = 0.0f; }
+  if (!b_nz) { o.br = 0.0f; o.bi = 0.0f; }
   if constexpr (MODE == SSR_MODE_PAIR && IN64 == SSR_IN_BOTH64) {
-    const double e = hypot((double)zk.x + (double)zn.x, (double)zk.y - (double)zn.y);
-    const double t = hypot((double)zk.y + (double)zn.y, (double)zn.x - (double)zk.x);
+    const double e = a_nz ? hypot((double)zk.x + (double)zn.x, (double)zk.y - (double)zn.y) : 0.0;
+    const double t = b_nz ? hypot((double)zk.y + (double)zn.y, (double)zn.x - (double)zk.x) : 0.0;
     if (p.out_kind == SSR_OUT_MAG) {
       row_a0[k] = (float)e;
       row_b0[k] = (float)t;
@@ -193,7 +199,7 @@ SSR_DEV void ssr_emit_bin(const SsrStftParams<T>& p, double* acc, unsigned k, cx
   } else if constexpr (MODE == SSR_MODE_PAIR && IN64 == SSR_IN_EST64) {
     // numpy.abs(complex128) of the unrounded est spectrum; the SSIM image keeps its float32 layout (the
     // rounding moves SSIM by < 2e-7, tests/test_gpu_parity.py)
-    const double e = hypot((double)zk.x + (double)zn.x, (double)zk.y - (double)zn.y);
+    const double e = a_nz ? hypot((double)zk.x + (double)zn.x, (double)zk.y - (double)zn.y) : 0.0;
     const float t = ssr_cabsf(o.br, o.bi);
     if (p.out_kind == SSR_OUT_MAG) {
       row_a0[k] = (float)e;
@@ -226,7 +232,7 @@ SSR_DEV void ssr_emit_bin(const SsrStftParams<T>& p, double* acc, unsigned k, cx
 // together) + the Nyquist bin on thread 0.
 template <typename T, int LOGN, int MODE, int PPT, int IN64 = 0>
 SSR_DEV void ssr_epilogue_direct(const SsrStftParams<T>& p, double* acc, int tid, const T* re, const T* im,
-                                 float* ra0, float* ra1, float* rb0, float* rb1, bool b_ok) {
+                                 float* ra0, float* ra1, float* rb0, float* rb1, bool b_ok, bool a_nz, bool b_nz) {
   constexpr int N = 1 << LOGN, NT = N / PPT, RND = PPT / 2;   // F = N/2 + 1 = RND * NT + 1
   cx<T> zk[RND], zn[RND];
 #pragma unroll
@@ -237,10 +243,10 @@ SSR_DEV void ssr_epilogue_direct(const SsrStftParams<T>& p, double* acc, int tid
   }
 #pragma unroll
   for (int i = 0; i < RND; ++i)
-    ssr_emit_bin<T, MODE, IN64>(p, acc, (unsigned)(tid + i * NT), zk[i], zn[i], ra0, ra1, rb0, rb1, b_ok);
+    ssr_emit_bin<T, MODE, IN64>(p, acc, (unsigned)(tid + i * NT), zk[i], zn[i], ra0, ra1, rb0, rb1, b_ok, a_nz, b_nz);
   if (tid == 0) {
     const cx<T> zq = {re[ssr_pad(N / 2)], im[ssr_pad(N / 2)]};
-    ssr_emit_bin<T, MODE, IN64>(p, acc, (unsigned)(N / 2), zq, zq, ra0, ra1, rb0, rb1, b_ok);
+    ssr_emit_bin<T, MODE, IN64>(p, acc, (unsigned)(N / 2), zq, zq, ra0, ra1, rb0, rb1, b_ok, a_nz, b_nz);
   }
 }
 
@@ -250,15 +256,26 @@ template <typename T, int LOGN, int PPT = 8> struct SsrStftLds {
   static constexpr int PN = ssr_padded_len(1 << LOGN);
   static constexpr int NW = (NT + 63) / 64;
   // sc1: per-wave LSD sums of the current frame; wacc: per-wave running SISpec sums [6][NW];
-  // res[0]: running sum over frames of the per-frame LSD (thread 0)
-  static constexpr size_t bytes() { return sizeof(double) * (16 + 6 * 16 + 8) + sizeof(T) * 2 * PN; }
-  double* sc1; double* wacc; double* res; T* re; T* im;
+  // res[0]: running sum over frames of the per-frame LSD (thread 0);
+  // nz: per-wave "this frame of signal A / B has a non-zero sample" flags [2][16]
+  static constexpr size_t bytes() { return sizeof(double) * (16 + 6 * 16 + 8 + 16) + sizeof(T) * 2 * PN; }
+  double* sc1; double* wacc; double* res; int* nz; T* re; T* im;
   SSR_MEMBER explicit SsrStftLds(char* base) {
     sc1 = reinterpret_cast<double*>(base);
     wacc = sc1 + 16;
     res = wacc + 6 * 16;
-    re = reinterpret_cast<T*>(res + 8);
+    nz = reinterpret_cast<int*>(res + 8);
+    re = reinterpret_cast<T*>(res + 8 + 16);
     im = re + PN;
+  }
+  // block-uniform: does the current frame of signal A (which = 0) / B (which = 1) contain any non-zero sample?
+  SSR_MEMBER bool any_nonzero(int which) const {
+    int f = 0;
+    for (int w = 0; w < NW; ++w) f |= nz[which * 16 + w];
+#ifndef SSR_HOST_EMU
+    f = __builtin_amdgcn_readfirstlane(f);      // every lane read the same words: make the uniformity explicit (scalar branch)
+#endif
+    return f != 0;
   }
 };
 
@@ -319,10 +336,12 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
     // branch-free, always-valid addresses, so the frame pays ONE memory latency instead of 24 dependent
     // ones.  Thread 0 also closes the PREVIOUS frame's LSD (per-wave sums left in sc1 by its epilogue).
     SSR_PHASE(blk, regs, {
+      int nz_a_wave = 1, nz_b_wave = 1;
       if constexpr (BLUESTEIN) {
         // Four points at a time (sample pair + window*chirp value each), fenced, so that at 16 points per
         // thread the address and table registers of one group die before the next group is issued.
         // Groups whose indices all lie beyond n_fft (at least the upper half of M) are skipped outright.
+        bool nza = false, nzb = false;
         SSR_UNROLL for (int r0 = 0; r0 < PPT; r0 += 4) {
           const int m_lo = ssr_fft_first_index<LOGN, PPT>(0, r0);   // smallest index any thread's group can hold
           bool any = false;
@@ -345,12 +364,16 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
               const int m = ssr_fft_first_index<LOGN, PPT>(tid, r0 + r);
               const cx<T> z = cmul(cx<T>{a_ok ? (T)fa[r] : (T)0, b_ok ? (T)fb[r] : (T)0}, wc[r]);
               R.v[r0 + r] = (m < n_fft) ? z : cx<T>{(T)0, (T)0};
+              nza = nza || (m < n_fft && fa[r] != 0);
+              nzb = nzb || (m < n_fft && fb[r] != 0);
             }
           } else {
             SSR_UNROLL for (int r = 0; r < 4; ++r) R.v[r0 + r] = cx<T>{(T)0, (T)0};
           }
           SSR_SCHED_FENCE();
         }
+        SSR_WAVE_ANY_STORE(tid, nza, L.nz);
+        SSR_WAVE_ANY_STORE(tid, nzb, L.nz + 16);
       } else {
         SA fa[PPT];
         SB fb[PPT];
@@ -372,9 +395,21 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
         T w[PPT];
         SSR_UNROLL for (int r = 0; r < PPT; ++r) w[r] = p.window[SSR_UIDX(ssr_fft_first_index<LOGN, PPT>(tid, r))];
         SSR_UNROLL for (int r = 0; r < PPT; ++r) R.v[r] = {a_ok ? (T)fa[r] * w[r] : (T)0, b_ok ? (T)fb[r] * w[r] : (T)0};
+        // silent-frame flags: OR of the samples' magnitude bits, one register per signal
+        // (register 0 of thread 0 is sample m = 0, whose window weight is exactly 0: it never reaches the transform)
+        unsigned ora = 0u, orb = 0u;
+        SSR_UNROLL for (int r = 1; r < PPT; ++r) { ora |= ssr_mag_bits(fa[r]); orb |= ssr_mag_bits(fb[r]); }
+        ora |= (tid == 0) ? 0u : ssr_mag_bits(fa[0]);
+        orb |= (tid == 0) ? 0u : ssr_mag_bits(fb[0]);
+        nz_a_wave = SSR_WAVE_ANY(ora != 0u);      // reduced to a wave-uniform scalar before the butterflies start
+        nz_b_wave = SSR_WAVE_ANY(orb != 0u);
       }
       ssr_fft_compute<T, LOGN, 0, PPT>(tid, R.v, p.tw);
       ssr_fft_store<T, LOGN, 0, PPT>(tid, L.re, L.im, R.v);
+      if constexpr (!BLUESTEIN) {
+        SSR_WAVE_FLAG_STORE(tid, nz_a_wave, L.nz);
+        SSR_WAVE_FLAG_STORE(tid, nz_b_wave, L.nz + 16);
+      }
       if (want_lsd && u > u0 && tid == 0) {
         double s = 0.0;
         for (int w = 0; w < NW; ++w) s += L.sc1[w];
@@ -425,20 +460,23 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
     if (MODE == SSR_MODE_PAIR) { ra1 = ra0; rb1 = rb0; }
     SSR_PHASE(blk, regs, {
       double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      const bool a_nz = L.any_nonzero(0), b_nz = L.any_nonzero(1);
 #if defined(SSR_ABL_NOEPI)     /* developer ablation: WRONG results, timing only */
       if (tid == 0) {
         const cx<T> z0 = {L.re[0], L.im[0]};
-        ssr_emit_bin<T, MODE, IN64>(p, acc, 0u, z0, z0, ra0, ra1, rb0, rb1, b_ok);
+        ssr_emit_bin<T, MODE, IN64>(p, acc, 0u, z0, z0, ra0, ra1, rb0, rb1, b_ok, true, true);
       }
 #else
       if constexpr (!BLUESTEIN) {
-        ssr_epilogue_direct<T, LOGN, MODE, PPT, IN64>(p, acc, tid, L.re, L.im, ra0, ra1, rb0, rb1, b_ok);
+        // block-uniform branch: the common case (no silent frame) carries no zero-forcing selects at all
+        if (a_nz && b_nz) ssr_epilogue_direct<T, LOGN, MODE, PPT, IN64>(p, acc, tid, L.re, L.im, ra0, ra1, rb0, rb1, b_ok, true, true);
+        else ssr_epilogue_direct<T, LOGN, MODE, PPT, IN64>(p, acc, tid, L.re, L.im, ra0, ra1, rb0, rb1, b_ok, a_nz, b_nz);
       } else {
         for (int k = tid; k < F; k += NT) {
           const int kn = (k == 0) ? 0 : n_fft - k;
           const cx<T> zk = {L.re[ssr_pad(k)], L.im[ssr_pad(k)]};
           const cx<T> zn = {L.re[ssr_pad(kn)], L.im[ssr_pad(kn)]};
-          ssr_emit_bin<T, MODE, IN64>(p, acc, (unsigned)k, zk, zn, ra0, ra1, rb0, rb1, b_ok);
+          ssr_emit_bin<T, MODE, IN64>(p, acc, (unsigned)k, zk, zn, ra0, ra1, rb0, rb1, b_ok, a_nz, b_nz);
         }
       }
 #endif

@@ -81,6 +81,7 @@ SSR_BODY void ssr_stft_r3_body(const SsrStftParams<T>& p, BLK& blk, int chunk, i
       // ---- decimated frame (samples 3m + r) -> registers, pre-multiply, pass 0, store.
       // Only indices m < q are non-zero; q <= M/2, so at least the upper half of the registers is skipped.
       SSR_PHASE(blk, regs, {
+        bool nza = false, nzb = false;
         SSR_UNROLL for (int g = 0; g < PPT; ++g) {
           const int m_min = ssr_fft_first_index<LOGN, PPT>(0, g);          // block-uniform: smallest index of this register
           if (m_min < q) {
@@ -93,10 +94,15 @@ SSR_BODY void ssr_stft_r3_body(const SsrStftParams<T>& p, BLK& blk, int chunk, i
             const SB fb = sb[SSR_UIDX(ib)];
             const cx<T> z = cmul(cx<T>{a_ok ? (T)fa : (T)0, b_ok ? (T)fb : (T)0}, wch[SSR_UIDX(mc)]);
             R.v[g] = (m < q) ? z : cx<T>{(T)0, (T)0};
+            nza = nza || (m < q && fa != 0);
+            nzb = nzb || (m < q && fb != 0);
           } else {
             R.v[g] = cx<T>{(T)0, (T)0};
           }
         }
+        // non-zero flags of the frame: one slot per decimation round (three rounds make a frame)
+        SSR_WAVE_ANY_STORE(tid, nza, L.nz + r * 4);
+        SSR_WAVE_ANY_STORE(tid, nzb, L.nz + 16 + r * 4);
         ssr_fft_compute<T, LOGN, 0, PPT>(tid, R.v, p.tw);
         ssr_fft_store<T, LOGN, 0, PPT>(tid, L.re, L.im, R.v);
         if (r == 0 && want_lsd && u > u0 && tid == 0) {               // close the previous unit's LSD
@@ -139,11 +145,15 @@ SSR_BODY void ssr_stft_r3_body(const SsrStftParams<T>& p, BLK& blk, int chunk, i
     if (MODE == SSR_MODE_PAIR) { ra1 = ra0; rb1 = rb0; }
     SSR_PHASE(blk, regs, {
       double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      bool a_nz = false, b_nz = false;
+      for (int i = 0; i < 3 * 4; ++i) {
+        if ((i & 3) < NW) { a_nz = a_nz || L.nz[i] != 0; b_nz = b_nz || L.nz[16 + i] != 0; }
+      }
       for (int K = tid; K < F; K += NT) {
         const int Kn = (K == 0) ? 0 : n_fft - K;
         const cx<T> zk = ssr_r3_combine<T>(yre, yim, q, K);
         const cx<T> zn = ssr_r3_combine<T>(yre, yim, q, Kn);
-        ssr_emit_bin<T, MODE, IN64>(p, acc, (unsigned)K, zk, zn, ra0, ra1, rb0, rb1, b_ok);
+        ssr_emit_bin<T, MODE, IN64>(p, acc, (unsigned)K, zk, zn, ra0, ra1, rb0, rb1, b_ok, a_nz, b_nz);
       }
       if (want_lsd) SSR_WAVE_SUM_STORE(tid, NT, acc[0], L.sc1);
       if constexpr (SUMS)

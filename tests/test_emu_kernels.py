@@ -218,3 +218,31 @@ def test_xcorr_argmax_matches_scipy_correlate(golden):
     assert list(got) == want
     # the shift the reference derives from it: argmax - len(x)  (zero delay -> -1, eval.py:319)
     assert int(got[2]) - 2049 == -1
+
+
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (2229, 480), (743, 160)])
+def test_all_zero_frames_have_exactly_zero_spectra(n_fft, hop):
+    """Digital silence: the reference transforms each signal on its own, so an all-zero frame has an exactly zero
+    spectrum and the metrics hit their EPS guards exactly (LSD = 12 for 0 vs 0, SISpec = -120 dB for a zero estimate).
+    The packed transform must not leak the other signal into it."""
+    rng = np.random.default_rng(n_fft)
+    n = 4 * n_fft
+    x = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    z = np.zeros(n, np.float32)
+    half = x.copy()
+    half[: n // 2 + n_fft] = 0.0                       # silence for the first frames only
+    for est, tgt in [(z, x), (x, z), (z, z), (half, x)]:
+        ea, tb, _ = E.stft([est], [tgt], n_fft, hop, precision=1, units_per_chunk=3)
+        ra, rb = ostft.stft_mag_TF(est, n_fft, hop), ostft.stft_mag_TF(tgt, n_fft, hop)
+        assert ((ea[0] == 0) == (ra == 0)).all() and ((tb[0] == 0) == (rb == 0)).all()
+        got = E.pair_metrics([est], [tgt], n_fft, hop, precision=1, units_per_chunk=3, rows_per_tile=7)[0]
+        want = om.evaluation(est, tgt, n_fft=n_fft, hop=hop)
+        want = np.array([want["lsd"], want["log_sispec"], want["sispec"], want["ssim"]])
+        keep = [0, 2, 3] if (est is z and tgt is z) else [0, 1, 2, 3]        # log-SISpec(0, 0) is round-off defined
+        # the SISpec pair in dB near 0: the reference's float32 torch sums over a constant (-12) log-target carry
+        # ~1e-5 relative summation error of their own, i.e. ~1e-4 dB; everything else to the 1e-5 bar
+        np.testing.assert_allclose(got[keep], want[keep], rtol=1e-5, atol=2e-4)
+        np.testing.assert_allclose(got[[0, 3]], want[[0, 3]], rtol=1e-5, atol=1e-12)
+    sa, _, _ = E.stft([half], None, n_fft, hop, precision=1, mode=1, units_per_chunk=2)   # single mode: frame pairs
+    ra = ostft.stft_mag_TF(half, n_fft, hop)
+    assert ((sa[0] == 0) == (ra == 0)).all()

@@ -606,3 +606,27 @@ def test_mp3_degradation_with_stub_codec(tmp_path, monkeypatch):
                          setting_mp3_compression={"low_kbps": [8]})
     with pytest.raises(RuntimeError):
         h3.evaluate_arrays([(x, x)])                               # no file to hand to the codec
+
+
+def test_degenerate_signals_follow_the_reference_arithmetic():
+    """All-zero estimates / targets (EPS paths: LSD = 12, SISpec = -120 dB, SSIM = 1) and non-finite samples."""
+    from ssr_eval_amd import backend as B
+    from oracle import metrics as om
+    rng = np.random.default_rng(3)
+    plan = B.get_plan(2048, 512, "f64")
+    n = 9000
+    x = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    z = np.zeros(n, np.float32)
+    got = B.pair_metrics(plan, [z, z, x], [z, x, z])
+    for (e, t), g in zip([(z, z), (z, x), (x, z)], got):
+        want = om.evaluation(e, t, n_fft=2048, hop=512)
+        keep = [0, 2, 3] if (e is z and t is z) else [0, 1, 2, 3]   # log-SISpec of identical logs is round-off defined
+        # SISpec pair near 0 dB against a constant log-target: the reference's own float32 sums are good to ~1e-4 dB
+        np.testing.assert_allclose(g[keep], _vec(want)[keep], rtol=1e-5, atol=2e-4)
+        np.testing.assert_allclose(g[[0, 3]], _vec(want)[[0, 3]], rtol=1e-5, atol=1e-12)
+    assert got[0][0] == pytest.approx(12.0, rel=1e-6) and got[0][3] == pytest.approx(1.0, rel=1e-12)
+    bad = x.copy()
+    bad[4000] = np.nan
+    g = B.pair_metrics(plan, [bad], [x])[0]
+    assert np.isnan(g).all()                      # a NaN sample reaches every metric, as in the reference
+    assert B.pair_metrics(plan, [], []).shape == (0, 4)

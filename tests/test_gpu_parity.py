@@ -630,3 +630,38 @@ def test_degenerate_signals_follow_the_reference_arithmetic():
     g = B.pair_metrics(plan, [bad], [x])[0]
     assert np.isnan(g).all()                      # a NaN sample reaches every metric, as in the reference
     assert B.pair_metrics(plan, [], []).shape == (0, 4)
+
+
+def test_full_size_properties_cfg4():
+    """BASELINE config 4's geometry: 2,937 ragged utterances (VCTK test-set speaker counts, 1.5-9 s @ 48 kHz), one launch
+    sequence.  Size-independent properties: batch-composition invariance (the same pair gives the same numbers alone, in
+    a shard, in the full batch), the sharded sums+counts aggregate equals the mean of speaker means, oracle spot checks."""
+    from ssr_eval_amd import backend as B, dist as D
+    from oracle import metrics as om
+    counts = [424, 424, 123, 419, 301, 424, 424, 398]
+    assert sum(counts) == 2937
+    g = torch.Generator(device="cuda").manual_seed(4)
+    rng = np.random.default_rng(4)
+    lens = rng.integers(int(1.5 * 48000), 9 * 48000, sum(counts))
+    tgt = [0.1 * torch.randn(int(n), generator=g, device="cuda") for n in lens]
+    est = [t + 0.02 * torch.randn(t.shape[0], generator=g, device="cuda") for t in tgt]
+    plan = B.get_plan(2048, 512, "f64")
+    full = B.pair_metrics(plan, est, tgt)
+    assert full.shape == (2937, 4) and np.isfinite(full).all()
+    # shards of a 2-rank job (round-robin) reproduce the rows of the full batch
+    rows = np.empty_like(full)
+    for rank in range(2):
+        mine = D.shard_indices(2937, rank, 2)
+        rows[mine] = B.pair_metrics(plan, [est[i] for i in mine], [tgt[i] for i in mine])
+    np.testing.assert_allclose(rows, full, rtol=1e-12)
+    spk = np.repeat(np.arange(8), counts)
+    buf = sum(D.speaker_sums(full[D.shard_indices(2937, r, 2)], spk[D.shard_indices(2937, r, 2)], 8) for r in range(2))
+    per_spk, avg = D.mean_of_speaker_means(buf)
+    want_spk = np.stack([full[spk == s].mean(axis=0) for s in range(8)])
+    np.testing.assert_allclose(per_spk, want_spk, rtol=1e-12)
+    np.testing.assert_allclose(avg, want_spk.mean(axis=0), rtol=1e-12)
+    for i in (0, 1234, 2936):
+        alone = B.pair_metrics(plan, [est[i]], [tgt[i]])[0]
+        np.testing.assert_allclose(alone, full[i], rtol=1e-12)   # launch geometry (chunking of the float64 sums) differs
+        want = om.evaluation(est[i].cpu().numpy(), tgt[i].cpu().numpy(), n_fft=2048, hop=512)
+        np.testing.assert_allclose(full[i], _vec(want), rtol=1e-5)

@@ -99,26 +99,41 @@ SSR_DEV void ssr_fft_load(int tid, const T* re, const T* im, cx<T>* v) {
   }
 }
 
+// The three table twiddles (w^1, w^2, w^4; radix 4: w^1, w^2) of butterfly b of pass PASS: thread-constant
+// addresses, so they can be requested a phase early (ssr_fft_mid_passes<..., PF = true>).
 template <typename T, int LOGN, int PASS, int PPT = 8>
-SSR_DEV void ssr_fft_compute(int tid, cx<T>* v, const cx<T>* __restrict__ tw) {
+SSR_DEV void ssr_fft_load_tw(int tid, const cx<T>* __restrict__ tw, cx<T>* w) {
+  using P = SsrFftPlan<LOGN, PPT>;
+  constexpr int R = P::radix(PASS), NB = PPT / R, NS = P::ns(PASS);
+  if constexpr (NS > 1) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int j = tid + b * P::NT;
+      const unsigned ub = (unsigned)((j & (NS - 1)) * (P::N / (NS * R)));   // scalar table base + 32-bit lane offset
+      w[3 * b] = tw[ub];
+      w[3 * b + 1] = tw[2 * ub];
+      if constexpr (R == 8) w[3 * b + 2] = tw[4 * ub];
+    }
+  }
+}
+
+// butterflies of pass PASS with the table twiddles already in registers
+template <typename T, int LOGN, int PASS, int PPT = 8>
+SSR_DEV void ssr_fft_compute_tw(cx<T>* v, const cx<T>* w) {
   using P = SsrFftPlan<LOGN, PPT>;
   constexpr int R = P::radix(PASS), NB = PPT / R, NS = P::ns(PASS);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     if constexpr (NS > 1) {
       static_assert(R == P::RW || NS == 1, "only the leading pass may have a smaller radix");
-      const int j = tid + b * P::NT;
-      const int k = j & (NS - 1);
-      const int base = k * (P::N / (NS * R));
-      const unsigned ub = (unsigned)base;          // scalar table base + 32-bit lane offset
       cx<T>* x = v + b * R;
+      const cx<T> w1 = w[3 * b], w2 = w[3 * b + 1];
       if constexpr (R == 4) {
-        const cx<T> w1 = tw[ub], w2 = tw[2 * ub];
         x[1] = cmul(x[1], w1);
         x[2] = cmul(x[2], w2);
         x[3] = cmul(x[3], cmul(w1, w2));
       } else {
-        const cx<T> w1 = tw[ub], w2 = tw[2 * ub], w4 = tw[4 * ub];
+        const cx<T> w4 = w[3 * b + 2];
         // twiddle powers are formed just before use to keep few of them live (register pressure)
         x[1] = cmul(x[1], w1);
         x[2] = cmul(x[2], w2);
@@ -132,6 +147,14 @@ SSR_DEV void ssr_fft_compute(int tid, cx<T>* v, const cx<T>* __restrict__ tw) {
     }
     ssr_bfly<R>(v + b * R);
   }
+}
+
+template <typename T, int LOGN, int PASS, int PPT = 8>
+SSR_DEV void ssr_fft_compute(int tid, cx<T>* v, const cx<T>* __restrict__ tw) {
+  using P = SsrFftPlan<LOGN, PPT>;
+  cx<T> w[3 * (PPT / P::radix(PASS))];
+  ssr_fft_load_tw<T, LOGN, PASS, PPT>(tid, tw, w);
+  ssr_fft_compute_tw<T, LOGN, PASS, PPT>(v, w);
 }
 
 // natural output index of register `reg` after pass PASS
@@ -159,10 +182,22 @@ SSR_DEV void ssr_fft_store(int tid, T* re, T* im, const cx<T>* v) {
 // (ssr_fft_out_index<LOGN, NPASS-1> gives each register's natural frequency index).
 // Pre-condition: pass 0 results already stored to (re, im) and a barrier passed.
 // Regs must expose `cx<T> v[PPT]`.
-template <typename T, int LOGN, int PASS, int PPT, typename BLK, typename REGS>
+// PF = true: the table twiddles of a pass are requested one phase early - in the store phase of the previous pass,
+// whose data registers are dead by then - so their L1/L2 latency overlaps the barrier and the LDS reads.  Regs must
+// then expose `cx<T> twp[3 * PPT / 8]`, and the CALLER has requested pass PASS's twiddles (ssr_fft_load_tw into
+// R.twp) in the phase that stored pass PASS - 1.
+template <typename T, int LOGN, int PASS, int PPT, bool PF = false, typename BLK, typename REGS>
 SSR_BODY void ssr_fft_mid_passes(BLK& blk, REGS& regs, T* re, T* im, const cx<T>* tw) {
   using P = SsrFftPlan<LOGN, PPT>;
-  if constexpr (PASS < P::NPASS - 1) {
+  if constexpr (PF) {
+    SSR_PHASE(blk, regs, ssr_fft_load<T, LOGN, PASS, PPT>(tid, re, im, R.v);
+              ssr_fft_compute_tw<T, LOGN, PASS, PPT>(R.v, R.twp));
+    if constexpr (PASS < P::NPASS - 1) {
+      SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, PASS, PPT>(tid, re, im, R.v);
+                ssr_fft_load_tw<T, LOGN, PASS + 1, PPT>(tid, tw, R.twp));
+      ssr_fft_mid_passes<T, LOGN, PASS + 1, PPT, true>(blk, regs, re, im, tw);
+    }
+  } else if constexpr (PASS < P::NPASS - 1) {
     SSR_PHASE(blk, regs, ssr_fft_load<T, LOGN, PASS, PPT>(tid, re, im, R.v);
               ssr_fft_compute<T, LOGN, PASS, PPT>(tid, R.v, tw));
     SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, PASS, PPT>(tid, re, im, R.v));

@@ -74,6 +74,7 @@ template <> struct SsrSample<true> { typedef double type; };
 template <typename T, bool SUMS = false, int PPT = 8> struct SsrStftRegs {
   cx<T> v[PPT];              // FFT points
   double sums[SUMS ? 6 : 1]; // SISpec / log-SISpec running sums (kernel variants that do not need them carry none)
+  cx<T> twp[3 * (PPT >= 8 ? PPT / 8 : 1)];   // table twiddles of the next pass, requested a phase early (direct engine)
 };
 
 SSR_DEV int ssr_num_frames_dev(int n, int n_fft, int hop) { return 1 + (n + 2 * (n_fft / 2) - n_fft) / hop; }
@@ -407,6 +408,7 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
       ssr_fft_compute<T, LOGN, 0, PPT>(tid, R.v, p.tw);
       ssr_fft_store<T, LOGN, 0, PPT>(tid, L.re, L.im, R.v);
       if constexpr (!BLUESTEIN) {
+        ssr_fft_load_tw<T, LOGN, 1, PPT>(tid, p.tw, R.twp);      // pass 1's twiddles, in flight across the barrier
         SSR_WAVE_FLAG_STORE(tid, nz_a_wave, L.nz);
         SSR_WAVE_FLAG_STORE(tid, nz_b_wave, L.nz + 16);
       }
@@ -417,7 +419,8 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
       }
     });
     // remaining forward passes; last pass stays in registers
-    ssr_fft_mid_passes<T, LOGN, 1, PPT>(blk, regs, L.re, L.im, p.tw);
+    if constexpr (!BLUESTEIN) ssr_fft_mid_passes<T, LOGN, 1, PPT, true>(blk, regs, L.re, L.im, p.tw);
+    else ssr_fft_mid_passes<T, LOGN, 1, PPT>(blk, regs, L.re, L.im, p.tw);
 
     if constexpr (BLUESTEIN) {
       // forward spectrum * filter, stored as the INPUT of the inverse transform.  The inverse is the

@@ -27,6 +27,7 @@
 #define SSR_UNROLL4
 struct SsrBlk { int nt; };
 static inline void ssr_launder(SsrBlk&) {}
+static inline unsigned ssr_launder_index(unsigned i) { return i; }
 #define SSR_REGS(TYPE, name, blk) std::vector<TYPE> name((blk).nt)
 #define SSR_PHASE(blk, regs, ...)                                  \
   for (int tid = 0; tid < (blk).nt; ++tid) {                       \
@@ -85,6 +86,9 @@ struct SsrBlk { int tid; };
 // otherwise hoists EVERY per-register LDS / table address of every pass out of the frame loop; at 16
 // points per thread that is several hundred values which end up in scratch memory.
 SSR_DEV void ssr_launder(SsrBlk& b) { asm volatile("" : "+v"(b.tid)); }
+// the same for one index: the address built from it is recomputed where it is used instead of living (or being
+// spilled) across the whole frame loop
+SSR_DEV unsigned ssr_launder_index(unsigned i) { asm volatile("" : "+v"(i)); return i; }
 #define SSR_REGS(TYPE, name, blk) TYPE name
 #define SSR_PHASE(blk, regs, ...)                                  \
   {                                                                \

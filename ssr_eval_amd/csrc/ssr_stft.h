@@ -77,6 +77,23 @@ template <typename T, bool SUMS = false, int PPT = 8> struct SsrStftRegs {
   cx<T> twp[3 * (PPT >= 8 ? PPT / 8 : 1)];   // table twiddles of the next pass, requested a phase early (direct engine)
 };
 
+// Direct engine: the NEXT frame's samples and window values are requested at the top of the current frame's epilogue,
+// ahead of its magnitude stores (vmcnt retires in order on this hardware: a load issued after those stores cannot be
+// waited for without also waiting for the stores' acknowledgements).  Only half of the window values are loaded: the
+// (half-scaled) periodic Hann window satisfies w[m + N/2] = 1/2 - w[m], and a thread's registers come in such pairs.
+template <typename T, bool SUMS, int PPT, typename SA, typename SB> struct SsrStftRegsPf : SsrStftRegs<T, SUMS, PPT> {
+  SA pa[PPT];
+  SB pb[PPT];
+  T pw[PPT / 2];
+};
+template <bool BLUESTEIN, typename T, bool SUMS, int PPT, typename SA, typename SB> struct SsrStftPickRegs {
+  typedef SsrStftRegsPf<T, SUMS, PPT, SA, SB> type;
+};
+template <typename T, bool SUMS, int PPT, typename SA, typename SB> struct SsrStftPickRegs<true, T, SUMS, PPT, SA, SB> {
+  typedef SsrStftRegs<T, SUMS, PPT> type;
+};
+
+
 SSR_DEV int ssr_num_frames_dev(int n, int n_fft, int hop) { return 1 + (n + 2 * (n_fft / 2) - n_fft) / hop; }
 
 // one reflect-padded sample of frame `t`, branch-free: a frame that does not exist re-reads the last
@@ -280,6 +297,41 @@ template <typename T, int LOGN, int PPT = 8> struct SsrStftLds {
   }
 };
 
+// Direct engine: request unit u's samples (first-pass order) and half of its window values into the prefetch
+// registers.  Branch-free, always-valid addresses: a frame that does not exist re-reads the last one (the consumer
+// scales it by 0); frames that touch the signal ends go through the reflection index.
+template <typename T, int LOGN, int MODE, int PPT, typename SA, typename SB, typename REGS>
+SSR_DEV void ssr_stft_prefetch(const SsrStftParams<T>& p, REGS& R, int tid, const SA* sa, const SB* sb, int u, int n,
+                               int n_frames) {
+  using P = SsrFftPlan<LOGN, PPT>;
+  constexpr int N = 1 << LOGN, R0 = P::R0;
+  const int ta = (MODE == SSR_MODE_PAIR) ? u : 2 * u;
+  const int tb = (MODE == SSR_MODE_PAIR) ? u : 2 * u + 1;
+  const int ta_c = (ta < n_frames) ? ta : n_frames - 1, tb_c = (tb < n_frames) ? tb : n_frames - 1;
+  const int base_a = ta_c * p.hop - N / 2, base_b = tb_c * p.hop - N / 2;
+  // block-uniform: both frames lie fully inside the signal -> no reflection arithmetic at all
+  const bool interior = base_a >= 0 && base_b >= 0 && base_a + N <= n && base_b + N <= n;
+  if (interior) {
+    const SA* qa = sa + base_a;
+    const SB* qb = sb + base_b;
+    SSR_UNROLL for (int r = 0; r < PPT; ++r) {
+      const int m = ssr_fft_first_index<LOGN, PPT>(tid, r);
+      R.pa[r] = qa[SSR_UIDX(m)];
+      R.pb[r] = qb[SSR_UIDX(m)];
+    }
+  } else {
+    SSR_UNROLL for (int r = 0; r < PPT; ++r) {
+      const int m = ssr_fft_first_index<LOGN, PPT>(tid, r);
+      R.pa[r] = sa[SSR_UIDX(ssr_reflect(base_a + m, n))];
+      R.pb[r] = sb[SSR_UIDX(ssr_reflect(base_b + m, n))];
+    }
+  }
+  // registers (b, q) and (b, q + R0/2) are N/2 samples apart: load the lower one of each pair
+  SSR_UNROLL for (int r = 0; r < PPT; ++r)
+    if ((r % R0) < R0 / 2)
+      R.pw[(r / R0) * (R0 / 2) + (r % R0)] = p.window[ssr_launder_index(SSR_UIDX(ssr_fft_first_index<LOGN, PPT>(tid, r)))];
+}
+
 // ---------------------------------------------------------------------------------------------------
 // The body.  LOGN: FFT length of the engine (n_fft for direct, M for bluestein).
 // grid = (n_chunks, n_items); block = 2^LOGN / 8 threads.
@@ -287,7 +339,10 @@ template <typename T, int LOGN, bool BLUESTEIN, int MODE, bool SUMS, int PPT, in
 SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
   using P = SsrFftPlan<LOGN, PPT>;
   constexpr int N = P::N, NT = P::NT, LAST = P::NPASS - 1, NW = (NT + 63) / 64;
-  using Regs = SsrStftRegs<T, SUMS, PPT>;
+  static_assert(IN64 == 0 || MODE == SSR_MODE_PAIR, "float64 signals exist on the pair path only");
+  using SA = typename SsrSample<(IN64 & 1) != 0>::type;
+  using SB = typename SsrSample<(IN64 & 2) != 0>::type;
+  using Regs = typename SsrStftPickRegs<BLUESTEIN, T, SUMS, PPT, SA, SB>::type;
   SsrStftLds<T, LOGN, PPT> L(lds_base);
 
   const int n = p.len[item];
@@ -296,9 +351,6 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
   const int n_units = (MODE == SSR_MODE_PAIR) ? n_frames : (n_frames + 1) / 2;
   const int u0 = chunk * p.units_per_chunk;
   const int u1 = (u0 + p.units_per_chunk < n_units) ? u0 + p.units_per_chunk : n_units;
-  static_assert(IN64 == 0 || MODE == SSR_MODE_PAIR, "float64 signals exist on the pair path only");
-  using SA = typename SsrSample<(IN64 & 1) != 0>::type;
-  using SB = typename SsrSample<(IN64 & 2) != 0>::type;
   const SA* sa;
   if constexpr (IN64 & 1) sa = p.a64 + p.a_off[item];
   else sa = p.a + p.a_off[item];
@@ -315,6 +367,8 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
     for (int i = tid; i < 6 * 16; i += NT) L.wacc[i] = 0.0;   // NT may be as small as 32
     if (tid == 0) L.res[0] = 0.0;
     for (int q = 0; q < (SUMS ? 6 : 1); ++q) R.sums[q] = 0.0;
+    if constexpr (!BLUESTEIN)
+      if (u0 < u1) ssr_stft_prefetch<T, LOGN, MODE, PPT>(p, R, tid, sa, sb, u0, n, n_frames);
   });
 
   BLK blk0 = blk;
@@ -376,32 +430,19 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
         SSR_WAVE_ANY_STORE(tid, nza, L.nz);
         SSR_WAVE_ANY_STORE(tid, nzb, L.nz + 16);
       } else {
-        SA fa[PPT];
-        SB fb[PPT];
-        if (interior) {
-          const SA* qa = sa + base_a;
-          const SB* qb = sb + base_b;
-          SSR_UNROLL for (int r = 0; r < PPT; ++r) {
-            const int m = ssr_fft_first_index<LOGN, PPT>(tid, r);
-            fa[r] = qa[SSR_UIDX(m)];
-            fb[r] = qb[SSR_UIDX(m)];
-          }
-        } else {
-          SSR_UNROLL for (int r = 0; r < PPT; ++r) {
-            const int m = ssr_fft_first_index<LOGN, PPT>(tid, r);
-            fa[r] = sa[SSR_UIDX(ssr_reflect(base_a + m, n))];
-            fb[r] = sb[SSR_UIDX(ssr_reflect(base_b + m, n))];
-          }
+        // samples and window values were requested one frame ahead (ssr_stft_prefetch)
+        constexpr int R0 = P::R0;
+        SSR_UNROLL for (int r = 0; r < PPT; ++r) {
+          const T wl = R.pw[(r / R0) * (R0 / 2) + (r % R0) % (R0 / 2)];
+          const T w = ((r % R0) < R0 / 2) ? wl : (T)0.5 - wl;           // w[m + N/2] = 1/2 - w[m]
+          R.v[r] = {a_ok ? (T)R.pa[r] * w : (T)0, b_ok ? (T)R.pb[r] * w : (T)0};
         }
-        T w[PPT];
-        SSR_UNROLL for (int r = 0; r < PPT; ++r) w[r] = p.window[SSR_UIDX(ssr_fft_first_index<LOGN, PPT>(tid, r))];
-        SSR_UNROLL for (int r = 0; r < PPT; ++r) R.v[r] = {a_ok ? (T)fa[r] * w[r] : (T)0, b_ok ? (T)fb[r] * w[r] : (T)0};
         // silent-frame flags: OR of the samples' magnitude bits, one register per signal
         // (register 0 of thread 0 is sample m = 0, whose window weight is exactly 0: it never reaches the transform)
         unsigned ora = 0u, orb = 0u;
-        SSR_UNROLL for (int r = 1; r < PPT; ++r) { ora |= ssr_mag_bits(fa[r]); orb |= ssr_mag_bits(fb[r]); }
-        ora |= (tid == 0) ? 0u : ssr_mag_bits(fa[0]);
-        orb |= (tid == 0) ? 0u : ssr_mag_bits(fb[0]);
+        SSR_UNROLL for (int r = 1; r < PPT; ++r) { ora |= ssr_mag_bits(R.pa[r]); orb |= ssr_mag_bits(R.pb[r]); }
+        ora |= (tid == 0) ? 0u : ssr_mag_bits(R.pa[0]);
+        orb |= (tid == 0) ? 0u : ssr_mag_bits(R.pb[0]);
         nz_a_wave = SSR_WAVE_ANY(ora != 0u);      // reduced to a wave-uniform scalar before the butterflies start
         nz_b_wave = SSR_WAVE_ANY(orb != 0u);
       }
@@ -462,6 +503,8 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
     float* rb1 = p.out_b ? p.out_b + (row0 + tb) * F : nullptr;
     if (MODE == SSR_MODE_PAIR) { ra1 = ra0; rb1 = rb0; }
     SSR_PHASE(blk, regs, {
+      if constexpr (!BLUESTEIN)
+        if (u + 1 < u1) ssr_stft_prefetch<T, LOGN, MODE, PPT>(p, R, tid, sa, sb, u + 1, n, n_frames);
       double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       const bool a_nz = L.any_nonzero(0), b_nz = L.any_nonzero(1);
 #if defined(SSR_ABL_NOEPI)     /* developer ablation: WRONG results, timing only */

@@ -343,6 +343,7 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
   using SA = typename SsrSample<(IN64 & 1) != 0>::type;
   using SB = typename SsrSample<(IN64 & 2) != 0>::type;
   using Regs = typename SsrStftPickRegs<BLUESTEIN, T, SUMS, PPT, SA, SB>::type;
+  constexpr bool PF = PPT <= 8;      // early twiddle requests: everywhere but the register-critical 16-point engine
   SsrStftLds<T, LOGN, PPT> L(lds_base);
 
   const int n = p.len[item];
@@ -448,8 +449,8 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
       }
       ssr_fft_compute<T, LOGN, 0, PPT>(tid, R.v, p.tw);
       ssr_fft_store<T, LOGN, 0, PPT>(tid, L.re, L.im, R.v);
+      if constexpr (PF) ssr_fft_load_tw<T, LOGN, 1, PPT>(tid, p.tw, R.twp);   // pass 1's twiddles, in flight across the barrier
       if constexpr (!BLUESTEIN) {
-        ssr_fft_load_tw<T, LOGN, 1, PPT>(tid, p.tw, R.twp);      // pass 1's twiddles, in flight across the barrier
         SSR_WAVE_FLAG_STORE(tid, nz_a_wave, L.nz);
         SSR_WAVE_FLAG_STORE(tid, nz_b_wave, L.nz + 16);
       }
@@ -460,8 +461,7 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
       }
     });
     // remaining forward passes; last pass stays in registers
-    if constexpr (!BLUESTEIN) ssr_fft_mid_passes<T, LOGN, 1, PPT, true>(blk, regs, L.re, L.im, p.tw);
-    else ssr_fft_mid_passes<T, LOGN, 1, PPT>(blk, regs, L.re, L.im, p.tw);
+    ssr_fft_mid_passes<T, LOGN, 1, PPT, PF>(blk, regs, L.re, L.im, p.tw);
 
     if constexpr (BLUESTEIN) {
       // forward spectrum * filter, stored as the INPUT of the inverse transform.  The inverse is the
@@ -479,8 +479,9 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
       });
       SSR_PHASE(blk, regs, ssr_fft_load<T, LOGN, 0, PPT>(tid, L.im, L.re, R.v);
                 ssr_fft_compute<T, LOGN, 0, PPT>(tid, R.v, p.tw));
-      SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, 0, PPT>(tid, L.im, L.re, R.v));
-      ssr_fft_mid_passes<T, LOGN, 1, PPT>(blk, regs, L.im, L.re, p.tw);
+      SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, 0, PPT>(tid, L.im, L.re, R.v);
+                if constexpr (PF) ssr_fft_load_tw<T, LOGN, 1, PPT>(tid, p.tw, R.twp));
+      ssr_fft_mid_passes<T, LOGN, 1, PPT, PF>(blk, regs, L.im, L.re, p.tw);
       // registers hold swap(IFFT*M): true real part = .y, true imaginary part = .x
       SSR_PHASE(blk, regs, {
         SSR_UNROLL for (int r = 0; r < PPT; ++r) {

@@ -105,13 +105,14 @@ SSR_BODY void ssr_stft_r3_body(const SsrStftParams<T>& p, BLK& blk, int chunk, i
         SSR_WAVE_ANY_STORE(tid, nzb, L.nz + 16 + r * 4);
         ssr_fft_compute<T, LOGN, 0, PPT>(tid, R.v, p.tw);
         ssr_fft_store<T, LOGN, 0, PPT>(tid, L.re, L.im, R.v);
+        ssr_fft_load_tw<T, LOGN, 1, PPT>(tid, p.tw, R.twp);          // pass 1's twiddles, in flight across the barrier
         if (r == 0 && want_lsd && u > u0 && tid == 0) {               // close the previous unit's LSD
           double s = 0.0;
           for (int w = 0; w < NW; ++w) s += L.sc1[w];
           L.res[0] += sqrt(s / (double)F);
         }
       });
-      ssr_fft_mid_passes<T, LOGN, 1, PPT>(blk, regs, L.re, L.im, p.tw);
+      ssr_fft_mid_passes<T, LOGN, 1, PPT, true>(blk, regs, L.re, L.im, p.tw);
       SSR_PHASE(blk, regs, {
         SSR_UNROLL for (int g = 0; g < PPT; ++g) {
           const int k = ssr_fft_out_index<LOGN, LAST, PPT>(tid, g);
@@ -122,8 +123,9 @@ SSR_BODY void ssr_stft_r3_body(const SsrStftParams<T>& p, BLK& blk, int chunk, i
       });
       SSR_PHASE(blk, regs, ssr_fft_load<T, LOGN, 0, PPT>(tid, L.im, L.re, R.v);
                 ssr_fft_compute<T, LOGN, 0, PPT>(tid, R.v, p.tw));
-      SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, 0, PPT>(tid, L.im, L.re, R.v));
-      ssr_fft_mid_passes<T, LOGN, 1, PPT>(blk, regs, L.im, L.re, p.tw);
+      SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, 0, PPT>(tid, L.im, L.re, R.v);
+                ssr_fft_load_tw<T, LOGN, 1, PPT>(tid, p.tw, R.twp));
+      ssr_fft_mid_passes<T, LOGN, 1, PPT, true>(blk, regs, L.im, L.re, p.tw);
       // registers hold swap(IFFT * M): true real part = .y, true imaginary part = .x.  Park Y_r.
       // (yre / yim are only read by the epilogue, after the barrier that ends the r = 2 round.)
       SSR_PHASE(blk, regs, {

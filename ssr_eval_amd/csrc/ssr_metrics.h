@@ -65,28 +65,44 @@ template <int CPT> struct SsrSsimLds {
   }
 };
 
+// One [T, F] float32 image of the batch as the row loads see it.  Device: a raw buffer resource (scalar base +
+// scalar row offset + 32-bit lane offset in ONE instruction - the compiler otherwise keeps twenty per-lane 64-bit
+// pointers and advances each with a vector add every row); host emulation: a plain pointer.
+struct SsrImage {
+#ifdef SSR_HOST_EMU
+  const float* base;
+  SSR_MEMBER SsrImage(const float* p, int64_t) : base(p) {}
+  SSR_MEMBER float at(int64_t row_elems, unsigned col) const { return base[row_elems + col]; }
+#else
+  __amdgpu_buffer_rsrc_t rsrc;
+  SSR_MEMBER SsrImage(const float* p, int64_t n_elems)
+      : rsrc(__builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(n_elems * 4), 0x00020000)) {}   // raw dwords
+  SSR_MEMBER float at(int64_t row_elems, unsigned col) const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(col * 4u), (int)(row_elems * 4), 0));
+  }
+#endif
+};
+
 // Row step, split in two so that the loads of the NEXT step are in flight while the current one is consumed:
-// ssr_ssim_row_load issues the global loads of the row entering the 7-row window (row_add) and of the row leaving
-// it (row_sub; re-reads row_add when there is none) with clamped, always valid column addresses;
+// ssr_ssim_row_load issues the loads of the row entering the 7-row window (row_add) and of the row leaving
+// it (row_sub; re-reads row_add when there is none) with clamped, always valid column indices;
 // ssr_ssim_row_apply folds the loaded values into the thread's running column sums.
 template <int CPT>
-SSR_DEV void ssr_ssim_row_load(const SsrSsimParams& p, SsrSsimRegs<CPT>& R, int tid, const float* x, const float* y,
+SSR_DEV void ssr_ssim_row_load(const SsrSsimParams& p, SsrSsimRegs<CPT>& R, int tid, const SsrImage& x, const SsrImage& y,
                                int row_add, int row_sub, int c_in0, int ncol_in) {
   constexpr int VC = CPT + 1;
   const bool sub = row_sub >= 0;
-  // block-uniform row base pointers + 32-bit lane offsets (scalar-base addressing, no 64-bit VALU math)
-  const float* xra = x + (int64_t)row_add * p.F + c_in0;
-  const float* yra = y + (int64_t)row_add * p.F + c_in0;
-  const float* xrs = x + (int64_t)(sub ? row_sub : row_add) * p.F + c_in0;
-  const float* yrs = y + (int64_t)(sub ? row_sub : row_add) * p.F + c_in0;
+  const int64_t ea = (int64_t)row_add * p.F + c_in0;                       // block-uniform element offsets of the rows
+  const int64_t es = (int64_t)(sub ? row_sub : row_add) * p.F + c_in0;
 #pragma unroll
   for (int i = 0; i < VC; ++i) {
     int c = tid + SSR_SSIM_NT * i;
     if (c >= ncol_in) c = ncol_in - 1;
-    R.px[0][i] = xra[c];
-    R.px[1][i] = yra[c];
-    R.px[2][i] = xrs[c];
-    R.px[3][i] = yrs[c];
+    const unsigned uc = (unsigned)c;
+    R.px[0][i] = x.at(ea, uc);
+    R.px[1][i] = y.at(ea, uc);
+    R.px[2][i] = x.at(es, uc);
+    R.px[3][i] = y.at(es, uc);
   }
 }
 
@@ -152,8 +168,8 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
   const int ncol_in = (p.F - c_in0 < NT * CPT + (W - 1)) ? p.F - c_in0 : NT * CPT + (W - 1);
   const int ncol_out = ncol_in - (W - 1);
   double* part = p.part + (int64_t)item * p.n_row_tiles * p.n_strips + tile;
-  const float* x = p.x + p.frame_off[item] * p.F;
-  const float* y = p.y + p.frame_off[item] * p.F;
+  const SsrImage x(p.x + p.frame_off[item] * p.F, (int64_t)T * p.F);
+  const SsrImage y(p.y + p.frame_off[item] * p.F, (int64_t)T * p.F);
 
   SSR_REGS(Regs, regs, blk);
   if (r0 >= r1 || ncol_out <= 0) {

@@ -155,6 +155,29 @@ SSR_DEV unsigned ssr_mag_bits(double v) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// A read-only device array as the streaming loads see it: element `idx` (per lane, 32-bit) past a block-uniform
+// element offset.  Device: a raw buffer resource, i.e. scalar base + scalar offset + 32-bit lane offset in ONE
+// instruction (the compiler otherwise keeps a per-lane 64-bit pointer per load and advances each one with a vector
+// add every loop trip).  Host emulation: a plain pointer.  Arrays are limited to 4 GiB (checked on the host).
+template <typename E> struct SsrView {
+#ifdef SSR_HOST_EMU
+  const E* base;
+  SSR_MEMBER SsrView(const E* p, int64_t) : base(p) {}
+  SSR_MEMBER E at(unsigned idx, int64_t uniform_off = 0) const { return base[uniform_off + idx]; }
+#else
+  __amdgpu_buffer_rsrc_t rsrc;
+  SSR_MEMBER SsrView(const E* p, int64_t n_elems)
+      : rsrc(__builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(unsigned)(n_elems * (int64_t)sizeof(E)), 0x00020000)) {}
+  SSR_MEMBER E at(unsigned idx, int64_t uniform_off = 0) const {
+    const int vo = (int)(idx * (unsigned)sizeof(E)), so = (int)(unsigned)(uniform_off * (int64_t)sizeof(E));
+    if constexpr (sizeof(E) == 4) return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vo, so, 0));
+    else if constexpr (sizeof(E) == 8) return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b64(rsrc, vo, so, 0));
+    else return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, so, 0));
+  }
+#endif
+};
+
+// ------------------------------------------------------------------------------------------------
 // complex helpers
 template <typename T> struct cx { T x, y; };
 template <typename T> SSR_DEV cx<T> cadd(cx<T> a, cx<T> b) { return {a.x + b.x, a.y + b.y}; }

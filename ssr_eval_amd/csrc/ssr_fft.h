@@ -101,8 +101,12 @@ SSR_DEV void ssr_fft_load(int tid, const T* re, const T* im, cx<T>* v) {
 
 // The three table twiddles (w^1, w^2, w^4; radix 4: w^1, w^2) of butterfly b of pass PASS: thread-constant
 // addresses, so they can be requested a phase early (ssr_fft_mid_passes<..., PF = true>).
-template <typename T, int LOGN, int PASS, int PPT = 8>
-SSR_DEV void ssr_fft_load_tw(int tid, const cx<T>* __restrict__ tw, cx<T>* w) {
+// table access through a plain pointer or through an SsrView (raw buffer resource)
+template <typename T> SSR_DEV cx<T> ssr_tw_at(const cx<T>* tw, unsigned i) { return tw[i]; }
+template <typename T> SSR_DEV cx<T> ssr_tw_at(const SsrView<cx<T>>& tw, unsigned i) { return tw.at(i); }
+
+template <typename T, int LOGN, int PASS, int PPT = 8, typename TW>
+SSR_DEV void ssr_fft_load_tw(int tid, const TW& tw, cx<T>* w) {
   using P = SsrFftPlan<LOGN, PPT>;
   constexpr int R = P::radix(PASS), NB = PPT / R, NS = P::ns(PASS);
   if constexpr (NS > 1) {
@@ -110,9 +114,9 @@ SSR_DEV void ssr_fft_load_tw(int tid, const cx<T>* __restrict__ tw, cx<T>* w) {
     for (int b = 0; b < NB; ++b) {
       const int j = tid + b * P::NT;
       const unsigned ub = (unsigned)((j & (NS - 1)) * (P::N / (NS * R)));   // scalar table base + 32-bit lane offset
-      w[3 * b] = tw[ub];
-      w[3 * b + 1] = tw[2 * ub];
-      if constexpr (R == 8) w[3 * b + 2] = tw[4 * ub];
+      w[3 * b] = ssr_tw_at<T>(tw, ub);
+      w[3 * b + 1] = ssr_tw_at<T>(tw, 2 * ub);
+      if constexpr (R == 8) w[3 * b + 2] = ssr_tw_at<T>(tw, 4 * ub);
     }
   }
 }
@@ -149,8 +153,8 @@ SSR_DEV void ssr_fft_compute_tw(cx<T>* v, const cx<T>* w) {
   }
 }
 
-template <typename T, int LOGN, int PASS, int PPT = 8>
-SSR_DEV void ssr_fft_compute(int tid, cx<T>* v, const cx<T>* __restrict__ tw) {
+template <typename T, int LOGN, int PASS, int PPT = 8, typename TW>
+SSR_DEV void ssr_fft_compute(int tid, cx<T>* v, const TW& tw) {
   using P = SsrFftPlan<LOGN, PPT>;
   cx<T> w[3 * (PPT / P::radix(PASS))];
   ssr_fft_load_tw<T, LOGN, PASS, PPT>(tid, tw, w);
@@ -186,8 +190,8 @@ SSR_DEV void ssr_fft_store(int tid, T* re, T* im, const cx<T>* v) {
 // whose data registers are dead by then - so their L1/L2 latency overlaps the barrier and the LDS reads.  Regs must
 // then expose `cx<T> twp[3 * PPT / 8]`, and the CALLER has requested pass PASS's twiddles (ssr_fft_load_tw into
 // R.twp) in the phase that stored pass PASS - 1.
-template <typename T, int LOGN, int PASS, int PPT, bool PF = false, typename BLK, typename REGS>
-SSR_BODY void ssr_fft_mid_passes(BLK& blk, REGS& regs, T* re, T* im, const cx<T>* tw) {
+template <typename T, int LOGN, int PASS, int PPT, bool PF = false, typename BLK, typename REGS, typename TW>
+SSR_BODY void ssr_fft_mid_passes(BLK& blk, REGS& regs, T* re, T* im, const TW& tw) {
   using P = SsrFftPlan<LOGN, PPT>;
   if constexpr (PF) {
     SSR_PHASE(blk, regs, ssr_fft_load<T, LOGN, PASS, PPT>(tid, re, im, R.v);

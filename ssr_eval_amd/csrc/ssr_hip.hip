@@ -407,6 +407,7 @@ extern "C" int ssr_stft(const ssr_plan* pl, const float* wav, const int64_t* wav
   if (out_kind == SSR_STFT_COMPLEX && !out_b) return fail(SSR_ERR_INVALID_ARG, "complex output needs out_b");
   if (n_items <= 0) return SSR_OK;
   if (max_len < 1) return fail(SSR_ERR_INVALID_ARG, "empty signals");
+  if (max_len >= (1 << 29)) return fail(SSR_ERR_UNSUPPORTED, "signals of 2^29 samples or more (4 GiB buffer views)");
   hipStream_t s = (hipStream_t)stream;
   return pl->precision == SSR_F64
              ? stft_single_t<double>(pl, wav, wav_off, wav_len, frame_off, n_items, max_len, out_kind, out_a, out_b, s)
@@ -573,9 +574,12 @@ static int pair_metrics_impl(const ssr_plan* pl, const float* est, const double*
     return fail(SSR_ERR_INVALID_ARG, "null argument");
   if (n_items <= 0) return SSR_OK;
   if (max_len < 1) return fail(SSR_ERR_INVALID_ARG, "empty signals");
+  if (max_len >= (1 << 29)) return fail(SSR_ERR_UNSUPPORTED, "signals of 2^29 samples or more (4 GiB buffer views)");
   if ((mask & ~SSR_METRIC_ALL) || mask == 0) return fail(SSR_ERR_INVALID_ARG, "bad metric mask");
   const int max_T = (int)ssr_num_frames(pl, max_len);
   const bool want_ssim = mask & SSR_METRIC_SSIM;
+  if (want_ssim && (int64_t)max_T * pl->n_bins >= ((int64_t)1 << 30))
+    return fail(SSR_ERR_UNSUPPORTED, "spectrogram of 2^30 elements or more (4 GiB buffer views)");
   if (want_ssim && (max_T < 7 || pl->n_bins < 7)) return fail(SSR_ERR_INVALID_ARG, "win_size exceeds image extent");
   const PairWs w = pair_ws(pl, n_items, max_len, total_rows);
   // rows array lives at the tail of the ssim partial area's alignment slack: allocate it explicitly
@@ -663,6 +667,8 @@ extern "C" int ssr_spectrogram_metrics(const float* est_sp, const float* tgt_sp,
   if (n_items <= 0) return SSR_OK;
   if ((mask & ~SSR_METRIC_ALL) || mask == 0) return fail(SSR_ERR_INVALID_ARG, "bad metric mask");
   if (max_rows < 1 || n_bins < 1) return fail(SSR_ERR_INVALID_ARG, "empty spectrogram");
+  if ((int64_t)max_rows * n_bins >= ((int64_t)1 << 30))
+    return fail(SSR_ERR_UNSUPPORTED, "spectrogram of 2^30 elements or more (4 GiB buffer views)");
   const bool want_ssim = mask & SSR_METRIC_SSIM;
   if (want_ssim && (max_rows < 7 || n_bins < 7)) return fail(SSR_ERR_INVALID_ARG, "win_size exceeds image extent");
   const SpecWs w = spec_ws(n_items, max_rows, n_bins);

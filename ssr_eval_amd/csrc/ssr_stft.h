@@ -301,8 +301,8 @@ template <typename T, int LOGN, int PPT = 8> struct SsrStftLds {
 // registers.  Branch-free, always-valid addresses: a frame that does not exist re-reads the last one (the consumer
 // scales it by 0); frames that touch the signal ends go through the reflection index.
 template <typename T, int LOGN, int MODE, int PPT, typename SA, typename SB, typename REGS>
-SSR_DEV void ssr_stft_prefetch(const SsrStftParams<T>& p, REGS& R, int tid, const SA* sa, const SB* sb, int u, int n,
-                               int n_frames) {
+SSR_DEV void ssr_stft_prefetch(const SsrStftParams<T>& p, REGS& R, int tid, const SsrView<SA>& va, const SsrView<SB>& vb,
+                               const SsrView<T>& vw, int u, int n, int n_frames) {
   using P = SsrFftPlan<LOGN, PPT>;
   constexpr int N = 1 << LOGN, R0 = P::R0;
   const int ta = (MODE == SSR_MODE_PAIR) ? u : 2 * u;
@@ -312,24 +312,21 @@ SSR_DEV void ssr_stft_prefetch(const SsrStftParams<T>& p, REGS& R, int tid, cons
   // block-uniform: both frames lie fully inside the signal -> no reflection arithmetic at all
   const bool interior = base_a >= 0 && base_b >= 0 && base_a + N <= n && base_b + N <= n;
   if (interior) {
-    const SA* qa = sa + base_a;
-    const SB* qb = sb + base_b;
     SSR_UNROLL for (int r = 0; r < PPT; ++r) {
-      const int m = ssr_fft_first_index<LOGN, PPT>(tid, r);
-      R.pa[r] = qa[SSR_UIDX(m)];
-      R.pb[r] = qb[SSR_UIDX(m)];
+      const unsigned m = SSR_UIDX(ssr_fft_first_index<LOGN, PPT>(tid, r));
+      R.pa[r] = va.at(m, base_a);
+      R.pb[r] = vb.at(m, base_b);
     }
   } else {
     SSR_UNROLL for (int r = 0; r < PPT; ++r) {
       const int m = ssr_fft_first_index<LOGN, PPT>(tid, r);
-      R.pa[r] = sa[SSR_UIDX(ssr_reflect(base_a + m, n))];
-      R.pb[r] = sb[SSR_UIDX(ssr_reflect(base_b + m, n))];
+      R.pa[r] = va.at(SSR_UIDX(ssr_reflect(base_a + m, n)));
+      R.pb[r] = vb.at(SSR_UIDX(ssr_reflect(base_b + m, n)));
     }
   }
   // registers (b, q) and (b, q + R0/2) are N/2 samples apart: load the lower one of each pair
   SSR_UNROLL for (int r = 0; r < PPT; ++r)
-    if ((r % R0) < R0 / 2)
-      R.pw[(r / R0) * (R0 / 2) + (r % R0)] = p.window[ssr_launder_index(SSR_UIDX(ssr_fft_first_index<LOGN, PPT>(tid, r)))];
+    if ((r % R0) < R0 / 2) R.pw[(r / R0) * (R0 / 2) + (r % R0)] = vw.at(SSR_UIDX(ssr_fft_first_index<LOGN, PPT>(tid, r)));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -362,6 +359,10 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
   double* part = p.part ? p.part + ((int64_t)item * p.n_chunks + chunk) * SSR_NPART : nullptr;
   const bool want_lsd = (MODE == SSR_MODE_PAIR) && (p.metric_mask & SSR_M_LSD);
   const int pad = n_fft / 2;
+  const SsrView<SA> va(sa, n);                 // the item's two signals and the window table as the frame loads see them
+  const SsrView<SB> vb(sb, n);
+  const SsrView<T> vw(p.window, BLUESTEIN ? 0 : N);
+  const SsrView<cx<T>> vt(p.tw, N);           // twiddle table exp(-2 pi i k / N), k < N
 
   SSR_REGS(Regs, regs, blk);
   SSR_PHASE(blk, regs, {
@@ -369,7 +370,7 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
     if (tid == 0) L.res[0] = 0.0;
     for (int q = 0; q < (SUMS ? 6 : 1); ++q) R.sums[q] = 0.0;
     if constexpr (!BLUESTEIN)
-      if (u0 < u1) ssr_stft_prefetch<T, LOGN, MODE, PPT>(p, R, tid, sa, sb, u0, n, n_frames);
+      if (u0 < u1) ssr_stft_prefetch<T, LOGN, MODE, PPT>(p, R, tid, va, vb, vw, u0, n, n_frames);
   });
 
   BLK blk0 = blk;
@@ -447,9 +448,9 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
         nz_a_wave = SSR_WAVE_ANY(ora != 0u);      // reduced to a wave-uniform scalar before the butterflies start
         nz_b_wave = SSR_WAVE_ANY(orb != 0u);
       }
-      ssr_fft_compute<T, LOGN, 0, PPT>(tid, R.v, p.tw);
+      ssr_fft_compute<T, LOGN, 0, PPT>(tid, R.v, vt);
       ssr_fft_store<T, LOGN, 0, PPT>(tid, L.re, L.im, R.v);
-      if constexpr (PF) ssr_fft_load_tw<T, LOGN, 1, PPT>(tid, p.tw, R.twp);   // pass 1's twiddles, in flight across the barrier
+      if constexpr (PF) ssr_fft_load_tw<T, LOGN, 1, PPT>(tid, vt, R.twp);   // pass 1's twiddles, in flight across the barrier
       if constexpr (!BLUESTEIN) {
         SSR_WAVE_FLAG_STORE(tid, nz_a_wave, L.nz);
         SSR_WAVE_FLAG_STORE(tid, nz_b_wave, L.nz + 16);
@@ -461,7 +462,7 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
       }
     });
     // remaining forward passes; last pass stays in registers
-    ssr_fft_mid_passes<T, LOGN, 1, PPT, PF>(blk, regs, L.re, L.im, p.tw);
+    ssr_fft_mid_passes<T, LOGN, 1, PPT, PF>(blk, regs, L.re, L.im, vt);
 
     if constexpr (BLUESTEIN) {
       // forward spectrum * filter, stored as the INPUT of the inverse transform.  The inverse is the
@@ -478,10 +479,10 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
         }
       });
       SSR_PHASE(blk, regs, ssr_fft_load<T, LOGN, 0, PPT>(tid, L.im, L.re, R.v);
-                ssr_fft_compute<T, LOGN, 0, PPT>(tid, R.v, p.tw));
+                ssr_fft_compute<T, LOGN, 0, PPT>(tid, R.v, vt));
       SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, 0, PPT>(tid, L.im, L.re, R.v);
-                if constexpr (PF) ssr_fft_load_tw<T, LOGN, 1, PPT>(tid, p.tw, R.twp));
-      ssr_fft_mid_passes<T, LOGN, 1, PPT, PF>(blk, regs, L.im, L.re, p.tw);
+                if constexpr (PF) ssr_fft_load_tw<T, LOGN, 1, PPT>(tid, vt, R.twp));
+      ssr_fft_mid_passes<T, LOGN, 1, PPT, PF>(blk, regs, L.im, L.re, vt);
       // registers hold swap(IFFT*M): true real part = .y, true imaginary part = .x
       SSR_PHASE(blk, regs, {
         SSR_UNROLL for (int r = 0; r < PPT; ++r) {
@@ -505,7 +506,7 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
     if (MODE == SSR_MODE_PAIR) { ra1 = ra0; rb1 = rb0; }
     SSR_PHASE(blk, regs, {
       if constexpr (!BLUESTEIN)
-        if (u + 1 < u1) ssr_stft_prefetch<T, LOGN, MODE, PPT>(p, R, tid, sa, sb, u + 1, n, n_frames);
+        if (u + 1 < u1) ssr_stft_prefetch<T, LOGN, MODE, PPT>(p, R, tid, va, vb, vw, u + 1, n, n_frames);
       double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       const bool a_nz = L.any_nonzero(0), b_nz = L.any_nonzero(1);
 #if defined(SSR_ABL_NOEPI)     /* developer ablation: WRONG results, timing only */

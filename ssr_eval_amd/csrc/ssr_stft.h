@@ -363,6 +363,7 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
   const SsrView<SB> vb(sb, n);
   const SsrView<T> vw(p.window, BLUESTEIN ? 0 : N);
   const SsrView<cx<T>> vt(p.tw, N);           // twiddle table exp(-2 pi i k / N), k < N
+  const SsrView<cx<T>> vwc(p.wchirp, BLUESTEIN ? n_fft : 0), vbf(p.bfilt, BLUESTEIN ? N : 0), vch(p.chirp, BLUESTEIN ? n_fft : 0);
 
   SSR_REGS(Regs, regs, blk);
   SSR_PHASE(blk, regs, {
@@ -413,9 +414,9 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
               const int mc = (m < n_fft) ? m : n_fft - 1;
               const int ia = interior ? base_a + mc : ssr_reflect(base_a + mc, n);
               const int ib = interior ? base_b + mc : ssr_reflect(base_b + mc, n);
-              fa[r] = sa[SSR_UIDX(ia)];
-              fb[r] = sb[SSR_UIDX(ib)];
-              wc[r] = p.wchirp[SSR_UIDX(mc)];
+              fa[r] = va.at(SSR_UIDX(ia));
+              fb[r] = vb.at(SSR_UIDX(ib));
+              wc[r] = vwc.at(SSR_UIDX(mc));
             }
             SSR_UNROLL for (int r = 0; r < 4; ++r) {
               const int m = ssr_fft_first_index<LOGN, PPT>(tid, r0 + r);
@@ -471,7 +472,7 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
         SSR_UNROLL for (int r0 = 0; r0 < PPT; r0 += 4) {
           SSR_UNROLL for (int r = r0; r < r0 + 4; ++r) {
             const int k = ssr_fft_out_index<LOGN, LAST, PPT>(tid, r);
-            const cx<T> y = cmul(R.v[r], p.bfilt[SSR_UIDX(k)]);
+            const cx<T> y = cmul(R.v[r], vbf.at(SSR_UIDX(k)));
             L.re[ssr_pad(k)] = y.x;
             L.im[ssr_pad(k)] = y.y;
           }
@@ -488,7 +489,7 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
         SSR_UNROLL for (int r = 0; r < PPT; ++r) {
           const int k = ssr_fft_out_index<LOGN, LAST, PPT>(tid, r);
           if (k < n_fft) {
-            const cx<T> zk = cmul(cx<T>{R.v[r].y, R.v[r].x}, p.chirp[SSR_UIDX(k)]);
+            const cx<T> zk = cmul(cx<T>{R.v[r].y, R.v[r].x}, vch.at(SSR_UIDX(k)));
             L.re[ssr_pad(k)] = zk.x;
             L.im[ssr_pad(k)] = zk.y;
           }

@@ -59,6 +59,10 @@ SSR_BODY void ssr_stft_r3_body(const SsrStftParams<T>& p, BLK& blk, int chunk, i
   double* part = p.part ? p.part + ((int64_t)item * p.n_chunks + chunk) * SSR_NPART : nullptr;
   const bool want_lsd = (MODE == SSR_MODE_PAIR) && (p.metric_mask & SSR_M_LSD);
   const int pad = n_fft / 2;
+  // the item's signals and the plan tables as the loads see them (raw buffer resources on the device)
+  const SsrView<SA> va(sa, n);
+  const SsrView<SB> vb(sb, n);
+  const SsrView<cx<T>> vwc(p.wchirp, n_fft), vbf(p.bfilt, (int64_t)1 << LOGN), vch(p.chirp, n_fft), vt(p.tw, (int64_t)1 << LOGN);
 
   SSR_REGS(Regs, regs, blk);
   SSR_PHASE(blk, regs, {
@@ -76,8 +80,7 @@ SSR_BODY void ssr_stft_r3_body(const SsrStftParams<T>& p, BLK& blk, int chunk, i
     const bool interior = base_a >= 0 && base_b >= 0 && base_a + n_fft <= n && base_b + n_fft <= n;
 
     for (int r = 0; r < 3; ++r) {
-      const cx<T>* wch = p.wchirp + (size_t)r * q;
-      const cx<T>* post = p.chirp + (size_t)r * q;
+      const int64_t wch_off = (int64_t)r * q, post_off = (int64_t)r * q;      // round r's slice of the two chirp tables
       // ---- decimated frame (samples 3m + r) -> registers, pre-multiply, pass 0, store.
       // Only indices m < q are non-zero; q <= M/2, so at least the upper half of the registers is skipped.
       SSR_PHASE(blk, regs, {
@@ -90,9 +93,9 @@ SSR_BODY void ssr_stft_r3_body(const SsrStftParams<T>& p, BLK& blk, int chunk, i
             const int s3 = 3 * mc + r;
             const int ia = interior ? base_a + s3 : ssr_reflect(base_a + s3, n);
             const int ib = interior ? base_b + s3 : ssr_reflect(base_b + s3, n);
-            const SA fa = sa[SSR_UIDX(ia)];
-            const SB fb = sb[SSR_UIDX(ib)];
-            const cx<T> z = cmul(cx<T>{a_ok ? (T)fa : (T)0, b_ok ? (T)fb : (T)0}, wch[SSR_UIDX(mc)]);
+            const SA fa = va.at(SSR_UIDX(ia));
+            const SB fb = vb.at(SSR_UIDX(ib));
+            const cx<T> z = cmul(cx<T>{a_ok ? (T)fa : (T)0, b_ok ? (T)fb : (T)0}, vwc.at(SSR_UIDX(mc), wch_off));
             R.v[g] = (m < q) ? z : cx<T>{(T)0, (T)0};
             nza = nza || (m < q && fa != 0);
             nzb = nzb || (m < q && fb != 0);
@@ -103,36 +106,36 @@ SSR_BODY void ssr_stft_r3_body(const SsrStftParams<T>& p, BLK& blk, int chunk, i
         // non-zero flags of the frame: one slot per decimation round (three rounds make a frame)
         SSR_WAVE_ANY_STORE(tid, nza, L.nz + r * 4);
         SSR_WAVE_ANY_STORE(tid, nzb, L.nz + 16 + r * 4);
-        ssr_fft_compute<T, LOGN, 0, PPT>(tid, R.v, p.tw);
+        ssr_fft_compute<T, LOGN, 0, PPT>(tid, R.v, vt);
         ssr_fft_store<T, LOGN, 0, PPT>(tid, L.re, L.im, R.v);
-        ssr_fft_load_tw<T, LOGN, 1, PPT>(tid, p.tw, R.twp);          // pass 1's twiddles, in flight across the barrier
+        ssr_fft_load_tw<T, LOGN, 1, PPT>(tid, vt, R.twp);          // pass 1's twiddles, in flight across the barrier
         if (r == 0 && want_lsd && u > u0 && tid == 0) {               // close the previous unit's LSD
           double s = 0.0;
           for (int w = 0; w < NW; ++w) s += L.sc1[w];
           L.res[0] += sqrt(s / (double)F);
         }
       });
-      ssr_fft_mid_passes<T, LOGN, 1, PPT, true>(blk, regs, L.re, L.im, p.tw);
+      ssr_fft_mid_passes<T, LOGN, 1, PPT, true>(blk, regs, L.re, L.im, vt);
       SSR_PHASE(blk, regs, {
         SSR_UNROLL for (int g = 0; g < PPT; ++g) {
           const int k = ssr_fft_out_index<LOGN, LAST, PPT>(tid, g);
-          const cx<T> y = cmul(R.v[g], p.bfilt[SSR_UIDX(k)]);
+          const cx<T> y = cmul(R.v[g], vbf.at(SSR_UIDX(k)));
           L.re[ssr_pad(k)] = y.x;
           L.im[ssr_pad(k)] = y.y;
         }
       });
       SSR_PHASE(blk, regs, ssr_fft_load<T, LOGN, 0, PPT>(tid, L.im, L.re, R.v);
-                ssr_fft_compute<T, LOGN, 0, PPT>(tid, R.v, p.tw));
+                ssr_fft_compute<T, LOGN, 0, PPT>(tid, R.v, vt));
       SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, 0, PPT>(tid, L.im, L.re, R.v);
-                ssr_fft_load_tw<T, LOGN, 1, PPT>(tid, p.tw, R.twp));
-      ssr_fft_mid_passes<T, LOGN, 1, PPT, true>(blk, regs, L.im, L.re, p.tw);
+                ssr_fft_load_tw<T, LOGN, 1, PPT>(tid, vt, R.twp));
+      ssr_fft_mid_passes<T, LOGN, 1, PPT, true>(blk, regs, L.im, L.re, vt);
       // registers hold swap(IFFT * M): true real part = .y, true imaginary part = .x.  Park Y_r.
       // (yre / yim are only read by the epilogue, after the barrier that ends the r = 2 round.)
       SSR_PHASE(blk, regs, {
         SSR_UNROLL for (int g = 0; g < PPT; ++g) {
           const int k = ssr_fft_out_index<LOGN, LAST, PPT>(tid, g);
           if (k < q) {
-            const cx<T> y = cmul(cx<T>{R.v[g].y, R.v[g].x}, post[SSR_UIDX(k)]);
+            const cx<T> y = cmul(cx<T>{R.v[g].y, R.v[g].x}, vch.at(SSR_UIDX(k), post_off));
             yre[r * q + k] = y.x;
             yim[r * q + k] = y.y;
           }

@@ -192,46 +192,53 @@ SSR_DEV void ssr_accumulate_metrics(double e, double t, int mask, double* acc) {
   }
 }
 
-// Emit bin k of the current unit.  zk = Z[k], zn = Z[(n-k) mod n].  out_a_row / out_b_row: block-uniform
-// row base pointers (scalar base + 32-bit lane offset addressing).
-template <typename T, int MODE, int IN64 = 0>
-SSR_DEV void ssr_emit_bin(const SsrStftParams<T>& p, double* acc, unsigned k, cx<T> zk, cx<T> zn,
-                          float* row_a0, float* row_a1, float* row_b0, float* row_b1, bool b_valid, bool a_nz, bool b_nz) {
-  // An all-zero frame has an exactly zero spectrum in the reference (separate real FFTs).  In the packed transform
-  // the other signal leaks into it at round-off level (1e-16 of ITS magnitude), which is not negligible against
-  // the 1e-12 guards of the metrics - so the outputs of an all-zero frame are forced to exact zeros (a_nz / b_nz
-  // are block-uniform).
-  // PAIR  : row_a0 = est magnitudes row,  row_b0 = target magnitudes row
-  // SINGLE: row_a0 / row_a1 = rows of frames 2g / 2g+1 in out_a; row_b0 / row_b1 the same rows in out_b
+// One (est, target) bin of a pair: the two magnitudes out, the metric terms accumulated.  zk = Z[k], zn = Z[(n-k) mod n].
+// An all-zero frame has an exactly zero spectrum in the reference (separate real FFTs).  In the packed transform
+// the other signal leaks into it at round-off level (1e-16 of ITS magnitude), which is not negligible against
+// the 1e-12 guards of the metrics - so the outputs of an all-zero frame are forced to exact zeros (a_nz / b_nz
+// are block-uniform).
+template <typename T, int IN64>
+SSR_DEV void ssr_pair_bin(int mask, double* acc, cx<T> zk, cx<T> zn, bool a_nz, bool b_nz, float& e_out, float& t_out) {
   SsrBinOut<T> o = ssr_separate<T>(zk, zn);
   if (!a_nz) { o.ar = 0.0f; o.ai = 0.0f; }
   if (!b_nz) { o.br = 0.0f; o.bi = 0.0f; }
-  if constexpr (MODE == SSR_MODE_PAIR && IN64 == SSR_IN_BOTH64) {
+  if constexpr (IN64 == SSR_IN_BOTH64) {
     const double e = a_nz ? hypot((double)zk.x + (double)zn.x, (double)zk.y - (double)zn.y) : 0.0;
     const double t = b_nz ? hypot((double)zk.y + (double)zn.y, (double)zn.x - (double)zk.x) : 0.0;
-    if (p.out_kind == SSR_OUT_MAG) {
-      row_a0[k] = (float)e;
-      row_b0[k] = (float)t;
-    }
-    ssr_accumulate_metrics(e, t, p.metric_mask, acc);
-  } else if constexpr (MODE == SSR_MODE_PAIR && IN64 == SSR_IN_EST64) {
+    e_out = (float)e; t_out = (float)t;
+    ssr_accumulate_metrics(e, t, mask, acc);
+  } else if constexpr (IN64 == SSR_IN_EST64) {
     // numpy.abs(complex128) of the unrounded est spectrum; the SSIM image keeps its float32 layout (the
     // rounding moves SSIM by < 2e-7, tests/test_gpu_parity.py)
     const double e = a_nz ? hypot((double)zk.x + (double)zn.x, (double)zk.y - (double)zn.y) : 0.0;
     const float t = ssr_cabsf(o.br, o.bi);
-    if (p.out_kind == SSR_OUT_MAG) {
-      row_a0[k] = (float)e;
-      row_b0[k] = t;
-    }
-    ssr_accumulate_metrics(e, t, p.metric_mask, acc);
-  } else if constexpr (MODE == SSR_MODE_PAIR) {
+    e_out = (float)e; t_out = t;
+    ssr_accumulate_metrics(e, t, mask, acc);
+  } else {
     const float e = ssr_cabsf(o.ar, o.ai), t = ssr_cabsf(o.br, o.bi);
+    e_out = e; t_out = t;
+    ssr_accumulate_metrics(e, t, mask, acc);
+  }
+}
+
+// Emit bin k of the current unit.  out_a_row / out_b_row: block-uniform row base pointers (scalar base + 32-bit lane
+// offset addressing).
+// PAIR  : row_a0 = est magnitudes row,  row_b0 = target magnitudes row
+// SINGLE: row_a0 / row_a1 = rows of frames 2g / 2g+1 in out_a; row_b0 / row_b1 the same rows in out_b
+template <typename T, int MODE, int IN64 = 0>
+SSR_DEV void ssr_emit_bin(const SsrStftParams<T>& p, double* acc, unsigned k, cx<T> zk, cx<T> zn,
+                          float* row_a0, float* row_a1, float* row_b0, float* row_b1, bool b_valid, bool a_nz, bool b_nz) {
+  if constexpr (MODE == SSR_MODE_PAIR) {
+    float e, t;
+    ssr_pair_bin<T, IN64>(p.metric_mask, acc, zk, zn, a_nz, b_nz, e, t);
     if (p.out_kind == SSR_OUT_MAG) {
       row_a0[k] = e;
       row_b0[k] = t;
     }
-    ssr_accumulate_metrics(e, t, p.metric_mask, acc);
   } else {
+    SsrBinOut<T> o = ssr_separate<T>(zk, zn);
+    if (!a_nz) { o.ar = 0.0f; o.ai = 0.0f; }
+    if (!b_nz) { o.br = 0.0f; o.bi = 0.0f; }
     if (p.out_kind == SSR_OUT_MAG) {
       row_a0[k] = ssr_cabsf(o.ar, o.ai);
       if (b_valid) row_a1[k] = ssr_cabsf(o.br, o.bi);
@@ -268,6 +275,27 @@ SSR_DEV void ssr_epilogue_direct(const SsrStftParams<T>& p, double* acc, int tid
   }
 }
 
+// PAIR mode, direct engine: the same bins, but the magnitudes stay in registers - the caller stores them after it has
+// consumed the prefetched samples of the next frame (see the frame loop).
+template <typename T, int LOGN, int PPT, int IN64>
+SSR_DEV void ssr_epilogue_direct_pair(int mask, double* acc, int tid, const T* re, const T* im, bool a_nz, bool b_nz,
+                                      float* ev, float* tv, float& eq, float& tq) {
+  constexpr int N = 1 << LOGN, NT = N / PPT, RND = PPT / 2;
+  cx<T> zk[RND], zn[RND];
+#pragma unroll
+  for (int i = 0; i < RND; ++i) {
+    const int k = tid + i * NT, kn = (N - k) & (N - 1);
+    zk[i] = {re[ssr_pad(k)], im[ssr_pad(k)]};
+    zn[i] = {re[ssr_pad(kn)], im[ssr_pad(kn)]};
+  }
+#pragma unroll
+  for (int i = 0; i < RND; ++i) ssr_pair_bin<T, IN64>(mask, acc, zk[i], zn[i], a_nz, b_nz, ev[i], tv[i]);
+  if (tid == 0) {
+    const cx<T> zq = {re[ssr_pad(N / 2)], im[ssr_pad(N / 2)]};
+    ssr_pair_bin<T, IN64>(mask, acc, zq, zq, a_nz, b_nz, eq, tq);
+  }
+}
+
 // LDS carve-out (doubles first so every array stays 8-byte aligned)
 template <typename T, int LOGN, int PPT = 8> struct SsrStftLds {
   static constexpr int NT = (1 << LOGN) / PPT;
@@ -275,7 +303,8 @@ template <typename T, int LOGN, int PPT = 8> struct SsrStftLds {
   static constexpr int NW = (NT + 63) / 64;
   // sc1: per-wave LSD sums of the current frame; wacc: per-wave running SISpec sums [6][NW];
   // res[0]: running sum over frames of the per-frame LSD (thread 0);
-  // nz: per-wave "this frame of signal A / B has a non-zero sample" flags [2][16]
+  // nz: per-wave "this frame of signal A / B has a non-zero sample" flags [2][16]; the direct engine (<= 8 waves)
+  // keeps two sets [2][2][8], written one frame ahead
   static constexpr size_t bytes() { return sizeof(double) * (16 + 6 * 16 + 8 + 16) + sizeof(T) * 2 * PN; }
   double* sc1; double* wacc; double* res; int* nz; T* re; T* im;
   SSR_MEMBER explicit SsrStftLds(char* base) {
@@ -287,9 +316,9 @@ template <typename T, int LOGN, int PPT = 8> struct SsrStftLds {
     im = re + PN;
   }
   // block-uniform: does the current frame of signal A (which = 0) / B (which = 1) contain any non-zero sample?
-  SSR_MEMBER bool any_nonzero(int which) const {
+  SSR_MEMBER bool any_nonzero(int which, int par = 0) const {
     int f = 0;
-    for (int w = 0; w < NW; ++w) f |= nz[which * 16 + w];
+    for (int w = 0; w < NW; ++w) f |= nz[which * 16 + par * 8 + w];
 #ifndef SSR_HOST_EMU
     f = __builtin_amdgcn_readfirstlane(f);      // every lane read the same words: make the uniformity explicit (scalar branch)
 #endif
@@ -327,6 +356,20 @@ SSR_DEV void ssr_stft_prefetch(const SsrStftParams<T>& p, REGS& R, int tid, cons
   // registers (b, q) and (b, q + R0/2) are N/2 samples apart: load the lower one of each pair
   SSR_UNROLL for (int r = 0; r < PPT; ++r)
     if ((r % R0) < R0 / 2) R.pw[(r / R0) * (R0 / 2) + (r % R0)] = vw.at(SSR_UIDX(ssr_fft_first_index<LOGN, PPT>(tid, r)));
+}
+
+// Direct engine: silent-frame flags of the PREFETCHED unit (OR of the samples' magnitude bits per signal, reduced per
+// wave with a ballot) into flag set `par`.  Register 0 of thread 0 is sample m = 0, whose window weight is exactly 0:
+// it never reaches the transform and does not count.  Consuming the prefetched registers here is also what places
+// the wait for those loads (s_waitcnt vmcnt) at this point of the program.
+template <int PPT, typename REGS>
+SSR_DEV void ssr_stft_prefetched_flags(const REGS& R, int tid, int* nz, int par) {
+  unsigned ora = 0u, orb = 0u;
+  SSR_UNROLL for (int r = 1; r < PPT; ++r) { ora |= ssr_mag_bits(R.pa[r]); orb |= ssr_mag_bits(R.pb[r]); }
+  ora |= (tid == 0) ? 0u : ssr_mag_bits(R.pa[0]);
+  orb |= (tid == 0) ? 0u : ssr_mag_bits(R.pb[0]);
+  SSR_WAVE_ANY_STORE(tid, ora != 0u, nz + par * 8);
+  SSR_WAVE_ANY_STORE(tid, orb != 0u, nz + 16 + par * 8);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -371,7 +414,11 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
     if (tid == 0) L.res[0] = 0.0;
     for (int q = 0; q < (SUMS ? 6 : 1); ++q) R.sums[q] = 0.0;
     if constexpr (!BLUESTEIN)
-      if (u0 < u1) ssr_stft_prefetch<T, LOGN, MODE, PPT>(p, R, tid, va, vb, vw, u0, n, n_frames);
+      if (u0 < u1) {
+        ssr_stft_prefetch<T, LOGN, MODE, PPT>(p, R, tid, va, vb, vw, u0, n, n_frames);
+        ssr_stft_prefetched_flags<PPT>(R, tid, L.nz, 0);
+        SSR_UNROLL for (int i = 0; i < PPT / 2; ++i) ssr_touch(R.pw[i]);   // same state at the loop head on both paths
+      }
   });
 
   BLK blk0 = blk;
@@ -394,7 +441,6 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
     // branch-free, always-valid addresses, so the frame pays ONE memory latency instead of 24 dependent
     // ones.  Thread 0 also closes the PREVIOUS frame's LSD (per-wave sums left in sc1 by its epilogue).
     SSR_PHASE(blk, regs, {
-      int nz_a_wave = 1, nz_b_wave = 1;
       if constexpr (BLUESTEIN) {
         // Four points at a time (sample pair + window*chirp value each), fenced, so that at 16 points per
         // thread the address and table registers of one group die before the next group is issued.
@@ -440,22 +486,10 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
           const T w = ((r % R0) < R0 / 2) ? wl : (T)0.5 - wl;           // w[m + N/2] = 1/2 - w[m]
           R.v[r] = {a_ok ? (T)R.pa[r] * w : (T)0, b_ok ? (T)R.pb[r] * w : (T)0};
         }
-        // silent-frame flags: OR of the samples' magnitude bits, one register per signal
-        // (register 0 of thread 0 is sample m = 0, whose window weight is exactly 0: it never reaches the transform)
-        unsigned ora = 0u, orb = 0u;
-        SSR_UNROLL for (int r = 1; r < PPT; ++r) { ora |= ssr_mag_bits(R.pa[r]); orb |= ssr_mag_bits(R.pb[r]); }
-        ora |= (tid == 0) ? 0u : ssr_mag_bits(R.pa[0]);
-        orb |= (tid == 0) ? 0u : ssr_mag_bits(R.pb[0]);
-        nz_a_wave = SSR_WAVE_ANY(ora != 0u);      // reduced to a wave-uniform scalar before the butterflies start
-        nz_b_wave = SSR_WAVE_ANY(orb != 0u);
       }
       ssr_fft_compute<T, LOGN, 0, PPT>(tid, R.v, vt);
       ssr_fft_store<T, LOGN, 0, PPT>(tid, L.re, L.im, R.v);
       if constexpr (PF) ssr_fft_load_tw<T, LOGN, 1, PPT>(tid, vt, R.twp);   // pass 1's twiddles, in flight across the barrier
-      if constexpr (!BLUESTEIN) {
-        SSR_WAVE_FLAG_STORE(tid, nz_a_wave, L.nz);
-        SSR_WAVE_FLAG_STORE(tid, nz_b_wave, L.nz + 16);
-      }
       if (want_lsd && u > u0 && tid == 0) {
         double s = 0.0;
         for (int w = 0; w < NW; ++w) s += L.sc1[w];
@@ -509,17 +543,45 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
       if constexpr (!BLUESTEIN)
         if (u + 1 < u1) ssr_stft_prefetch<T, LOGN, MODE, PPT>(p, R, tid, va, vb, vw, u + 1, n, n_frames);
       double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      const bool a_nz = L.any_nonzero(0), b_nz = L.any_nonzero(1);
+      const int par = BLUESTEIN ? 0 : ((u - u0) & 1);               // flag set of this unit (direct engine: two sets)
+      const bool a_nz = L.any_nonzero(0, par), b_nz = L.any_nonzero(1, par);
 #if defined(SSR_ABL_NOEPI)     /* developer ablation: WRONG results, timing only */
       if (tid == 0) {
         const cx<T> z0 = {L.re[0], L.im[0]};
         ssr_emit_bin<T, MODE, IN64>(p, acc, 0u, z0, z0, ra0, ra1, rb0, rb1, b_ok, true, true);
       }
 #else
-      if constexpr (!BLUESTEIN) {
+      if constexpr (!BLUESTEIN && MODE == SSR_MODE_PAIR) {
+        // The magnitudes stay in registers until the next unit's prefetched samples have been consumed (their flags):
+        // vmcnt retires in order, so loads that are waited for BEFORE this unit's stores are issued never wait on the
+        // stores' acknowledgements - and the next unit's first phase finds its samples already there.
+        constexpr int RND = PPT / 2;
+        float ev[RND], tv[RND], eq = 0.0f, tq = 0.0f;
         // block-uniform branch: the common case (no silent frame) carries no zero-forcing selects at all
+        if (a_nz && b_nz) ssr_epilogue_direct_pair<T, LOGN, PPT, IN64>(p.metric_mask, acc, tid, L.re, L.im, true, true, ev, tv, eq, tq);
+        else ssr_epilogue_direct_pair<T, LOGN, PPT, IN64>(p.metric_mask, acc, tid, L.re, L.im, a_nz, b_nz, ev, tv, eq, tq);
+        if (u + 1 < u1) {
+          ssr_stft_prefetched_flags<PPT>(R, tid, L.nz, par ^ 1);
+          SSR_UNROLL for (int i = 0; i < PPT / 2; ++i) ssr_touch(R.pw[i]);       // the window values as well
+        }
+        SSR_SCHED_BARRIER();
+        if (p.out_kind == SSR_OUT_MAG) {
+          SSR_UNROLL for (int i = 0; i < RND; ++i) {
+            ra0[SSR_UIDX(tid + i * NT)] = ev[i];
+            rb0[SSR_UIDX(tid + i * NT)] = tv[i];
+          }
+          if (tid == 0) {
+            ra0[N / 2] = eq;
+            rb0[N / 2] = tq;
+          }
+        }
+      } else if constexpr (!BLUESTEIN) {
         if (a_nz && b_nz) ssr_epilogue_direct<T, LOGN, MODE, PPT, IN64>(p, acc, tid, L.re, L.im, ra0, ra1, rb0, rb1, b_ok, true, true);
         else ssr_epilogue_direct<T, LOGN, MODE, PPT, IN64>(p, acc, tid, L.re, L.im, ra0, ra1, rb0, rb1, b_ok, a_nz, b_nz);
+        if (u + 1 < u1) {
+          ssr_stft_prefetched_flags<PPT>(R, tid, L.nz, par ^ 1);
+          SSR_UNROLL for (int i = 0; i < PPT / 2; ++i) ssr_touch(R.pw[i]);
+        }
       } else {
         for (int k = tid; k < F; k += NT) {
           const int kn = (k == 0) ? 0 : n_fft - k;

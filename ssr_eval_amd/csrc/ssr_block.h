@@ -24,7 +24,7 @@
 #define SSR_HD static inline
 #define SSR_SCHED_FENCE() do {} while (0)
 #define SSR_SCHED_BARRIER() do {} while (0)
-template <typename V> static inline void ssr_touch(const V&) {}
+template <typename V> static inline void ssr_touch(V&) {}
 #define SSR_UNROLL
 #define SSR_UNROLL4
 struct SsrBlk { int nt; };
@@ -82,10 +82,11 @@ static inline double ssr_fadd_rn(double a, double b) { volatile double r = a + b
 #define SSR_SCHED_FENCE() asm volatile("" ::: "memory")
 // instruction-scheduler barrier: nothing is moved across this point
 #define SSR_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
-// "this register is needed here": a zero-instruction use that makes the compiler place the wait for an outstanding
-// load that fills it at this point
-SSR_DEV void ssr_touch(const float& v) { asm volatile("" ::"v"(v)); }
-SSR_DEV void ssr_touch(const double& v) { asm volatile("" ::"v"(v)); }
+// "this register is needed here": a zero-instruction read-modify-write that makes the compiler place the wait for an
+// outstanding load that fills it at this point - and makes the value a product of this point of the program, no
+// longer of the load (nothing downstream is tied to the memory counters any more)
+SSR_DEV void ssr_touch(float& v) { asm volatile("" : "+v"(v)); }
+SSR_DEV void ssr_touch(double& v) { asm volatile("" : "+v"(v)); }
 // full unroll (usable inside SSR_PHASE macro arguments): register arrays must only be indexed statically
 #define SSR_UNROLL _Pragma("unroll")
 #define SSR_UNROLL4 _Pragma("unroll 4")

@@ -360,10 +360,12 @@ SSR_DEV void ssr_stft_prefetch(const SsrStftParams<T>& p, REGS& R, int tid, cons
 
 // Direct engine: silent-frame flags of the PREFETCHED unit (OR of the samples' magnitude bits per signal, reduced per
 // wave with a ballot) into flag set `par`.  Register 0 of thread 0 is sample m = 0, whose window weight is exactly 0:
-// it never reaches the transform and does not count.  Consuming the prefetched registers here is also what places
-// the wait for those loads (s_waitcnt vmcnt) at this point of the program.
+// it never reaches the transform and does not count.  Touching the prefetched registers (samples and window values)
+// here is also what places the wait for those loads (s_waitcnt vmcnt) at this point of the program.
 template <int PPT, typename REGS>
-SSR_DEV void ssr_stft_prefetched_flags(const REGS& R, int tid, int* nz, int par) {
+SSR_DEV void ssr_stft_prefetched_flags(REGS& R, int tid, int* nz, int par) {
+  SSR_UNROLL for (int r = 0; r < PPT; ++r) { ssr_touch(R.pa[r]); ssr_touch(R.pb[r]); }
+  SSR_UNROLL for (int i = 0; i < PPT / 2; ++i) ssr_touch(R.pw[i]);
   unsigned ora = 0u, orb = 0u;
   SSR_UNROLL for (int r = 1; r < PPT; ++r) { ora |= ssr_mag_bits(R.pa[r]); orb |= ssr_mag_bits(R.pb[r]); }
   ora |= (tid == 0) ? 0u : ssr_mag_bits(R.pa[0]);
@@ -417,7 +419,6 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
       if (u0 < u1) {
         ssr_stft_prefetch<T, LOGN, MODE, PPT>(p, R, tid, va, vb, vw, u0, n, n_frames);
         ssr_stft_prefetched_flags<PPT>(R, tid, L.nz, 0);
-        SSR_UNROLL for (int i = 0; i < PPT / 2; ++i) ssr_touch(R.pw[i]);   // same state at the loop head on both paths
       }
   });
 
@@ -560,10 +561,7 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
         // block-uniform branch: the common case (no silent frame) carries no zero-forcing selects at all
         if (a_nz && b_nz) ssr_epilogue_direct_pair<T, LOGN, PPT, IN64>(p.metric_mask, acc, tid, L.re, L.im, true, true, ev, tv, eq, tq);
         else ssr_epilogue_direct_pair<T, LOGN, PPT, IN64>(p.metric_mask, acc, tid, L.re, L.im, a_nz, b_nz, ev, tv, eq, tq);
-        if (u + 1 < u1) {
-          ssr_stft_prefetched_flags<PPT>(R, tid, L.nz, par ^ 1);
-          SSR_UNROLL for (int i = 0; i < PPT / 2; ++i) ssr_touch(R.pw[i]);       // the window values as well
-        }
+        if (u + 1 < u1) ssr_stft_prefetched_flags<PPT>(R, tid, L.nz, par ^ 1);
         SSR_SCHED_BARRIER();
         if (p.out_kind == SSR_OUT_MAG) {
           SSR_UNROLL for (int i = 0; i < RND; ++i) {
@@ -578,10 +576,7 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
       } else if constexpr (!BLUESTEIN) {
         if (a_nz && b_nz) ssr_epilogue_direct<T, LOGN, MODE, PPT, IN64>(p, acc, tid, L.re, L.im, ra0, ra1, rb0, rb1, b_ok, true, true);
         else ssr_epilogue_direct<T, LOGN, MODE, PPT, IN64>(p, acc, tid, L.re, L.im, ra0, ra1, rb0, rb1, b_ok, a_nz, b_nz);
-        if (u + 1 < u1) {
-          ssr_stft_prefetched_flags<PPT>(R, tid, L.nz, par ^ 1);
-          SSR_UNROLL for (int i = 0; i < PPT / 2; ++i) ssr_touch(R.pw[i]);
-        }
+        if (u + 1 < u1) ssr_stft_prefetched_flags<PPT>(R, tid, L.nz, par ^ 1);
       } else {
         for (int k = tid; k < F; k += NT) {
           const int kn = (k == 0) ? 0 : n_fft - k;

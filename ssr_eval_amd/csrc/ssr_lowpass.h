@@ -45,6 +45,10 @@ SSR_BODY void ssr_lowpass_frames_body(const SsrLowpassParams<T>& p, BLK& blk, in
   const float* sig = analysis ? p.in + p.in_off[item] : nullptr;
   const int cut = analysis ? p.cut[item] : F;
   const T inv_n = (T)1 / (T)N;
+  // signal and plan tables as the loads see them (raw buffer resources on the device)
+  const SsrView<float> vs(analysis ? sig : p.spec_re, analysis ? n : 0);
+  const SsrView<T> vw(p.window, N);
+  const SsrView<cx<T>> vt(p.tw, N);
 
   SSR_REGS(Regs, regs, blk);
   for (int g = g0; g < g1; ++g) {
@@ -56,15 +60,17 @@ SSR_BODY void ssr_lowpass_frames_body(const SsrLowpassParams<T>& p, BLK& blk, in
         T w[8];
         SSR_UNROLL for (int r = 0; r < 8; ++r) {       // all loads first (branch-free addresses), then the arithmetic
           const int m = ssr_fft_first_index<LOGN>(tid, r);
-          fa[r] = ssr_frame_sample_raw(sig, n, ta, n_frames, m, N, hop);
-          fb[r] = ssr_frame_sample_raw(sig, n, tb, n_frames, m, N, hop);
-          w[r] = p.window[m];
+          const int tb_c = (tb < n_frames) ? tb : n_frames - 1;          // a missing frame re-reads the last one
+          fa[r] = vs.at(SSR_UIDX(ssr_reflect(ta * hop + m - N / 2, n)));
+          fb[r] = vs.at(SSR_UIDX(ssr_reflect(tb_c * hop + m - N / 2, n)));
+          w[r] = vw.at(SSR_UIDX(m));
         }
         SSR_UNROLL for (int r = 0; r < 8; ++r) R.v[r] = {(T)fa[r] * w[r], b_valid ? (T)fb[r] * w[r] : (T)0};
-        ssr_fft_compute<T, LOGN, 0>(tid, R.v, p.tw);
+        ssr_fft_compute<T, LOGN, 0>(tid, R.v, vt);
         ssr_fft_store<T, LOGN, 0>(tid, L.re, L.im, R.v);
+        ssr_fft_load_tw<T, LOGN, 1, 8>(tid, vt, R.twp);                 // pass 1's twiddles, in flight across the barrier
       });
-      ssr_fft_mid_passes<T, LOGN, 1, 8>(blk, regs, L.re, L.im, p.tw);
+      ssr_fft_mid_passes<T, LOGN, 1, 8, true>(blk, regs, L.re, L.im, vt);
       SSR_PHASE(blk, regs, {
         SSR_UNROLL for (int r = 0; r < 8; ++r) {
           const int k = ssr_fft_out_index<LOGN, LAST>(tid, r);
@@ -75,7 +81,7 @@ SSR_BODY void ssr_lowpass_frames_body(const SsrLowpassParams<T>& p, BLK& blk, in
       });
       // inverse = forward engine on exchanged arrays
       SSR_PHASE(blk, regs, ssr_fft_load<T, LOGN, 0>(tid, L.im, L.re, R.v);
-                ssr_fft_compute<T, LOGN, 0>(tid, R.v, p.tw));
+                ssr_fft_compute<T, LOGN, 0>(tid, R.v, vt));
     } else {
       // ISTFT mode: pack Z = Xa + i*Xb (Hermitian-extended) straight into inverse pass-0 registers
       SSR_PHASE(blk, regs, {
@@ -91,16 +97,17 @@ SSR_BODY void ssr_lowpass_frames_body(const SsrLowpassParams<T>& p, BLK& blk, in
           // Z = (ar - bi) + i (ai + br); inverse engine input is swap(Z)
           R.v[r] = {ai + br, ar - bi};
         }
-        ssr_fft_compute<T, LOGN, 0>(tid, R.v, p.tw);
+        ssr_fft_compute<T, LOGN, 0>(tid, R.v, vt);
       });
     }
-    SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, 0>(tid, L.im, L.re, R.v));
-    ssr_fft_mid_passes<T, LOGN, 1, 8>(blk, regs, L.im, L.re, p.tw);
+    SSR_PHASE(blk, regs, ssr_fft_store<T, LOGN, 0>(tid, L.im, L.re, R.v);
+              ssr_fft_load_tw<T, LOGN, 1, 8>(tid, vt, R.twp));
+    ssr_fft_mid_passes<T, LOGN, 1, 8, true>(blk, regs, L.im, L.re, vt);
     // registers: swap(N * IFFT): frame ta = .y, frame tb = .x.  Window, scale, write (coalesced).
     SSR_PHASE(blk, regs, {
       SSR_UNROLL for (int r = 0; r < 8; ++r) {
         const int m = ssr_fft_out_index<LOGN, LAST>(tid, r);
-        const T w = p.window[m] * inv_n;
+        const T w = vw.at(SSR_UIDX(m)) * inv_n;
         p.frames[(row0 + ta) * N + m] = (float)(R.v[r].y * w);
         if (b_valid) p.frames[(row0 + tb) * N + m] = (float)(R.v[r].x * w);
       }

@@ -51,7 +51,12 @@ static inline unsigned ssr_launder_index(unsigned i) { return i; }
     if (((tid) & 63) == 0) (dst)[(tid) >> 6] = 0;           \
     if (flag) (dst)[(tid) >> 6] = 1;                        \
   } while (0)
-#define SSR_WAVE_ANY_STORE(tid, pred, dst) SSR_WAVE_FLAG_STORE(tid, SSR_WAVE_ANY(pred), dst)
+// (the wave-wide vote is taken BEFORE the single-lane store: inside that branch only one lane would be voting)
+#define SSR_WAVE_ANY_STORE(tid, pred, dst)                  \
+  do {                                                      \
+    const int any_ = SSR_WAVE_ANY(pred);                    \
+    SSR_WAVE_FLAG_STORE(tid, any_, dst);                    \
+  } while (0)
 static inline float ssr_fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 static inline float ssr_fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 static inline double ssr_fmul_rn(double a, double b) { volatile double r = a * b; return r; }
@@ -129,7 +134,12 @@ SSR_DEV int ssr_wave_index(int tid) { return __builtin_amdgcn_readfirstlane(tid)
   do {                                                                             \
     if (((tid) & 63) == 0) (dst)[ssr_wave_index(tid)] = (flag);                    \
   } while (0)
-#define SSR_WAVE_ANY_STORE(tid, pred, dst) SSR_WAVE_FLAG_STORE(tid, SSR_WAVE_ANY(pred), dst)
+// (the wave-wide vote is taken BEFORE the single-lane store: inside that branch only one lane would be voting)
+#define SSR_WAVE_ANY_STORE(tid, pred, dst)                  \
+  do {                                                      \
+    const int any_ = SSR_WAVE_ANY(pred);                    \
+    SSR_WAVE_FLAG_STORE(tid, any_, dst);                    \
+  } while (0)
 // Separately rounded multiply and add.  HIP's __fmul_rn/__fadd_rn are plain `*` / `+` and hipcc's default
 // -ffp-contract=fast would fuse them into one v_fma_f32; the pragma strips the `contract` flag from
 // these two instructions so they can never be fused (needed for bit-identity with SciPy's upfirdn).

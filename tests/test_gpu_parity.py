@@ -668,3 +668,33 @@ def test_full_size_properties_cfg4():
         # SISpec on utterances of up to 9 s: the reference's float32 torch.norm / sum over ~1e6 elements (vectorised,
         # thread-count dependent) is itself only good to ~1e-5 relative; the kernels accumulate in float64
         np.testing.assert_allclose(full[i][[1, 2]], want[[1, 2]], rtol=3e-5)
+
+
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (2229, 480), (743, 160), (256, 64), (4096, 1024)])
+def test_partially_silent_signals(n_fft, hop):
+    """A stretch of digital silence in the middle of one signal: only SOME frames are all-zero, and only some waves of
+    a frame see non-zero samples - the per-wave vote that gates the zero-forcing has to be taken by the whole wave
+    (a vote taken inside the single-lane store branch passed the CPU emulation and failed here)."""
+    from ssr_eval_amd import backend as B
+    from oracle import metrics as om, stft as ostft
+    rng = np.random.default_rng(n_fft + 1)
+    plan = B.get_plan(n_fft, hop, "f64")
+    n = 7 * hop + 5 * n_fft + 1234
+    t = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    e = (t + 0.02 * rng.standard_normal(n)).astype(np.float32)
+    e_sil, t_sil = e.copy(), t.copy()
+    e_sil[n // 3: n // 3 + 2 * n_fft + 77] = 0.0
+    t_sil[n // 2: n // 2 + n_fft + hop + 5] = 0.0
+    ests, tgts = [e_sil, e, e_sil], [t, t_sil, t_sil]
+    got = B.pair_metrics(plan, ests, tgts)
+    for x_e, x_t, g in zip(ests, tgts, got):
+        np.testing.assert_allclose(g, _vec(om.evaluation(x_e, x_t, n_fft=n_fft, hop=hop)), rtol=2e-5, atol=1e-5)
+    for x, m in zip([e_sil, t_sil], B.stft(plan, [e_sil, t_sil])):           # frame pairs of ONE signal (single mode)
+        ref = ostft.stft_mag_TF(x, n_fft, hop)
+        m = m.cpu().numpy()
+        assert ((m == 0) == (ref == 0)).all() and (ref == 0).all(axis=1).any()
+        assert np.abs(m - ref).max() <= 3e-7 * ref.max()
+    re, im = B.stft(plan, [t_sil], kind="complex")
+    spec = ostft.librosa_stft(t_sil, n_fft, hop).T
+    assert np.abs(re[0].cpu().numpy() - spec.real).max() <= 3e-7 * np.abs(spec).max()
+    assert np.abs(im[0].cpu().numpy() - spec.imag).max() <= 3e-7 * np.abs(spec).max()

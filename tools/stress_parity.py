@@ -1,0 +1,53 @@
+"""Developer tool: long randomized HIP-vs-oracle sweep (pair metrics, STFT magnitude / complex, silent segments, ragged
+batches, every engine).  Prints the worst relative errors; exits non-zero on a miss.  Not part of the test suite."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ssr_eval_amd import backend as B
+from oracle import metrics as om, stft as ostft
+
+def main():
+    n_cases = int(os.environ.get("CASES", "60"))
+    rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
+    sizes = [(2048, 512), (2229, 480), (2048, 441), (1024, 256), (743, 160), (1114, 240), (1486, 320), (512, 100), (4096, 1024), (256, 64), (771, 100)]
+    worst = np.zeros(4); worst_mag = 0.0; bad = 0
+    for case in range(n_cases):
+        n_fft, hop = sizes[int(rng.integers(0, len(sizes)))]
+        plan = B.get_plan(n_fft, hop, "f64")
+        n_items = int(rng.integers(1, 7))
+        ests, tgts = [], []
+        for _ in range(n_items):
+            n = int(rng.integers(7 * hop + n_fft // 2 + 1, 7 * hop + 5 * n_fft + 3000))
+            t = (0.1 * rng.standard_normal(n)).astype(np.float32)
+            kind = int(rng.integers(0, 5))
+            if kind == 0: e = (t + 0.02 * rng.standard_normal(n)).astype(np.float32)
+            elif kind == 1: e = (0.3 * t + 0.05 * rng.standard_normal(n)).astype(np.float32)
+            elif kind == 2: e = np.convolve(t, np.ones(9, np.float32) / 9, mode="same").astype(np.float32)
+            elif kind == 3:                       # silent stretch in the estimate
+                e = (t + 0.02 * rng.standard_normal(n)).astype(np.float32); a = int(rng.integers(0, n // 2)); e[a:a + int(rng.integers(n_fft, 3 * n_fft))] = 0
+            else:                                 # silent stretch in the target
+                e = (t + 0.02 * rng.standard_normal(n)).astype(np.float32); t = t.copy(); a = int(rng.integers(0, n // 2)); t[a:a + int(rng.integers(n_fft, 3 * n_fft))] = 0
+            ests.append(e); tgts.append(t)
+        got = B.pair_metrics(plan, ests, tgts)
+        mags = B.stft(plan, ests)
+        re, im = B.stft(plan, tgts, kind="complex")
+        for i, (e, t) in enumerate(zip(ests, tgts)):
+            w = om.evaluation(e, t, n_fft=n_fft, hop=hop)
+            want = np.array([w["lsd"], w["log_sispec"], w["sispec"], w["ssim"]])
+            rel = np.abs(got[i] - want) / np.maximum(np.abs(want), 1e-3)
+            worst = np.maximum(worst, rel)
+            ref = ostft.stft_mag_TF(e, n_fft, hop)
+            dm = np.abs(mags[i].cpu().numpy() - ref).max() / ref.max()
+            spec = ostft.librosa_stft(t, n_fft, hop).T
+            dc = max(np.abs(re[i].cpu().numpy() - spec.real).max(), np.abs(im[i].cpu().numpy() - spec.imag).max()) / np.abs(spec).max()
+            zero_ok = ((mags[i].cpu().numpy() == 0) == (ref == 0)).all()
+            worst_mag = max(worst_mag, dm, dc)
+            if (rel > 3e-5).any() or dm > 3e-7 or dc > 3e-7 or not zero_ok:
+                bad += 1
+                print("MISS case %d n_fft=%d hop=%d n=%d rel=%s dm=%.2e dc=%.2e zero_ok=%s got=%s want=%s" % (case, n_fft, hop, len(e), rel, dm, dc, zero_ok, got[i], want))
+    print("cases", n_cases, "worst rel (lsd, log_sispec, sispec, ssim)", worst, "worst mag", worst_mag, "misses", bad)
+    sys.exit(1 if bad else 0)
+
+if __name__ == "__main__":
+    main()

@@ -215,6 +215,8 @@ def stft(plan, wavs, kind="mag", torch_style_pad=False):
     otherwise short signals are reflect-padded repeatedly, as numpy.pad / librosa do."""
     with torch.cuda.device(plan.device):
         r = wavs if isinstance(wavs, Ragged) else Ragged.from_list(wavs, plan.device)
+        if r.n == 0:
+            return ([], []) if kind == "complex" else []
         if torch_style_pad:
             _check_reflect(plan, r.lens_host)
         _check_nonempty(r.lens_host)
@@ -313,6 +315,8 @@ def fft_lowpass(plan, wavs, cut_bins):
     """STFT-domain hard low-pass (K6) of a list of waveforms; cut_bins: first zeroed bin per item."""
     with torch.cuda.device(plan.device):
         r = wavs if isinstance(wavs, Ragged) else Ragged.from_list(wavs, plan.device)
+        if r.n == 0:
+            return []
         _check_reflect(plan, r.lens_host)
         rows = _Rows(plan, r.lens_host, r.device)
         cut = torch.from_numpy(np.asarray(cut_bins, dtype=np.int32)).to(r.device)
@@ -331,6 +335,8 @@ def istft(plan, res, ims, lengths):
     with torch.cuda.device(plan.device):
         dev = plan.device
         lens = np.asarray(lengths, dtype=np.int64)
+        if len(lens) == 0:
+            return []
         _check_reflect(plan, lens)
         rows = _Rows(plan, lens, dev)
         for r_, t_ in zip(res, rows.T):
@@ -426,7 +432,9 @@ def sosfiltfilt(sos, wavs, device=None):
     edge = 3 * ntaps
     with torch.cuda.device(dev):
         r = wavs if isinstance(wavs, Ragged) else Ragged.from_list_keep64(wavs, dev)
-        if r.n and int(r.lens_host.min()) <= edge:
+        if r.n == 0:
+            return []
+        if int(r.lens_host.min()) <= edge:
             raise ValueError("The length of the input vector x must be greater than padlen, which is %d." % edge)
         lib = _lib.load()
         total = int(r.lens_host.sum())

@@ -39,7 +39,10 @@ extern "C" int ssr_version(void) { return SSR_VERSION; }
 #ifndef SSR_MINW
 #define SSR_MINW 4
 #endif
-constexpr int ssr_stft_min_waves(int logn, bool blu, bool sums) { return (logn == 11 && !blu && !sums) ? SSR_MINW : 1; }
+#ifndef SSR_MINW_SUMS
+#define SSR_MINW_SUMS 0
+#endif
+constexpr int ssr_stft_min_waves(int logn, bool blu, bool sums) { return (logn == 11 && !blu && (!sums || SSR_MINW_SUMS)) ? SSR_MINW : 1; }
 // E64 (SSR_IN_EST64 / SSR_IN_BOTH64): float64 signals (pair mode only); their float64 epilogue needs more registers,
 // so those variants are left to the allocator (min waves 1).
 template <typename T, int LOGN, bool BLU, int MODE, bool SUMS, int E64>

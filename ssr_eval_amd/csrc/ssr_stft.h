@@ -96,13 +96,6 @@ template <typename T, bool SUMS, int PPT, typename SA, typename SB> struct SsrSt
 
 SSR_DEV int ssr_num_frames_dev(int n, int n_fft, int hop) { return 1 + (n + 2 * (n_fft / 2) - n_fft) / hop; }
 
-// one reflect-padded sample of frame `t`, branch-free: a frame that does not exist re-reads the last
-// one (always a valid address) and the caller selects 0 for it
-SSR_DEV float ssr_frame_sample_raw(const float* sig, int n, int t, int n_frames, int m, int n_fft, int hop) {
-  const int tc = (t < n_frames) ? t : n_frames - 1;
-  return sig[ssr_reflect(tc * hop + m - n_fft / 2, n)];
-}
-
 // ---- shared epilogue: one bin of the separated spectra ---------------------------------------------
 template <typename T> struct SsrBinOut { float ar, ai, br, bi; };
 

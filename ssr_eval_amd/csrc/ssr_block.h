@@ -132,7 +132,8 @@ SSR_DEV int ssr_wave_index(int tid) { return __builtin_amdgcn_readfirstlane(tid)
 #define SSR_WAVE_ANY(pred) (__builtin_amdgcn_ballot_w64(pred) != 0ull ? 1 : 0)
 #define SSR_WAVE_FLAG_STORE(tid, flag, dst)                                        \
   do {                                                                             \
-    if (((tid) & 63) == 0) (dst)[ssr_wave_index(tid)] = (flag);                    \
+    const int flag_ = (flag);   /* evaluated by the WHOLE wave, outside the branch */ \
+    if (((tid) & 63) == 0) (dst)[ssr_wave_index(tid)] = flag_;                     \
   } while (0)
 // (the wave-wide vote is taken BEFORE the single-lane store: inside that branch only one lane would be voting)
 #define SSR_WAVE_ANY_STORE(tid, pred, dst)                  \

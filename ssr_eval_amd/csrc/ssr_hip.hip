@@ -705,6 +705,7 @@ static int run_inverse(const ssr_plan* pl, const float* in, const int64_t* in_of
                        const int64_t* out_off, int n_items, int max_len, int64_t total_rows, float* out,
                        void* workspace, size_t workspace_bytes, hipStream_t s) {
   if (max_len <= pl->n_fft / 2) return fail(SSR_ERR_INVALID_ARG, "reflect padding needs len > n_fft/2");
+  if (max_len >= (1 << 29)) return fail(SSR_ERR_UNSUPPORTED, "signals of 2^29 samples or more (4 GiB buffer views)");
   if (!workspace || workspace_bytes < ssr_ola_workspace_bytes(pl, total_rows)) return fail(SSR_ERR_WORKSPACE, "workspace too small");
   const int max_pairs = (int)((ssr_num_frames(pl, max_len) + 1) / 2);
   const int ppc = units_per_chunk_for(max_pairs, n_items);

@@ -63,9 +63,7 @@ static inline double ssr_fmul_rn(double a, double b) { volatile double r = a * b
 static inline double ssr_fadd_rn(double a, double b) { volatile double r = a + b; return r; }
 #else
 #include <hip/hip_runtime.h>
-#if defined(SSR_ABL_NOBAR)   /* developer ablation: WRONG results, timing only */
-#define SSR_BARRIER() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
-#elif defined(SSR_FULL_BARRIER)
+#if defined(SSR_FULL_BARRIER)
 #define SSR_BARRIER() __syncthreads()
 #else
 // Workgroup barrier that orders LDS traffic only.  All cross-thread hand-offs inside a kernel body go

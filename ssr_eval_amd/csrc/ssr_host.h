@@ -1,0 +1,79 @@
+// Host-side glue shared by the translation units of libssrhip.so (not part of the C ABI; see include/ssr_hip.h).
+// The library is compiled as several .hip files (one per kernel family / precision) so that the few hundred kernel
+// instantiations build in parallel; this header carries what they share: the error state, the plan object, launch
+// geometry and the launcher entry points each unit defines.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ssr_hip.h"
+#include "ssr_block.h"
+#include "ssr_tables.h"
+
+int ssr_fail(int code, const std::string& msg);   // records the thread-local message behind ssr_last_error()
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return ssr_fail(SSR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+template <typename T> struct DevTables {
+  T* window = nullptr;
+  T* window_h = nullptr;
+  cx<T>*tw = nullptr, *wchirp = nullptr, *bfilt = nullptr, *chirp = nullptr;
+};
+
+struct ssr_plan {
+  int n_fft, hop, n_bins, precision, device;
+  SsrEngine eng;
+  DevTables<float> f32;
+  DevTables<double> f64;
+  double* window64 = nullptr;  // always present (OLA normalisation)
+  std::vector<void*> allocs;
+};
+
+template <typename T> inline const DevTables<T>& ssr_tables_of(const ssr_plan* pl);
+template <> inline const DevTables<float>& ssr_tables_of<float>(const ssr_plan* pl) { return pl->f32; }
+template <> inline const DevTables<double>& ssr_tables_of<double>(const ssr_plan* pl) { return pl->f64; }
+
+// Every entry point that takes a plan runs on the plan's device: its tables live there.  (The Python mirror selects
+// the device before calling in; a C caller that forgot gets an error instead of an illegal address.)
+int ssr_check_plan_device(const ssr_plan* pl);
+
+// Opt a kernel into more than 48 KiB of dynamic LDS, once per (kernel, device) instead of once per launch.
+// `slot` is a per-kernel static the caller owns (one per template instantiation).
+inline int ssr_allow_lds(const void* fn, size_t lds, int* slot) {
+  if (lds <= 48 * 1024) return SSR_OK;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (*slot == dev + 1) return SSR_OK;
+  HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  *slot = dev + 1;
+  return SSR_OK;
+}
+
+// ---- launch geometry (deterministic functions of the batch shape; they also define the workspace layout) ----
+inline int ssr_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+inline size_t ssr_align256(size_t x) { return (x + 255) & ~(size_t)255; }
+int ssr_target_wgs();                                  // workgroups per launch aimed for when chunking items
+int ssr_units_per_chunk_for(int max_units, int n_items);
+
+// ---- launchers defined by the kernel translation units --------------------------------------------------------
+template <typename T> struct SsrStftParams;
+template <typename T> struct SsrLowpassParams;
+// tu_stft_*.hip: direct / Bluestein engines.  part 0: float32 pairs, part 1: float64-signal pairs, part 2: single
+template <typename T> int ssr_launch_stft_pair(const ssr_plan*, SsrStftParams<T>&, int grid, hipStream_t);
+template <typename T> int ssr_launch_stft_pair64(const ssr_plan*, SsrStftParams<T>&, int grid, hipStream_t);
+template <typename T> int ssr_launch_stft_single(const ssr_plan*, SsrStftParams<T>&, int grid, hipStream_t);
+// radix-3 engine (n_fft = 3q)
+template <typename T> int ssr_launch_stft_r3(const ssr_plan*, SsrStftParams<T>&, int grid, hipStream_t);
+template <typename T> int ssr_launch_stft_r3_64(const ssr_plan*, SsrStftParams<T>&, int grid, hipStream_t);
+// dispatcher (tu_core.hip): fills the plan tables into p and picks the unit
+template <typename T> int ssr_launch_stft(const ssr_plan*, SsrStftParams<T>&, int grid, hipStream_t);
+// tu_lowpass.hip
+template <typename T> int ssr_launch_lowpass(const ssr_plan*, SsrLowpassParams<T>&, int grid, hipStream_t);

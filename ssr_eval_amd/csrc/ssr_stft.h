@@ -539,12 +539,6 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
       double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       const int par = BLUESTEIN ? 0 : ((u - u0) & 1);               // flag set of this unit (direct engine: two sets)
       const bool a_nz = L.any_nonzero(0, par), b_nz = L.any_nonzero(1, par);
-#if defined(SSR_ABL_NOEPI)     /* developer ablation: WRONG results, timing only */
-      if (tid == 0) {
-        const cx<T> z0 = {L.re[0], L.im[0]};
-        ssr_emit_bin<T, MODE, IN64>(p, acc, 0u, z0, z0, ra0, ra1, rb0, rb1, b_ok, true, true);
-      }
-#else
       if constexpr (!BLUESTEIN && MODE == SSR_MODE_PAIR) {
         // The magnitudes stay in registers until the next unit's prefetched samples have been consumed (their flags):
         // vmcnt retires in order, so loads that are waited for BEFORE this unit's stores are issued never wait on the
@@ -578,7 +572,6 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
           ssr_emit_bin<T, MODE, IN64>(p, acc, (unsigned)k, zk, zn, ra0, ra1, rb0, rb1, b_ok, a_nz, b_nz);
         }
       }
-#endif
       if (want_lsd) SSR_WAVE_SUM_STORE(tid, NT, acc[0], L.sc1);
       if constexpr (SUMS)
         for (int q = 0; q < 6; ++q) R.sums[q] += acc[1 + q];

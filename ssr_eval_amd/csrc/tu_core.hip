@@ -1,0 +1,256 @@
+// libssrhip.so translation unit: error state, plans, the STFT entry point and dispatcher, small elementwise kernels.
+// See include/ssr_hip.h for the contract; kernel bodies live in the ssr_*.h headers (shared with the host emulation
+// used by the CPU tests).
+#include "ssr_host.h"
+#include "ssr_stft.h"
+
+#define SSR_VERSION 200
+
+static thread_local std::string g_err;
+int ssr_fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+extern "C" const char* ssr_last_error(void) { return g_err.c_str(); }
+extern "C" int ssr_version(void) { return SSR_VERSION; }
+
+int ssr_check_plan_device(const ssr_plan* pl) {
+  int dev = -1;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev != pl->device)
+    return ssr_fail(SSR_ERR_INVALID_ARG, "plan was created on HIP device " + std::to_string(pl->device) +
+                                             " but the current device is " + std::to_string(dev));
+  return SSR_OK;
+}
+
+// workgroups per launch aimed for when chunking items
+int ssr_target_wgs() {
+#ifdef SSR_DEV_KNOBS
+  static const int v = getenv("SSR_TARGET_WGS") ? atoi(getenv("SSR_TARGET_WGS")) : 4096;
+  return v;
+#else
+  return 4096;
+#endif
+}
+
+int ssr_units_per_chunk_for(int max_units, int n_items) {
+  const int target = ssr_target_wgs();
+  int64_t u = ((int64_t)max_units * n_items + target - 1) / target;
+  if (u < 4) u = 4;
+  if (u > 128) u = 128;             // ragged batches: short workgroups keep the tail of a launch balanced
+  if (u > max_units) u = max_units;
+  if (u < 1) u = 1;
+  return (int)u;
+}
+
+__global__ __launch_bounds__(256) void k_magphase(const float* re, const float* im, int64_t n, float eps, float* mag,
+                                                  float* cosv, float* sinv) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float r = re[i], q = im[i];
+    float p = r * r + q * q;          // torch: clamp(real**2 + imag**2, eps, inf) ** 0.5   (dsp.py:78)
+    p = p < eps ? eps : p;
+    const float m = sqrtf(p);
+    mag[i] = m;
+    cosv[i] = r / m;
+    sinv[i] = q / m;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// plan
+template <typename V> static int upload(ssr_plan* pl, const std::vector<V>& h, V** d) {
+  *d = nullptr;
+  if (h.empty()) return SSR_OK;
+  HIP_TRY(hipMalloc((void**)d, h.size() * sizeof(V)));
+  pl->allocs.push_back((void*)*d);
+  HIP_TRY(hipMemcpy(*d, h.data(), h.size() * sizeof(V), hipMemcpyHostToDevice));
+  return SSR_OK;
+}
+
+template <typename T> static int build_dev_tables(ssr_plan* pl, DevTables<T>& d) {
+  SsrTables<T> t;
+  if (!ssr_build_tables<T>(pl->n_fft, t)) return ssr_fail(SSR_ERR_UNSUPPORTED, "unsupported n_fft");
+  int rc;
+  if ((rc = upload(pl, t.window, &d.window))) return rc;
+  if ((rc = upload(pl, t.window_h, &d.window_h))) return rc;
+  if ((rc = upload(pl, t.tw, &d.tw))) return rc;
+  if ((rc = upload(pl, t.wchirp, &d.wchirp))) return rc;
+  if ((rc = upload(pl, t.bfilt, &d.bfilt))) return rc;
+  if ((rc = upload(pl, t.chirp, &d.chirp))) return rc;
+  return SSR_OK;
+}
+
+template <typename T> int ssr_launch_stft(const ssr_plan* pl, SsrStftParams<T>& p, int grid, hipStream_t s) {
+  const DevTables<T>& d = ssr_tables_of<T>(pl);
+  p.window = d.window_h; p.tw = d.tw; p.wchirp = d.wchirp; p.bfilt = d.bfilt; p.chirp = d.chirp;
+  const bool in64 = p.a64 != nullptr;
+  if (pl->eng.radix == 3) return in64 ? ssr_launch_stft_r3_64<T>(pl, p, grid, s) : ssr_launch_stft_r3<T>(pl, p, grid, s);
+  if (p.mode != SSR_MODE_PAIR) return ssr_launch_stft_single<T>(pl, p, grid, s);
+  return in64 ? ssr_launch_stft_pair64<T>(pl, p, grid, s) : ssr_launch_stft_pair<T>(pl, p, grid, s);
+}
+template int ssr_launch_stft<float>(const ssr_plan*, SsrStftParams<float>&, int, hipStream_t);
+template int ssr_launch_stft<double>(const ssr_plan*, SsrStftParams<double>&, int, hipStream_t);
+
+extern "C" int ssr_plan_create(int n_fft, int hop, int precision, ssr_plan** out) {
+  if (!out) return ssr_fail(SSR_ERR_INVALID_ARG, "plan output pointer is null");
+  *out = nullptr;
+  if (n_fft < 2 || hop < 1) return ssr_fail(SSR_ERR_INVALID_ARG, "n_fft must be >= 2 and hop >= 1");
+  if (precision != SSR_F32 && precision != SSR_F64) return ssr_fail(SSR_ERR_INVALID_ARG, "precision must be SSR_F32 or SSR_F64");
+  SsrEngine eng = ssr_pick_engine(n_fft);
+  if (!eng.ok) return ssr_fail(SSR_ERR_UNSUPPORTED, "n_fft too large: Bluestein length would exceed 8192 (n_fft <= 4096)");
+  ssr_plan* pl = new ssr_plan();
+  pl->n_fft = n_fft; pl->hop = hop; pl->n_bins = n_fft / 2 + 1; pl->precision = precision; pl->eng = eng;
+  int rc = SSR_OK;
+  if (hipGetDevice(&pl->device) != hipSuccess) rc = ssr_fail(SSR_ERR_HIP, "hipGetDevice failed (no HIP device?)");
+  if (!rc) rc = (precision == SSR_F64) ? build_dev_tables<double>(pl, pl->f64) : build_dev_tables<float>(pl, pl->f32);
+  if (!rc) {
+    SsrTables<double> t;
+    ssr_build_tables<double>(n_fft, t);
+    rc = upload(pl, t.window, &pl->window64);
+  }
+  if (rc) { ssr_plan_destroy(pl); return rc; }
+  *out = pl;
+  return SSR_OK;
+}
+
+extern "C" int ssr_plan_destroy(ssr_plan* pl) {
+  if (!pl) return SSR_OK;
+  for (void* p : pl->allocs) (void)hipFree(p);
+  delete pl;
+  return SSR_OK;
+}
+
+extern "C" int ssr_plan_query(const ssr_plan* pl, int* n_fft, int* hop, int* n_bins, int* fft_len, int* bluestein,
+                              int* precision) {
+  if (!pl) return ssr_fail(SSR_ERR_INVALID_ARG, "plan is null");
+  if (n_fft) *n_fft = pl->n_fft;
+  if (hop) *hop = pl->hop;
+  if (n_bins) *n_bins = pl->n_bins;
+  if (fft_len) *fft_len = 1 << pl->eng.logn;
+  if (bluestein) *bluestein = pl->eng.bluestein ? 1 : 0;
+  if (precision) *precision = pl->precision;
+  return SSR_OK;
+}
+
+extern "C" int64_t ssr_num_frames(const ssr_plan* pl, int64_t n) {
+  if (!pl) return -1;
+  return 1 + (n + 2 * (int64_t)(pl->n_fft / 2) - pl->n_fft) / pl->hop;
+}
+
+// ----------------------------------------------------------------------------------------------------
+template <typename T>
+static int stft_single_t(const ssr_plan* pl, const float* wav, const int64_t* off, const int32_t* len,
+                         const int64_t* frame_off, int n_items, int max_len, int out_kind, float* out_a, float* out_b,
+                         hipStream_t s) {
+  SsrStftParams<T> p{};
+  p.a = wav; p.b = wav; p.a_off = off; p.b_off = off; p.len = len; p.frame_off = frame_off;
+  p.mode = SSR_MODE_SINGLE; p.out_kind = out_kind; p.metric_mask = 0;
+  p.n_fft = pl->n_fft; p.hop = pl->hop; p.n_bins = pl->n_bins;
+  const int max_units = (int)((ssr_num_frames(pl, max_len) + 1) / 2);
+  p.units_per_chunk = ssr_units_per_chunk_for(max_units, n_items);
+  p.n_chunks = ssr_ceil_div(max_units, p.units_per_chunk);
+  p.out_a = out_a; p.out_b = out_b; p.part = nullptr;
+  return ssr_launch_stft<T>(pl, p, n_items * p.n_chunks, s);
+}
+
+extern "C" int ssr_stft(const ssr_plan* pl, const float* wav, const int64_t* wav_off, const int32_t* wav_len,
+                        const int64_t* frame_off, int n_items, int max_len, int out_kind, float* out_a, float* out_b,
+                        void* stream) {
+  if (!pl || !wav || !wav_off || !wav_len || !frame_off || !out_a) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (out_kind != SSR_STFT_MAG && out_kind != SSR_STFT_COMPLEX) return ssr_fail(SSR_ERR_INVALID_ARG, "bad out_kind");
+  if (out_kind == SSR_STFT_COMPLEX && !out_b) return ssr_fail(SSR_ERR_INVALID_ARG, "complex output needs out_b");
+  if (n_items <= 0) return SSR_OK;
+  if (int rc_dev = ssr_check_plan_device(pl)) return rc_dev;
+  if (max_len < 1) return ssr_fail(SSR_ERR_INVALID_ARG, "empty signals");
+  if (max_len >= (1 << 29)) return ssr_fail(SSR_ERR_UNSUPPORTED, "signals of 2^29 samples or more (4 GiB buffer views)");
+  hipStream_t s = (hipStream_t)stream;
+  return pl->precision == SSR_F64
+             ? stft_single_t<double>(pl, wav, wav_off, wav_len, frame_off, n_items, max_len, out_kind, out_a, out_b, s)
+             : stft_single_t<float>(pl, wav, wav_off, wav_len, frame_off, n_items, max_len, out_kind, out_a, out_b, s);
+}
+
+extern "C" int ssr_magphase(const float* re, const float* im, int64_t n, float eps, float* mag, float* cosv,
+                            float* sinv, void* stream) {
+  if (!re || !im || !mag || !cosv || !sinv) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n <= 0) return SSR_OK;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_magphase, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, re, im, n, eps, mag, cosv, sinv);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// A6: the tensor helpers of ssr_eval/utils.py as stand-alone calls (AudioMetrics.sispec has them fused in-kernel).
+enum { SSR_EW_TO_LOG = 0, SSR_EW_FROM_LOG = 1 };
+__global__ __launch_bounds__(256) void k_elementwise(int op, const float* x, int64_t n, float* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = x[i];
+    if (op == SSR_EW_TO_LOG) out[i] = log10f(v + 1e-12f);               // utils.py:43-44
+    else out[i] = powf(10.0f, v > 5.0f ? 5.0f : v);                     // utils.py:47-49 (clip(max=5), NaN passes through)
+  }
+}
+
+// sums[item] = {sum a^2, sum b^2, sum a*b} over per_item contiguous elements; one workgroup per item, float64
+// accumulation in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void k_energy_sums(const float* a, const float* b, int64_t per_item, double* sums) {
+  __shared__ double sh[3][4];
+  const float* pa = a + (int64_t)blockIdx.x * per_item;
+  const float* pb = b + (int64_t)blockIdx.x * per_item;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int64_t i = threadIdx.x; i < per_item; i += 256) {
+    const double u = (double)pa[i], v = (double)pb[i];
+    s0 += u * u; s1 += v * v; s2 += u * v;
+  }
+  s0 = ssr_wave_sum<64>(s0); s1 = ssr_wave_sum<64>(s1); s2 = ssr_wave_sum<64>(s2);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s0; sh[1][threadIdx.x >> 6] = s1; sh[2][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x < 3) sums[(int64_t)blockIdx.x * 3 + threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+
+// out[item][j] = (x[item][j] * mul[item]) / div[item], two float32 roundings as in energy_unify (utils.py:79-82)
+__global__ __launch_bounds__(256) void k_scale_items(const float* x, const float* mul, const float* div, int64_t per_item,
+                                                     int64_t n, float* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t item = i / per_item;
+    out[i] = ssr_fmul_rn(x[i], mul[item]) / div[item];
+  }
+}
+
+static unsigned ew_blocks(int64_t n) {
+  int64_t blocks = (n + 255) / 256;
+  return (unsigned)(blocks > 8192 ? 8192 : blocks);
+}
+
+extern "C" int ssr_to_log(const float* x, int64_t n, float* out, void* stream) {
+  if (!x || !out) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n <= 0) return SSR_OK;
+  hipLaunchKernelGGL(k_elementwise, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (int)SSR_EW_TO_LOG, x, n, out);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+
+extern "C" int ssr_from_log(const float* x, int64_t n, float* out, void* stream) {
+  if (!x || !out) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n <= 0) return SSR_OK;
+  hipLaunchKernelGGL(k_elementwise, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (int)SSR_EW_FROM_LOG, x, n, out);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+
+extern "C" int ssr_energy_sums(const float* a, const float* b, int n_items, int64_t per_item, double* sums, void* stream) {
+  if (!a || !b || !sums) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n_items <= 0) return SSR_OK;
+  if (per_item < 0) return ssr_fail(SSR_ERR_INVALID_ARG, "negative item size");
+  hipLaunchKernelGGL(k_energy_sums, dim3((unsigned)n_items), dim3(256), 0, (hipStream_t)stream, a, b, per_item, sums);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+
+extern "C" int ssr_scale_items(const float* x, const float* mul, const float* div, int n_items, int64_t per_item,
+                               float* out, void* stream) {
+  if (!x || !mul || !div || !out) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  const int64_t n = (int64_t)n_items * per_item;
+  if (n <= 0) return SSR_OK;
+  hipLaunchKernelGGL(k_scale_items, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, mul, div, per_item, n, out);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}

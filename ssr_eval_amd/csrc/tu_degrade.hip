@@ -1,0 +1,162 @@
+// libssrhip.so translation unit: degradation-side kernels and entry points - polyphase resampler (K7),
+// zero-phase IIR (N1), cross-correlation alignment (N4).
+#include "ssr_host.h"
+#include "ssr_iir.h"
+#include "ssr_xcorr.h"
+#include "ssr_resample.h"
+
+__global__ __launch_bounds__(SSR_XC_NT) void k_xcorr(SsrXcorrParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  SsrBlk blk{(int)threadIdx.x};
+  ssr_xcorr_body(p, blk, blockIdx.x % p.n_lag_blocks, blockIdx.x / p.n_lag_blocks, smem);
+}
+
+__global__ __launch_bounds__(64) void k_xcorr_pick(const double* best_val, const int64_t* best_idx, int n_lag_blocks,
+                                                   int n_items, int64_t* argmax_out) {
+  const int item = blockIdx.x * 64 + threadIdx.x;
+  if (item < n_items) ssr_xcorr_pick(best_val, best_idx, n_lag_blocks, item, argmax_out);
+}
+
+template <typename S>
+__global__ __launch_bounds__(SSR_RESAMPLE_NT) void k_resample(SsrResampleParamsT<S> p, int blocks_per_item) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  SsrBlk blk{(int)threadIdx.x};
+  ssr_resample_body<S>(p, blk, blockIdx.x % blocks_per_item, blockIdx.x / blocks_per_item, smem);
+}
+
+template <int G, typename X>
+__global__ __launch_bounds__(64) void k_sosfiltfilt(SsrIirParamsT<X> p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ssr_iir_wave<G, X>(p, blockIdx.x, threadIdx.x, smem);
+}
+
+// ----------------------------------------------------------------------------------------------------
+static int64_t gcd64(int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a; }
+
+extern "C" int ssr_resample_plan(int64_t n_in, int up, int down, int* up_r, int* down_r, int64_t* n_out, int* half_len,
+                                 int* n_pre_pad, int* n_pre_remove) {
+  if (up < 1 || down < 1 || n_in < 0) return ssr_fail(SSR_ERR_INVALID_ARG, "up and down must be >= 1");
+  const int g = (int)gcd64(up, down);
+  up /= g; down /= g;
+  const int64_t prod = n_in * up;
+  const int mx = up > down ? up : down;
+  const int hl = 10 * mx;
+  const int pre_pad = down - hl % down;
+  if (up_r) *up_r = up;
+  if (down_r) *down_r = down;
+  if (n_out) *n_out = prod / down + ((prod % down) ? 1 : 0);
+  if (half_len) *half_len = hl;
+  if (n_pre_pad) *n_pre_pad = pre_pad;
+  if (n_pre_remove) *n_pre_remove = (hl + pre_pad) / down;
+  return SSR_OK;
+}
+
+template <typename S>
+static int resample_poly_t(const S* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
+                           const int32_t* out_len, int n_items, int max_out_len, int up, int down, const S* taps,
+                           int n_taps, int n_pre_remove, S* out, void* stream) {
+  if (!in || !in_off || !in_len || !out_off || !out_len || !taps || !out) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (up < 1 || down < 1 || n_taps < 1) return ssr_fail(SSR_ERR_INVALID_ARG, "bad resampling plan");
+  if (n_items <= 0 || max_out_len <= 0) return SSR_OK;
+  SsrResampleParamsT<S> p{in, in_off, in_len, out_off, out_len, up, down, taps, n_taps, n_pre_remove,
+                          ssr_resample_pick_groups(up, down), 1, out};
+  if (ssr_resample_lds_bytes(p) > 96 * 1024) p.taps_in_lds = 0;      // huge tap tables stay in HBM / L2
+  const size_t lds = ssr_resample_lds_bytes(p);
+  if (lds > 160 * 1024) return ssr_fail(SSR_ERR_UNSUPPORTED, "input window does not fit LDS");
+  static thread_local int slot = 0;
+  static thread_local size_t slot_lds = 0;          // the LDS size depends on the rate pair: remember the largest one
+  if (lds > slot_lds) slot = 0;
+  if (int rc = ssr_allow_lds((const void*)k_resample<S>, lds, &slot)) return rc;
+  if (lds > slot_lds) slot_lds = lds;
+  const int bpi = ssr_ceil_div(max_out_len, ssr_resample_opb(p));
+  hipLaunchKernelGGL((k_resample<S>), dim3((unsigned)((int64_t)n_items * bpi)), dim3(SSR_RESAMPLE_NT), lds, (hipStream_t)stream, p, bpi);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+
+extern "C" int ssr_resample_poly(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
+                                 const int32_t* out_len, int n_items, int max_out_len, int up, int down,
+                                 const float* taps, int n_taps, int n_pre_remove, float* out, void* stream) {
+  return resample_poly_t<float>(in, in_off, in_len, out_off, out_len, n_items, max_out_len, up, down, taps, n_taps,
+                                n_pre_remove, out, stream);
+}
+
+extern "C" int ssr_resample_poly_f64(const double* in, const int64_t* in_off, const int32_t* in_len,
+                                     const int64_t* out_off, const int32_t* out_len, int n_items, int max_out_len, int up,
+                                     int down, const double* taps, int n_taps, int n_pre_remove, double* out,
+                                     void* stream) {
+  return resample_poly_t<double>(in, in_off, in_len, out_off, out_len, n_items, max_out_len, up, down, taps, n_taps,
+                                 n_pre_remove, out, stream);
+}
+
+// ----------------------------------------------------------------------------------------------------
+static int xcorr_blocks(int max_len) { return max_len > 0 ? ssr_ceil_div(2 * (int64_t)max_len - 1, SSR_XC_LAGS) : 1; }
+
+extern "C" size_t ssr_xcorr_workspace_bytes(int n_items, int max_len) {
+  if (n_items <= 0) return 0;
+  return 2 * ssr_align256((size_t)n_items * xcorr_blocks(max_len) * sizeof(double));
+}
+
+extern "C" int ssr_xcorr_argmax(const float* a, const int64_t* a_off, const float* b, const int64_t* b_off,
+                                const int32_t* len, int n_items, int max_len, int64_t* argmax_out, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  if (!a || !a_off || !b || !b_off || !len || !argmax_out) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n_items <= 0) return SSR_OK;
+  if (max_len <= 0) return ssr_fail(SSR_ERR_INVALID_ARG, "empty signals");
+  const int nb = xcorr_blocks(max_len);
+  const size_t half = ssr_align256((size_t)n_items * nb * sizeof(double));
+  if (!workspace || workspace_bytes < 2 * half) return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small");
+  if ((int64_t)n_items * nb > 0x7fffffff) return ssr_fail(SSR_ERR_UNSUPPORTED, "batch too large for one launch");
+  SsrXcorrParams p{a, a_off, b, b_off, len, nb, (double*)workspace, (int64_t*)((char*)workspace + half)};
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_xcorr, dim3((unsigned)(n_items * nb)), dim3(SSR_XC_NT), SsrXcorrLds::bytes(), s, p);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_xcorr_pick, dim3(ssr_ceil_div(n_items, 64)), dim3(64), 0, s, p.best_val, p.best_idx, nb, n_items, argmax_out);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------
+extern "C" size_t ssr_sosfiltfilt_workspace_bytes(int64_t total_len, int n_items, int edge) {
+  if (total_len <= 0 || n_items <= 0 || edge < 0) return 0;
+  return ssr_align256(((size_t)total_len + (size_t)2 * edge * n_items) * sizeof(double));
+}
+
+template <typename X>
+static int sosfiltfilt_t(const X* x, const int64_t* off, const int32_t* len, int n_items, int64_t total_len,
+                         const double* sos, const double* zi, int n_sections, int edge, double* y, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  if (!x || !off || !len || !sos || !zi || !y) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n_sections < 1 || n_sections > 16) return ssr_fail(SSR_ERR_UNSUPPORTED, "n_sections must be in [1, 16]");
+  if (edge < 0) return ssr_fail(SSR_ERR_INVALID_ARG, "negative edge");
+  if (n_items <= 0) return SSR_OK;
+  if (!workspace || workspace_bytes < ssr_sosfiltfilt_workspace_bytes(total_len, n_items, edge))
+    return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small");
+  SsrIirParamsT<X> p{x, off, len, sos, zi, n_sections, edge, n_items, (double*)workspace, y};
+  hipStream_t s = (hipStream_t)stream;
+  if (n_sections <= 8) {
+    const int per_wave = 8 * SSR_IIR_U;                           // utterances per one-wave workgroup
+    const size_t lds = (size_t)per_wave * 4 * SSR_IIR_CH * sizeof(double);
+    static thread_local int slot = 0;
+    if (int rc = ssr_allow_lds((const void*)k_sosfiltfilt<8, X>, lds, &slot)) return rc;
+    hipLaunchKernelGGL((k_sosfiltfilt<8, X>), dim3(ssr_ceil_div(n_items, per_wave)), dim3(64), lds, s, p);
+  } else {
+    const int per_wave = 4 * SSR_IIR_U;
+    const size_t lds = (size_t)per_wave * 4 * SSR_IIR_CH * sizeof(double);
+    hipLaunchKernelGGL((k_sosfiltfilt<16, X>), dim3(ssr_ceil_div(n_items, per_wave)), dim3(64), lds, s, p);
+  }
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+
+extern "C" int ssr_sosfiltfilt(const float* x, const int64_t* off, const int32_t* len, int n_items, int64_t total_len,
+                               const double* sos, const double* zi, int n_sections, int edge, double* y,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  return sosfiltfilt_t<float>(x, off, len, n_items, total_len, sos, zi, n_sections, edge, y, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ssr_sosfiltfilt_f64(const double* x, const int64_t* off, const int32_t* len, int n_items, int64_t total_len,
+                                   const double* sos, const double* zi, int n_sections, int edge, double* y,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  return sosfiltfilt_t<double>(x, off, len, n_items, total_len, sos, zi, n_sections, edge, y, workspace, workspace_bytes, stream);
+}

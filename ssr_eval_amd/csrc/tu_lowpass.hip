@@ -1,0 +1,103 @@
+// libssrhip.so translation unit: STFT-domain low-pass / inverse STFT (K6) kernels and entry points.
+#include "ssr_host.h"
+#include "ssr_lowpass.h"
+
+#ifndef SSR_LOWPASS_WAVES_PER_EU
+#define SSR_LOWPASS_WAVES_PER_EU 3   /* 168 VGPRs, no spill: 3 workgroups per CU instead of 2 */
+#endif
+template <typename T, int LOGN>
+__global__ __launch_bounds__((1 << LOGN) / 8, SSR_LOWPASS_WAVES_PER_EU) void k_lowpass_frames(SsrLowpassParams<T> p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  SsrBlk blk{(int)threadIdx.x};
+  const int item = blockIdx.x / p.n_chunks, chunk = blockIdx.x % p.n_chunks;
+  ssr_lowpass_frames_body<T, LOGN>(p, blk, chunk, item, smem);
+}
+
+__global__ __launch_bounds__(256) void k_ola(SsrOlaParams p, int blocks_per_item) {
+  const int item = blockIdx.x / blocks_per_item;
+  const int s = (blockIdx.x % blocks_per_item) * 256 + threadIdx.x;
+  ssr_ola_sample(p, item, s);
+}
+
+template <typename T, int LOGN> static int launch_lowpass_inst(SsrLowpassParams<T>& p, int grid, hipStream_t s) {
+  const size_t lds = SsrStftLds<T, LOGN>::bytes();
+  static thread_local int slot = 0;
+  if (int rc = ssr_allow_lds((const void*)k_lowpass_frames<T, LOGN>, lds, &slot)) return rc;
+  hipLaunchKernelGGL((k_lowpass_frames<T, LOGN>), dim3(grid), dim3((1 << LOGN) / 8), lds, s, p);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+
+template <typename T> int ssr_launch_lowpass(const ssr_plan* pl, SsrLowpassParams<T>& p, int grid, hipStream_t s) {
+  const DevTables<T>& d = ssr_tables_of<T>(pl);
+  p.window = d.window; p.tw = d.tw;
+  if (pl->eng.bluestein) return ssr_fail(SSR_ERR_UNSUPPORTED, "inverse STFT needs a power-of-two n_fft in [256, 4096]");
+  switch (pl->eng.logn) {
+    case 8: return launch_lowpass_inst<T, 8>(p, grid, s);
+    case 9: return launch_lowpass_inst<T, 9>(p, grid, s);
+    case 10: return launch_lowpass_inst<T, 10>(p, grid, s);
+    case 11: return launch_lowpass_inst<T, 11>(p, grid, s);
+    case 12: return launch_lowpass_inst<T, 12>(p, grid, s);
+  }
+  return ssr_fail(SSR_ERR_UNSUPPORTED, "no kernel for this FFT length");
+}
+template int ssr_launch_lowpass<float>(const ssr_plan*, SsrLowpassParams<float>&, int, hipStream_t);
+template int ssr_launch_lowpass<double>(const ssr_plan*, SsrLowpassParams<double>&, int, hipStream_t);
+
+// ----------------------------------------------------------------------------------------------------
+extern "C" size_t ssr_ola_workspace_bytes(const ssr_plan* pl, int64_t total_rows) {
+  if (!pl || total_rows <= 0) return 0;
+  return ssr_align256((size_t)total_rows * pl->n_fft * sizeof(float));
+}
+
+static int run_inverse(const ssr_plan* pl, const float* in, const int64_t* in_off, const int32_t* len,
+                       const int32_t* cut, const float* re, const float* im, const int64_t* frame_off,
+                       const int64_t* out_off, int n_items, int max_len, int64_t total_rows, float* out,
+                       void* workspace, size_t workspace_bytes, hipStream_t s) {
+  if (max_len <= pl->n_fft / 2) return ssr_fail(SSR_ERR_INVALID_ARG, "reflect padding needs len > n_fft/2");
+  if (max_len >= (1 << 29)) return ssr_fail(SSR_ERR_UNSUPPORTED, "signals of 2^29 samples or more (4 GiB buffer views)");
+  if (!workspace || workspace_bytes < ssr_ola_workspace_bytes(pl, total_rows)) return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small");
+  const int max_pairs = (int)((ssr_num_frames(pl, max_len) + 1) / 2);
+  const int ppc = ssr_units_per_chunk_for(max_pairs, n_items);
+  const int n_chunks = ssr_ceil_div(max_pairs, ppc);
+  int rc;
+  if (pl->precision == SSR_F64) {
+    SsrLowpassParams<double> p{};
+    p.in = in; p.in_off = in_off; p.len = len; p.cut = cut; p.frame_off = frame_off;
+    p.n_fft = pl->n_fft; p.hop = pl->hop; p.pairs_per_chunk = ppc; p.n_chunks = n_chunks;
+    p.spec_re = re; p.spec_im = im; p.frames = (float*)workspace;
+    rc = ssr_launch_lowpass<double>(pl, p, n_items * n_chunks, s);
+  } else {
+    SsrLowpassParams<float> p{};
+    p.in = in; p.in_off = in_off; p.len = len; p.cut = cut; p.frame_off = frame_off;
+    p.n_fft = pl->n_fft; p.hop = pl->hop; p.pairs_per_chunk = ppc; p.n_chunks = n_chunks;
+    p.spec_re = re; p.spec_im = im; p.frames = (float*)workspace;
+    rc = ssr_launch_lowpass<float>(pl, p, n_items * n_chunks, s);
+  }
+  if (rc) return rc;
+  SsrOlaParams q{(const float*)workspace, frame_off, len, out_off, pl->n_fft, pl->hop, pl->window64, out};
+  const int bpi = ssr_ceil_div(max_len, 256);
+  hipLaunchKernelGGL(k_ola, dim3((unsigned)((int64_t)n_items * bpi)), dim3(256), 0, s, q, bpi);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+
+extern "C" int ssr_fft_lowpass(const ssr_plan* pl, const float* in, const int64_t* off, const int32_t* len,
+                               const int32_t* cut, const int64_t* frame_off, int n_items, int max_len,
+                               int64_t total_rows, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!pl || !in || !off || !len || !cut || !frame_off || !out) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n_items <= 0) return SSR_OK;
+  if (int rc_dev = ssr_check_plan_device(pl)) return rc_dev;
+  return run_inverse(pl, in, off, len, cut, nullptr, nullptr, frame_off, off, n_items, max_len, total_rows, out, workspace,
+                     workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int ssr_istft(const ssr_plan* pl, const float* re, const float* im, const int64_t* frame_off,
+                         const int32_t* len, const int64_t* out_off, int n_items, int max_len, int64_t total_rows,
+                         float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!pl || !re || !im || !frame_off || !len || !out_off || !out) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n_items <= 0) return SSR_OK;
+  if (int rc_dev = ssr_check_plan_device(pl)) return rc_dev;
+  return run_inverse(pl, nullptr, nullptr, len, nullptr, re, im, frame_off, out_off, n_items, max_len, total_rows, out,
+                     workspace, workspace_bytes, (hipStream_t)stream);
+}

@@ -1,0 +1,251 @@
+// libssrhip.so translation unit: SSIM / spectrogram reductions / finalisation kernels (K3-K5) and the metric entry
+// points (ssr_pair_metrics*, ssr_spectrogram_metrics).
+#include "ssr_host.h"
+#include "ssr_metrics.h"
+
+#ifndef SSR_SSIM_WAVES_PER_EU
+#define SSR_SSIM_WAVES_PER_EU 1
+#endif
+template <int CPT>
+__global__ __launch_bounds__(SSR_SSIM_NT, SSR_SSIM_WAVES_PER_EU) void k_ssim(SsrSsimParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  SsrBlk blk{(int)threadIdx.x};
+  const int tiles = p.n_row_tiles * p.n_strips;
+  ssr_ssim_body<CPT>(p, blk, blockIdx.x % tiles, blockIdx.x / tiles, smem);
+}
+
+__global__ __launch_bounds__(256) void k_specred(SsrSpecRedParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  SsrBlk blk{(int)threadIdx.x};
+  ssr_specred_body(p, blk, blockIdx.x % p.n_chunks, blockIdx.x / p.n_chunks, smem);
+}
+
+__global__ __launch_bounds__(64) void k_finalize(SsrFinalizeParams p) {
+  const int item = blockIdx.x * 64 + threadIdx.x;
+  if (item < p.n_items) ssr_finalize_item(p, item);
+}
+
+struct SsimGeom { int rows_per_tile, n_row_tiles, n_strips, cpt; };
+static SsimGeom ssim_geom(int max_rows, int n_bins, int n_items) {
+  SsimGeom g;
+  const int out_rows = max_rows - 6 > 1 ? max_rows - 6 : 1;
+  int64_t r = ((int64_t)out_rows * n_items + ssr_target_wgs() - 1) / ssr_target_wgs();
+  if (r < 8) r = 8;
+  if (r > 128) r = 128;
+  if (r > out_rows) r = out_rows;
+  g.rows_per_tile = (int)r;
+  g.n_row_tiles = ssr_ceil_div(out_rows, g.rows_per_tile);
+  g.cpt = ssr_ssim_pick_cpt(n_bins);
+#ifdef SSR_DEV_KNOBS
+  static const int cpt_env = getenv("SSR_SSIM_CPT") ? atoi(getenv("SSR_SSIM_CPT")) : 0;
+  if (cpt_env >= 1 && cpt_env <= SSR_SSIM_MAXCPT) g.cpt = cpt_env;
+#endif
+  g.n_strips = n_bins > 6 ? ssr_ceil_div(n_bins - 6, ssr_ssim_strip_out(g.cpt)) : 1;
+  return g;
+}
+
+
+struct PairWs {
+  size_t off_est, off_tgt, off_part, off_ssim, total;
+  int units_per_chunk, n_chunks;
+  SsimGeom sg;
+};
+static PairWs pair_ws(const ssr_plan* pl, int n_items, int max_len, int64_t total_rows) {
+  PairWs w;
+  const int max_T = (int)ssr_num_frames(pl, max_len);
+  w.units_per_chunk = ssr_units_per_chunk_for(max_T, n_items);
+  w.n_chunks = ssr_ceil_div(max_T, w.units_per_chunk);
+  w.sg = ssim_geom(max_T, pl->n_bins, n_items);
+  size_t o = 0;
+  w.off_est = o; o += ssr_align256((size_t)total_rows * pl->n_bins * sizeof(float));
+  w.off_tgt = o; o += ssr_align256((size_t)total_rows * pl->n_bins * sizeof(float));
+  w.off_part = o; o += ssr_align256((size_t)n_items * w.n_chunks * SSR_NPART * sizeof(double));
+  w.off_ssim = o; o += ssr_align256((size_t)n_items * w.sg.n_row_tiles * w.sg.n_strips * sizeof(double));
+  w.total = o;
+  return w;
+}
+
+// ----------------------------------------------------------------------------------------------------
+extern "C" size_t ssr_pair_metrics_workspace_bytes(const ssr_plan* pl, int n_items, int max_len, int64_t total_rows) {
+  if (!pl || n_items <= 0) return 0;
+  return pair_ws(pl, n_items, max_len, total_rows).total + ssr_align256((size_t)n_items * sizeof(int32_t));
+}
+
+template <int CPT> static int launch_ssim_inst(const SsrSsimParams& p, int grid, hipStream_t s) {
+  const size_t lds = SsrSsimLds<CPT>::bytes();
+  static thread_local int slot = 0;
+  if (int rc = ssr_allow_lds((const void*)k_ssim<CPT>, lds, &slot)) return rc;
+  hipLaunchKernelGGL((k_ssim<CPT>), dim3(grid), dim3(SSR_SSIM_NT), lds, s, p);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+
+static int launch_ssim(const float* x, const float* y, const int64_t* frame_off, const int32_t* n_rows, int n_items,
+                       int F, const SsimGeom& g, double* part, hipStream_t s) {
+  SsrSsimParams p{x, y, frame_off, n_rows, F, g.rows_per_tile, g.n_row_tiles, g.n_strips, part};
+  const int grid = n_items * g.n_row_tiles * g.n_strips;
+  switch (g.cpt) {
+    case 1: return launch_ssim_inst<1>(p, grid, s);
+    case 2: return launch_ssim_inst<2>(p, grid, s);
+    case 3: return launch_ssim_inst<3>(p, grid, s);
+    case 4: return launch_ssim_inst<4>(p, grid, s);
+    case 5: return launch_ssim_inst<5>(p, grid, s);
+    case 6: return launch_ssim_inst<6>(p, grid, s);
+  }
+  return ssr_fail(SSR_ERR_UNSUPPORTED, "bad SSIM geometry");
+}
+
+static int launch_finalize(const double* part, int n_chunks, const double* ssim_part, int n_tiles, const int32_t* n_rows,
+                           int F, unsigned mask, int n_items, double* out, hipStream_t s) {
+  SsrFinalizeParams p{part, n_chunks, ssim_part, n_tiles, n_rows, F, (int)mask, n_items, out};
+  hipLaunchKernelGGL(k_finalize, dim3(ssr_ceil_div(n_items, 64)), dim3(64), 0, s, p);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+
+// n_rows (T_i) for the finalisation is derived on device from len: a tiny kernel fills it.
+__global__ void k_rows_from_len(const int32_t* len, int n_items, int n_fft, int hop, int32_t* rows) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_items) rows[i] = ssr_num_frames_dev(len[i], n_fft, hop);
+}
+
+template <typename T>
+static int pair_stage_stft(const ssr_plan* pl, const float* est, const double* est64, const int64_t* est_off, const float* tgt, const double* tgt64,
+                           const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off, int n_items,
+                           unsigned mask, bool need_mag, const PairWs& w, char* ws, hipStream_t s) {
+  SsrStftParams<T> p{};
+  p.a = est; p.a64 = est64; p.b = tgt; p.b64 = tgt64; p.a_off = est_off; p.b_off = tgt_off; p.len = len; p.frame_off = frame_off;
+  p.mode = SSR_MODE_PAIR; p.out_kind = need_mag ? SSR_OUT_MAG : SSR_OUT_NONE; p.metric_mask = (int)mask;
+  p.n_fft = pl->n_fft; p.hop = pl->hop; p.n_bins = pl->n_bins;
+  p.units_per_chunk = w.units_per_chunk; p.n_chunks = w.n_chunks;
+  p.out_a = (float*)(ws + w.off_est); p.out_b = (float*)(ws + w.off_tgt);
+  p.part = (double*)(ws + w.off_part);
+  return ssr_launch_stft<T>(pl, p, n_items * w.n_chunks, s);
+}
+
+// stages: 1 = STFT + LSD/SISpec epilogue, 2 = SSIM, 4 = finalise (bench.py times stages separately)
+static int pair_metrics_impl(const ssr_plan* pl, const float* est, const double* est64, const int64_t* est_off,
+                             const float* tgt, const double* tgt64, const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off,
+                             int n_items, int max_len, int64_t total_rows, unsigned mask, double* out,
+                             void* workspace, size_t workspace_bytes, void* stream, int stages) {
+  if (!pl || (!est && !est64) || (!tgt && !tgt64) || !est_off || !tgt_off || !len || !frame_off || !out)
+    return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n_items <= 0) return SSR_OK;
+  if (int rc_dev = ssr_check_plan_device(pl)) return rc_dev;
+  if (max_len < 1) return ssr_fail(SSR_ERR_INVALID_ARG, "empty signals");
+  if (max_len >= (1 << 29)) return ssr_fail(SSR_ERR_UNSUPPORTED, "signals of 2^29 samples or more (4 GiB buffer views)");
+  if ((mask & ~SSR_METRIC_ALL) || mask == 0) return ssr_fail(SSR_ERR_INVALID_ARG, "bad metric mask");
+  const int max_T = (int)ssr_num_frames(pl, max_len);
+  const bool want_ssim = mask & SSR_METRIC_SSIM;
+  if (want_ssim && (int64_t)max_T * pl->n_bins >= ((int64_t)1 << 30))
+    return ssr_fail(SSR_ERR_UNSUPPORTED, "spectrogram of 2^30 elements or more (4 GiB buffer views)");
+  if (want_ssim && (max_T < 7 || pl->n_bins < 7)) return ssr_fail(SSR_ERR_INVALID_ARG, "win_size exceeds image extent");
+  const PairWs w = pair_ws(pl, n_items, max_len, total_rows);
+  // rows array lives at the tail of the ssim partial area's alignment slack: allocate it explicitly
+  const size_t rows_bytes = ssr_align256((size_t)n_items * sizeof(int32_t));
+  if (!workspace || workspace_bytes < w.total + rows_bytes) return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small");
+  char* ws = (char*)workspace;
+  int32_t* rows = (int32_t*)(ws + w.total);
+  hipStream_t s = (hipStream_t)stream;
+  int rc = SSR_OK;
+  if (stages & 1) {
+    hipLaunchKernelGGL(k_rows_from_len, dim3(ssr_ceil_div(n_items, 256)), dim3(256), 0, s, len, n_items, pl->n_fft, pl->hop, rows);
+    HIP_TRY(hipGetLastError());
+    rc = pl->precision == SSR_F64
+             ? pair_stage_stft<double>(pl, est, est64, est_off, tgt, tgt64, tgt_off, len, frame_off, n_items, mask, want_ssim, w, ws, s)
+             : pair_stage_stft<float>(pl, est, est64, est_off, tgt, tgt64, tgt_off, len, frame_off, n_items, mask, want_ssim, w, ws, s);
+    if (rc) return rc;
+  }
+  if ((stages & 2) && want_ssim) {
+    rc = launch_ssim((const float*)(ws + w.off_est), (const float*)(ws + w.off_tgt), frame_off, rows, n_items,
+                     pl->n_bins, w.sg, (double*)(ws + w.off_ssim), s);
+    if (rc) return rc;
+  }
+  if (stages & 4) {
+    rc = launch_finalize((const double*)(ws + w.off_part), w.n_chunks, want_ssim ? (const double*)(ws + w.off_ssim) : nullptr,
+                         w.sg.n_row_tiles * w.sg.n_strips, rows, pl->n_bins, mask, n_items, out, s);
+  }
+  return rc;
+}
+
+extern "C" int ssr_pair_metrics_stages(const ssr_plan* pl, const float* est, const int64_t* est_off, const float* tgt,
+                                       const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off,
+                                       int n_items, int max_len, int64_t total_rows, unsigned mask, double* out,
+                                       void* workspace, size_t workspace_bytes, void* stream, int stages) {
+  return pair_metrics_impl(pl, est, nullptr, est_off, tgt, nullptr, tgt_off, len, frame_off, n_items, max_len, total_rows,
+                           mask, out, workspace, workspace_bytes, stream, stages);
+}
+
+extern "C" int ssr_pair_metrics(const ssr_plan* pl, const float* est, const int64_t* est_off, const float* tgt,
+                                const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off, int n_items,
+                                int max_len, int64_t total_rows, unsigned mask, double* out, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  return pair_metrics_impl(pl, est, nullptr, est_off, tgt, nullptr, tgt_off, len, frame_off, n_items, max_len, total_rows,
+                           mask, out, workspace, workspace_bytes, stream, 7);
+}
+
+extern "C" int ssr_pair_metrics_est64(const ssr_plan* pl, const double* est, const int64_t* est_off, const float* tgt,
+                                      const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off, int n_items,
+                                      int max_len, int64_t total_rows, unsigned mask, double* out, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  return pair_metrics_impl(pl, nullptr, est, est_off, tgt, nullptr, tgt_off, len, frame_off, n_items, max_len, total_rows,
+                           mask, out, workspace, workspace_bytes, stream, 7);
+}
+
+extern "C" int ssr_pair_metrics_f64(const ssr_plan* pl, const double* est, const int64_t* est_off, const double* tgt,
+                                    const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off, int n_items,
+                                    int max_len, int64_t total_rows, unsigned mask, double* out, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  return pair_metrics_impl(pl, nullptr, est, est_off, nullptr, tgt, tgt_off, len, frame_off, n_items, max_len, total_rows,
+                           mask, out, workspace, workspace_bytes, stream, 7);
+}
+
+// ----------------------------------------------------------------------------------------------------
+struct SpecWs { size_t off_part, off_ssim, total; int rows_per_chunk, n_chunks; SsimGeom sg; };
+static SpecWs spec_ws(int n_items, int max_rows, int n_bins) {
+  SpecWs w;
+  w.rows_per_chunk = ssr_units_per_chunk_for(max_rows, n_items);
+  w.n_chunks = ssr_ceil_div(max_rows, w.rows_per_chunk);
+  w.sg = ssim_geom(max_rows, n_bins, n_items);
+  size_t o = 0;
+  w.off_part = o; o += ssr_align256((size_t)n_items * w.n_chunks * SSR_NPART * sizeof(double));
+  w.off_ssim = o; o += ssr_align256((size_t)n_items * w.sg.n_row_tiles * w.sg.n_strips * sizeof(double));
+  w.total = o;
+  return w;
+}
+
+extern "C" size_t ssr_spectrogram_metrics_workspace_bytes(int n_items, int max_rows, int n_bins) {
+  if (n_items <= 0) return 0;
+  return spec_ws(n_items, max_rows, n_bins).total;
+}
+
+extern "C" int ssr_spectrogram_metrics(const float* est_sp, const float* tgt_sp, const int64_t* frame_off,
+                                       const int32_t* n_rows, int n_items, int max_rows, int n_bins, unsigned mask,
+                                       double* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!est_sp || !tgt_sp || !frame_off || !n_rows || !out) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n_items <= 0) return SSR_OK;
+  if ((mask & ~SSR_METRIC_ALL) || mask == 0) return ssr_fail(SSR_ERR_INVALID_ARG, "bad metric mask");
+  if (max_rows < 1 || n_bins < 1) return ssr_fail(SSR_ERR_INVALID_ARG, "empty spectrogram");
+  if ((int64_t)max_rows * n_bins >= ((int64_t)1 << 30))
+    return ssr_fail(SSR_ERR_UNSUPPORTED, "spectrogram of 2^30 elements or more (4 GiB buffer views)");
+  const bool want_ssim = mask & SSR_METRIC_SSIM;
+  if (want_ssim && (max_rows < 7 || n_bins < 7)) return ssr_fail(SSR_ERR_INVALID_ARG, "win_size exceeds image extent");
+  const SpecWs w = spec_ws(n_items, max_rows, n_bins);
+  if (!workspace || workspace_bytes < w.total) return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small");
+  char* ws = (char*)workspace;
+  hipStream_t s = (hipStream_t)stream;
+  const bool want_red = mask & (SSR_METRIC_LSD | SSR_METRIC_SISPEC | SSR_METRIC_LOG_SISPEC);
+  if (want_red) {
+    SsrSpecRedParams p{est_sp, tgt_sp, frame_off, n_rows, n_bins, (int)mask, w.rows_per_chunk, w.n_chunks,
+                       (double*)(ws + w.off_part)};
+    hipLaunchKernelGGL(k_specred, dim3(n_items * w.n_chunks), dim3(256), SsrSpecRedLds::bytes(), s, p);
+    HIP_TRY(hipGetLastError());
+  }
+  if (want_ssim) {
+    int rc = launch_ssim(est_sp, tgt_sp, frame_off, n_rows, n_items, n_bins, w.sg, (double*)(ws + w.off_ssim), s);
+    if (rc) return rc;
+  }
+  return launch_finalize(want_red ? (const double*)(ws + w.off_part) : nullptr, w.n_chunks,
+                         want_ssim ? (const double*)(ws + w.off_ssim) : nullptr, w.sg.n_row_tiles * w.sg.n_strips, n_rows,
+                         n_bins, mask, n_items, out, s);
+}

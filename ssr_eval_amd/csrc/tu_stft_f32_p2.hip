@@ -1,0 +1,4 @@
+// libssrhip.so translation unit: STFT kernels, transform precision float, part 2 (see tu_stft.inc)
+#define SSR_TU_T float
+#define SSR_TU_PART 2
+#include "tu_stft.inc"

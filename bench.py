@@ -1,20 +1,26 @@
 #!/usr/bin/env python
-"""bench.py - throughput of the ssr_eval metric hot path on MI355X.
+"""bench.py - throughput of the ssr_eval DSP / metric hot path on MI355X.
 
-A "step" is one pass of the hot path (ssr_pair_metrics: STFT n_fft=2048 / hop=512 of both signals,
-fused LSD epilogue, SSIM) over one batch of synthetic (estimate, target) pairs that is ALREADY RESIDENT
-IN HBM when the timed region starts.  Workload = BASELINE.json configs[1]: 1024 pairs of 4 s @ 48 kHz
-float32 per GPU (weak scaling: every rank owns its own 1024 pairs; the only collective is one float64
-all-reduce of the per-rank metric sums per step - the final mean-LSD/SSIM - over RCCL).
-
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--config cfg2|cfg3|cfg5] [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (see the task contract): metric/value/unit..., plus
-  "roofline":     dominant-kernel algorithmic HBM GB/s (2*n*4+32 bytes per pair) vs 8 TB/s,
-                  the kernel's duration measured here with HIP events on the launch stream;
-  "cpu_baseline": the CPU oracle (NumPy pocketfft f64 STFT + torch-CPU LSD + scipy.ndimage SSIM, i.e. the
-                  reference's arithmetic restated) timed on this box's host cores on a bounded sample.
+`--gpus N` with N > 1 and no torchrun environment spawns the N ranks itself (one process per GPU, RCCL) and fails if
+fewer than N devices exist.  Rank 0 prints ONE JSON line (the task contract) with `roofline` and `cpu_baseline`.
+
+A "step" is one pass of the hot path over one batch of synthetic input that is ALREADY RESIDENT IN HBM when the timed
+region starts.  Workloads (BASELINE.json `configs`; weak scaling: every rank owns its own batch, the only collective
+is one float64 all-reduce of the per-rank metric sums per step - the final mean - over RCCL):
+
+  cfg2 (default, the headline metric): 1024 (est, target) pairs of 4 s @ 48 kHz per GPU -> ssr_pair_metrics with
+        STFT 2048/512, LSD + SSIM.  Unit: pairs/s.
+  cfg3: 1024 targets per GPU x the cutoff sweep {2,4,8,12,16,24,32 kHz} (cut bins 42..683 at fs 48 kHz):
+        est = ssr_fft_lowpass(target, cut) (FDomainHelper 2048/441), then the full metric set.  Unit: pairs/s,
+        a pair = (utterance, cutoff).
+  cfg5: 12,500 utterances of 64,000 samples @ 16 kHz per GPU (100 k on 8 GPUs): ssr_resample_poly 441/160 then
+        160/147, then LSD (2048/512) against a 48 kHz target.  Unit: resampled samples/s (192,000 per utterance).
+
+With the default config at N = 1 the cfg3 / cfg5 / API-true / end-to-end figures are measured too (short runs, outside
+the timed region) and reported under "extra".
 """
 import argparse
 import json
@@ -31,31 +37,10 @@ if ROOT not in sys.path:
 
 SR, SECONDS, N_FFT, HOP = 48000, 4, 2048, 512
 N_SAMPLES = SR * SECONDS                     # 192,000
-BYTES_PER_PAIR = 2 * N_SAMPLES * 4 + 32      # read est + target once, write 4 doubles
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6
-
-
-def make_inputs(n_pairs, device, seed):
-    g = torch.Generator(device=device).manual_seed(seed)
-    tgt = 0.1 * torch.randn((n_pairs, N_SAMPLES), generator=g, device=device, dtype=torch.float32)
-    est = tgt + 0.01 * torch.randn((n_pairs, N_SAMPLES), generator=g, device=device, dtype=torch.float32)
-    return est.contiguous(), tgt.contiguous()
-
-
-def pmc_traffic(kernel_key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/rNN_traffic.json, produced by tools/collect_profiles.sh + tools/pmc_to_json.py: separate --pmc
-    FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).  None if absent."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-    if not files:
-        return None, None
-    try:
-        d = json.load(open(files[-1]))
-        return d["traffic_bytes_per_launch"][kernel_key]["total_bytes"], os.path.basename(files[-1])
-    except Exception:
-        return None, None
+CUTOFFS_HZ = [1000, 2000, 4000, 6000, 8000, 12000, 16000]    # sweep labels 2..32 kHz = 2 x cutoff
+CUT_BINS = [int(1025 * (c / int(SR / 2))) for c in CUTOFFS_HZ]  # 42 85 170 256 341 512 683
 
 
 def event_time_ms(fn, iters):
@@ -71,89 +56,474 @@ def event_time_ms(fn, iters):
     return start.elapsed_time(stop) / iters
 
 
-def _cpu_pair(args):
-    """LSD + SSIM of one pair through the oracle (the reference's arithmetic restated on the CPU)."""
-    est, tgt = args
-    torch.set_num_threads(1)
-    from oracle import metrics as om
-    es, ts = om.wav_to_spectrogram(est, N_FFT, HOP), om.wav_to_spectrogram(tgt, N_FFT, HOP)
-    return float(om.lsd(es, ts)), float(om.ssim(es, ts))
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/rNN_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, corrected per MI355X_MICROARCH.md)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))["traffic_bytes_per_launch"]
+            for k, v in d.items():
+                if kernel_key in k:
+                    return v["total_bytes"], os.path.basename(f)
+        except Exception:
+            continue
+    return None, None
 
 
-def cpu_baseline(est, tgt, budget_s=20.0):
-    """pairs/s of the oracle on the host: (i) 1 process / 1 thread, (ii) one process per core."""
-    import multiprocessing as mp
-    n_avail = est.shape[0]
-    pairs = [(est[i].cpu().numpy(), tgt[i].cpu().numpy()) for i in range(min(n_avail, 256))]
+def hbm_roofline(kernel, alg_bytes, ms, traffic_key=None, note=None):
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    traffic, src = pmc_traffic(traffic_key) if traffic_key else (None, None)
+    r = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": src,
+         "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(ms, 4)}
+    if note:
+        r["note"] = note
+    return r
+
+
+# ----------------------------------------------------------------------------------------------------------
+# workloads
+class Cfg2:
+    name = "cfg2"
+    metric = "utterance-pairs/sec (LSD+SSIM, 48kHz, n_fft=2048)"
+    unit = "pairs/s"
+
+    def __init__(self, a, dev, rank):
+        from ssr_eval_amd import backend as B
+        self.B, self.a, self.dev = B, a, dev
+        g = torch.Generator(device=dev).manual_seed(20220328 + rank)
+        n = a.pairs
+        self.tgt = (0.1 * torch.randn((n, N_SAMPLES), generator=g, device=dev, dtype=torch.float32)).contiguous()
+        self.est = (self.tgt + 0.01 * torch.randn((n, N_SAMPLES), generator=g, device=dev, dtype=torch.float32)).contiguous()
+        self.plan = B.get_plan(N_FFT, HOP, a.precision, dev)
+        self.batch = B.PairBatch(self.plan, B.Ragged.from_uniform(self.est), B.Ragged.from_uniform(self.tgt))
+        self.mask = B.M_LSD | B.M_SSIM
+        self.units_per_step = n
+        self.cnt = torch.full((1,), float(n), dtype=torch.float64, device=dev)
+        self.agg = torch.zeros(3, dtype=torch.float64, device=dev)
+
+    def step(self):
+        out = self.batch.run(self.mask)
+        # per-rank sums (LSD, SSIM, count) -> the job-wide mean needs exactly one tiny all-reduce
+        torch.cat([out[:, 0].sum(0, keepdim=True), out[:, 3].sum(0, keepdim=True), self.cnt], out=self.agg)
+        return self.agg
+
+    def config(self, world):
+        a = self.a
+        return {"workload": "cfg-2: %d synthetic 48 kHz 4 s float32 (est, target) pairs per GPU resident in HBM, STFT n_fft=2048 "
+                            "hop=512 (T=376, F=1025), LSD + SSIM, transform precision %s" % (a.pairs, a.precision),
+                "pairs_per_gpu": a.pairs, "samples_per_utterance": N_SAMPLES, "n_fft": N_FFT, "hop": HOP,
+                "parallelism": "utterance-sharded x%d, one float64 all-reduce (24 B) per step" % world}
+
+    def report(self, a):
+        B, batch, mask = self.B, self.batch, self.mask
+        it = max(3, min(10, a.steps))
+        ms_stft = event_time_ms(lambda: batch.run(mask, stages=1), it)
+        ms_ssim = event_time_ms(lambda: batch.run(mask, stages=2), it)
+        ms_fin = event_time_ms(lambda: batch.run(mask, stages=4), it)
+        ms_all4 = event_time_ms(lambda: batch.run(B.M_ALL), it)
+        alg = (2 * N_SAMPLES * 4 + 32) * a.pairs          # SURVEY 8(d): read est + target once, write 4 doubles
+        fft_tflops = 2 * 376 * 2.5 * 2048 * 11 * a.pairs / (ms_stft * 1e-3) / 1e12   # 42.4 MFLOP of real-FFT work per pair
+        dom = ("ssr_stft_pair(k_stft)", ms_stft, "k_stft<double, 11") if ms_stft >= ms_ssim else ("ssr_ssim(k_ssim)", ms_ssim, "k_ssim")
+        default_wl = a.pairs == 1024 and a.precision == "f64"
+        roof = hbm_roofline(dom[0], alg, dom[1], dom[2] if default_wl else None,
+                            "fused path is compute-side (f64 FFT + f64 SSIM moments); secondary: STFT kernel runs at %.2f TFLOP/s "
+                            "of real-FFT work = %.3f of the f64 vector peak" % (fft_tflops, fft_tflops / FP64_PEAK_TFLOPS))
+        extra = {"stage_ms": {"stft+lsd": round(ms_stft, 4), "ssim": round(ms_ssim, 4), "finalize": round(ms_fin, 4)},
+                 "full_metric_set_pairs_per_s_per_gpu": round(a.pairs / (ms_all4 * 1e-3), 1)}
+        return roof, extra
+
+    # CPU baseline: LSD + SSIM of one pair through the oracle
+    def cpu_inputs(self, n):
+        return [(self.est[i].cpu().numpy(), self.tgt[i].cpu().numpy()) for i in range(min(n, self.a.pairs))]
+
+    @staticmethod
+    def cpu_unit(item):
+        from oracle import metrics as om
+        est, tgt = item
+        es, ts = om.wav_to_spectrogram(est, N_FFT, HOP), om.wav_to_spectrogram(tgt, N_FFT, HOP)
+        return float(om.lsd(es, ts)), float(om.ssim(es, ts))
+
+    cpu_desc = "pairs of the same workload (4 s @ 48 kHz, STFT 2048/512 + LSD + SSIM) through the NumPy/SciPy/torch-CPU oracle"
+
+    def parity(self, out_vals, n):
+        got = self.batch.run(self.mask)[:n].cpu().numpy()
+        return max(max(abs(got[i, 0] - v[0]) / abs(v[0]), abs(got[i, 3] - v[1]) / abs(v[1])) for i, v in enumerate(out_vals[:n]))
+
+
+class Cfg3:
+    name = "cfg3"
+    metric = "utterance-pairs/sec (full metric set + FFT low-pass degradation, cutoff sweep {2k..32k}, 48kHz, n_fft=2048)"
+    unit = "pairs/s"
+
+    def __init__(self, a, dev, rank):
+        from ssr_eval_amd import backend as B
+        self.B, self.a, self.dev = B, a, dev
+        g = torch.Generator(device=dev).manual_seed(20220328 + rank)
+        n = a.pairs
+        self.tgt = (0.1 * torch.randn((n, N_SAMPLES), generator=g, device=dev, dtype=torch.float32)).contiguous()
+        tr = B.Ragged.from_uniform(self.tgt)
+        self.lp_plan = B.get_plan(2048, 441, a.precision, dev)            # FDomainHelper() of ssr_eval/lowpass.py:167
+        self.plan = B.get_plan(N_FFT, HOP, a.precision, dev)
+        # the seven cutoffs run one after the other on the stream and share the low-pass output / workspace buffers; only
+        # the cut-bin descriptor changes
+        self.lp = B.LowpassBatch(self.lp_plan, tr, [CUT_BINS[0]] * n)
+        self.cuts = [torch.full((n,), c, dtype=torch.int32, device=dev) for c in CUT_BINS]
+        self.batch = B.PairBatch(self.plan, self.lp.out_ragged(), tr)
+        self.units_per_step = n * len(CUT_BINS)
+        self.cnt = torch.full((1,), float(self.units_per_step), dtype=torch.float64, device=dev)
+        self.acc = torch.zeros(4, dtype=torch.float64, device=dev)
+        self.agg = torch.zeros(5, dtype=torch.float64, device=dev)
+
+    def step(self):
+        lp = self.lp
+        self.acc.zero_()
+        for cut in self.cuts:
+            lp.cut = cut
+            lp.run()                                     # est <- fft_lowpass(target, cut)
+            self.acc += self.batch.run(self.B.M_ALL).sum(0)
+        torch.cat([self.acc, self.cnt], out=self.agg)
+        return self.agg
+
+    def config(self, world):
+        a = self.a
+        return {"workload": "cfg-3: %d synthetic 48 kHz 4 s float32 targets per GPU resident in HBM x 7 cutoffs "
+                            "(cut bins %s of FDomainHelper 2048/441 at fs 48 kHz): est = ssr_fft_lowpass(target, cut), then LSD + "
+                            "log-SISpec + SISpec + SSIM at STFT 2048/512, transform precision %s" % (a.pairs, CUT_BINS, a.precision),
+                "targets_per_gpu": a.pairs, "cutoffs_hz": CUTOFFS_HZ, "cut_bins": CUT_BINS, "samples_per_utterance": N_SAMPLES,
+                "parallelism": "utterance-sharded x%d, one float64 all-reduce (40 B) per step" % world}
+
+    def report(self, a):
+        B, lp, batch = self.B, self.lp, self.batch
+        it = 3
+        lp.cut = self.cuts[3]
+        ms_lp = event_time_ms(lambda: lp.run(), it)
+        ms_stft = event_time_ms(lambda: batch.run(B.M_ALL, stages=1), it)
+        ms_ssim = event_time_ms(lambda: batch.run(B.M_ALL, stages=2), it)
+        n = a.pairs
+        stages = {"fft_lowpass": (ms_lp, 2 * N_SAMPLES * 4 * n), "stft+lsd+sispec": (ms_stft, (2 * N_SAMPLES * 4 + 32) * n),
+                  "ssim": (ms_ssim, (2 * N_SAMPLES * 4 + 32) * n)}
+        dom = max(stages, key=lambda k: stages[k][0])
+        roof = hbm_roofline("ssr_pair_metrics:" + dom if dom != "fft_lowpass" else "ssr_fft_lowpass(k_lowpass_frames+k_ola)",
+                            stages[dom][1], stages[dom][0], None,
+                            "per cutoff and 1024 utterances; algorithmic bytes: low-pass 2*n*4 per (utterance, cutoff), pair metrics "
+                            "2*n*4+32 per pair (SURVEY 8(d))")
+        extra = {"stage_ms_per_cutoff": {k: round(v[0], 4) for k, v in stages.items()},
+                 "fft_lowpass_utterances_per_s": round(n / (ms_lp * 1e-3), 1),
+                 "fft_lowpass_algorithmic_GBs": round(stages["fft_lowpass"][1] / (ms_lp * 1e-3) / 1e9, 1)}
+        return roof, extra
+
+    def cpu_inputs(self, n):
+        return [(self.tgt[i % self.a.pairs].cpu().numpy(), CUTOFFS_HZ[i % 7]) for i in range(n)]
+
+    @staticmethod
+    def cpu_unit(item):
+        from oracle import lowpass as olp, metrics as om
+        tgt, cutoff = item
+        est = olp.lowpass(tgt, cutoff, SR, 1, "stft_hard")
+        r = om.evaluation(est, tgt, n_fft=N_FFT, hop=HOP)
+        return r["lsd"], r["ssim"]
+
+    cpu_desc = "(utterance, cutoff) pairs of the same workload (oracle stft_hard low-pass 2048/441 + 4 metrics at 2048/512)"
+    parity = None
+
+
+class Cfg5:
+    name = "cfg5"
+    metric = "resampled-samples/sec (polyphase 16000->44100->48000 + LSD, 64000-sample utterances)"
+    unit = "samples/s"
+    N_IN = 64000
+
+    def __init__(self, a, dev, rank):
+        from ssr_eval_amd import backend as B
+        self.B, self.a, self.dev = B, a, dev
+        n = a.utterances
+        g = torch.Generator(device=dev).manual_seed(20220328 + rank)
+        self.x = (0.1 * torch.randn((n, self.N_IN), generator=g, device=dev, dtype=torch.float32)).contiguous()
+        self.tgt = (0.1 * torch.randn((n, N_SAMPLES), generator=g, device=dev, dtype=torch.float32)).contiguous()
+        self.s1 = B.ResampleBatch(B.Ragged.from_uniform(self.x), 44100, 16000)
+        assert int(self.s1.out_len[0]) == 176400
+        self.s2 = B.ResampleBatch(self.s1.out_ragged(), 48000, 44100)
+        assert int(self.s2.out_len[0]) == N_SAMPLES
+        self.plan = B.get_plan(N_FFT, HOP, a.precision, dev)
+        self.batch = B.PairBatch(self.plan, self.s2.out_ragged(), B.Ragged.from_uniform(self.tgt))
+        self.units_per_step = n * N_SAMPLES
+        self.cnt = torch.full((1,), float(n), dtype=torch.float64, device=dev)
+        self.agg = torch.zeros(2, dtype=torch.float64, device=dev)
+
+    def step(self):
+        self.s1.run()
+        self.s2.run()
+        out = self.batch.run(self.B.M_LSD)
+        torch.cat([out[:, 0].sum(0, keepdim=True), self.cnt], out=self.agg)
+        return self.agg
+
+    def config(self, world):
+        a = self.a
+        return {"workload": "cfg-5: %d synthetic utterances of 64,000 float32 samples @ 16 kHz per GPU resident in HBM: polyphase "
+                            "resample 441/160 (8821 taps) then 160/147 (3201 taps) -> 192,000 samples, LSD at STFT 2048/512 against a "
+                            "48 kHz target; value counts the 192,000 output samples per utterance" % a.utterances,
+                "utterances_per_gpu": a.utterances, "samples_in": self.N_IN, "samples_out": N_SAMPLES,
+                "parallelism": "utterance-sharded x%d (100k utterances = 8 x 12,500), one float64 all-reduce (16 B) per step" % world}
+
+    def report(self, a):
+        it = 3
+        n = a.utterances
+        ms1 = event_time_ms(lambda: self.s1.run(), it)
+        ms2 = event_time_ms(lambda: self.s2.run(), it)
+        ms3 = event_time_ms(lambda: self.batch.run(self.B.M_LSD), it)
+        stages = {"resample_441_160": (ms1, 4 * (64000 + 176400) * n), "resample_160_147": (ms2, 4 * (176400 + 192000) * n),
+                  "stft+lsd": (ms3, (2 * N_SAMPLES * 4 + 32) * n)}
+        # SURVEY 8(d): the fused resampling chain's algorithmic bytes are 4*(n_in + n_out_final) = 1,024,000 B / utterance
+        chain_alg = 4 * (64000 + 192000) * n
+        roof = hbm_roofline("ssr_resample_poly x2 (k_resample, both stages)", chain_alg, ms1 + ms2, None,
+                            "the resampling chain is the HBM-side kernel of this config; per-stage read+write rates and the LSD "
+                            "stage are under extra.stage_ms / extra.stage_GBs")
+        extra = {"stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
+                 "stage_GBs_read_plus_write": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) for k, v in stages.items()},
+                 "resample_only_output_samples_per_s": round(n * N_SAMPLES / ((ms1 + ms2) * 1e-3), 1)}
+        return roof, extra
+
+    def cpu_inputs(self, n):
+        return [(self.x[i % self.a.utterances].cpu().numpy(), self.tgt[i % self.a.utterances].cpu().numpy()) for i in range(n)]
+
+    @staticmethod
+    def cpu_unit(item):
+        from scipy import signal
+        from oracle import metrics as om
+        x, tgt = item
+        y = signal.resample_poly(signal.resample_poly(x, 441, 160), 160, 147)
+        return float(om.lsd(om.wav_to_spectrogram(y, N_FFT, HOP), om.wav_to_spectrogram(tgt, N_FFT, HOP))), 0.0
+
+    cpu_desc = "utterances of the same workload (scipy.signal.resample_poly 441/160 + 160/147, oracle STFT 2048/512 + LSD)"
+    cpu_scale = N_SAMPLES          # value unit = output samples
+    parity = None
+
+
+class Skeleton:
+    """No kernels: exercises the launcher, the barrier / MAX-over-ranks timing and the all-reduce on CPU (gloo) in
+    tests/test_bench_skeleton.py.  Selected by --_cpu-skeleton only; never a measurement."""
+    name = "skeleton"
+    metric = "skeleton-units/sec (no kernels; launcher self-test)"
+    unit = "units/s"
+    parity = None
+
+    def __init__(self, a, dev, rank):
+        self.a, self.units_per_step = a, 10
+        self.agg = torch.tensor([float(rank + 1), 1.0], dtype=torch.float64, device=dev)
+        self.rank = rank
+
+    def step(self):
+        self.agg[0], self.agg[1] = float(self.rank + 1), 1.0
+        return self.agg
+
+    def config(self, world):
+        return {"workload": "skeleton", "parallelism": "x%d" % world}
+
+    def report(self, a):
+        return None, {}
+
+
+WORKLOADS = {"cfg2": Cfg2, "cfg3": Cfg3, "cfg5": Cfg5}
+
+# ----------------------------------------------------------------------------------------------------------
+# CPU baseline (SURVEY 8(d) protocol): >= 64 units where a unit is short, first 4 discarded as warm-up, median of 3
+# repeats; (i) 1 process / 1 thread, (ii) one process per host core.  Workers inherit the inputs by fork (copy-on-write)
+# and receive only indices: shipping 1.5 MB waveforms through the pool's pipe was what capped round 1's 64-process
+# figure at 3.7x one thread.
+_CPU_ITEMS, _CPU_FN = None, None
+
+
+def _cpu_run(idx):
     torch.set_num_threads(1)
-    _cpu_pair(pairs[0])                                   # warm-up
     t0 = time.perf_counter()
-    vals = [_cpu_pair(pairs[i]) for i in range(4)]
-    one = (time.perf_counter() - t0) / 4
-    cores = max(1, min(os.cpu_count() or 1, 64))
-    n_pool = int(max(cores, min(len(pairs), cores * max(1, int(budget_s * 0.6 / max(one, 1e-3))))))
-    n_pool = min(n_pool, len(pairs))
-    pool_rate = None
+    vals = [_CPU_FN(_CPU_ITEMS[i]) for i in idx]
+    return time.perf_counter() - t0, vals
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(wl, budget_s=24.0):
+    import multiprocessing as mp
+    global _CPU_ITEMS, _CPU_FN
+    _CPU_FN = wl.cpu_unit
+    probe = wl.cpu_inputs(2)
+    _CPU_ITEMS = probe
+    torch.set_num_threads(1)
+    _cpu_run([0])
+    t_unit = _cpu_run([1])[0]
+    scale = getattr(wl, "cpu_scale", 1)
+    # (i) one thread
+    n1 = 64 if t_unit * 68 * 3 <= budget_s * 0.4 else max(4, int(budget_s * 0.4 / 3 / t_unit) - 4)
+    cores = os.cpu_count() or 1
+    per_worker = 2 if t_unit * 2 * 3 * 2 <= budget_s * 0.5 else 1
+    n_pool = max(64, cores * per_worker)
+    _CPU_ITEMS = wl.cpu_inputs(max(n1 + 4, min(n_pool, 512)))
+    n_items = len(_CPU_ITEMS)
+    reps1, vals = [], None
+    for _ in range(3):
+        _cpu_run(list(range(4)))                                        # discarded warm-up
+        dt, v = _cpu_run([4 + i for i in range(n1)])
+        vals = vals or v
+        reps1.append(n1 / dt)
+    rate1 = float(np.median(reps1)) * scale
+    # (ii) one process per core, fork: inputs are inherited
+    rate_pool, err = None, None
     try:
         ctx = mp.get_context("fork")
+        chunks = [[(w * per_worker + j) % n_items for j in range(per_worker)] for w in range(max(cores, n_pool // per_worker))]
         with ctx.Pool(cores) as pool:
-            pool.map(_cpu_pair, pairs[:cores])            # warm the workers
-            t0 = time.perf_counter()
-            pool.map(_cpu_pair, pairs[:n_pool], chunksize=max(1, n_pool // (cores * 4)))
-            pool_rate = n_pool / (time.perf_counter() - t0)
-    except Exception as e:                                # a locked-down box: report the 1-thread number only
-        sys.stderr.write("cpu_baseline pool failed: %r\n" % (e,))
-    return vals, 1.0 / one, pool_rate, cores, n_pool
+            pool.map(_cpu_run, [[i % n_items] for i in range(cores)])   # warm the workers (discarded)
+            reps = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                pool.map(_cpu_run, chunks, chunksize=1)
+                reps.append(sum(len(c) for c in chunks) / (time.perf_counter() - t0))
+            rate_pool = float(np.median(reps)) * scale
+    except Exception as e:                                              # a locked-down box: report the 1-thread number only
+        err = repr(e)
+    out = {"value": round(rate_pool if rate_pool else rate1, 3), "unit": wl.unit, "cores": cores if rate_pool else 1, "kind": "port",
+           "cpu_model": _cpu_model(), "value_1thread": round(rate1, 3),
+           "sample": "%s: 1 thread = median of 3 repeats of %d units after 4 discarded; %d processes (os.cpu_count(), 1 thread "
+                     "each, inputs inherited by fork) = median of 3 repeats of %d units after one discarded unit per worker"
+                     % (wl.cpu_desc, n1, cores, sum(len(c) for c in chunks) if rate_pool else 0)}
+    if err:
+        out["pool_error"] = err
+    return out, vals
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=1024, help="pairs per GPU per step (BASELINE config: 1024)")
-    ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
-
+# ----------------------------------------------------------------------------------------------------------
+def side_figures(a, dev):
+    """Short measurements of the other BASELINE configs, the API-true STFT size and the end-to-end helper (N = 1 only,
+    outside the timed region) -> dict for `extra`."""
     from ssr_eval_amd import backend as B
+    ex = {}
+
+    def guarded(name, fn):
+        try:
+            ex[name] = fn()
+        except Exception as e:  # pragma: no cover
+            ex[name] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+
+    def api_true():
+        nb = a.pairs
+        g = torch.Generator(device=dev).manual_seed(7)
+        tgt = (0.1 * torch.randn((nb, N_SAMPLES), generator=g, device=dev)).contiguous()
+        est = (tgt + 0.01 * torch.randn((nb, N_SAMPLES), generator=g, device=dev)).contiguous()
+        b2 = B.PairBatch(B.get_plan(2229, 480, a.precision, dev), B.Ragged.from_uniform(est), B.Ragged.from_uniform(tgt))
+        mask = B.M_LSD | B.M_SSIM
+        ms = event_time_ms(lambda: b2.run(mask), 3)
+        ms_stft = event_time_ms(lambda: b2.run(mask, stages=1), 3)
+        return {"workload": "AudioMetrics(48000) sizes: n_fft 2229 (radix-3 x Bluestein-743, M = 2048) / hop 480, %d pairs of 4 s @ 48 kHz, "
+                            "LSD + SSIM" % nb,
+                "pairs_per_s": round(nb / (ms * 1e-3), 1),
+                "roofline": hbm_roofline("ssr_stft_pair(k_stft_r3)", (2 * N_SAMPLES * 4 + 32) * nb, ms_stft)}
+
+    def other(cfg, steps):
+        def run():
+            wl = WORKLOADS[cfg](a, dev, 0)
+            for _ in range(1):
+                wl.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                wl.step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            roof, extra = wl.report(a)
+            return {"metric": wl.metric, "value": round(wl.units_per_step * steps / dt, 1), "unit": wl.unit, "steps": steps,
+                    "ms_per_step": round(dt / steps * 1e3, 3), "config": wl.config(1), "roofline": roof, "extra": extra}
+        return run
+
+    def e2e():
+        import tempfile
+        import shutil
+        from ssr_eval_amd import SSR_Eval_Helper, BasicTestee
+        from ssr_eval_amd.io import write_wav
+        rng = np.random.default_rng(4)
+        root = tempfile.mkdtemp(prefix="ssr_e2e_")
+        try:
+            n_files = 0
+            for s in range(8):
+                os.makedirs(os.path.join(root, "p%03d" % (360 + s)))
+                for i in range(8):
+                    n = int(rng.integers(int(1.5 * 44100), 9 * 44100))
+                    write_wav(os.path.join(root, "p%03d" % (360 + s), "u%03d.wav" % i), 0.1 * rng.standard_normal(n), 44100)
+                    n_files += 1
+            h = SSR_Eval_Helper(BasicTestee(), input_sr=44100, output_sr=44100, evaluation_sr=48000, test_data_root=root,
+                                setting_fft={"cutoff_freq": [12000]})
+            h.evaluate(limit_test_nums=2, limit_test_speaker=1, save_json=False)        # warm-up (plans, taps)
+            t0 = time.perf_counter()
+            res = h.evaluate(save_json=False)
+            dt = time.perf_counter() - t0
+            return {"workload": "SSR_Eval_Helper.evaluate() on %d PCM .wav files (8 speakers, 1.5-9 s @ 44.1 kHz, cfg-4's length "
+                                "distribution), identity testee, setting_fft cutoff 12 kHz, evaluation_sr 48000: host decode + H2D + "
+                                "resample + low-pass + 4 metrics + aggregation" % n_files,
+                    "files_per_s": round(n_files / dt, 1), "seconds": round(dt, 3),
+                    "averaged_lsd": float(res["averaged"]["proc_fft_24000_44100"]["lsd"])}
+        finally:
+            shutil.rmtree(root, ignore_errors=True)
+
+    guarded("api_true_2229_480", api_true)
+    guarded("cfg3", other("cfg3", 2))
+    guarded("cfg5", other("cfg5", 2))
+    guarded("evaluate_end_to_end", e2e)
+    return ex
+
+
+def run(a):
     from ssr_eval_amd import dist as D
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (launch with --nproc-per-node == --gpus)" % (a.gpus, world))
+    if a.cpu_skeleton:
+        dev, sync, backend = torch.device("cpu"), (lambda: None), "gloo"
+    else:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X"
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit("bench.py: rank %d has no device (%d visible)" % (local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        dev, sync, backend = torch.device("cuda", local_rank), torch.cuda.synchronize, "nccl"
     if world > 1:
-        D.init_from_env("nccl")
-    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
-    dev = torch.device("cuda", local_rank)
+        D.init_from_env(backend)
+        joined = dist.get_world_size()                # the ranks that actually joined the group
+        if joined != a.gpus:
+            raise SystemExit("bench.py: %d ranks joined the %s group, expected %d" % (joined, backend, a.gpus))
+    else:
+        joined = 1
 
-    est, tgt = make_inputs(a.pairs, dev, 20220328 + rank)
-    plan = B.get_plan(N_FFT, HOP, a.precision, dev)
-    batch = B.PairBatch(plan, B.Ragged.from_uniform(est), B.Ragged.from_uniform(tgt))
-    mask = B.M_LSD | B.M_SSIM
-    cnt = torch.full((1,), float(a.pairs), dtype=torch.float64, device=dev)
-    agg = torch.zeros(3, dtype=torch.float64, device=dev)
+    wl = (Skeleton if a.cpu_skeleton else WORKLOADS[a.config])(a, dev, rank)
+    wl_cls = type(wl)
 
     def step():
-        out = batch.run(mask)
-        # per-rank sums (LSD, SSIM, count) -> the job-wide mean needs exactly one tiny all-reduce
-        torch.cat([out[:, 0].sum(0, keepdim=True), out[:, 3].sum(0, keepdim=True), cnt], out=agg)
+        agg = wl.step()
         if world > 1:
             dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        return out
+        return agg
 
     for _ in range(a.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = step()
-    torch.cuda.synchronize()
+        agg = step()
+    sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -161,9 +531,10 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    total_pairs = a.pairs * world * a.steps
-    value = total_pairs / elapsed
-    mean_lsd, mean_ssim = float(agg[0] / agg[2]), float(agg[1] / agg[2])
+    value = wl.units_per_step * joined * a.steps / elapsed
+    agg = agg.cpu().numpy()
+    means = (agg[:-1] / agg[-1]).tolist()
+    payload = int(agg.nbytes)
 
     if rank != 0:
         if world > 1:
@@ -171,66 +542,71 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- dominant-kernel timing (HIP events on the launch stream), outside the timed region ----------
-    it = max(3, min(10, a.steps))
-    ms_stft = event_time_ms(lambda: batch.run(mask, stages=1), it)
-    ms_ssim = event_time_ms(lambda: batch.run(mask, stages=2), it)
-    ms_fin = event_time_ms(lambda: batch.run(mask, stages=4), it)
-    ms_all4 = event_time_ms(lambda: batch.run(B.M_ALL), it)
-    dom_name, dom_ms = ("ssr_stft_pair(k_stft)", ms_stft) if ms_stft >= ms_ssim else ("ssr_ssim(k_ssim)", ms_ssim)
-    alg_bytes = BYTES_PER_PAIR * a.pairs
-    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic("k_stft<double, 11" if ms_stft >= ms_ssim else "k_ssim")
-    if a.pairs != 1024 or a.precision != "f64":
-        traffic, traffic_src = None, None          # the PMC file was collected at the default workload only
-    fft_flops = 2 * 376 * 2.5 * 2048 * 11 * a.pairs          # 42.4 MFLOP of real-FFT work per pair
-    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(dom_ms, 4),
-                "note": "fused path is compute-side (f64 FFT + f64 SSIM moments); secondary: STFT kernel runs at "
-                        "%.2f TFLOP/s of real-FFT work = %.3f of the f64 vector peak"
-                        % (fft_flops / (ms_stft * 1e-3) / 1e12, fft_flops / (ms_stft * 1e-3) / 1e12 / FP64_PEAK_TFLOPS)}
-
-    # ---- API-true variant AudioMetrics(48000): n_fft 2229 (Bluestein, M = 8192) / hop 480, small batch ---
-    extra = {"stage_ms": {"stft+lsd": round(ms_stft, 4), "ssim": round(ms_ssim, 4), "finalize": round(ms_fin, 4)},
-             "full_metric_set_pairs_per_s_per_gpu": round(a.pairs / (ms_all4 * 1e-3), 1),
-             "mean_lsd": mean_lsd, "mean_ssim": mean_ssim}
-    try:
-        if world > 1:
-            raise RuntimeError("skipped at N > 1 (other ranks are waiting at the barrier)")
-        nb = min(a.pairs, 128)
-        plan2 = B.get_plan(2229, 480, a.precision, dev)
-        b2 = B.PairBatch(plan2, B.Ragged.from_uniform(est[:nb].contiguous()), B.Ragged.from_uniform(tgt[:nb].contiguous()))
-        ms2 = event_time_ms(lambda: b2.run(mask), 3)
-        extra["api_true_2229_480_pairs_per_s_per_gpu"] = round(nb / (ms2 * 1e-3), 1)
-    except Exception as e:  # pragma: no cover
-        extra["api_true_error"] = repr(e)
-
+    roofline, extra = wl.report(a)
+    extra["job_means"] = means
+    extra["allreduce_payload_bytes_per_step"] = payload if world > 1 else 0
     cpu = None
-    if not a.no_cpu_baseline and world == 1:      # contract: the CPU baseline is timed on rank 0 at N = 1 only
-        vals, rate1, rate_pool, cores, n_pool = cpu_baseline(est, tgt)
-        got = out[:len(vals)].cpu().numpy()
-        rel = max(max(abs(got[i, 0] - v[0]) / abs(v[0]), abs(got[i, 3] - v[1]) / abs(v[1])) for i, v in enumerate(vals))
-        extra["parity_vs_oracle_max_rel_err"] = float(rel)
-        cpu = {"value": round(rate_pool if rate_pool else rate1, 3), "unit": "pairs/s", "cores": cores if rate_pool else 1,
-               "kind": "port",
-               "sample": "%d pairs of the same workload (4 s @ 48 kHz, STFT 2048/512 + LSD + SSIM) through the NumPy/SciPy "
-                         "oracle, one process per core (1 thread each)" % (n_pool if rate_pool else 4),
-               "value_1thread": round(rate1, 3)}
+    if not a.no_cpu_baseline and world == 1 and not a.cpu_skeleton:      # contract: the CPU baseline is timed on rank 0 at N = 1 only
+        cpu, vals = cpu_baseline(wl)
+        if wl.parity is not None:
+            extra["parity_vs_oracle_max_rel_err"] = float(wl.parity(vals, min(4, len(vals))))
+    if world == 1 and a.config == "cfg2" and not a.no_side and not a.cpu_skeleton:
+        del wl
+        torch.cuda.empty_cache()
+        extra.update(side_figures(a, dev))
 
-    line = {"metric": "utterance-pairs/sec (LSD+SSIM, 48kHz, n_fft=2048)", "value": round(value, 2), "unit": "pairs/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": "cfg-2: %d synthetic 48 kHz 4 s float32 (est, target) pairs per GPU resident in HBM, "
-                                   "STFT n_fft=2048 hop=512 (T=376, F=1025), LSD + SSIM, transform precision %s"
-                                   % (a.pairs, a.precision),
-                       "pairs_per_gpu": a.pairs, "samples_per_utterance": N_SAMPLES, "n_fft": N_FFT, "hop": HOP,
-                       "parallelism": "utterance-sharded x%d, one float64 all-reduce per step" % world},
+    line = {"metric": wl_cls.metric, "value": round(value, 2), "unit": wl_cls.unit, "n_gpus": joined,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "config": _config_of(wl_cls, a, joined),
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _config_of(cls, a, world):
+    """The config description without building the workload again."""
+    shell = cls.__new__(cls)
+    shell.a = a
+    return cls.config(shell, world)
+
+
+def _spawned(local_rank, a, port):
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    run(a)
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=1024, help="cfg2/cfg3: pairs (targets) per GPU per step (BASELINE: 1024)")
+    ap.add_argument("--utterances", type=int, default=12500, help="cfg5: utterances per GPU per step (100k over 8 GPUs)")
+    ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true", help="skip the cfg3 / cfg5 / API-true / end-to-end side figures")
+    ap.add_argument("--_cpu-skeleton", dest="cpu_skeleton", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # self-launch: one process per GPU.  Never degrade to fewer ranks than asked for.
+        n_dev = torch.cuda.device_count()
+        if n_dev < a.gpus and not a.cpu_skeleton:
+            raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) are visible" % (a.gpus, n_dev))
+        import torch.multiprocessing as mp
+        port = 29400 + os.getpid() % 2000
+        mp.spawn(_spawned, args=(a, port), nprocs=a.gpus, join=True)
+        return
+    run(a)
 
 
 if __name__ == "__main__":

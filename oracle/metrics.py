@@ -75,6 +75,15 @@ def sispec(est, target):
     return torch.sum(loss) / loss.size()[0]
 
 
+def sispec_exact(est, target):
+    """The SAME formula (metrics.py:114-121 + utils.py:79-82) evaluated in float64 on the float32 inputs: what the
+    reference would return if its reductions were exact.  The reference's float32 torch.norm / torch.sum over the
+    ~1e6 elements of a long utterance are only good to ~1e-5 relative (measured in
+    tests/test_oracle.py::test_reference_float32_sispec_noise_is_measured), so this is the yardstick that separates
+    "the kernel is wrong" from "the reference's own round-off"."""
+    return sispec(est.double(), target.double())
+
+
 def ssim(est, target):
     """ssr_eval/metrics.py:123-132 -> float64 [B, C, 1, 1]."""
     e, t = est.numpy(), target.numpy()
@@ -93,6 +102,17 @@ def spectrogram_metrics(est_sp, target_sp):
         "sispec": float(sispec(est_sp.clone(), target_sp.clone())),
         "ssim": float(ssim(est_sp.clone(), target_sp.clone())),
     }
+
+
+def evaluation_with_exact(est, target, rate=None, n_fft=None, hop=None):
+    """(evaluation(...), {"log_sispec": ..., "sispec": ...} through sispec_exact) on the same spectrograms."""
+    assert est.ndim == 1 and target.ndim == 1
+    if n_fft is None:
+        n_fft, hop = stft_params(rate)
+    m = min(target.shape[0], est.shape[0])
+    es, ts = wav_to_spectrogram(est[:m], n_fft, hop), wav_to_spectrogram(target[:m], n_fft, hop)
+    exact = {"log_sispec": float(sispec_exact(to_log(es.clone()), to_log(ts.clone()))), "sispec": float(sispec_exact(es, ts))}
+    return spectrogram_metrics(es, ts), exact
 
 
 def evaluation(est, target, rate=None, n_fft=None, hop=None):

@@ -311,23 +311,44 @@ def spectrogram_metrics(est_sps, tgt_sps, mask=M_ALL):
         return out
 
 
+class LowpassBatch:
+    """A ragged batch + cached descriptors / workspace / output for repeated ssr_fft_lowpass calls (K6): one cut bin per
+    item.  `run()` enqueues the launch sequence on the current stream and returns the flat output buffer (same layout as
+    the input batch); `out_ragged()` views it as a Ragged batch for the metric stage."""
+
+    def __init__(self, plan, ragged, cut_bins):
+        _check_reflect(plan, ragged.lens_host)
+        if ragged.data.dtype != torch.float32:
+            raise ValueError("the STFT-domain low-pass takes float32 signals (torchlibrosa's convolution does too)")
+        self.plan, self.r = plan, ragged
+        self.rows = _Rows(plan, ragged.lens_host, ragged.device)
+        self.cut = torch.from_numpy(np.asarray(cut_bins, dtype=np.int32)).to(ragged.device)
+        if self.cut.numel() != ragged.n:
+            raise ValueError("one cut bin per item")
+        self.ws_bytes = int(plan.lib.ssr_ola_workspace_bytes(plan.handle, self.rows.total))
+        self.ws = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=ragged.device)
+        self.out = torch.empty_like(ragged.data)
+
+    def run(self):
+        p, r = self.plan, self.r
+        if r.n:
+            _lib.check(p.lib.ssr_fft_lowpass(p.handle, _vp(r.data), _vp(r.off), _vp(r.len), _vp(self.cut), _vp(self.rows.off),
+                                             r.n, r.max_len, self.rows.total, _vp(self.out), _vp(self.ws), self.ws_bytes,
+                                             _stream()))
+        return self.out
+
+    def out_ragged(self):
+        return Ragged(self.out, self.r.off, self.r.len, self.r.lens_host)
+
+
 def fft_lowpass(plan, wavs, cut_bins):
     """STFT-domain hard low-pass (K6) of a list of waveforms; cut_bins: first zeroed bin per item."""
     with torch.cuda.device(plan.device):
         r = wavs if isinstance(wavs, Ragged) else Ragged.from_list(wavs, plan.device)
         if r.n == 0:
             return []
-        _check_reflect(plan, r.lens_host)
-        rows = _Rows(plan, r.lens_host, r.device)
-        cut = torch.from_numpy(np.asarray(cut_bins, dtype=np.int32)).to(r.device)
-        if cut.numel() != r.n:
-            raise ValueError("one cut bin per item")
-        ws_bytes = int(plan.lib.ssr_ola_workspace_bytes(plan.handle, rows.total))
-        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=r.device)
-        out = torch.empty_like(r.data)
-        _lib.check(plan.lib.ssr_fft_lowpass(plan.handle, _vp(r.data), _vp(r.off), _vp(r.len), _vp(cut), _vp(rows.off), r.n,
-                                            r.max_len, rows.total, _vp(out), _vp(ws), ws_bytes, _stream()))
-        return r.split(out)
+        b = LowpassBatch(plan, r, cut_bins)
+        return r.split(b.run())
 
 
 def istft(plan, res, ims, lengths):
@@ -396,27 +417,47 @@ class ResamplePlan:
         return -(-int(n_in) * self.up // self.down)
 
 
+class ResampleBatch:
+    """A ragged batch + cached output descriptors / buffer for repeated ssr_resample_poly calls (K7)."""
+
+    def __init__(self, ragged, up, down):
+        dev = ragged.device
+        self.r, self.rp = ragged, ResamplePlan.get(up, down, dev)
+        self.f64 = ragged.data.dtype == torch.float64
+        if self.rp.identity:
+            self.out_len = ragged.lens_host.copy()
+        else:
+            self.out_len = np.array([self.rp.n_out(n) for n in ragged.lens_host], dtype=np.int64)
+        self.out_off = np.concatenate(([0], np.cumsum(self.out_len)[:-1])).astype(np.int64) if ragged.n else np.zeros(0, np.int64)
+        self.out_off_d = torch.from_numpy(self.out_off).to(dev)
+        self.out_len_d = torch.from_numpy(self.out_len.astype(np.int32)).to(dev)
+        self.out = torch.empty(int(self.out_len.sum()), dtype=ragged.data.dtype, device=dev)
+
+    def run(self):
+        r, rp = self.r, self.rp
+        if rp.identity:
+            self.out.copy_(r.data)             # scipy returns x.copy() before designing any filter
+        elif r.n and self.out_len.max() > 0:
+            taps = rp.taps64 if self.f64 else rp.taps
+            fn = _lib.load().ssr_resample_poly_f64 if self.f64 else _lib.load().ssr_resample_poly
+            _lib.check(fn(_vp(r.data), _vp(r.off), _vp(r.len), _vp(self.out_off_d), _vp(self.out_len_d), r.n,
+                          int(self.out_len.max()), rp.up, rp.down, _vp(taps), int(taps.numel()), rp.n_pre_remove,
+                          _vp(self.out), _stream()))
+        return self.out
+
+    def out_ragged(self):
+        return Ragged(self.out, self.out_off_d, self.out_len_d, self.out_len)
+
+
 def resample_poly(wavs, up, down, device=None):
     """Polyphase resampling (K7) of a list of waveforms; bit-identical to scipy.signal.resample_poly.  A batch
     holding float64 signals is resampled in float64 (float64 taps and accumulation), everything else in float32."""
     dev = torch.device(device) if device is not None else default_device()
     with torch.cuda.device(dev):
         r = wavs if isinstance(wavs, Ragged) else Ragged.from_list_keep64(wavs, dev)
-        rp = ResamplePlan.get(up, down, dev)
-        if rp.identity:
-            return [w.clone() for w in r.split()]
-        f64 = r.data.dtype == torch.float64
-        out_len = np.array([rp.n_out(n) for n in r.lens_host], dtype=np.int64)
-        out_off = np.concatenate(([0], np.cumsum(out_len)[:-1])).astype(np.int64)
-        out = torch.empty(int(out_len.sum()), dtype=r.data.dtype, device=dev)
-        if r.n and out_len.max() > 0:
-            out_off_d = torch.from_numpy(out_off).to(dev)          # keep alive across the call (see istft)
-            out_len_d = torch.from_numpy(out_len.astype(np.int32)).to(dev)
-            taps = rp.taps64 if f64 else rp.taps
-            fn = _lib.load().ssr_resample_poly_f64 if f64 else _lib.load().ssr_resample_poly
-            _lib.check(fn(_vp(r.data), _vp(r.off), _vp(r.len), _vp(out_off_d), _vp(out_len_d), r.n, int(out_len.max()),
-                          rp.up, rp.down, _vp(taps), int(taps.numel()), rp.n_pre_remove, _vp(out), _stream()))
-        return [out[out_off[i]:out_off[i] + out_len[i]] for i in range(r.n)]
+        b = ResampleBatch(r, up, down)
+        out = b.run()
+        return [out[b.out_off[i]:b.out_off[i] + b.out_len[i]] for i in range(r.n)]
 
 
 def sosfiltfilt(sos, wavs, device=None):

@@ -115,3 +115,31 @@ SSR_BODY void ssr_resample_body(const SsrResampleParamsT<S>& p, BLK& blk, int bl
     }
   });
 }
+
+
+// Fallback for rate pairs whose reduced `up` is so large that even the smallest block of the kernel above (up * J
+// outputs, all phases once) needs an input window beyond the LDS - e.g. the reference's subsampling of a 16 kHz input at
+// cutoff 8000 Hz (low_rate == sr -> -1 quirk: 7349 / 7350, ssr_eval/lowpass.py:134-140, eval.py:404-405).  One output per
+// thread, consecutive outputs on consecutive lanes; samples and taps come through L1 / L2 (the tap index advances by
+// `down mod up` per output, the input index by about down / up).  Same arithmetic: ascending input index, separately
+// rounded multiply and add -> the same bits as SciPy.
+template <typename S>
+SSR_DEV void ssr_resample_direct_output(const SsrResampleParamsT<S>& p, int item, int64_t m) {
+  const int n_in = p.in_len[item], n_out = p.out_len[item];
+  if (m >= n_out) return;
+  const int hpp = ssr_resample_hpp(p), up = p.up;
+  const S* x = p.in + p.in_off[item];
+  const int64_t t0 = (m + p.n_pre_remove) * p.down;
+  const int64_t q0 = t0 / up;
+  const int ph = (int)(t0 - q0 * up);
+  S acc = (S)0;
+  int64_t hi = ph + (int64_t)(hpp - 1) * up;
+  for (int k = 0; k < hpp; ++k) {
+    const int64_t i = q0 - (hpp - 1) + k;
+    const S hv = (hi < p.n_taps) ? p.taps[hi] : (S)0;
+    const S xv = (i >= 0 && i < n_in) ? x[i] : (S)0;
+    hi -= up;
+    acc = ssr_fadd_rn(acc, ssr_fmul_rn(xv, hv));
+  }
+  p.out[p.out_off[item] + m] = acc;
+}

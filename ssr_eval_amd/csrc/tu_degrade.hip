@@ -24,6 +24,12 @@ __global__ __launch_bounds__(SSR_RESAMPLE_NT) void k_resample(SsrResampleParamsT
   ssr_resample_body<S>(p, blk, blockIdx.x % blocks_per_item, blockIdx.x / blocks_per_item, smem);
 }
 
+template <typename S>
+__global__ __launch_bounds__(256) void k_resample_direct(SsrResampleParamsT<S> p, int blocks_per_item) {
+  const int item = blockIdx.x / blocks_per_item;
+  ssr_resample_direct_output<S>(p, item, (int64_t)(blockIdx.x % blocks_per_item) * 256 + threadIdx.x);
+}
+
 template <int G, typename X>
 __global__ __launch_bounds__(64) void k_sosfiltfilt(SsrIirParamsT<X> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -62,7 +68,12 @@ static int resample_poly_t(const S* in, const int64_t* in_off, const int32_t* in
                           ssr_resample_pick_groups(up, down), 1, out};
   if (ssr_resample_lds_bytes(p) > 96 * 1024) p.taps_in_lds = 0;      // huge tap tables stay in HBM / L2
   const size_t lds = ssr_resample_lds_bytes(p);
-  if (lds > 160 * 1024) return ssr_fail(SSR_ERR_UNSUPPORTED, "input window does not fit LDS");
+  if (lds > 160 * 1024) {           // huge reduced `up`: the phase-blocked kernel's window does not fit LDS
+    const int bpi = ssr_ceil_div(max_out_len, 256);
+    hipLaunchKernelGGL((k_resample_direct<S>), dim3((unsigned)((int64_t)n_items * bpi)), dim3(256), 0, (hipStream_t)stream, p, bpi);
+    HIP_TRY(hipGetLastError());
+    return SSR_OK;
+  }
   static thread_local int slot = 0;
   static thread_local size_t slot_lds = 0;          // the LDS size depends on the rate pair: remember the largest one
   if (lds > slot_lds) slot = 0;

@@ -60,8 +60,10 @@ def allreduce_sums(buf):
 
 def allgather_rows(local_rows, global_index, n_total):
     """Scatter rank-local rows [n_local, K] (owning global indices `global_index`) into [n_total, K] on every rank."""
-    local_rows = np.asarray(local_rows, dtype=np.float64).reshape(len(global_index), -1)
-    K = local_rows.shape[1] if local_rows.size else 0
+    local_rows = np.asarray(local_rows, dtype=np.float64)
+    # a rank that owns nothing passes an empty array: its width is whatever the other ranks agree on (MAX below)
+    local_rows = local_rows.reshape(len(global_index), -1) if local_rows.size else np.empty((len(global_index), 0))
+    K = local_rows.shape[1]
     rank, world = rank_world()
     if world == 1:
         out = np.full((n_total, K), np.nan)
@@ -73,7 +75,7 @@ def allgather_rows(local_rows, global_index, n_total):
     cap = -(-n_total // world)
     pack = torch.full((cap, K + 1), float("nan"), dtype=torch.float64)
     pack[:, 0] = -1.0
-    if len(global_index):
+    if len(global_index) and local_rows.shape[1] == K:
         pack[:len(global_index), 0] = torch.as_tensor(np.asarray(global_index, dtype=np.float64))
         pack[:len(global_index), 1:] = torch.as_tensor(local_rows)
     pack = pack.to(_comm_device())
@@ -90,7 +92,7 @@ def allgather_rows(local_rows, global_index, n_total):
 def speaker_sums(rows, speaker_ids, n_speakers):
     """[n_speakers, K + 1]: per-speaker column sums of `rows` plus the row count in the last column."""
     rows = np.asarray(rows, dtype=np.float64)
-    K = rows.shape[1] if rows.ndim == 2 else 0
+    K = rows.shape[1] if rows.ndim == 2 else 0     # an empty shard still carries its width: shape (0, K)
     buf = np.zeros((n_speakers, K + 1))
     for r, s in zip(rows, speaker_ids):
         buf[s, :K] += r

@@ -76,7 +76,9 @@ class FDomainHelper(torch.nn.Module):
     def spectrogram_to_wav(self, input, spectrogram, length=None):
         wavs = []
         for c in range(input.shape[1]):
-            _, cos, sin = self.spectrogram_phase(input[:, c, :], eps=1e-10)   # torchlibrosa magphase clamp
+            # torchlibrosa.magphase divides by clamp(mag, 1e-10): ssr_magphase clamps the POWER re^2 + im^2, so the
+            # equivalent floor is 1e-20 (dsp.py:147-152)
+            _, cos, sin = self.spectrogram_phase(input[:, c, :], eps=1e-20)
             wavs.append(self._istft(spectrogram[:, c:c + 1] * cos, spectrogram[:, c:c + 1] * sin, length))
         return torch.stack(wavs, dim=1)
 

@@ -381,21 +381,25 @@ class SSR_Eval_Helper:
         return self._assemble(work, speakers, mine, local, save_json, datetime.now())
 
     def _assemble(self, work, speakers, mine, local, save_json, now):
-        keys = sorted({k for r in local for k in r}) if local else []
+        # Key order of the reference = insertion order of preprocess() (eval.py:243-269); metric order = the four
+        # AudioMetrics keys, then whatever the testee added.  A rank that owns no file (world_size > number of files) has
+        # neither, so the lists are agreed on across ranks: the first rank that has results defines the order.
         rank, world = D.rank_world()
-        if world > 1:                                               # agree on the key / metric lists
+        order = list(local[0].keys()) if local else []
+        order += sorted({k for r in local for k in r} - set(order))
+        mets = {m for r in local for v in r.values() for m in v}
+        if world > 1:
             import torch.distributed as dist
             box = [None] * world
-            dist.all_gather_object(box, (keys, sorted({m for r in local for v in r.values() for m in v})))
-            keys = sorted({k for b in box for k in b[0]})
-            mets = sorted({m for b in box for m in b[1]}, key=lambda m: (_METRIC_KEYS.index(m) if m in _METRIC_KEYS else 99, m))
-        else:
-            mets = sorted({m for r in local for v in r.values() for m in v},
-                          key=lambda m: (_METRIC_KEYS.index(m) if m in _METRIC_KEYS else 99, m))
-        # key order of the reference = insertion order of preprocess(); recover it from any local result
-        order = list(local[0].keys()) if local else keys
-        keys = [k for k in order if k in keys] + [k for k in keys if k not in order]
-        rows = np.array([[r[k][m] for k in keys for m in mets] for r in local], dtype=np.float64).reshape(len(local), -1)
+            dist.all_gather_object(box, (order, sorted(mets)))
+            first = next((b[0] for b in box if b[0]), [])
+            order = list(first) + sorted({k for b in box for k in b[0]} - set(first))
+            mets = {m for b in box for m in b[1]}
+        keys = order
+        mets = sorted(mets, key=lambda m: (_METRIC_KEYS.index(m) if m in _METRIC_KEYS else 99, m))
+        rows = np.empty((len(local), len(keys) * len(mets)), dtype=np.float64)
+        for i, r in enumerate(local):
+            rows[i] = [r[k][m] for k in keys for m in mets]
         table = D.allgather_rows(rows, mine, len(work))             # [n_files, n_keys * n_metrics]
         final_result = {s: {} for s in speakers}
         for (spk, f), row in zip(work, table):

@@ -87,35 +87,53 @@ class AudioMetrics:
     # ---- reductions on [B, C, T, F] tensors (est first)
     @staticmethod
     def _images(x):
+        """The B*C [T, F] images of a [B, C, T, F] tensor, batch-major (the reference loops b, then c: metrics.py:128-131)."""
         if x.dim() != 4:
             raise ValueError("expected a [B, C, T, F] tensor, got %s" % (tuple(x.shape),))
-        if x.shape[1] != 1:
-            raise NotImplementedError("multi-channel spectrograms are not produced by AudioMetrics; C must be 1")
-        return [x[b, 0] for b in range(x.shape[0])]
+        return [x[b, c] for b in range(x.shape[0]) for c in range(x.shape[1])]
 
-    def _reduce(self, est, target, mask, log_domain=False):
-        e, t = self._images(est), self._images(target)
-        return B.spectrogram_metrics(e, t, mask)
+    def _reduce(self, est, target, mask):
+        if est.shape != target.shape:
+            raise ValueError("spectrogram shape mismatch: %s vs %s" % (tuple(est.shape), tuple(target.shape)))
+        return B.spectrogram_metrics(self._images(est), self._images(target), mask)
 
     def lsd(self, est, target):
-        """[B, 1, T, F] x2 -> [B, 1, 1, 1] float32 (metrics.py:109-112)."""
+        """[B, C, T, F] x2 -> [B, C, 1, 1] float32 (metrics.py:109-112; one value per image)."""
         v = self._reduce(est, target, B.M_LSD)[:, 0]
-        return v.to(torch.float32).to(est.device)[:, None, None, None]
+        return v.to(torch.float32).to(est.device).reshape(est.shape[0], est.shape[1], 1, 1)
+
+    def _sispec_multichannel(self, est, target, log_domain):
+        """metrics.py:114-121 for C > 1: pow_norm (utils.py:85-92) is per (b, c), pow_p_norm (utils.py:68-76) is over
+        every dimension but the batch - so the per-channel projections share ONE all-channel target energy and the ratio
+        is formed per batch item.  The image energies come from ssr_energy_sums (float64 accumulation)."""
+        Bn, Cn = est.shape[0], est.shape[1]
+        e, t = (B.elementwise("to_log", est), B.elementwise("to_log", target)) if log_domain else (est, target)
+        s = B.energy_sums(e, t, Bn * Cn).reshape(Bn, Cn, 3)                 # see, stt, set per image
+        see, stt, set_ = s[..., 0], s[..., 1], s[..., 2]
+        alpha = set_ / (stt.sum(dim=1, keepdim=True) + EPS)
+        tt = (alpha * alpha * stt).sum(dim=1)
+        nn = torch.clamp((see - 2.0 * alpha * set_ + alpha * alpha * stt).sum(dim=1), min=0.0)
+        v = 10.0 * torch.log10(tt / (nn + EPS) + EPS)
+        return (v.sum() / Bn).to(torch.float32).to(est.device)
 
     def sispec(self, est, target):
         """Scale-invariant spectrogram-to-noise ratio, mean over the batch, 0-dim float32 (metrics.py:114-121)."""
+        if est.dim() == 4 and est.shape[1] != 1:
+            return self._sispec_multichannel(est, target, False)
         v = self._reduce(est, target, B.M_SISPEC)[:, 2]
         return (v.sum() / v.shape[0]).to(torch.float32).to(est.device)
 
     def log_sispec(self, est, target):
         """sispec(to_log(est), to_log(target)) of metrics.py:99-101 with the log10(x + 1e-12) fused in-kernel."""
+        if est.dim() == 4 and est.shape[1] != 1:
+            return self._sispec_multichannel(est, target, True)
         v = self._reduce(est, target, B.M_LOG_SISPEC)[:, 1]
         return (v.sum() / v.shape[0]).to(torch.float32).to(est.device)
 
     def ssim(self, est, target):
-        """[B, 1, T, F] x2 -> [B, 1, 1, 1] float64 (metrics.py:123-132)."""
+        """[B, C, T, F] x2 -> [B, C, 1, 1] float64 (metrics.py:123-132; one skimage call per image)."""
         v = self._reduce(est, target, B.M_SSIM)[:, 3]
-        return v.to(est.device)[:, None, None, None]
+        return v.to(est.device).reshape(est.shape[0], est.shape[1], 1, 1)
 
     def center_crop(self, x, y):
         """Crop the longer of two [B, C, T, F] tensors around its centre (metrics.py:32-49; unused there)."""

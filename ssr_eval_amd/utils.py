@@ -41,14 +41,16 @@ def pow_norm(s1, s2):
 
 
 def energy_unify(estimated, original):
-    """(estimated, original * <estimated, original> / (|original|^2 + EPS)) (utils.py:79-82).  C must be 1, as for
-    every spectrogram AudioMetrics produces (the reference broadcasts a per-batch norm against per-channel products)."""
+    """(estimated, original * <estimated, original> / (|original|^2 + EPS)) (utils.py:79-82).  With C > 1 the inner
+    product is per (batch, channel) while the norm runs over every dimension but the batch, exactly as the reference
+    broadcasts them."""
     from . import backend as B
-    if original.dim() < 2 or original.shape[1] != 1:
-        raise NotImplementedError("energy_unify: channel dimension must be 1")
-    mul = pow_norm(estimated, original).reshape(-1)
-    div = pow_p_norm(original).reshape(-1) + torch.tensor(EPS, dtype=torch.float32)
-    return estimated, B.scale_items(original, mul, div).to(original.device)
+    if original.dim() < 2:
+        raise ValueError("energy_unify needs [B, C, ...] tensors")
+    C = original.shape[1]
+    mul = pow_norm(estimated, original).reshape(-1)                                  # [B * C]
+    div = pow_p_norm(original).reshape(-1) + torch.tensor(EPS, dtype=torch.float32)  # [B]
+    return estimated, B.scale_items(original, mul, div.repeat_interleave(C)).to(original.device)
 
 
 def dict_mean(dict_list):

@@ -31,6 +31,13 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_r2():
+    """Round-2 vectors (tests/golden/make_golden_r2.py: multi-channel tensors, the cfg-3 sweep in small, the 16 kHz
+    subsampling quirk), produced by importing the reference."""
+    return np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors_r2.npz"))
+
+
+@pytest.fixture(scope="session")
 def golden_manifest():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "manifest.json")) as f:

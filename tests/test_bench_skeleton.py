@@ -1,0 +1,39 @@
+"""CPU tests of bench.py's launcher: --gpus N spawns N ranks by itself, times between barriers, takes the MAX over
+ranks, all-reduces the per-step sums, and can never report fewer ranks than asked for."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args, env=None):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True,
+                          timeout=300, env=e)
+
+
+def test_self_launch_two_ranks_gloo():
+    r = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--_cpu-skeleton")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                                  # exactly ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["extra"]["job_means"] == [1.5]                           # (1 + 2) / (1 + 1): both ranks' sums arrived
+    assert d["extra"]["allreduce_payload_bytes_per_step"] == 16
+    assert abs(d["value"] - 10 * 2 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3   # whole-job units / max-rank time
+
+
+def test_more_gpus_than_devices_fails_loudly():
+    r = _bench("--gpus", "8", "--steps", "1", "--warmup", "0", env={"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
+    assert r.returncode != 0 and "--gpus 8" in (r.stderr + r.stdout) and "{" not in r.stdout
+
+
+def test_world_size_mismatch_fails_loudly():
+    r = _bench("--gpus", "2", "--_cpu-skeleton", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE is 1" in (r.stderr + r.stdout)

@@ -43,6 +43,38 @@ def test_sharded_assembly_world2(tmp_path):
     assert open(tmp_path / "ok0").read() == "1" and open(tmp_path / "ok1").read() == "1"
 
 
+def _worker_one_file(rank, world, port, out_dir):
+    """world_size 2, ONE (speaker, file) item: rank 1 owns nothing (the idle rank used to die in a reshape
+    while rank 0 blocked in the collective)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from datetime import datetime
+    from ssr_eval_amd import SSR_Eval_Helper, BasicTestee
+    from ssr_eval_amd import dist as D
+    D.init_from_env(backend="gloo")
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "aggregate.json")))
+    spk = g["speakers"][0]
+    work = [(spk, g["files"][spk][0])]
+    mine = D.shard_indices(len(work))
+    assert len(mine) == (1 if rank == 0 else 0)
+    local = [g["per_file"][os.path.join(*work[i])] for i in mine]
+    h = SSR_Eval_Helper(BasicTestee(), 44100, 44100, test_data_root=None)
+    os.chdir(out_dir)
+    final = h._assemble(work, [spk], mine, local, False, datetime(2022, 1, 1))
+    want = g["per_file"][os.path.join(*work[0])]
+    ok = final[spk][work[0][1]] == want and final["averaged"] == want and final["each_speaker"][spk] == want
+    ok = ok and list(final["averaged"].keys()) == list(want.keys())          # key order agreed on across ranks
+    open(os.path.join(out_dir, "one%d" % rank), "w").write("1" if ok else "0")
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_sharded_assembly_with_an_idle_rank(tmp_path):
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_worker_one_file, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / "one0").read() == "1" and open(tmp_path / "one1").read() == "1"
+
+
 def test_single_process_primitives():
     sys.path.insert(0, ROOT)
     from ssr_eval_amd import dist as D

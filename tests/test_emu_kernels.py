@@ -113,6 +113,19 @@ def test_resampler_bit_exact_vs_scipy(golden, up, down):
         np.testing.assert_array_equal(o, signal.resample_poly(s, up, down))
 
 
+@pytest.mark.parametrize("up,down", [(7349, 7350), (7350, 7349), (11024, 11025), (160, 147)])
+def test_resampler_fallback_for_huge_rate_pairs_bit_exact_vs_scipy(up, down):
+    """Rate pairs whose reduced `up` is too large for the phase-blocked kernel's LDS window (the subsampling degradation
+    of a 16 kHz / 24 kHz input at its Nyquist cutoff: 7349/7350, 11024/11025) run one output per thread."""
+    rng = np.random.default_rng(up)
+    sig = [(0.1 * rng.standard_normal(n)).astype(np.float32) for n in (3000, 41)]
+    p = ors.poly_plan(len(sig[0]), up, down)
+    taps = p["h_full"][:p["n_pre_pad"] + len(p["h"])]
+    out = E.resample(sig, up, down, taps, p["n_pre_remove"], groups=-1)
+    for s, o in zip(sig, out):
+        np.testing.assert_array_equal(o, signal.resample_poly(s, up, down))
+
+
 @pytest.mark.parametrize("ppt", [4, 8, 16])
 @pytest.mark.parametrize("n_fft,hop", [(2048, 512), (2229, 480), (512, 128), (743, 160)])
 def test_fft_engine_points_per_thread(ppt, n_fft, hop, golden):

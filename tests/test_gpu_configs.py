@@ -1,0 +1,245 @@
+"""GPU parity tests (-m gpu) at BASELINE.json's configurations (cfg-2 at the full 1024-pair batch, the cfg-3 cutoff sweep
+at 4 s @ 48 kHz, cfg-5's chain), the round-2 reference vectors, and an RCCL world-size-1 smoke of the collectives.
+Everything goes ctypes -> libssrhip.so; nothing here reads /root/reference."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+from scipy import signal
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ("lsd", "log_sispec", "sispec", "ssim")
+CUTOFFS = [1000, 2000, 4000, 6000, 8000, 12000, 16000]
+CUT_BINS = [42, 85, 170, 256, 341, 512, 683]                      # int(1025 * c / 24000)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "-m gpu tests need an MI355X"
+    from ssr_eval_amd import _lib
+    _lib.load()
+
+
+def _vec(d):
+    return np.array([d[k] for k in KEYS])
+
+
+def _oracle_pair(args):
+    """(est, target) -> (reference float32 metrics, float64 evaluation of the two SISpec terms); runs in a worker."""
+    torch.set_num_threads(1)
+    from oracle import metrics as om
+    est, tgt = args
+    want, exact = om.evaluation_with_exact(est, tgt, n_fft=2048, hop=512)
+    return _vec(want), np.array([exact["log_sispec"], exact["sispec"]])
+
+
+def _oracle_many(pairs):
+    import multiprocessing as mp
+    cores = min(os.cpu_count() or 1, 32, len(pairs))
+    if cores >= 4:
+        try:
+            with mp.get_context("fork").Pool(cores) as pool:
+                return pool.map(_oracle_pair, pairs, chunksize=1)
+        except Exception:
+            pass
+    return [_oracle_pair(p) for p in pairs]
+
+
+def _check_rows(got, oracle_rows, what):
+    from test_gpu_parity import assert_sispec_parity
+    for i, (g, (want, exact)) in enumerate(zip(got, oracle_rows)):
+        np.testing.assert_allclose(g[[0, 3]], want[[0, 3]], rtol=1e-5, err_msg="%s pair %d (lsd, ssim)" % (what, i))
+        assert_sispec_parity(g[1], want[1], exact[0], "%s pair %d log_sispec" % (what, i))
+        assert_sispec_parity(g[2], want[2], exact[1], "%s pair %d sispec" % (what, i))
+
+
+# ---- cfg-2 at the real batch: 1024 pairs (launch geometry: 94 frames per workgroup, 4 chunks per pair) ------------------
+def test_cfg2_full_batch_1024_pairs():
+    from ssr_eval_amd import backend as B
+    N, n = 1024, 192000
+    g = torch.Generator(device="cuda").manual_seed(20220328)
+    tgt = (0.1 * torch.randn((N, n), generator=g, device="cuda", dtype=torch.float32)).contiguous()
+    est = (tgt + 0.01 * torch.randn((N, n), generator=g, device="cuda", dtype=torch.float32)).contiguous()
+    plan = B.get_plan(2048, 512, "f64")
+    assert plan.frames(n) == 376 and plan.n_bins == 1025
+    batch = B.PairBatch(plan, B.Ragged.from_uniform(est), B.Ragged.from_uniform(tgt))
+    full = batch.run(B.M_ALL).cpu().numpy().copy()
+    assert full.shape == (N, 4) and np.isfinite(full).all()
+    spots = [0, 1, 255, 256, 511, 512, 777, 1023]                   # spread over the whole grid
+    _check_rows(full[spots], _oracle_many([(est[i].cpu().numpy(), tgt[i].cpu().numpy()) for i in spots]), "cfg2")
+    # the bench's mask (LSD + SSIM) gives the same two numbers, the other two stay NaN
+    two = batch.run(B.M_LSD | B.M_SSIM).cpu().numpy()
+    np.testing.assert_array_equal(two[:, [0, 3]], full[:, [0, 3]])
+    assert np.isnan(two[:, [1, 2]]).all()
+    # batch-composition invariance: a pair alone (6 frames per workgroup) equals the pair inside the 1024 batch
+    for i in (0, 511, 1023):
+        alone = B.pair_metrics(plan, [est[i]], [tgt[i]])[0]
+        np.testing.assert_allclose(alone, full[i], rtol=1e-12)
+    # statistics of the synthetic workload: i.i.d. pairs -> tight spread (a wrong chunk anywhere would stick out)
+    assert full[:, 0].std() / full[:, 0].mean() < 0.01 and full[:, 3].std() < 0.01
+
+
+# ---- cfg-3: the cutoff sweep at 4 s @ 48 kHz, full metric set -------------------------------------------------------------
+def test_cfg3_cutoff_sweep_full_metric_set():
+    from ssr_eval_amd import backend as B
+    from ssr_eval_amd import lowpass as L
+    from oracle import lowpass as olp
+    n_t, n = 16, 192000
+    # cut bins: the dispatcher's integer arithmetic (lowpass.py:193-194 -> :24), bit-exact
+    assert [L.cut_bin(c / int(48000 / 2)) for c in CUTOFFS] == CUT_BINS
+    assert [olp.cut_bin(c, 48000) for c in CUTOFFS] == CUT_BINS
+    g = torch.Generator(device="cuda").manual_seed(20220328)
+    tgt = (0.1 * torch.randn((n_t, n), generator=g, device="cuda", dtype=torch.float32)).contiguous()
+    # one ragged batch of 16 x 7 (utterance, cutoff) items
+    rep = tgt.repeat_interleave(len(CUT_BINS), dim=0).contiguous()                  # item = t * 7 + c
+    cuts = CUT_BINS * n_t
+    lp = B.LowpassBatch(B.get_plan(2048, 441, "f64"), B.Ragged.from_uniform(rep), cuts)
+    est = lp.run().view(n_t * 7, n)
+    torch.cuda.synchronize()
+    est_h, tgt_h = est.cpu().numpy(), tgt.cpu().numpy()
+    # the degradation itself against the oracle's torchlibrosa restatement (float32 dense-DFT convolution there)
+    for t, c in ((0, 0), (3, 3), (7, 5), (15, 6)):
+        ref = olp.lowpass(tgt_h[t], CUTOFFS[c], 48000, 1, "stft_hard")
+        np.testing.assert_allclose(est_h[t * 7 + c], ref, atol=3e-7)                # 0.1-amplitude noise: |y| up to ~0.5
+    # metrics of every (degraded, target) pair: HIP vs the oracle on the SAME degraded signal
+    plan = B.get_plan(2048, 512, "f64")
+    got = B.PairBatch(plan, lp.out_ragged(), B.Ragged.from_uniform(rep)).run(B.M_ALL).cpu().numpy()
+    assert np.isfinite(got).all()
+    n_check = n_t if (os.cpu_count() or 1) >= 16 else 4                           # all 112 pairs where the host has the cores
+    idx = [t * 7 + c for t in range(n_check) for c in range(7)]
+    _check_rows(got[idx], _oracle_many([(est_h[i], tgt_h[i // 7]) for i in idx]), "cfg3")
+    # LSD falls monotonically as the cutoff rises, for every target
+    lsd = got[:, 0].reshape(n_t, 7)
+    assert (np.diff(lsd, axis=1) < 0).all()
+    # the helper's own route gives the same degraded signals (keys as the reference names them)
+    from ssr_eval_amd import SSR_Eval_Helper, BasicTestee
+    h = SSR_Eval_Helper(BasicTestee(), input_sr=48000, output_sr=48000, evaluation_sr=48000, test_data_root=None,
+                        setting_fft={"cutoff_freq": list(CUTOFFS)})
+    d = h.lowpass_stft_hard("", tgt_h[2], 48000)
+    assert list(d.keys()) == ["proc_fft_%d_48000" % (2 * c) for c in CUTOFFS]
+    for c, y in enumerate(d.values()):
+        np.testing.assert_array_equal(y, est_h[2 * 7 + c])
+
+
+def test_cfg3_reference_vectors(golden_r2):
+    """The sweep in small, against outputs of the imported reference (tests/golden/make_golden_r2.py)."""
+    from ssr_eval_amd import SSR_Eval_Helper, BasicTestee, AudioMetrics
+    x = golden_r2["c3_x"]
+    h = SSR_Eval_Helper(BasicTestee(), input_sr=48000, output_sr=48000, evaluation_sr=48000, test_data_root=None,
+                        setting_fft={"cutoff_freq": list(CUTOFFS)})
+    d = h.lowpass_stft_hard("", x, 48000)
+    assert list(d.keys()) == [str(k) for k in golden_r2["c3_keys"]]
+    assert [int(c) for c in golden_r2["c3_cut_bins"]] == CUT_BINS
+    am_api, am_b = AudioMetrics(48000), AudioMetrics(48000, n_fft=2048, hop_length=512)
+    for j, (k, y) in enumerate(d.items()):
+        ref_y = golden_r2["c3_y_" + k]
+        np.testing.assert_allclose(y, ref_y, atol=3e-8)
+        # metrics on the REFERENCE's degraded signal (the stop band is round-off: it has to be the same round-off)
+        np.testing.assert_allclose(_vec(am_b.evaluation(ref_y, x, "")), golden_r2["c3_metrics_2048_512"][j], rtol=1e-5)
+        np.testing.assert_allclose(_vec(am_api.evaluation(ref_y, x, "")), golden_r2["c3_metrics_api2229"][j], rtol=1e-5)
+
+
+# ---- multi-channel tensors on the metric API --------------------------------------------------------------------------------
+def test_multichannel_tensor_reductions_match_reference_vectors(golden_r2):
+    from ssr_eval_amd import AudioMetrics, utils as U
+    am = AudioMetrics(44100)
+    for dev in ("cpu", "cuda"):
+        e, t = torch.tensor(golden_r2["mc_est"], device=dev), torch.tensor(golden_r2["mc_tgt"], device=dev)
+        lsd = am.lsd(e, t)
+        assert tuple(lsd.shape) == (2, 3, 1, 1) and lsd.dtype == torch.float32 and lsd.device.type == dev
+        np.testing.assert_allclose(lsd.cpu().numpy(), golden_r2["mc_lsd"], rtol=1e-5)
+        ss = am.ssim(e, t)
+        assert tuple(ss.shape) == (2, 3, 1, 1) and ss.dtype == torch.float64
+        np.testing.assert_allclose(ss.cpu().numpy(), golden_r2["mc_ssim"], rtol=2e-7)
+        np.testing.assert_allclose(float(am.sispec(e, t)), float(golden_r2["mc_sispec"]), rtol=1e-5)
+        np.testing.assert_allclose(float(am.sispec(U.to_log(e), U.to_log(t))), float(golden_r2["mc_log_sispec"]), rtol=1e-5)
+        np.testing.assert_allclose(float(am.log_sispec(e, t)), float(golden_r2["mc_log_sispec"]), rtol=1e-5)
+        _, ut = U.energy_unify(e, t)
+        np.testing.assert_allclose(ut.cpu().numpy(), golden_r2["mc_energy_unify_tgt"], rtol=2e-6)
+
+
+# ---- subsampling at a rate pair whose reduced `up` is huge (7349 / 7350) ----------------------------------------------------
+def test_subsampling_quirk_rate_pair_16k(golden_r2):
+    from ssr_eval_amd import SSR_Eval_Helper, BasicTestee, lowpass
+    from ssr_eval_amd import backend as B
+    x = golden_r2["ssq_x"]
+    h = SSR_Eval_Helper(BasicTestee(), input_sr=16000, output_sr=16000, evaluation_sr=16000, test_data_root=None,
+                        setting_subsampling={"cutoff_freq": [8000]})
+    d = h.lowpass_subsampling("", x, 16000)
+    assert list(d.keys()) == [str(golden_r2["ssq_key"])] == ["proc_subsampling_15999_16000"]
+    np.testing.assert_array_equal(d["proc_subsampling_15999_16000"], golden_r2["ssq_y"])       # bit-exact
+    np.testing.assert_array_equal(lowpass(x, 7999, 16000, order=1, _type="subsampling"), golden_r2["ssq_y"])
+    rng = np.random.default_rng(7349)
+    for up, down, n in ((7349, 7350, 20000), (7350, 7349, 777), (11024, 11025, 5000)):
+        s = (0.1 * rng.standard_normal(n)).astype(np.float32)
+        np.testing.assert_array_equal(B.resample_poly([s], up, down)[0].cpu().numpy(), signal.resample_poly(s, up, down))
+        s64 = s.astype(np.float64) * 1.0000001
+        np.testing.assert_array_equal(B.resample_poly([s64], up, down)[0].cpu().numpy(), signal.resample_poly(s64, up, down))
+
+
+# ---- FDomainHelper.spectrogram_to_wav on near-silent frames (torchlibrosa.magphase clamps the MAGNITUDE at 1e-10) -------------
+def test_spectrogram_to_wav_near_silent_bins():
+    from ssr_eval_amd.dsp import FDomainHelper
+    from oracle import stft as ostft
+    rng = np.random.default_rng(12)
+    n = 6000
+    x = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    x[2000:4200] *= 1e-9                                   # bins with magnitude between 1e-10 and 1e-5
+    fh = FDomainHelper()
+    wav = torch.tensor(x[None, None, :])
+    sp = fh.wav_to_spectrogram(wav, eps=1e-8)
+    y = fh.spectrogram_to_wav(wav, sp, length=n)
+    assert tuple(y.shape) == (1, 1, n)
+    re, im = ostft.tl_stft(x[None, :])
+    mag = np.sqrt(re ** 2 + im ** 2)
+    den = np.clip(mag, np.float32(1e-10), np.inf)          # dsp.py:147-152 via torchlibrosa.magphase
+    spn = np.clip(re ** 2 + im ** 2, np.float32(1e-8), np.inf) ** np.float32(0.5)
+    want = ostft.tl_istft(spn * (re / den), spn * (im / den), n)[0]
+    quiet = slice(2600, 3600)
+    assert np.abs(want[quiet]).max() > 1e-6                # the clamp at 1e-8 dominates there: phase errors would show
+    np.testing.assert_allclose(y[0, 0].numpy(), want, atol=2e-7, rtol=1e-4)
+
+
+# ---- RCCL smoke: the collectives of ssr_eval_amd.dist on a world of one GPU --------------------------------------------------
+def test_nccl_world_size_one_collectives(tmp_path):
+    code = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29%%03d" %% (os.getpid() %% 1000), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", init_method="env://", world_size=1, rank=0)
+from ssr_eval_amd import dist as D
+assert D.rank_world() == (0, 1) and dist.get_backend() == "nccl"
+red = D.allreduce_sums(np.arange(5.0))
+t = torch.arange(6, dtype=torch.float64, device="cuda")
+dist.all_reduce(t)                                   # RCCL kernel on the device
+rows = np.arange(12.0).reshape(4, 3)
+tab = D.allgather_rows(rows, [0, 1, 2, 3], 4)
+dist.barrier()
+dist.destroy_process_group()
+print(json.dumps({"red": red.tolist(), "t": t.cpu().tolist(), "tab": tab.tolist()}))
+""" % ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["red"] == [0, 1, 2, 3, 4] and d["t"] == [0, 1, 2, 3, 4, 5]
+    assert d["tab"] == np.arange(12.0).reshape(4, 3).tolist()
+
+
+def test_bench_cli_configs_smoke():
+    """bench.py --config cfg3 / cfg5 at a small batch: one JSON line with the contract's fields."""
+    for cfg, extra in (("cfg3", ["--pairs", "32"]), ("cfg5", ["--utterances", "64"])):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--steps", "2", "--warmup", "1",
+                            "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["frac"] > 0 and d["config"]["workload"].startswith(cfg[:3] + "-" + cfg[3])

@@ -29,6 +29,24 @@ def _vec(d):
     return np.array([d[k] for k in KEYS])
 
 
+def assert_sispec_parity(got, ref32, exact, what=""):
+    """SISpec / log-SISpec of one pair: `got` (HIP, float64 accumulation) against the reference's float32 value `ref32`
+    and the float64 evaluation `exact` of the same formula on the same float32 spectrograms (oracle.metrics.sispec_exact).
+
+      * the kernel is held to 1e-6 against the float64 evaluation (absolute 1e-6 dB near 0 dB);
+      * it is held to the north_star bar of 1e-5 against the reference's float32 value WHEREVER that value is itself
+        defined to better than 1e-5 (|ref32 - exact| <= 3e-6 relative), and otherwise has to lie inside the band the
+        reference's own float32 round-off spans (tests/test_oracle.py::test_reference_float32_sispec_noise_is_measured
+        shows that band exceeding 1e-5 for ~9 s utterances and for constant log-targets)."""
+    scale = max(abs(exact), 1e-30)
+    assert abs(got - exact) <= 1e-6 * scale + 1e-6, (what, got, exact)
+    band = abs(ref32 - exact)
+    if band <= 3e-6 * scale:
+        assert abs(got - ref32) <= 1e-5 * abs(ref32), (what, got, ref32)
+    else:
+        assert abs(got - ref32) <= band + 1e-6 * scale + 1e-6, (what, got, ref32, exact)
+
+
 @pytest.mark.parametrize("name", EV)
 def test_evaluation_matches_reference_vectors(golden, name):
     from ssr_eval_amd import AudioMetrics
@@ -619,11 +637,11 @@ def test_degenerate_signals_follow_the_reference_arithmetic():
     z = np.zeros(n, np.float32)
     got = B.pair_metrics(plan, [z, z, x], [z, x, z])
     for (e, t), g in zip([(z, z), (z, x), (x, z)], got):
-        want = om.evaluation(e, t, n_fft=2048, hop=512)
-        keep = [0, 2, 3] if (e is z and t is z) else [0, 1, 2, 3]   # log-SISpec of identical logs is round-off defined
-        # SISpec pair near 0 dB against a constant log-target: the reference's own float32 sums are good to ~1e-4 dB
-        np.testing.assert_allclose(g[keep], _vec(want)[keep], rtol=1e-5, atol=2e-4)
+        want, exact = om.evaluation_with_exact(e, t, n_fft=2048, hop=512)
         np.testing.assert_allclose(g[[0, 3]], _vec(want)[[0, 3]], rtol=1e-5, atol=1e-12)
+        assert_sispec_parity(g[2], want["sispec"], exact["sispec"], "sispec")
+        if not (e is z and t is z):                                 # log-SISpec of identical logs is round-off defined
+            assert_sispec_parity(g[1], want["log_sispec"], exact["log_sispec"], "log_sispec")
     assert got[0][0] == pytest.approx(12.0, rel=1e-6) and got[0][3] == pytest.approx(1.0, rel=1e-12)
     bad = x.copy()
     bad[4000] = np.nan
@@ -663,11 +681,12 @@ def test_full_size_properties_cfg4():
     for i in (0, 1234, 2936):
         alone = B.pair_metrics(plan, [est[i]], [tgt[i]])[0]
         np.testing.assert_allclose(alone, full[i], rtol=1e-12)   # launch geometry (chunking of the float64 sums) differs
-        want = _vec(om.evaluation(est[i].cpu().numpy(), tgt[i].cpu().numpy(), n_fft=2048, hop=512))
-        np.testing.assert_allclose(full[i][[0, 3]], want[[0, 3]], rtol=1e-5)
-        # SISpec on utterances of up to 9 s: the reference's float32 torch.norm / sum over ~1e6 elements (vectorised,
-        # thread-count dependent) is itself only good to ~1e-5 relative; the kernels accumulate in float64
-        np.testing.assert_allclose(full[i][[1, 2]], want[[1, 2]], rtol=3e-5)
+        want, exact = om.evaluation_with_exact(est[i].cpu().numpy(), tgt[i].cpu().numpy(), n_fft=2048, hop=512)
+        np.testing.assert_allclose(full[i][[0, 3]], _vec(want)[[0, 3]], rtol=1e-5)
+        # SISpec on utterances of up to 9 s: the reference's float32 torch.norm / sum over ~1e6 elements is itself only
+        # good to ~1e-5 relative (measured in tests/test_oracle.py); the kernels accumulate in float64
+        assert_sispec_parity(full[i][1], want["log_sispec"], exact["log_sispec"], "log_sispec")
+        assert_sispec_parity(full[i][2], want["sispec"], exact["sispec"], "sispec")
 
 
 @pytest.mark.parametrize("n_fft,hop", [(2048, 512), (2229, 480), (743, 160), (256, 64), (4096, 1024)])
@@ -688,7 +707,7 @@ def test_partially_silent_signals(n_fft, hop):
     ests, tgts = [e_sil, e, e_sil], [t, t_sil, t_sil]
     got = B.pair_metrics(plan, ests, tgts)
     for x_e, x_t, g in zip(ests, tgts, got):
-        np.testing.assert_allclose(g, _vec(om.evaluation(x_e, x_t, n_fft=n_fft, hop=hop)), rtol=2e-5, atol=1e-5)
+        np.testing.assert_allclose(g, _vec(om.evaluation(x_e, x_t, n_fft=n_fft, hop=hop)), rtol=1e-5)
     for x, m in zip([e_sil, t_sil], B.stft(plan, [e_sil, t_sil])):           # frame pairs of ONE signal (single mode)
         ref = ostft.stft_mag_TF(x, n_fft, hop)
         m = m.cpu().numpy()

@@ -147,8 +147,10 @@ class Cfg2:
 
     cpu_desc = "pairs of the same workload (4 s @ 48 kHz, STFT 2048/512 + LSD + SSIM) through the NumPy/SciPy/torch-CPU oracle"
 
-    def parity(self, out_vals, n):
-        got = self.batch.run(self.mask)[:n].cpu().numpy()
+    def parity(self, out_vals, n, first):
+        """max relative error of (LSD, SSIM) of pairs first .. first + n - 1 against the oracle values the CPU baseline
+        produced for exactly those pairs."""
+        got = self.batch.run(self.mask)[first:first + n].cpu().numpy()
         return max(max(abs(got[i, 0] - v[0]) / abs(v[0]), abs(got[i, 3] - v[1]) / abs(v[1])) for i, v in enumerate(out_vals[:n]))
 
 
@@ -342,6 +344,33 @@ def _cpu_run(idx):
     return time.perf_counter() - t0, vals
 
 
+def _usable_cores():
+    """Host cores this process may actually use: os.cpu_count() capped by the scheduler affinity mask and by the cgroup
+    CPU quota (a container that SEES 256 logical CPUs but is throttled to a few cores' worth of time runs a 256-process
+    pool slower than a small one)."""
+    n = os.cpu_count() or 1
+    info = {"os_cpu_count": n}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+        n = min(n, info["affinity"])
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                info["cgroup_quota_cores"] = round(float(quota) / period, 2)
+                n = max(1, min(n, int(float(quota) / period + 0.5)))
+            break
+        except Exception:
+            continue
+    return n, info
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -364,7 +393,7 @@ def cpu_baseline(wl, budget_s=24.0):
     scale = getattr(wl, "cpu_scale", 1)
     # (i) one thread
     n1 = 64 if t_unit * 68 * 3 <= budget_s * 0.4 else max(4, int(budget_s * 0.4 / 3 / t_unit) - 4)
-    cores = os.cpu_count() or 1
+    cores, core_info = _usable_cores()
     per_worker = 2 if t_unit * 2 * 3 * 2 <= budget_s * 0.5 else 1
     n_pool = max(64, cores * per_worker)
     _CPU_ITEMS = wl.cpu_inputs(max(n1 + 4, min(n_pool, 512)))
@@ -392,8 +421,8 @@ def cpu_baseline(wl, budget_s=24.0):
     except Exception as e:                                              # a locked-down box: report the 1-thread number only
         err = repr(e)
     out = {"value": round(rate_pool if rate_pool else rate1, 3), "unit": wl.unit, "cores": cores if rate_pool else 1, "kind": "port",
-           "cpu_model": _cpu_model(), "value_1thread": round(rate1, 3),
-           "sample": "%s: 1 thread = median of 3 repeats of %d units after 4 discarded; %d processes (os.cpu_count(), 1 thread "
+           "cpu_model": _cpu_model(), "host_cores": core_info, "value_1thread": round(rate1, 3),
+           "sample": "%s: 1 thread = median of 3 repeats of %d units after 4 discarded; %d processes (usable host cores, 1 thread "
                      "each, inputs inherited by fork) = median of 3 repeats of %d units after one discarded unit per worker"
                      % (wl.cpu_desc, n1, cores, sum(len(c) for c in chunks) if rate_pool else 0)}
     if err:
@@ -549,7 +578,7 @@ def run(a):
     if not a.no_cpu_baseline and world == 1 and not a.cpu_skeleton:      # contract: the CPU baseline is timed on rank 0 at N = 1 only
         cpu, vals = cpu_baseline(wl)
         if wl.parity is not None:
-            extra["parity_vs_oracle_max_rel_err"] = float(wl.parity(vals, min(4, len(vals))))
+            extra["parity_vs_oracle_max_rel_err"] = float(wl.parity(vals, min(4, len(vals)), 4))   # vals[i] is pair 4 + i
     if world == 1 and a.config == "cfg2" and not a.no_side and not a.cpu_skeleton:
         del wl
         torch.cuda.empty_cache()

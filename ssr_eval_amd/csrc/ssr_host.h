@@ -61,7 +61,11 @@ inline int ssr_allow_lds(const void* fn, size_t lds, int* slot) {
 inline int ssr_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 inline size_t ssr_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 int ssr_target_wgs();                                  // workgroups per launch aimed for when chunking items
-int ssr_units_per_chunk_for(int max_units, int n_items);
+int ssr_units_per_chunk_for(int max_units, int n_items, int target_wgs = 0);
+// Pair transform of this plan on float32 (in64 = false) signals runs the wave-autonomous engine (ssr_stft_wave.h: one
+// wave per workgroup) -> the chunking aims for 4x as many (one-wave) workgroups.
+bool ssr_stft_uses_wave_engine(const ssr_plan* pl, bool in64);
+int ssr_pair_units_per_chunk(const ssr_plan* pl, int max_units, int n_items, bool in64);
 
 // ---- launchers defined by the kernel translation units --------------------------------------------------------
 template <typename T> struct SsrStftParams;

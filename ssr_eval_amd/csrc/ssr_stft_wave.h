@@ -1,0 +1,352 @@
+// Kernel body K1-K4, wave-autonomous engine: the 2048-point pair STFT + fused LSD / SISpec epilogue with ONE WAVE PER
+// FRAME and no workgroup barrier anywhere.
+//
+// Why: the 256-thread engine of ssr_stft.h runs a frame on four waves in lock step - eight s_barrier per frame (14 % of
+// the kernel, measured), three LDS exchanges, and four waves that all stall together.  Here a frame belongs to one wave:
+//   * 64 lanes x 32 points.  The first pass is a radix-32 DFT done entirely IN the lane's registers (4 x 8 with
+//     compile-time twiddles), so the transform is 32 x 8 x 8 = three passes and only TWO exchanges through LDS;
+//   * exchanges are ordered by the hardware (the DS operations of one wave execute in order), so a "phase boundary" is a
+//     compiler-only wave-scope fence: no s_barrier, no s_waitcnt between a wave's writes and its reads;
+//   * what a lane needs every frame is loop-invariant and stays in registers: its 16 window values
+//     (w[m + N/2] = 1/2 - w[m]) and the 7 twiddles of the second pass (w^(8 (l mod 32) q) does not depend on the
+//     butterfly); the first pass needs none.  Only the third pass loads 3 table twiddles per butterfly;
+//   * the per-frame LSD reduction is a wave shuffle, the silent-frame vote a ballot.
+// Occupancy is bounded by LDS, not by registers: one wave owns one 2048-point buffer (33 KB float64: 4 waves per CU, one
+// per SIMD, up to 512 VGPRs each) - or, with the re / im parts exchanged one after the other through a single array
+// (SPLIT = true), 17 KB: 8 waves per CU at <= 256 VGPRs.
+//
+// Arithmetic (window, two-for-one packing, separation, magnitudes, metric terms) is the one of ssr_stft.h; the parity
+// tests run both engines against the oracle and against each other.  Reference semantics: ssr_eval/metrics.py:26-30,
+// 109-121 (see ssr_stft.h).
+#pragma once
+#include "ssr_stft.h"
+
+#ifdef SSR_HOST_EMU
+#define SSR_WPHASE SSR_PHASE
+#else
+// wave-scope ordering point: constrains the compiler, emits nothing (same-wave LDS traffic is ordered by the hardware)
+#define SSR_WAVE_SYNC()                                             \
+  do {                                                              \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          \
+    __builtin_amdgcn_wave_barrier();                                \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");          \
+  } while (0)
+#define SSR_WPHASE(blk, regs, ...)                                   \
+  {                                                                  \
+    const int tid = (blk).tid; auto& R = (regs); (void)R; (void)tid; \
+    __VA_ARGS__;                                                     \
+  }                                                                  \
+  SSR_WAVE_SYNC();
+#endif
+
+constexpr int SSR_W_N = 2048, SSR_W_L = 64, SSR_W_P = 32;     // points, lanes, points per lane
+SSR_DEV int ssr_wpad(int i) { return i + (i >> 5); }            // lane stride 32 -> 33 doubles: conflict-free ds_*_b64
+constexpr int SSR_W_PN = SSR_W_N + (SSR_W_N >> 5) + 1;
+constexpr int SSR_W_IMOFF = 1024 + 32;    // SPLIT: the upper-half imaginary parts of the final exchange sit behind the real parts
+
+// exp(-2 pi i m / 32), m = 0..21 (the exponents n2 * k1 of the in-lane 4 x 8 decomposition)
+template <typename T> SSR_DEV cx<T> ssr_w32(int m) {
+  constexpr double c[22] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708, 0.70710678118654752440,
+                            0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785, 0.0,
+                            -0.19509032201612826785, -0.38268343236508977173, -0.55557023301960222474, -0.70710678118654752440,
+                            -0.83146961230254523708, -0.92387953251128675613, -0.98078528040323044913, -1.0,
+                            -0.98078528040323044913, -0.92387953251128675613, -0.83146961230254523708, -0.70710678118654752440,
+                            -0.55557023301960222474};
+  constexpr double s[22] = {0.0, -0.19509032201612826785, -0.38268343236508977173, -0.55557023301960222474, -0.70710678118654752440,
+                            -0.83146961230254523708, -0.92387953251128675613, -0.98078528040323044913, -1.0,
+                            -0.98078528040323044913, -0.92387953251128675613, -0.83146961230254523708, -0.70710678118654752440,
+                            -0.55557023301960222474, -0.38268343236508977173, -0.19509032201612826785, 0.0,
+                            0.19509032201612826785, 0.38268343236508977173, 0.55557023301960222474, 0.70710678118654752440,
+                            0.83146961230254523708};
+  return {(T)c[m], (T)s[m]};
+}
+
+// v[r], r = 8 n1 + n2  (n1 < 4, n2 < 8)   ->   v[8 k1 + k2] = DFT32(v)[k1 + 4 k2]      (in place, registers only)
+template <typename T> SSR_DEV void ssr_dft32(cx<T>* v) {
+  const T h = (T)0.70710678118654752440;
+  SSR_UNROLL for (int n2 = 0; n2 < 8; ++n2) {
+    cx<T> t[4] = {v[n2], v[8 + n2], v[16 + n2], v[24 + n2]};
+    ssr_bfly4(t);
+    SSR_UNROLL for (int k1 = 0; k1 < 4; ++k1) {
+      const int m = n2 * k1;                       // compile-time after unrolling: the special angles cost no multiply
+      cx<T> x = t[k1];
+      if (m == 0) {
+      } else if (m == 8) {
+        x = cmul_negi(x);
+      } else if (m == 16) {
+        x = {-x.x, -x.y};
+      } else if (m == 4) {
+        x = {h * (x.x + x.y), h * (x.y - x.x)};
+      } else if (m == 12) {
+        x = {h * (x.y - x.x), -h * (x.x + x.y)};
+      } else if (m == 20) {
+        x = {-h * (x.x + x.y), h * (x.x - x.y)};
+      } else {
+        x = cmul(x, ssr_w32<T>(m));
+      }
+      v[8 * k1 + n2] = x;
+    }
+  }
+  SSR_UNROLL for (int k1 = 0; k1 < 4; ++k1) ssr_bfly8(v + 8 * k1);
+}
+// frequency held by register rho after ssr_dft32
+SSR_DEV constexpr int ssr_dft32_freq(int rho) { return (rho >> 3) + 4 * (rho & 7); }
+
+template <typename T, bool SUMS> struct SsrWaveRegs {
+  cx<T> v[SSR_W_P];          // the lane's 32 points
+  T tx[SSR_W_P];             // SPLIT exchange: real parts read back while the imaginary parts are still to be written
+  float pa[SSR_W_P], pb[SSR_W_P];   // samples of the NEXT frame, requested one frame ahead
+  T wl[SSR_W_P / 2];         // 0.5 * hann[tid + 64 r], r < 16 of the next frame: requested at the TOP of the epilogue, ahead of
+                             // the magnitude stores (behind them in the in-order memory counter every frame would wait for
+                             // the stores' acknowledgements)
+  cx<T> tw1[7];              // w^(8 (tid mod 32) q), q = 1..7: requested while the first exchange is in flight
+  cx<T> tw2[12];             // w^j, w^2j, w^4j of the four third-pass butterflies: requested while the second one is
+  double sums[SUMS ? 6 : 1]; // SISpec / log-SISpec running sums
+  double lsd_total;          // lane 0: sum over the chunk's frames of the per-frame LSD
+};
+
+template <typename T, bool SPLIT> struct SsrWaveLds {
+  // scratch first (doubles), then the exchange array(s)
+  static constexpr size_t bytes() { return sizeof(double) * 4 + sizeof(int) * 8 + sizeof(T) * (SPLIT ? 1 : 2) * SSR_W_PN; }
+  double* sc1; int* nz; T* re; T* im;
+  SSR_MEMBER explicit SsrWaveLds(char* base) {
+    sc1 = reinterpret_cast<double*>(base);
+    nz = reinterpret_cast<int*>(sc1 + 4);           // [2 signals][2 flag sets]
+    re = reinterpret_cast<T*>(nz + 8);
+    im = SPLIT ? re : re + SSR_W_PN;
+  }
+  SSR_MEMBER bool nonzero(int which, int par) const {
+    int f = nz[which * 2 + par];
+#ifndef SSR_HOST_EMU
+    f = __builtin_amdgcn_readfirstlane(f);
+#endif
+    return f != 0;
+  }
+};
+
+// LDS slots as (per-lane base) + (compile-time offset): the offsets fold into the DS instructions' immediate fields.
+//  after pass 0 : register rho = frequency q = ssr_dft32_freq(rho) of sub-transform `tid` -> slot 32 tid + q, padded 33 tid + q
+//  radix-8 load : register 8 b + q = input q of butterfly j = tid + 64 b -> slot j + 256 q, padded tid + tid/32 + 66 b + 264 q
+//  after pass 1 : output q of butterfly j -> slot (j - k) 8 + k + 32 q, k = j mod 32,
+//                 padded 264 (tid/32) + tid mod 32 + 528 b + 33 q
+//  partner read : Z[2048 - k], k = tid + 64 b + 256 q, sits at upper-half slot 1024 - k,
+//                 padded 1056 - tid - ceil(tid/32) - 66 b - 264 q   (lane 0, b = q = 0 reads a slot it does not use)
+struct SsrWaveBase { int st0, ld8, st1, pr; };
+SSR_DEV SsrWaveBase ssr_wave_bases(int tid) {
+  return {33 * tid, tid + (tid >> 5), 264 * (tid >> 5) + (tid & 31), 1056 - tid - ((tid + 31) >> 5)};
+}
+SSR_DEV constexpr int ssr_w_off_st0(int i) { return ssr_dft32_freq(i); }
+SSR_DEV constexpr int ssr_w_off_ld8(int i) { return 66 * (i >> 3) + 264 * (i & 7); }
+SSR_DEV constexpr int ssr_w_off_st1(int i) { return 528 * (i >> 3) + 33 * (i & 7); }
+
+// One exchange through LDS: R.v[i] goes to slot WB + WO(i), then R.v[i] is reloaded from slot RB + RO(i).
+// SPLIT: real parts first, imaginary parts second, through the same array.
+// EXTRA: statements issued right after the (first) write phase - the table loads of the NEXT pass: the registers of the
+// values just written are free at that point, and the loads' latency overlaps the exchange.
+#define SSR_W_EXCHANGE(blk, regs, L, WB, WO, RB, RO, EXTRA)                                               \
+  if constexpr (!SPLIT) {                                                                                 \
+    SSR_WPHASE(blk, regs, { const int w_ = ssr_wave_bases(tid).WB;                                        \
+      SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) { (L).re[w_ + WO(i)] = R.v[i].x; (L).im[w_ + WO(i)] = R.v[i].y; } }); \
+    SSR_WPHASE(blk, regs, { SSR_SCHED_BARRIER(); EXTRA; const int r_ = ssr_wave_bases(tid).RB;           \
+      SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) R.v[i] = {(L).re[r_ + RO(i)], (L).im[r_ + RO(i)]}; });   \
+  } else {                                                                                                \
+    SSR_WPHASE(blk, regs, { const int w_ = ssr_wave_bases(tid).WB;                                        \
+      SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) (L).re[w_ + WO(i)] = R.v[i].x; });                     \
+    SSR_WPHASE(blk, regs, { SSR_SCHED_BARRIER(); EXTRA; const int r_ = ssr_wave_bases(tid).RB;           \
+      SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) R.tx[i] = (L).re[r_ + RO(i)]; });                      \
+    SSR_WPHASE(blk, regs, { const int w_ = ssr_wave_bases(tid).WB;                                        \
+      SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) (L).re[w_ + WO(i)] = R.v[i].y; });                     \
+    SSR_WPHASE(blk, regs, { const int r_ = ssr_wave_bases(tid).RB;                                        \
+      SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) R.v[i] = {R.tx[i], (L).re[r_ + RO(i)]}; });            \
+  }
+
+// Request unit u's samples into the prefetch registers (branch-free, always valid addresses, reflection only at the ends).
+template <typename T, typename REGS>
+SSR_DEV void ssr_wave_prefetch(const SsrStftParams<T>& p, REGS& R, int tid, const SsrView<float>& va, const SsrView<float>& vb,
+                               int u, int n, int n_frames) {
+  const int t_c = (u < n_frames) ? u : n_frames - 1;
+  const int base = t_c * p.hop - SSR_W_N / 2;
+  if (base >= 0 && base + SSR_W_N <= n) {            // wave-uniform: the frame lies fully inside the signal
+    SSR_UNROLL for (int r = 0; r < SSR_W_P; ++r) {
+      R.pa[r] = va.at(SSR_UIDX(tid + 64 * r), base);
+      R.pb[r] = vb.at(SSR_UIDX(tid + 64 * r), base);
+    }
+  } else {
+    SSR_UNROLL for (int r = 0; r < SSR_W_P; ++r) {
+      const unsigned m = SSR_UIDX(ssr_reflect(base + tid + 64 * r, n));
+      R.pa[r] = va.at(m);
+      R.pb[r] = vb.at(m);
+    }
+  }
+}
+
+// Silent-frame flags of the PREFETCHED unit into flag set `par` (see ssr_stft_prefetched_flags).
+template <typename REGS> SSR_DEV void ssr_wave_flags(REGS& R, int tid, int* nz, int par) {
+  SSR_UNROLL for (int r = 0; r < SSR_W_P; ++r) { ssr_touch(R.pa[r]); ssr_touch(R.pb[r]); }
+  unsigned ora = 0u, orb = 0u;
+  SSR_UNROLL for (int r = 1; r < SSR_W_P; ++r) { ora |= ssr_mag_bits(R.pa[r]); orb |= ssr_mag_bits(R.pb[r]); }
+  ora |= (tid == 0) ? 0u : ssr_mag_bits(R.pa[0]);    // sample m = 0 carries window weight exactly 0
+  orb |= (tid == 0) ? 0u : ssr_mag_bits(R.pb[0]);
+  SSR_WAVE_ANY_STORE(tid, ora != 0u, nz + par);
+  SSR_WAVE_ANY_STORE(tid, orb != 0u, nz + 2 + par);
+}
+
+// grid = n_items * n_chunks workgroups of ONE wave; PAIR mode, direct 2048-point engine, float32 signals.
+template <typename T, bool SUMS, bool SPLIT, typename BLK>
+SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
+  constexpr int N = SSR_W_N, F = N / 2 + 1;
+  using Regs = SsrWaveRegs<T, SUMS>;
+  SsrWaveLds<T, SPLIT> L(lds_base);
+  const int n = p.len[item], hop = p.hop;
+  const int n_frames = ssr_num_frames_dev(n, N, hop);
+  const int u0 = chunk * p.units_per_chunk;
+  const int u1 = (u0 + p.units_per_chunk < n_frames) ? u0 + p.units_per_chunk : n_frames;
+  const float* sa = p.a + p.a_off[item];
+  const float* sb = p.b + p.b_off[item];
+  const int64_t row0 = p.frame_off[item];
+  double* part = p.part ? p.part + ((int64_t)item * p.n_chunks + chunk) * SSR_NPART : nullptr;
+  // the variant without running sums is only launched when no SISpec bit is set: say so, and their code disappears
+  const int mask = SUMS ? p.metric_mask : (p.metric_mask & SSR_M_LSD);
+  const bool want_lsd = mask & SSR_M_LSD;
+  const SsrView<float> va(sa, n), vb(sb, n);
+  const SsrView<T> vw(p.window, N);
+  const SsrView<cx<T>> vt(p.tw, N);
+
+  SSR_REGS(Regs, regs, blk);
+  SSR_WPHASE(blk, regs, {
+    R.lsd_total = 0.0;
+    for (int q = 0; q < (SUMS ? 6 : 1); ++q) R.sums[q] = 0.0;
+    if (tid == 0) L.sc1[0] = 0.0;
+    if (u0 < u1) {
+      ssr_wave_prefetch<T>(p, R, tid, va, vb, u0, n, n_frames);
+      ssr_wave_flags(R, tid, L.nz, 0);
+      SSR_UNROLL for (int r = 0; r < SSR_W_P / 2; ++r) R.wl[r] = vw.at(SSR_UIDX(tid + 64 * r));
+    }
+  });
+
+  BLK blk0 = blk;
+  for (int u = u0; u < u1; ++u) {
+    // The lane's table values (window, twiddles) and addresses are loop-invariant, and 128 + 64 registers of data and
+    // prefetched samples leave no room to keep them: with the lane index opaque the optimiser cannot hoist them out of the
+    // loop (it would, and then shuffle some 250 values through the accumulator registers every frame).  Table values are
+    // re-requested from L1 / L2 a phase before they are needed; LDS slots are four per-lane bases plus immediates.
+    blk = blk0; ssr_launder(blk);
+    // ---- pass 0: window, radix-32 DFT in registers (Stockham pass with stride 1: no twiddle).  Lane 0 also closes the
+    // previous frame's LSD.
+    SSR_WPHASE(blk, regs, {
+      SSR_UNROLL for (int r = 0; r < SSR_W_P; ++r) {
+        const T w = (r < SSR_W_P / 2) ? R.wl[r] : (T)0.5 - R.wl[r - SSR_W_P / 2];       // w[m + N/2] = 1/2 - w[m]
+        R.v[r] = {(T)R.pa[r] * w, (T)R.pb[r] * w};
+      }
+      ssr_dft32(R.v);
+      if (want_lsd && u > u0 && tid == 0) R.lsd_total += sqrt(L.sc1[0] / (double)F);
+    });
+    blk = blk0; ssr_launder(blk);     // (fresh opaque lane index per stage: addresses are formed where they are used)
+#define SSR_W_LOAD_TW1 { const unsigned k8 = SSR_UIDX(8 * (tid & 31)); \
+                         SSR_UNROLL for (int q = 1; q < 8; ++q) R.tw1[q - 1] = vt.at(k8 * q); }
+    SSR_W_EXCHANGE(blk, regs, L, st0, ssr_w_off_st0, ld8, ssr_w_off_ld8, SSR_W_LOAD_TW1);
+    // ---- pass 1: four radix-8 butterflies, twiddles w^(8 (j mod 32) q) - the same seven for every butterfly of the lane
+    SSR_WPHASE(blk, regs, {
+      SSR_UNROLL for (int b = 0; b < 4; ++b) {
+        SSR_UNROLL for (int q = 1; q < 8; ++q) R.v[8 * b + q] = cmul(R.v[8 * b + q], R.tw1[q - 1]);
+        ssr_bfly8(R.v + 8 * b);
+      }
+    });
+    blk = blk0; ssr_launder(blk);
+#define SSR_W_LOAD_TW2 SSR_UNROLL for (int b = 0; b < 4; ++b) { const unsigned j = SSR_UIDX(tid + 64 * b); \
+                         R.tw2[3 * b] = vt.at(j); R.tw2[3 * b + 1] = vt.at(2 * j); R.tw2[3 * b + 2] = vt.at(4 * j); }
+    SSR_W_EXCHANGE(blk, regs, L, st1, ssr_w_off_st1, ld8, ssr_w_off_ld8, SSR_W_LOAD_TW2);
+    // ---- pass 2: four radix-8 butterflies, twiddles w^(j q), j = tid + 64 b: three table values + four products each
+    SSR_WPHASE(blk, regs, {
+      SSR_UNROLL for (int b = 0; b < 4; ++b) {
+        cx<T>* x = R.v + 8 * b;
+        const cx<T> w1 = R.tw2[3 * b], w2 = R.tw2[3 * b + 1], w4 = R.tw2[3 * b + 2];
+        x[1] = cmul(x[1], w1);
+        x[2] = cmul(x[2], w2);
+        x[4] = cmul(x[4], w4);
+        const cx<T> w3 = cmul(w1, w2);
+        x[3] = cmul(x[3], w3);
+        x[5] = cmul(x[5], cmul(w1, w4));
+        x[6] = cmul(x[6], cmul(w2, w4));
+        x[7] = cmul(x[7], cmul(w3, w4));
+        ssr_bfly8(x);
+      }
+    });
+    // register 8 b + q now holds Z[k], k = tid + 64 b + 256 q.  The bins k <= 1024 are this lane's to emit; each needs
+    // Z[2048 - k], which lives in the upper half (q >= 4) of lane 64 - tid: the upper halves go through LDS once.
+    if constexpr (!SPLIT) {
+      SSR_WPHASE(blk, regs, { const int w_ = ssr_wave_bases(tid).ld8;
+        SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int q = 4; q < 8; ++q) {
+          L.re[w_ + 66 * b + 264 * (q - 4)] = R.v[8 * b + q].x; L.im[w_ + 66 * b + 264 * (q - 4)] = R.v[8 * b + q].y; } });
+    } else {
+      SSR_WPHASE(blk, regs, { const int w_ = ssr_wave_bases(tid).ld8;
+        SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int q = 4; q < 8; ++q) {
+          L.re[w_ + 66 * b + 264 * (q - 4)] = R.v[8 * b + q].x;
+          L.re[SSR_W_IMOFF + w_ + 66 * b + 264 * (q - 4)] = R.v[8 * b + q].y; } });
+    }
+
+    // ---- epilogue: four groups of four bins (partner values in, magnitudes out per group: few registers live at once)
+    blk = blk0; ssr_launder(blk);
+    float* ra0 = p.out_a ? p.out_a + (row0 + u) * F : nullptr;   // wave-uniform row pointers
+    float* rb0 = p.out_b ? p.out_b + (row0 + u) * F : nullptr;
+    SSR_WPHASE(blk, regs, {
+      // UNCONDITIONAL (the last frame of a chunk re-requests a clamped, valid frame that nobody consumes): under a condition
+      // the previous contents of the 64 + 32 registers would stay live through all three passes for the path not taken
+      ssr_wave_prefetch<T>(p, R, tid, va, vb, u + 1, n, n_frames);
+      SSR_UNROLL for (int r = 0; r < SSR_W_P / 2; ++r) R.wl[r] = vw.at(SSR_UIDX(tid + 64 * r));
+      SSR_SCHED_BARRIER();
+      double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      const int par = (u - u0) & 1;
+      const bool a_nz = L.nonzero(0, par), b_nz = L.nonzero(1, par);
+      const bool both = a_nz && b_nz;                             // wave-uniform: the common case carries no selects
+      const int im_off = SPLIT ? SSR_W_IMOFF : 0;
+      const T* lre = L.re;
+      const T* lim = SPLIT ? L.re : L.im;
+      const bool store = p.out_kind == SSR_OUT_MAG;
+      const int pr = ssr_wave_bases(tid).pr;
+      SSR_UNROLL for (int b = 0; b < 4; ++b) {
+        cx<T> zn[4];
+        SSR_UNROLL for (int q = 0; q < 4; ++q)                    // Z[2048 - k] sits at upper-half slot 1024 - k
+          zn[q] = {lre[pr - 66 * b - 264 * q], lim[im_off + pr - 66 * b - 264 * q]};
+        SSR_UNROLL for (int q = 0; q < 4; ++q) {
+          const cx<T> zk = R.v[8 * b + q];
+          const cx<T> zz = (b == 0 && q == 0 && tid == 0) ? zk : zn[q];   // bin 0 pairs with itself
+          float e, t;
+          if (both) ssr_pair_bin<T, 0, true>(mask, acc, zk, zz, true, true, e, t);
+          else ssr_pair_bin<T, 0, true>(mask, acc, zk, zz, a_nz, b_nz, e, t);
+          if (store) {
+            ra0[SSR_UIDX(tid + 64 * b + 256 * q)] = e;
+            rb0[SSR_UIDX(tid + 64 * b + 256 * q)] = t;
+          }
+        }
+      }
+      if (tid == 0) {                                             // the Nyquist bin: Z[1024] pairs with itself
+        const cx<T> zq = {lre[0], lim[im_off]};
+        float e, t;
+        ssr_pair_bin<T, 0, true>(mask, acc, zq, zq, a_nz, b_nz, e, t);
+        if (store) { ra0[N / 2] = e; rb0[N / 2] = t; }
+      }
+      ssr_wave_flags(R, tid, L.nz, par ^ 1);
+      if (want_lsd) SSR_WAVE_SUM_STORE(tid, 64, acc[0], L.sc1);
+      if constexpr (SUMS)
+        for (int q = 0; q < 6; ++q) R.sums[q] += acc[1 + q];
+    });
+  }
+
+  if (part == nullptr) return;
+  // ---- chunk tail: last frame's LSD and the wave-sums of the SISpec accumulators
+  if constexpr (SUMS) {
+    for (int q = 0; q < 6; ++q) {
+      SSR_WPHASE(blk, regs, SSR_WAVE_SUM_STORE(tid, 64, R.sums[q], L.sc1 + 1));
+      SSR_WPHASE(blk, regs, if (tid == 0) part[1 + q] = L.sc1[1]);
+    }
+  } else {
+    SSR_WPHASE(blk, regs, if (tid == 0) for (int q = 0; q < 6; ++q) part[1 + q] = 0.0);
+  }
+  SSR_WPHASE(blk, regs, if (tid == 0) {
+    double lsd = R.lsd_total;
+    if (want_lsd && u1 > u0) lsd += sqrt(L.sc1[0] / (double)F);
+    part[0] = lsd;
+    part[7] = 0.0;
+  });
+}

@@ -31,8 +31,20 @@ int ssr_target_wgs() {
 #endif
 }
 
-int ssr_units_per_chunk_for(int max_units, int n_items) {
-  const int target = ssr_target_wgs();
+bool ssr_stft_uses_wave_engine(const ssr_plan* pl, bool in64) {
+#ifdef SSR_DEV_KNOBS
+  static const int off = getenv("SSR_NO_WAVE") ? atoi(getenv("SSR_NO_WAVE")) : 0;
+  if (off) return false;
+#endif
+  return !in64 && !pl->eng.bluestein && pl->eng.radix == 1 && pl->eng.logn == 11;
+}
+
+int ssr_pair_units_per_chunk(const ssr_plan* pl, int max_units, int n_items, bool in64) {
+  return ssr_units_per_chunk_for(max_units, n_items, ssr_stft_uses_wave_engine(pl, in64) ? 4 * ssr_target_wgs() : 0);
+}
+
+int ssr_units_per_chunk_for(int max_units, int n_items, int target_wgs) {
+  const int target = target_wgs > 0 ? target_wgs : ssr_target_wgs();
   int64_t u = ((int64_t)max_units * n_items + target - 1) / target;
   if (u < 4) u = 4;
   if (u > 128) u = 128;             // ragged batches: short workgroups keep the tail of a launch balanced

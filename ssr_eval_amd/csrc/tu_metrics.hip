@@ -50,10 +50,10 @@ struct PairWs {
   int units_per_chunk, n_chunks;
   SsimGeom sg;
 };
-static PairWs pair_ws(const ssr_plan* pl, int n_items, int max_len, int64_t total_rows) {
+static PairWs pair_ws(const ssr_plan* pl, int n_items, int max_len, int64_t total_rows, bool in64) {
   PairWs w;
   const int max_T = (int)ssr_num_frames(pl, max_len);
-  w.units_per_chunk = ssr_units_per_chunk_for(max_T, n_items);
+  w.units_per_chunk = ssr_pair_units_per_chunk(pl, max_T, n_items, in64);     // depends on the engine that will run
   w.n_chunks = ssr_ceil_div(max_T, w.units_per_chunk);
   w.sg = ssim_geom(max_T, pl->n_bins, n_items);
   size_t o = 0;
@@ -68,7 +68,9 @@ static PairWs pair_ws(const ssr_plan* pl, int n_items, int max_len, int64_t tota
 // ----------------------------------------------------------------------------------------------------
 extern "C" size_t ssr_pair_metrics_workspace_bytes(const ssr_plan* pl, int n_items, int max_len, int64_t total_rows) {
   if (!pl || n_items <= 0) return 0;
-  return pair_ws(pl, n_items, max_len, total_rows).total + ssr_align256((size_t)n_items * sizeof(int32_t));
+  // the float32 and float64-signal entry points may chunk differently (different engines): cover both
+  const size_t a = pair_ws(pl, n_items, max_len, total_rows, false).total, b = pair_ws(pl, n_items, max_len, total_rows, true).total;
+  return (a > b ? a : b) + ssr_align256((size_t)n_items * sizeof(int32_t));
 }
 
 template <int CPT> static int launch_ssim_inst(const SsrSsimParams& p, int grid, hipStream_t s) {
@@ -140,7 +142,7 @@ static int pair_metrics_impl(const ssr_plan* pl, const float* est, const double*
   if (want_ssim && (int64_t)max_T * pl->n_bins >= ((int64_t)1 << 30))
     return ssr_fail(SSR_ERR_UNSUPPORTED, "spectrogram of 2^30 elements or more (4 GiB buffer views)");
   if (want_ssim && (max_T < 7 || pl->n_bins < 7)) return ssr_fail(SSR_ERR_INVALID_ARG, "win_size exceeds image extent");
-  const PairWs w = pair_ws(pl, n_items, max_len, total_rows);
+  const PairWs w = pair_ws(pl, n_items, max_len, total_rows, est64 != nullptr);
   // rows array lives at the tail of the ssim partial area's alignment slack: allocate it explicitly
   const size_t rows_bytes = ssr_align256((size_t)n_items * sizeof(int32_t));
   if (!workspace || workspace_bytes < w.total + rows_bytes) return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small");

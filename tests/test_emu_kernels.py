@@ -259,3 +259,30 @@ def test_all_zero_frames_have_exactly_zero_spectra(n_fft, hop):
     sa, _, _ = E.stft([half], None, n_fft, hop, precision=1, mode=1, units_per_chunk=2)   # single mode: frame pairs
     ra = ostft.stft_mag_TF(half, n_fft, hop)
     assert ((sa[0] == 0) == (ra == 0)).all()
+
+
+@pytest.mark.parametrize("wave", ["full", "split"])
+def test_wave_autonomous_engine_matches_oracle_and_block_engine(wave):
+    """ssr_stft_wave.h (one wave per frame: in-register radix-32 first pass, two LDS exchanges, no barriers) against the
+    oracle and against the four-waves-per-frame engine of ssr_stft.h: ragged lengths, reflected edge frames, a chunk
+    boundary inside every signal, a stretch of digital silence, both exchange layouts."""
+    rng = np.random.default_rng(1)
+    lens = [9000, 2048 * 3 + 77, 3600, 5000]
+    tg = [(0.1 * rng.standard_normal(n)).astype(np.float32) for n in lens]
+    es = [(t + 0.02 * rng.standard_normal(len(t))).astype(np.float32) for t in tg]
+    es[3][1000:4200] = 0.0
+    mags_e, mags_t, _ = E.stft(es, tg, 2048, 512, 1, 0, 1, 15, 5, wave=wave)
+    for x, m in zip(es + tg, mags_e + mags_t):
+        ref = ostft.stft_mag_TF(x, 2048, 512)
+        assert np.abs(m - ref).max() <= 2e-7 * ref.max()
+        assert ((m == 0) == (ref == 0)).all()                       # silent frames: exact zeros, nowhere else
+    assert (mags_e[3] == 0).all(axis=1).any()
+    got = E.pair_metrics(es, tg, 2048, 512, 1, wave=wave, units_per_chunk=5)
+    blk = E.pair_metrics(es, tg, 2048, 512, 1, units_per_chunk=5)
+    for e, t, g, b in zip(es, tg, got, blk):
+        w = om.evaluation(e, t, n_fft=2048, hop=512)
+        np.testing.assert_allclose(g, [w[k] for k in ("lsd", "log_sispec", "sispec", "ssim")], rtol=1e-5)
+        np.testing.assert_allclose(g, b, rtol=1e-7)                # same arithmetic up to the magnitude's last ulp
+    # LSD-only variant (no running SISpec sums) gives the same LSD
+    lsd_only = E.pair_metrics(es, tg, 2048, 512, 1, mask=E.M_LSD | E.M_SSIM, wave=wave, units_per_chunk=7)
+    np.testing.assert_allclose(lsd_only[:, [0, 3]], got[:, [0, 3]], rtol=1e-12)

@@ -160,6 +160,43 @@ SSR_DEV constexpr int ssr_w_off_st1(int i) { return 528 * (i >> 3) + 33 * (i & 7
       SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) R.v[i] = {R.tx[i], (L).re[r_ + RO(i)]}; });            \
   }
 
+// The rest of the transform after the in-register radix-32 pass (ssr_dft32 applied to R.v): exchange, radix-8 pass with the
+// lane's seven twiddles, exchange, radix-8 pass with table twiddles.  On exit register 8 b + q holds Z[tid + 64 b + 256 q].
+// BLK0: the untouched block descriptor (a fresh opaque lane index per stage: addresses are formed where they are used).
+// EXTRA2: further table loads to issue with the last pass's twiddles (the low-pass kernel's synthesis window).
+#define SSR_W_LOAD_TW1 { const unsigned k8 = SSR_UIDX(8 * (tid & 31)); \
+                         SSR_UNROLL for (int q = 1; q < 8; ++q) R.tw1[q - 1] = VT.at(k8 * q); }
+#define SSR_W_LOAD_TW2 SSR_UNROLL for (int b = 0; b < 4; ++b) { const unsigned j = SSR_UIDX(tid + 64 * b); \
+                         R.tw2[3 * b] = VT.at(j); R.tw2[3 * b + 1] = VT.at(2 * j); R.tw2[3 * b + 2] = VT.at(4 * j); }
+#define SSR_W_FFT_TAIL(blk, BLK0, regs, L, EXTRA2)                                                                        \
+  blk = BLK0; ssr_launder(blk);                                                                                     \
+  SSR_W_EXCHANGE(blk, regs, L, st0, ssr_w_off_st0, ld8, ssr_w_off_ld8, SSR_W_LOAD_TW1);                             \
+  /* pass 1: four radix-8 butterflies, twiddles w^(8 (j mod 32) q) - the same seven for every butterfly of the lane */ \
+  SSR_WPHASE(blk, regs, {                                                                                           \
+    SSR_UNROLL for (int b = 0; b < 4; ++b) {                                                                        \
+      SSR_UNROLL for (int q = 1; q < 8; ++q) R.v[8 * b + q] = cmul(R.v[8 * b + q], R.tw1[q - 1]);                   \
+      ssr_bfly8(R.v + 8 * b);                                                                                       \
+    }                                                                                                               \
+  });                                                                                                               \
+  blk = BLK0; ssr_launder(blk);                                                                                     \
+  SSR_W_EXCHANGE(blk, regs, L, st1, ssr_w_off_st1, ld8, ssr_w_off_ld8, SSR_W_LOAD_TW2 EXTRA2);                      \
+  /* pass 2: four radix-8 butterflies, twiddles w^(j q), j = tid + 64 b: three table values + four products each */  \
+  SSR_WPHASE(blk, regs, {                                                                                           \
+    SSR_UNROLL for (int b = 0; b < 4; ++b) {                                                                        \
+      cx<T>* x = R.v + 8 * b;                                                                                       \
+      const cx<T> w1 = R.tw2[3 * b], w2 = R.tw2[3 * b + 1], w4 = R.tw2[3 * b + 2];                                  \
+      x[1] = cmul(x[1], w1);                                                                                        \
+      x[2] = cmul(x[2], w2);                                                                                        \
+      x[4] = cmul(x[4], w4);                                                                                        \
+      const cx<T> w3 = cmul(w1, w2);                                                                                \
+      x[3] = cmul(x[3], w3);                                                                                        \
+      x[5] = cmul(x[5], cmul(w1, w4));                                                                              \
+      x[6] = cmul(x[6], cmul(w2, w4));                                                                              \
+      x[7] = cmul(x[7], cmul(w3, w4));                                                                              \
+      ssr_bfly8(x);                                                                                                 \
+    }                                                                                                               \
+  });
+
 // Request unit u's samples into the prefetch registers (branch-free, always valid addresses, reflection only at the ends).
 template <typename T, typename REGS>
 SSR_DEV void ssr_wave_prefetch(const SsrStftParams<T>& p, REGS& R, int tid, const SsrView<float>& va, const SsrView<float>& vb,
@@ -241,37 +278,9 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
       ssr_dft32(R.v);
       if (want_lsd && u > u0 && tid == 0) R.lsd_total += sqrt(L.sc1[0] / (double)F);
     });
-    blk = blk0; ssr_launder(blk);     // (fresh opaque lane index per stage: addresses are formed where they are used)
-#define SSR_W_LOAD_TW1 { const unsigned k8 = SSR_UIDX(8 * (tid & 31)); \
-                         SSR_UNROLL for (int q = 1; q < 8; ++q) R.tw1[q - 1] = vt.at(k8 * q); }
-    SSR_W_EXCHANGE(blk, regs, L, st0, ssr_w_off_st0, ld8, ssr_w_off_ld8, SSR_W_LOAD_TW1);
-    // ---- pass 1: four radix-8 butterflies, twiddles w^(8 (j mod 32) q) - the same seven for every butterfly of the lane
-    SSR_WPHASE(blk, regs, {
-      SSR_UNROLL for (int b = 0; b < 4; ++b) {
-        SSR_UNROLL for (int q = 1; q < 8; ++q) R.v[8 * b + q] = cmul(R.v[8 * b + q], R.tw1[q - 1]);
-        ssr_bfly8(R.v + 8 * b);
-      }
-    });
-    blk = blk0; ssr_launder(blk);
-#define SSR_W_LOAD_TW2 SSR_UNROLL for (int b = 0; b < 4; ++b) { const unsigned j = SSR_UIDX(tid + 64 * b); \
-                         R.tw2[3 * b] = vt.at(j); R.tw2[3 * b + 1] = vt.at(2 * j); R.tw2[3 * b + 2] = vt.at(4 * j); }
-    SSR_W_EXCHANGE(blk, regs, L, st1, ssr_w_off_st1, ld8, ssr_w_off_ld8, SSR_W_LOAD_TW2);
-    // ---- pass 2: four radix-8 butterflies, twiddles w^(j q), j = tid + 64 b: three table values + four products each
-    SSR_WPHASE(blk, regs, {
-      SSR_UNROLL for (int b = 0; b < 4; ++b) {
-        cx<T>* x = R.v + 8 * b;
-        const cx<T> w1 = R.tw2[3 * b], w2 = R.tw2[3 * b + 1], w4 = R.tw2[3 * b + 2];
-        x[1] = cmul(x[1], w1);
-        x[2] = cmul(x[2], w2);
-        x[4] = cmul(x[4], w4);
-        const cx<T> w3 = cmul(w1, w2);
-        x[3] = cmul(x[3], w3);
-        x[5] = cmul(x[5], cmul(w1, w4));
-        x[6] = cmul(x[6], cmul(w2, w4));
-        x[7] = cmul(x[7], cmul(w3, w4));
-        ssr_bfly8(x);
-      }
-    });
+#define VT vt
+    SSR_W_FFT_TAIL(blk, blk0, regs, L, );
+#undef VT
     // register 8 b + q now holds Z[k], k = tid + 64 b + 256 q.  The bins k <= 1024 are this lane's to emit; each needs
     // Z[2048 - k], which lives in the upper half (q >= 4) of lane 64 - tid: the upper halves go through LDS once.
     if constexpr (!SPLIT) {

@@ -1,6 +1,6 @@
 // libssrhip.so translation unit: STFT-domain low-pass / inverse STFT (K6) kernels and entry points.
 #include "ssr_host.h"
-#include "ssr_lowpass.h"
+#include "ssr_lowpass_wave.h"
 
 #ifndef SSR_LOWPASS_WAVES_PER_EU
 #define SSR_LOWPASS_WAVES_PER_EU 3   /* 168 VGPRs, no spill: 3 workgroups per CU instead of 2 */
@@ -28,10 +28,34 @@ template <typename T, int LOGN> static int launch_lowpass_inst(SsrLowpassParams<
   return SSR_OK;
 }
 
+// Wave-autonomous engine for 2048-point plans (ssr_lowpass_wave.h): one wave per workgroup, 17 KB of LDS, 2 waves / SIMD.
+template <typename T, bool ANALYSIS>
+__global__ __launch_bounds__(64, 2) void k_lowpass_wave(SsrLowpassParams<T> p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  SsrBlk blk{(int)threadIdx.x};
+  const int item = blockIdx.x / p.n_chunks, chunk = blockIdx.x % p.n_chunks;
+  ssr_lowpass_wave_body<T, true, ANALYSIS>(p, blk, chunk, item, smem);
+}
+
+bool ssr_lowpass_uses_wave_engine(const ssr_plan* pl) {
+#ifdef SSR_DEV_KNOBS
+  static const int off = getenv("SSR_NO_WAVE") ? atoi(getenv("SSR_NO_WAVE")) : 0;
+  if (off) return false;
+#endif
+  return !pl->eng.bluestein && pl->eng.logn == 11;
+}
+
 template <typename T> int ssr_launch_lowpass(const ssr_plan* pl, SsrLowpassParams<T>& p, int grid, hipStream_t s) {
   const DevTables<T>& d = ssr_tables_of<T>(pl);
   p.window = d.window; p.tw = d.tw;
   if (pl->eng.bluestein) return ssr_fail(SSR_ERR_UNSUPPORTED, "inverse STFT needs a power-of-two n_fft in [256, 4096]");
+  if (ssr_lowpass_uses_wave_engine(pl)) {
+    typedef SsrWaveLds<T, true> WaveLds;
+    if (p.spec_re == nullptr) hipLaunchKernelGGL((k_lowpass_wave<T, true>), dim3(grid), dim3(64), WaveLds::bytes(), s, p);
+    else hipLaunchKernelGGL((k_lowpass_wave<T, false>), dim3(grid), dim3(64), WaveLds::bytes(), s, p);
+    HIP_TRY(hipGetLastError());
+    return SSR_OK;
+  }
   switch (pl->eng.logn) {
     case 8: return launch_lowpass_inst<T, 8>(p, grid, s);
     case 9: return launch_lowpass_inst<T, 9>(p, grid, s);
@@ -58,7 +82,7 @@ static int run_inverse(const ssr_plan* pl, const float* in, const int64_t* in_of
   if (max_len >= (1 << 29)) return ssr_fail(SSR_ERR_UNSUPPORTED, "signals of 2^29 samples or more (4 GiB buffer views)");
   if (!workspace || workspace_bytes < ssr_ola_workspace_bytes(pl, total_rows)) return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small");
   const int max_pairs = (int)((ssr_num_frames(pl, max_len) + 1) / 2);
-  const int ppc = ssr_units_per_chunk_for(max_pairs, n_items);
+  const int ppc = ssr_units_per_chunk_for(max_pairs, n_items, ssr_lowpass_uses_wave_engine(pl) ? 4 * ssr_target_wgs() : 0);
   const int n_chunks = ssr_ceil_div(max_pairs, ppc);
   int rc;
   if (pl->precision == SSR_F64) {

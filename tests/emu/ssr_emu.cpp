@@ -14,6 +14,7 @@
 #include "../../ssr_eval_amd/csrc/ssr_resample.h"
 #include "../../ssr_eval_amd/csrc/ssr_stft_r3.h"
 #include "../../ssr_eval_amd/csrc/ssr_stft_wave.h"
+#include "../../ssr_eval_amd/csrc/ssr_lowpass_wave.h"
 #include "../../ssr_eval_amd/csrc/ssr_tables.h"
 
 static std::vector<char> poisoned(size_t bytes) { return std::vector<char>(bytes + 64, (char)0xFF); }
@@ -245,6 +246,43 @@ extern "C" int emu_lowpass_frames(int precision, int n_fft, int hop, const float
                                         n_chunks, re_in, im_in, frames);
   return emu_lowpass_frames_t<float>(n_fft, hop, in, in_off, len, cut, frame_off, n_items, pairs_per_chunk, n_chunks,
                                      re_in, im_in, frames);
+}
+
+// wave-autonomous low-pass / ISTFT frames kernel (ssr_lowpass_wave.h; 2048-point plans)
+template <typename T>
+static int emu_lowpass_wave_t(int hop, int split, const float* in, const int64_t* in_off, const int32_t* len, const int32_t* cut,
+                              const int64_t* frame_off, int n_items, int pairs_per_chunk, int n_chunks, const float* re_in,
+                              const float* im_in, float* frames) {
+  SsrTables<T> t;
+  if (!ssr_build_tables<T>(2048, t)) return -3;
+  SsrLowpassParams<T> p{};
+  p.in = in; p.in_off = in_off; p.len = len; p.cut = cut; p.frame_off = frame_off;
+  p.n_fft = 2048; p.hop = hop; p.pairs_per_chunk = pairs_per_chunk; p.n_chunks = n_chunks;
+  p.window = t.window.data(); p.tw = t.tw.data();
+  p.spec_re = re_in; p.spec_im = im_in; p.frames = frames;
+  SsrBlk blk{64};
+  for (int item = 0; item < n_items; ++item)
+    for (int c = 0; c < n_chunks; ++c) {
+      if (split) {
+        auto lds = poisoned(SsrWaveLds<T, true>::bytes());
+        if (re_in) ssr_lowpass_wave_body<T, true, false>(p, blk, c, item, lds.data());
+        else ssr_lowpass_wave_body<T, true, true>(p, blk, c, item, lds.data());
+      } else {
+        auto lds = poisoned(SsrWaveLds<T, false>::bytes());
+        if (re_in) ssr_lowpass_wave_body<T, false, false>(p, blk, c, item, lds.data());
+        else ssr_lowpass_wave_body<T, false, true>(p, blk, c, item, lds.data());
+      }
+    }
+  return 0;
+}
+extern "C" int emu_lowpass_wave(int precision, int hop, int split, const float* in, const int64_t* in_off, const int32_t* len,
+                                const int32_t* cut, const int64_t* frame_off, int n_items, int pairs_per_chunk, int n_chunks,
+                                const float* re_in, const float* im_in, float* frames) {
+  if (precision == 1)
+    return emu_lowpass_wave_t<double>(hop, split, in, in_off, len, cut, frame_off, n_items, pairs_per_chunk, n_chunks, re_in,
+                                      im_in, frames);
+  return emu_lowpass_wave_t<float>(hop, split, in, in_off, len, cut, frame_off, n_items, pairs_per_chunk, n_chunks, re_in, im_in,
+                                   frames);
 }
 
 extern "C" int emu_ola(int n_fft, int hop, const float* frames, const int64_t* frame_off, const int32_t* len,

@@ -132,14 +132,44 @@ SSR_DEV float ssr_cabsf_fast(float re, float im) {
 #endif
 }
 
+// float32 helpers of the wave engine's epilogue (FASTM variants).  Both stay within ~1 ulp of the correctly rounded result,
+// i.e. inside the rounding noise the reference's own float32 tensor arithmetic has (metrics.py:110, utils.py:43-44), and cost
+// a third of the library sequences:
+//  * ssr_divf_fast : a / b by the hardware reciprocal (1 ulp) plus one residual correction; the operands here are squares of
+//    magnitudes guarded by 1e-12, nowhere near the ranges where div_scale / div_fixup would matter.
+//  * ssr_log10f_fast: log10(x) = log2(x) * log10(2) with the constant split in two (the sequence LLVM uses for
+//    llvm.log10.f32), without the denormal-input rescaling: every argument carries a +1e-12 guard.
+SSR_DEV float ssr_divf_fast(float a, float b) {
+#ifdef SSR_HOST_EMU
+  return a / b;
+#else
+  const float r = __builtin_amdgcn_rcpf(b);
+  const float q = a * r;
+  return __builtin_fmaf(__builtin_fmaf(-q, b, a), r, q);
+#endif
+}
+SSR_DEV float ssr_log10f_fast(float x) {
+#ifdef SSR_HOST_EMU
+  return log10f(x);
+#else
+  const float y = __builtin_amdgcn_logf(x);                       // log2(x), 1 ulp
+  const float c = 0x1.344134p-2f, cc = 0x1.09f79ep-26f;           // log10(2) = c + cc
+  const float r = y * c;
+  return r + __builtin_fmaf(y, cc, __builtin_fmaf(y, c, -r));
+#endif
+}
+
 // LSD term and SISpec sums for one (est, target) magnitude pair, float32 elementwise arithmetic in
 // the order of ssr_eval/metrics.py:110 and ssr_eval/utils.py:43-44; accumulation in float64.
+template <bool FASTM = false>
 SSR_DEV void ssr_accumulate_metrics(float e, float t, int mask, double* acc) {
   const float EPSF = 1e-12f;
   if (mask & SSR_M_LSD) {
     const float ee = e + EPSF;
-    const float r = (t * t) / (ee * ee) + EPSF;     // IEEE division + accurate log10f: cheaper variants measured no faster
-    const float d = log10f(r);
+    // block engines: IEEE division + the library's log10f (cheaper variants measured no faster there - they are not bound
+    // by instruction issue); wave engine (FASTM): the two ~1-ulp sequences above
+    const float r = (FASTM ? ssr_divf_fast(t * t, ee * ee) : (t * t) / (ee * ee)) + EPSF;
+    const float d = FASTM ? ssr_log10f_fast(r) : log10f(r);
     acc[0] += (double)(d * d);
   }
   if (mask & SSR_M_SISPEC) {
@@ -148,7 +178,8 @@ SSR_DEV void ssr_accumulate_metrics(float e, float t, int mask, double* acc) {
     acc[3] += (double)e * (double)t;
   }
   if (mask & SSR_M_LOG_SISPEC) {
-    const float le = log10f(e + EPSF), lt = log10f(t + EPSF);
+    const float le = FASTM ? ssr_log10f_fast(e + EPSF) : log10f(e + EPSF);
+    const float lt = FASTM ? ssr_log10f_fast(t + EPSF) : log10f(t + EPSF);
     acc[4] += (double)le * (double)le;
     acc[5] += (double)lt * (double)lt;
     acc[6] += (double)le * (double)lt;
@@ -228,7 +259,7 @@ SSR_DEV void ssr_pair_bin(int mask, double* acc, cx<T> zk, cx<T> zn, bool a_nz, 
     const float e = FASTABS ? ssr_cabsf_fast(o.ar, o.ai) : ssr_cabsf(o.ar, o.ai);
     const float t = FASTABS ? ssr_cabsf_fast(o.br, o.bi) : ssr_cabsf(o.br, o.bi);
     e_out = e; t_out = t;
-    ssr_accumulate_metrics(e, t, mask, acc);
+    ssr_accumulate_metrics<FASTABS>(e, t, mask, acc);
   }
 }
 

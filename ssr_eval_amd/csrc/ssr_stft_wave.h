@@ -313,19 +313,20 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
       const T* lim = SPLIT ? L.re : L.im;
       const bool store = p.out_kind == SSR_OUT_MAG;
       const int pr = ssr_wave_bases(tid).pr;
-      SSR_UNROLL for (int b = 0; b < 4; ++b) {
-        cx<T> zn[4];
-        SSR_UNROLL for (int q = 0; q < 4; ++q)                    // Z[2048 - k] sits at upper-half slot 1024 - k
-          zn[q] = {lre[pr - 66 * b - 264 * q], lim[im_off + pr - 66 * b - 264 * q]};
-        SSR_UNROLL for (int q = 0; q < 4; ++q) {
-          const cx<T> zk = R.v[8 * b + q];
-          const cx<T> zz = (b == 0 && q == 0 && tid == 0) ? zk : zn[q];   // bin 0 pairs with itself
+      constexpr int G = SUMS ? 2 : 4;                              // bins in flight (the variant with running sums is tighter)
+      SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int q0 = 0; q0 < 4; q0 += G) {
+        cx<T> zn[G];
+        SSR_UNROLL for (int q = 0; q < G; ++q)                    // Z[2048 - k] sits at upper-half slot 1024 - k
+          zn[q] = {lre[pr - 66 * b - 264 * (q0 + q)], lim[im_off + pr - 66 * b - 264 * (q0 + q)]};
+        SSR_UNROLL for (int q = 0; q < G; ++q) {
+          const cx<T> zk = R.v[8 * b + q0 + q];
+          const cx<T> zz = (b == 0 && q0 + q == 0 && tid == 0) ? zk : zn[q];   // bin 0 pairs with itself
           float e, t;
           if (both) ssr_pair_bin<T, 0, true>(mask, acc, zk, zz, true, true, e, t);
           else ssr_pair_bin<T, 0, true>(mask, acc, zk, zz, a_nz, b_nz, e, t);
           if (store) {
-            ra0[SSR_UIDX(tid + 64 * b + 256 * q)] = e;
-            rb0[SSR_UIDX(tid + 64 * b + 256 * q)] = t;
+            ra0[SSR_UIDX(tid + 64 * b + 256 * (q0 + q))] = e;
+            rb0[SSR_UIDX(tid + 64 * b + 256 * (q0 + q))] = t;
           }
         }
       }

@@ -74,7 +74,7 @@ def test_cfg2_full_batch_1024_pairs():
     _check_rows(full[spots], _oracle_many([(est[i].cpu().numpy(), tgt[i].cpu().numpy()) for i in spots]), "cfg2")
     # the bench's mask (LSD + SSIM) gives the same two numbers, the other two stay NaN
     two = batch.run(B.M_LSD | B.M_SSIM).cpu().numpy()
-    np.testing.assert_array_equal(two[:, [0, 3]], full[:, [0, 3]])
+    np.testing.assert_allclose(two[:, [0, 3]], full[:, [0, 3]], rtol=1e-12)      # (two separately compiled kernel variants)
     assert np.isnan(two[:, [1, 2]]).all()
     # batch-composition invariance: a pair alone (6 frames per workgroup) equals the pair inside the 1024 batch
     for i in (0, 511, 1023):

@@ -125,7 +125,7 @@ class Cfg2:
         ms_all4 = event_time_ms(lambda: batch.run(B.M_ALL), it)
         alg = (2 * N_SAMPLES * 4 + 32) * a.pairs          # read est + target once, write 4 doubles
         fft_tflops = 2 * 376 * 2.5 * 2048 * 11 * a.pairs / (ms_stft * 1e-3) / 1e12   # 42.4 MFLOP of real-FFT work per pair
-        dom = ("ssr_stft_pair(k_stft)", ms_stft, "k_stft<double, 11") if ms_stft >= ms_ssim else ("ssr_ssim(k_ssim)", ms_ssim, "k_ssim")
+        dom = ("ssr_stft_pair(k_stft_wave)", ms_stft, "k_stft_wave<double, false") if ms_stft >= ms_ssim else ("ssr_ssim(k_ssim)", ms_ssim, "k_ssim")
         default_wl = a.pairs == 1024 and a.precision == "f64"
         roof = hbm_roofline(dom[0], alg, dom[1], dom[2] if default_wl else None,
                             "fused path is compute-side (f64 FFT + f64 SSIM moments); secondary: STFT kernel runs at %.2f TFLOP/s "

@@ -171,6 +171,20 @@ int ssr_resample_poly_f64(const double* in, const int64_t* in_off, const int32_t
                           const int32_t* out_len, int n_items, int max_out_len, int up, int down, const double* taps,
                           int n_taps, int n_pre_remove, double* out, void* stream);
 
+/* N2.  Band-limited windowed-sinc resampler: the arithmetic of resampy.resample(x, sr_orig, sr_new, filter="kaiser_best"),
+ * i.e. of librosa.load(file, sr=...) / librosa.resample(res_type="kaiser_best") at the reference's ingest call sites
+ * (ssr_eval/eval.py:242 preprocess -> librosa.load(file, sr=sr); ssr_eval/metrics.py:22-23 AudioMetrics.read; and in place of
+ * the `sox -r` target resampling of eval.py:133-134).  The caller supplies, as DEVICE arrays, the interpolation filter
+ * (interp_win, already scaled by the ratio when downsampling, and interp_delta = its forward differences), resampy's
+ * `precision` as num_table = 2^precision, index_step = int(scale * num_table), scale = min(1, ratio), and the time register of
+ * every output index (t / ratio, accumulated sequentially as resampy does).  out_len[i] = int(in_len[i] * ratio).  float64
+ * weights, float32 running sum rounded after every tap, no fused multiply-add: bit-identical to the NumPy restatement in
+ * oracle/resampy.py.  (resampy itself is absent from the reference tree and the image: parity with the package is unpinned.) */
+int ssr_resample_sinc(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
+                      const int32_t* out_len, int n_items, int max_out_len, const double* time_register,
+                      const double* interp_win, const double* interp_delta, int n_win, int num_table, int index_step,
+                      double scale, float* out, void* stream);
+
 /* N4.  Position of the maximum of the full cross-correlation of two equal-length signals,
  *   z[k] = sum_l a[l] * b[l - k + n - 1],  k = 0 .. 2n-2   (scipy.signal.correlate(a, b, "full")),
  * first maximum on ties (numpy.argmax): the alignment step of SSR_Eval_Helper.mp3_encoding

@@ -460,6 +460,86 @@ def resample_poly(wavs, up, down, device=None):
         return [out[b.out_off[i]:b.out_off[i] + b.out_len[i]] for i in range(r.n)]
 
 
+# ------------------------------------------------------------------------------------------------------
+_SINC_FILTERS = {  # resampy filter name -> (num_zeros, precision, Kaiser beta, roll-off)   (resampy/filters.py)
+    "kaiser_best": (64, 9, 14.769656459379492, 0.9475937167399596),
+    "kaiser_fast": (16, 9, 8.555504641634386, 0.85),
+}
+
+
+class SincPlan:
+    """Interpolation tables of resampy.resample(x, sr_orig, sr_new, filter=name) on the device (N2): the right half of
+    the Kaiser-windowed sinc, regenerated from the filter's documented parameters on the host in float64 (a plan, like
+    the polyphase taps), its forward differences, and the running time register t_k = fl(t_{k-1} + 1/ratio)."""
+
+    _cache = {}
+
+    def __init__(self, sr_orig, sr_new, name, device):
+        from scipy.signal.windows import kaiser
+        if name not in _SINC_FILTERS:
+            raise NotImplementedError("resampling filter %r (supported: %s)" % (name, sorted(_SINC_FILTERS)))
+        nz, prec, beta, roll = _SINC_FILTERS[name]
+        self.ratio = float(sr_new) / float(sr_orig)
+        self.num_table = 2 ** prec
+        n = self.num_table * nz
+        win = kaiser(2 * n + 1, beta)[n:] * (roll * np.sinc(roll * np.linspace(0, nz, num=n + 1, endpoint=True)))
+        if self.ratio < 1:
+            win = win * self.ratio
+        delta = np.zeros_like(win)
+        delta[:-1] = np.diff(win)
+        self.scale = min(1.0, self.ratio)
+        self.index_step = int(self.scale * self.num_table)
+        self.n_win = int(win.shape[0])
+        self.device = device
+        self.win = torch.from_numpy(win).to(device)
+        self.delta = torch.from_numpy(delta).to(device)
+        self._tr, self._tr_len = None, 0
+
+    @classmethod
+    def get(cls, sr_orig, sr_new, name, device):
+        key = (float(sr_orig), float(sr_new), name, str(device))
+        p = cls._cache.get(key)
+        if p is None:
+            p = cls._cache[key] = cls(sr_orig, sr_new, name, device)
+        return p
+
+    def n_out(self, n_in):
+        return int(int(n_in) * self.ratio)                      # resampy: int(shape * sample_ratio)
+
+    def time_register(self, n):
+        """Device float64 [>= n]: resampy's `time_register += time_increment`, a SEQUENTIAL float64 sum (np.cumsum)."""
+        if n > self._tr_len:
+            m = max(n, 2 * self._tr_len, 1 << 16)
+            tr = np.empty(m)
+            tr[0] = 0.0
+            tr[1:] = np.cumsum(np.full(m - 1, 1.0 / self.ratio))
+            self._tr, self._tr_len = torch.from_numpy(tr).to(self.device), m
+        return self._tr
+
+
+def resample_sinc(wavs, sr_orig, sr_new, res_type="kaiser_best", device=None, fix=True):
+    """librosa.resample(y, sr_orig, sr_new, res_type="kaiser_best" | "kaiser_fast") for a list of float32 waveforms (N2):
+    resampy's band-limited interpolation on the GPU, then librosa's fix_length to ceil(n * ratio).  Device tensors out."""
+    dev = torch.device(device) if device is not None else default_device()
+    with torch.cuda.device(dev):
+        r = wavs if isinstance(wavs, Ragged) else Ragged.from_list(wavs, dev)
+        if float(sr_orig) == float(sr_new):
+            return [w.clone() for w in r.split()]
+        sp = SincPlan.get(sr_orig, sr_new, res_type, dev)
+        out_len = np.array([sp.n_out(n) for n in r.lens_host], dtype=np.int64)
+        want = np.array([int(np.ceil(n * sp.ratio)) for n in r.lens_host], dtype=np.int64) if fix else out_len
+        out_off = np.concatenate(([0], np.cumsum(want)[:-1])).astype(np.int64) if r.n else np.zeros(0, np.int64)
+        out = torch.zeros(int(want.sum()), dtype=torch.float32, device=dev)       # fix_length pads with zeros
+        if r.n and out_len.max() > 0:
+            out_off_d = torch.from_numpy(out_off).to(dev)
+            out_len_d = torch.from_numpy(out_len.astype(np.int32)).to(dev)
+            tr = sp.time_register(int(out_len.max()))
+            _lib.check(_lib.load().ssr_resample_sinc(_vp(r.data), _vp(r.off), _vp(r.len), _vp(out_off_d), _vp(out_len_d), r.n,
+                                                     int(out_len.max()), _vp(tr), _vp(sp.win), _vp(sp.delta), sp.n_win,
+                                                     sp.num_table, sp.index_step, float(sp.scale), _vp(out), _stream()))
+        return [out[out_off[i]:out_off[i] + want[i]] for i in range(r.n)]
+
+
 def sosfiltfilt(sos, wavs, device=None):
     """scipy.signal.sosfiltfilt(sos, x) for a list of float32 (or float64) waveforms on the GPU (N1); float64 tensors out.
     The section coefficients and sosfilt_zi come from SciPy on the host (filter design, as in the reference)."""

@@ -4,6 +4,7 @@
 #include "ssr_iir.h"
 #include "ssr_xcorr.h"
 #include "ssr_resample.h"
+#include "ssr_sinc.h"
 
 __global__ __launch_bounds__(SSR_XC_NT) void k_xcorr(SsrXcorrParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -28,6 +29,11 @@ template <typename S>
 __global__ __launch_bounds__(256) void k_resample_direct(SsrResampleParamsT<S> p, int blocks_per_item) {
   const int item = blockIdx.x / blocks_per_item;
   ssr_resample_direct_output<S>(p, item, (int64_t)(blockIdx.x % blocks_per_item) * 256 + threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void k_resample_sinc(SsrSincParams p, int blocks_per_item) {
+  const int item = blockIdx.x / blocks_per_item;
+  ssr_sinc_output(p, item, (int64_t)(blockIdx.x % blocks_per_item) * 256 + threadIdx.x);
 }
 
 template <int G, typename X>
@@ -98,6 +104,24 @@ extern "C" int ssr_resample_poly_f64(const double* in, const int64_t* in_off, co
                                      void* stream) {
   return resample_poly_t<double>(in, in_off, in_len, out_off, out_len, n_items, max_out_len, up, down, taps, n_taps,
                                  n_pre_remove, out, stream);
+}
+
+// ----------------------------------------------------------------------------------------------------
+extern "C" int ssr_resample_sinc(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
+                                 const int32_t* out_len, int n_items, int max_out_len, const double* time_register,
+                                 const double* interp_win, const double* interp_delta, int n_win, int num_table,
+                                 int index_step, double scale, float* out, void* stream) {
+  if (!in || !in_off || !in_len || !out_off || !out_len || !time_register || !interp_win || !interp_delta || !out)
+    return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n_win < 1 || num_table < 1 || index_step < 1 || !(scale > 0.0) || scale > 1.0)
+    return ssr_fail(SSR_ERR_INVALID_ARG, "bad interpolation filter description");
+  if (n_items <= 0 || max_out_len <= 0) return SSR_OK;
+  SsrSincParams p{in, in_off, in_len, out_off, out_len, time_register, interp_win, interp_delta, n_win, num_table, index_step,
+                  scale, out};
+  const int bpi = ssr_ceil_div(max_out_len, 256);
+  hipLaunchKernelGGL(k_resample_sinc, dim3((unsigned)((int64_t)n_items * bpi)), dim3(256), 0, (hipStream_t)stream, p, bpi);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
 }
 
 // ----------------------------------------------------------------------------------------------------

@@ -338,9 +338,12 @@ class SSR_Eval_Helper:
 
     def evaluate_files(self, files):
         """eval.py:128-156 for a LIST of files in one batched pass (decode on the host, everything else on the GPU)."""
-        from .io import load_audio, write_wav
-        items = [(load_audio(f, self.evaluationset_sr),            # the reference shells out to sox here
-                  load_audio(f, self.model_input_sr)) for f in files]
+        from .io import decode_batch, to_rate, write_wav
+        # decode once on host threads, one ragged resampling launch per (file rate -> rate) group (ssr_eval_amd.io, N2)
+        decoded = decode_batch(files)
+        targets = to_rate(decoded, self.evaluationset_sr)           # the reference shells out to `sox -r` here
+        inputs = to_rate(decoded, self.model_input_sr)              # librosa.load(file, sr=input_sr), eval.py:242
+        items = list(zip(targets, inputs))
         res = self.evaluate_arrays(items, files)
         if self.save_processed_result:
             for (i, k), y in self._last_processed.items():

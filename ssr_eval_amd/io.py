@@ -1,10 +1,15 @@
-"""Host-side audio file I/O (SURVEY 8(f) N2 - out of the accelerated path).
+"""Audio file ingest.
 
-The reference decodes with librosa.load (+ resampy) and shells out to ``sox`` (ssr_eval/eval.py:133-134,
-242).  Neither exists in the build image; this module decodes with ``soundfile`` when importable and with
-the standard-library ``wave`` module otherwise (PCM .wav only) and changes the sampling rate with the
-polyphase kernel (K7).  Resampling filters therefore differ from sox / resampy: end-to-end numbers on
-real VCTK files are comparable, not bit-identical ("Out of scope").
+The reference decodes with librosa.load - soundfile decode, mono mix, then resampy's "kaiser_best" band-limited
+interpolation when the file's rate differs from the requested one (ssr_eval/eval.py:242, ssr_eval/metrics.py:21-24) - and
+shells out to ``sox -r`` for the evaluation-rate target (eval.py:133-134).  Here:
+
+* decode: ``soundfile`` when importable (WAV / FLAC / OGG), otherwise the standard-library ``wave`` module (PCM .wav) -
+  host work, fanned out over a thread pool by ``load_audio_batch``;
+* rate change: ``ssr_resample_sinc`` on the GPU - resampy's kaiser_best algorithm and filter (bit-identical to the NumPy
+  restatement in oracle/resampy.py; resampy itself is not in the image, so parity with the package is unpinned), one
+  ragged launch per (file rate -> requested rate) group.  It also stands in for sox's ``rate`` effect, whose filter is not
+  published in the reference tree: targets produced by sox on real VCTK files are comparable, not bit-identical.
 """
 import os
 import wave
@@ -50,10 +55,39 @@ def write_wav(path, x, sr):
         f.writeframes((x * 32768.0).astype("<i2").tobytes())
 
 
-def load_audio(path, sr=None):
-    """Decode and (if sr is given and differs) resample with the polyphase kernel."""
-    x, file_sr = read_audio(path)
-    if sr is None or int(sr) == file_sr:
-        return x
-    from . import backend as B
-    return B.resample_poly([x], int(sr), file_sr)[0].cpu().numpy()
+def load_audio(path, sr=None, res_type="kaiser_best"):
+    """librosa.load(path, sr=sr): decode, mono, and - if sr is given and differs - kaiser_best resampling on the GPU."""
+    return load_audio_batch([path], sr, res_type)[0]
+
+
+def decode_batch(paths, threads=None):
+    """[(float32 mono waveform, file rate)] for a list of files; decoding fans out over host threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    paths = list(paths)
+    if len(paths) <= 1:
+        return [read_audio(p) for p in paths]
+    with ThreadPoolExecutor(max_workers=threads or min(16, os.cpu_count() or 1)) as ex:
+        return list(ex.map(read_audio, paths))
+
+
+def to_rate(decoded, sr, res_type="kaiser_best"):
+    """The rate change of librosa.load for decoded [(x, file_sr)] items: one ragged GPU launch per distinct file rate."""
+    out = [None] * len(decoded)
+    groups = {}
+    for i, (x, file_sr) in enumerate(decoded):
+        if sr is None or int(sr) == file_sr:
+            out[i] = x
+        else:
+            groups.setdefault(file_sr, []).append(i)
+    if groups:
+        from . import backend as B
+        for file_sr, idx in groups.items():
+            ys = B.resample_sinc([decoded[i][0] for i in idx], file_sr, int(sr), res_type)
+            for i, y in zip(idx, ys):
+                out[i] = y.cpu().numpy()
+    return out
+
+
+def load_audio_batch(paths, sr=None, res_type="kaiser_best", threads=None):
+    """librosa.load for a LIST of files -> list of float32 ndarrays."""
+    return to_rate(decode_batch(paths, threads), sr, res_type)

@@ -12,6 +12,7 @@
 #include "../../ssr_eval_amd/csrc/ssr_iir.h"
 #include "../../ssr_eval_amd/csrc/ssr_xcorr.h"
 #include "../../ssr_eval_amd/csrc/ssr_resample.h"
+#include "../../ssr_eval_amd/csrc/ssr_sinc.h"
 #include "../../ssr_eval_amd/csrc/ssr_stft_r3.h"
 #include "../../ssr_eval_amd/csrc/ssr_stft_wave.h"
 #include "../../ssr_eval_amd/csrc/ssr_lowpass_wave.h"
@@ -327,6 +328,16 @@ extern "C" int emu_resample_f64(const double* in, const int64_t* in_off, const i
                                 int n_taps, int n_pre_remove, int groups, int taps_in_lds, double* out) {
   return emu_resample_t<double>(in, in_off, in_len, out_off, out_len, n_items, max_out_len, up, down, taps, n_taps,
                                 n_pre_remove, groups, taps_in_lds, out);
+}
+
+// ---- windowed-sinc resampler (N2) ------------------------------------------------------------------------
+extern "C" int emu_resample_sinc(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
+                                 const int32_t* out_len, int n_items, int max_out_len, const double* tr, const double* win,
+                                 const double* delta, int n_win, int num_table, int index_step, double scale, float* out) {
+  SsrSincParams p{in, in_off, in_len, out_off, out_len, tr, win, delta, n_win, num_table, index_step, scale, out};
+  for (int item = 0; item < n_items; ++item)
+    for (int64_t t = 0; t < max_out_len; ++t) ssr_sinc_output(p, item, t);
+  return 0;
 }
 
 // ---- zero-phase IIR (sequential statement of the wavefront kernel's arithmetic) -------------------------------

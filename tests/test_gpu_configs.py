@@ -252,3 +252,37 @@ def test_bench_cli_configs_smoke():
         assert len(lines) == 1
         d = json.loads(lines[0])
         assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["frac"] > 0 and d["config"]["workload"].startswith(cfg[:3] + "-" + cfg[3])
+
+
+# ---- N2 ingest: windowed-sinc (resampy kaiser_best) resampling and the batched file loader ---------------------------------------
+@pytest.mark.parametrize("sr_orig,sr_new", [(44100, 48000), (48000, 44100), (48000, 16000), (16000, 44100)])
+def test_sinc_resampler_bit_exact_vs_restatement_gpu(sr_orig, sr_new):
+    from ssr_eval_amd import backend as B
+    from oracle import resampy as orsy
+    rng = np.random.default_rng(sr_orig + sr_new)
+    sigs = [(0.2 * rng.standard_normal(n)).astype(np.float32) for n in (20000, 4321, 50, 1)]
+    got = B.resample_sinc(sigs, sr_orig, sr_new)
+    for x, y in zip(sigs, got):
+        want = orsy.librosa_resample_kaiser(x, sr_orig, sr_new)
+        assert y.dtype == torch.float32 and tuple(y.shape) == want.shape          # ceil(n * ratio): fix_length applied
+        np.testing.assert_array_equal(y.cpu().numpy(), want)                      # bit-identical to the NumPy restatement
+    assert [tuple(y.shape) for y in B.resample_sinc(sigs, 48000, 48000)] == [x.shape for x in sigs]
+
+
+def test_load_audio_is_librosa_load_shaped(tmp_path):
+    """load_audio / load_audio_batch: decode + mono + kaiser_best to the requested rate (librosa.load semantics), batched."""
+    from ssr_eval_amd.io import write_wav, load_audio, load_audio_batch, read_audio
+    from oracle import resampy as orsy
+    rng = np.random.default_rng(1)
+    paths = []
+    for i, (sr, n) in enumerate([(44100, 30000), (48000, 25000), (44100, 12345), (16000, 9000)]):
+        p = str(tmp_path / ("f%d.wav" % i))
+        write_wav(p, 0.3 * np.sin(2 * np.pi * 440 * np.arange(n) / sr) + 0.01 * rng.standard_normal(n), sr)
+        paths.append(p)
+    got = load_audio_batch(paths, 48000)
+    for p, y in zip(paths, got):
+        x, sr = read_audio(p)
+        np.testing.assert_array_equal(y, orsy.librosa_resample_kaiser(x, sr, 48000))
+        np.testing.assert_array_equal(load_audio(p, 48000), y)
+    x, sr = read_audio(paths[0])
+    np.testing.assert_array_equal(load_audio(paths[0]), x)                          # sr=None: native rate

@@ -215,3 +215,36 @@ def test_reference_float32_sispec_noise_is_measured():
     r32, rex = om.evaluation_with_exact(e2, t2, n_fft=2048, hop=512)
     for k in ("log_sispec", "sispec"):
         assert abs(r32[k] - rex[k]) / abs(rex[k]) < 3e-6
+
+
+def test_resampy_restatement_known_answers():
+    """oracle.resampy (kaiser_best band-limited interpolation; resampy is absent, parity with the package unpinned):
+    closed forms and an independent implementation."""
+    from oracle import resampy as orsy
+    win, delta, num_table, step, scale = orsy.filter_tables(48000 / 44100)
+    assert win.shape == (64 * 512 + 1,) and num_table == 512 and step == 512 and scale == 1.0
+    assert abs(win[0] - 0.9475937167399596) < 1e-15 and abs(win[-1]) < 1e-7 and delta[-1] == 0.0
+    # zero crossings of the windowed sinc sit at multiples of 1 / roll-off input samples
+    z = int(round(512 / 0.9475937167399596))
+    assert abs(win[z]) < 2e-3 * win[0]
+    # a tone well inside the pass band is reproduced at the new rate (interior samples; edges see the truncated filter)
+    t0 = np.arange(6000) / 44100.0
+    x = (0.5 * np.sin(2 * np.pi * 1000 * t0)).astype(np.float32)
+    y = orsy.resample(x, 44100, 48000)
+    assert y.dtype == np.float32 and y.shape == (int(6000 * (48000 / 44100)),)
+    t1 = np.arange(y.shape[0]) / 48000.0
+    assert np.abs(y[300:-300] - 0.5 * np.sin(2 * np.pi * 1000 * t1)[300:-300]).max() < 1e-6
+    # and agrees with SciPy's polyphase resampler (a different Kaiser design) to the level the two filters differ
+    assert np.abs(y[300:-300] - signal.resample_poly(x, 160, 147)[300:y.shape[0] - 300]).max() < 1e-3
+    # unit DC gain when upsampling; the documented index_step truncation shows as a fraction of a percent when downsampling
+    assert abs(orsy.resample(np.ones(4000, np.float32), 44100, 48000)[1000:3000].mean() - 1.0) < 1e-6
+    assert abs(orsy.resample(np.ones(4000, np.float32), 48000, 16000)[300:1000].mean() - 1.0) < 5e-3
+    # librosa's wrapper: length ceil(n * ratio) (fix_length pads the one sample int() dropped), identity at equal rates
+    assert orsy.librosa_resample_kaiser(x, 44100, 48000).shape == (int(np.ceil(6000 * 48000 / 44100)),)
+    assert orsy.librosa_resample_kaiser(x, 44100, 44100) is not None and orsy.librosa_resample_kaiser(x, 16000, 16000).shape == x.shape
+    # time register: the running float64 sum, not t / ratio
+    tr = orsy.time_register(100000, 48000 / 44100)
+    acc = 0.0
+    for k in range(1, 2000):
+        acc += 1.0 / (48000 / 44100)
+        assert tr[k] == acc

@@ -44,78 +44,146 @@ template <typename S> SSR_HD size_t ssr_resample_lds_bytes(const SsrResamplePara
   const size_t taps = p.taps_in_lds ? (size_t)ssr_resample_hpp(p) * p.up : 0;
   return sizeof(S) * (taps + ssr_resample_win(p) + 8);
 }
-// host-side geometry: about 6144 outputs per block, input window capped at 8192 samples
+// host-side geometry.  A block's work items are (phase r < up, group g < G), J outputs each, dealt to the NT threads in
+// rounds: G is chosen for full rounds (441 phases x 1 group = 1.72 rounds -> a quarter of the lanes idle; x 4 = 6.9) under
+// a cap on the input window (which lives in LDS next to the tap table).
 SSR_HD int ssr_resample_pick_groups(int up, int down) {
-  int64_t target = 6144;
-  const int64_t cap = (int64_t)8192 * up / down;
-  if (cap < target) target = cap;
-  int64_t g = target / ((int64_t)up * SSR_RESAMPLE_J);
-  return g < 1 ? 1 : (int)g;
+  int best = 1;
+  double best_eff = 0.0;
+  for (int g = 1; g <= 16; ++g) {
+    const int64_t opb = (int64_t)up * SSR_RESAMPLE_J * g;
+    const int64_t win = opb * down / up + 64;
+    if (g > 1 && (win > 10240 || opb > 16384)) break;
+    const int64_t items = (int64_t)up * g, rounds = (items + SSR_RESAMPLE_NT - 1) / SSR_RESAMPLE_NT;
+    const double eff = (double)items / (double)(rounds * SSR_RESAMPLE_NT);
+    if (eff > best_eff + 0.02) { best_eff = eff; best = g; }
+  }
+  return best;
+}
+#define SSR_RESAMPLE_MAXPF 44   // prefetch registers per thread: ceil(max window / NT)
+
+// Per-block geometry: outputs [m0, m1) of an item and the input window [q_lo, q_lo + win) they read.
+struct SsrResampleBlock { int64_t m0, m1, q_lo; int win; bool live; };
+template <typename S>
+SSR_DEV SsrResampleBlock ssr_resample_block(const SsrResampleParamsT<S>& p, int item, int block) {
+  SsrResampleBlock b;
+  const int hpp = ssr_resample_hpp(p), opb = ssr_resample_opb(p);
+  const int n_out = p.out_len[item];
+  b.m0 = (int64_t)block * opb;
+  b.live = b.m0 < n_out;
+  b.m1 = (b.m0 + opb < n_out) ? b.m0 + opb : n_out;
+  if (!b.live) { b.m1 = b.m0; b.q_lo = 0; b.win = 0; return b; }
+  const int64_t q_first = ((b.m0 + p.n_pre_remove) * p.down) / p.up;
+  b.q_lo = q_first - (hpp - 1);
+  const int64_t q_hi = ((b.m1 - 1 + p.n_pre_remove) * p.down) / p.up;
+  b.win = (int)(q_hi - b.q_lo + 1);
+  return b;
 }
 
-// grid = (n_blocks, n_items), block = SSR_RESAMPLE_NT
-template <typename S, typename BLK>
-SSR_BODY void ssr_resample_body(const SsrResampleParamsT<S>& p, BLK& blk, int block, int item, char* lds_base) {
+// the multiply-adds of one block: window in xw, taps in h
+template <typename S>
+SSR_DEV void ssr_resample_compute(const SsrResampleParamsT<S>& p, int tid, int item, const SsrResampleBlock& b, const S* xw,
+                                  const S* h, int h_len) {
   constexpr int NT = SSR_RESAMPLE_NT, J = SSR_RESAMPLE_J;
-  struct Regs { int unused; };
   const int hpp = ssr_resample_hpp(p), up = p.up, down = p.down, G = p.groups;
-  const int opb = ssr_resample_opb(p);
-  const int n_in = p.in_len[item], n_out = p.out_len[item];
-  const int64_t m0 = (int64_t)block * opb;
-  if (m0 >= n_out) return;
-  const int64_t m1 = (m0 + opb < n_out) ? m0 + opb : n_out;
+  S* y = p.out + p.out_off[item];
+  const int64_t m0 = b.m0, m1 = b.m1, q_lo = b.q_lo;
+  // (m + n_pre_remove) * down = Q0 * up + P0 for the block's first output (one 64-bit division per block, uniform); a work
+  // item adds r * down + g * J * up * down to it: a 32-bit division of a number below up * (down + 1) per work item instead
+  // of a 64-bit one (~100 instructions, a quarter of the loop's arithmetic for 21 taps x 8 outputs)
+  const int64_t T0 = (m0 + p.n_pre_remove) * down;
+  const int64_t Q0 = T0 / up;
+  const unsigned P0 = (unsigned)(T0 - Q0 * up);
+  for (int it = tid; it < up * G; it += NT) {
+    const int r = it % up, g = it / up;
+    const int64_t mf = m0 + r + (int64_t)g * J * up;          // first output of this work item
+    if (mf < m1) {
+      const unsigned a = P0 + (unsigned)r * (unsigned)down;
+      const unsigned qa = a / (unsigned)up;
+      const int ph = (int)(a - qa * (unsigned)up);
+      const int base = (int)(Q0 - q_lo) + (int)qa + g * J * down;
+      S acc[J];
+      int xb[J];   // window slot of the OLDEST input sample of output j (outputs past m1 alias output 0, never stored)
+      SSR_UNROLL for (int j = 0; j < J; ++j) {
+        acc[j] = (S)0;
+        xb[j] = (mf + (int64_t)j * up < m1) ? base + j * down - (hpp - 1) : base - (hpp - 1);
+      }
+      // k ascending = input index ascending (tap index descending): SciPy's accumulation order.
+      // Partial unroll keeps several taps' worth of LDS reads in flight per wait.
+      int hi = ph + (hpp - 1) * up;
+      SSR_UNROLL4 for (int k = 0; k < hpp; ++k) {
+        const S hv = (hi < h_len) ? h[hi] : (S)0;
+        hi -= up;
+        SSR_UNROLL for (int j = 0; j < J; ++j) acc[j] = ssr_fadd_rn(acc[j], ssr_fmul_rn(xw[xb[j] + k], hv));
+      }
+      SSR_UNROLL for (int j = 0; j < J; ++j) {
+        const int64_t m = mf + (int64_t)j * up;
+        if (m < m1) y[m] = acc[j];
+      }
+    }
+  }
+}
+
+template <typename S> struct SsrResampleRegs { S nx[SSR_RESAMPLE_MAXPF]; };
+
+// PERSISTENT workgroup: stages the tap table ONCE, then walks the (item, block) pairs idx = first, first + stride, ...
+// (idx = item * blocks_per_item + block).  The next block's input window is requested into registers before the current
+// block's multiply-adds and written to LDS after them, so the HBM latency of a window hides behind a block of arithmetic
+// (the one-block-per-workgroup launch re-staged 37 KB of taps per 6144 outputs and waited out every window: 74 % of the
+// wave cycles were waits, profiles/r02_notes.md).
+template <typename S, typename BLK>
+SSR_BODY void ssr_resample_persistent_body(const SsrResampleParamsT<S>& p, BLK& blk, int first, int stride, int total,
+                                           int blocks_per_item, char* lds_base) {
+  constexpr int NT = SSR_RESAMPLE_NT, PF = SSR_RESAMPLE_MAXPF;
+  using Regs = SsrResampleRegs<S>;
+  const int hpp = ssr_resample_hpp(p), up = p.up;
   S* hl = reinterpret_cast<S*>(lds_base);
   S* xw = hl + (p.taps_in_lds ? hpp * up : 0);
   const S* h = p.taps_in_lds ? hl : p.taps;
   const int h_len = p.taps_in_lds ? hpp * up : p.n_taps;
-  const int64_t q_first = ((m0 + p.n_pre_remove) * down) / up;
-  const int64_t q_lo = q_first - (hpp - 1);
-  const int64_t q_hi = ((m1 - 1 + p.n_pre_remove) * down) / up;
-  const int win = (int)(q_hi - q_lo + 1);
-  const S* x = p.in + p.in_off[item];
-  S* y = p.out + p.out_off[item];
+  if (first >= total) return;
 
   SSR_REGS(Regs, regs, blk);
   SSR_PHASE(blk, regs, {
     if (p.taps_in_lds)
       for (int i = tid; i < hpp * up; i += NT) hl[i] = (i < p.n_taps) ? p.taps[i] : (S)0;
-    for (int i = tid; i < win; i += NT) {
-      const int64_t j = q_lo + i;
+    const int item = first / blocks_per_item;
+    const SsrResampleBlock b = ssr_resample_block(p, item, first % blocks_per_item);
+    const S* x = p.in + p.in_off[item];
+    const int n_in = p.in_len[item];
+    for (int i = tid; i < b.win; i += NT) {
+      const int64_t j = b.q_lo + i;
       xw[i] = (j >= 0 && j < n_in) ? x[j] : (S)0;
     }
   });
-  SSR_PHASE(blk, regs, {
-    for (int it = tid; it < up * G; it += NT) {
-      const int r = it % up, g = it / up;
-      const int64_t mf = m0 + r + (int64_t)g * J * up;          // first output of this item
-      if (mf < m1) {
-        const int64_t t0 = (mf + p.n_pre_remove) * down;
-        const int64_t q0 = t0 / up;
-        const int ph = (int)(t0 - q0 * up);
-        const int base = (int)(q0 - q_lo);
-        S acc[J];
-        int xb[J];   // window slot of the OLDEST input sample of output j (outputs past m1 alias output 0, never stored)
-        SSR_UNROLL for (int j = 0; j < J; ++j) {
-          acc[j] = (S)0;
-          xb[j] = (mf + (int64_t)j * up < m1) ? base + j * down - (hpp - 1) : base - (hpp - 1);
-        }
-        // k ascending = input index ascending (tap index descending): SciPy's accumulation order.
-        // Partial unroll keeps several taps' worth of LDS reads in flight per wait.
-        int hi = ph + (hpp - 1) * up;
-        SSR_UNROLL4 for (int k = 0; k < hpp; ++k) {
-          const S hv = (hi < h_len) ? h[hi] : (S)0;
-          hi -= up;
-          SSR_UNROLL for (int j = 0; j < J; ++j) acc[j] = ssr_fadd_rn(acc[j], ssr_fmul_rn(xw[xb[j] + k], hv));
-        }
-        SSR_UNROLL for (int j = 0; j < J; ++j) {
-          const int64_t m = mf + (int64_t)j * up;
-          if (m < m1) y[m] = acc[j];
-        }
+  for (int idx = first; idx < total; idx += stride) {
+    const int item = idx / blocks_per_item;
+    const SsrResampleBlock b = ssr_resample_block(p, item, idx % blocks_per_item);
+    const int nidx = idx + stride;
+    const bool more = nidx < total;
+    const int nitem = more ? nidx / blocks_per_item : item;
+    SsrResampleBlock nb = b;
+    if (more) nb = ssr_resample_block(p, nitem, nidx % blocks_per_item);
+    else nb.win = 0;
+    SSR_PHASE(blk, regs, {
+      const int n_in_n = p.in_len[nitem];
+      const SsrView<S> vn(p.in + p.in_off[nitem], n_in_n);       // (scalar base + 32-bit lane offset per load)
+      SSR_UNROLL for (int u = 0; u < PF; ++u) {                 // next window -> registers (in flight across the arithmetic)
+        const int i = tid + u * NT;
+        const int64_t j = nb.q_lo + i;
+        const bool ok = i < nb.win && j >= 0 && j < n_in_n;
+        R.nx[u] = ok ? vn.at((unsigned)(ok ? j : 0)) : (S)0;
       }
-    }
-  });
+      if (b.live) ssr_resample_compute<S>(p, tid, item, b, xw, h, h_len);
+    });
+    SSR_PHASE(blk, regs, {
+      SSR_UNROLL for (int u = 0; u < PF; ++u) {
+        const int i = tid + u * NT;
+        if (i < nb.win) xw[i] = R.nx[u];
+      }
+    });
+  }
 }
-
 
 // Fallback for rate pairs whose reduced `up` is so large that even the smallest block of the kernel above (up * J
 // outputs, all phases once) needs an input window beyond the LDS - e.g. the reference's subsampling of a 16 kHz input at

@@ -19,10 +19,10 @@ __global__ __launch_bounds__(64) void k_xcorr_pick(const double* best_val, const
 }
 
 template <typename S>
-__global__ __launch_bounds__(SSR_RESAMPLE_NT) void k_resample(SsrResampleParamsT<S> p, int blocks_per_item) {
+__global__ __launch_bounds__(SSR_RESAMPLE_NT) void k_resample(SsrResampleParamsT<S> p, int blocks_per_item, int total) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SsrBlk blk{(int)threadIdx.x};
-  ssr_resample_body<S>(p, blk, blockIdx.x % blocks_per_item, blockIdx.x / blocks_per_item, smem);
+  ssr_resample_persistent_body<S>(p, blk, (int)blockIdx.x, (int)gridDim.x, total, blocks_per_item, smem);
 }
 
 template <typename S>
@@ -80,13 +80,26 @@ static int resample_poly_t(const S* in, const int64_t* in_off, const int32_t* in
     HIP_TRY(hipGetLastError());
     return SSR_OK;
   }
+  if ((size_t)ssr_resample_win(p) > (size_t)SSR_RESAMPLE_MAXPF * SSR_RESAMPLE_NT)
+    return ssr_fail(SSR_ERR_UNSUPPORTED, "input window exceeds the prefetch registers");     // (geometry keeps it below)
   static thread_local int slot = 0;
   static thread_local size_t slot_lds = 0;          // the LDS size depends on the rate pair: remember the largest one
   if (lds > slot_lds) slot = 0;
   if (int rc = ssr_allow_lds((const void*)k_resample<S>, lds, &slot)) return rc;
   if (lds > slot_lds) slot_lds = lds;
   const int bpi = ssr_ceil_div(max_out_len, ssr_resample_opb(p));
-  hipLaunchKernelGGL((k_resample<S>), dim3((unsigned)((int64_t)n_items * bpi)), dim3(SSR_RESAMPLE_NT), lds, (hipStream_t)stream, p, bpi);
+  const int64_t total = (int64_t)n_items * bpi;
+  if (total > 0x7fffffff) return ssr_fail(SSR_ERR_UNSUPPORTED, "batch too large for one launch");
+  // persistent workgroups: as many as fit on the device at this LDS size (the tap table is staged once per workgroup)
+  int dev = 0, n_cu = 256;
+  HIP_TRY(hipGetDevice(&dev));
+  HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  int per_cu = (int)((160 * 1024) / (lds + 512));
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  int64_t wgs = (int64_t)n_cu * per_cu;
+  if (wgs > total) wgs = total;
+  hipLaunchKernelGGL((k_resample<S>), dim3((unsigned)wgs), dim3(SSR_RESAMPLE_NT), lds, (hipStream_t)stream, p, bpi, (int)total);
   HIP_TRY(hipGetLastError());
   return SSR_OK;
 }

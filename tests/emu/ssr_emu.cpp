@@ -310,11 +310,11 @@ static int emu_resample_t(const S* in, const int64_t* in_off, const int32_t* in_
   }
   SsrBlk blk{SSR_RESAMPLE_NT};
   const int n_blocks = (max_out_len + ssr_resample_opb(p) - 1) / ssr_resample_opb(p);
-  for (int item = 0; item < n_items; ++item)
-    for (int b = 0; b < n_blocks; ++b) {
-      auto lds = poisoned(ssr_resample_lds_bytes(p));
-      ssr_resample_body<S>(p, blk, b, item, lds.data());
-    }
+  const int total = n_items * n_blocks, n_wg = 3;                     // three "persistent workgroups" share the work
+  for (int w = 0; w < n_wg; ++w) {
+    auto lds = poisoned(ssr_resample_lds_bytes(p));
+    ssr_resample_persistent_body<S>(p, blk, w, n_wg, total, n_blocks, lds.data());
+  }
   return 0;
 }
 extern "C" int emu_resample(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,

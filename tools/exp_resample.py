@@ -1,0 +1,15 @@
+"""Developer experiment: time the two polyphase stages of BASELINE cfg-5 (16 k -> 44.1 k -> 48 k)."""
+import os, sys, json
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from ssr_eval_amd import backend as B
+
+n = int(os.environ.get("UTT", "4096"))
+dev = torch.device("cuda", 0)
+x = (0.1 * torch.randn((n, 64000), device=dev)).contiguous()
+s1 = B.ResampleBatch(B.Ragged.from_uniform(x), 44100, 16000)
+s2 = B.ResampleBatch(s1.out_ragged(), 48000, 44100)
+it = int(os.environ.get("ITERS", "5"))
+print(json.dumps({"utt": n, "ms_441_160": round(bench.event_time_ms(s1.run, it), 4), "ms_160_147": round(bench.event_time_ms(s2.run, it), 4)}))

@@ -300,12 +300,16 @@ struct SsrFinalizeParams {
   double* out;                             // [n_items, 4]
 };
 
-SSR_DEV double ssr_sispec_from_sums(double see, double stt, double set) {
-  // ssr_eval/metrics.py:114-121 with energy_unify (utils.py:79-82): scaled = (Set * t) / (Stt + EPS)
+SSR_DEV double ssr_sispec_from_sums(double sdd, double stt, double sdt) {
+  // ssr_eval/metrics.py:114-121 with energy_unify (utils.py:79-82): scaled = (Set * t) / (Stt + EPS), from the sums on
+  // the difference d = e - t:  Set = Stt + Sdt,  1 - alpha = (EPS - Sdt) / (Stt + EPS) (no cancellation),
+  // noise = e - alpha t = d + (1 - alpha) t  ->  ||noise||^2 = Sdd + 2 (1 - alpha) Sdt + (1 - alpha)^2 Stt.
   const double EPS = 1e-12;
-  const double alpha = set / (stt + EPS);
+  const double den = stt + EPS;
+  const double alpha = (stt + sdt) / den;
+  const double beta = (EPS - sdt) / den;                 // 1 - alpha
   const double tt = alpha * alpha * stt;
-  double nn = see - 2.0 * alpha * set + alpha * alpha * stt;
+  double nn = sdd + 2.0 * beta * sdt + beta * beta * stt;
   if (nn < 0.0) nn = 0.0;
   return 10.0 * log10(tt / (nn + EPS) + EPS);
 }

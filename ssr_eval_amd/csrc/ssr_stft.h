@@ -37,9 +37,12 @@ enum { SSR_M_LSD = 1, SSR_M_LOG_SISPEC = 2, SSR_M_SISPEC = 4, SSR_M_SSIM = 8 };
 
 #define SSR_NPART 8  // doubles per (item, chunk) partial record
 // partial record layout: [0] sum over frames of sqrt(mean_f d^2)   (LSD numerator)
-//                        [1] See [2] Stt [3] Set            (raw magnitudes)
-//                        [4] Slele [5] Sltlt [6] Slelt      (log10(mag + 1e-12))
+//                        [1] Sdd [2] Stt [3] Sdt            (raw magnitudes; d = est - target, elementwise, exact in float64)
+//                        [4] Sdd [5] Stt [6] Sdt            (the same on log10(mag + 1e-12))
 //                        [7] unused
+// The SISpec sums are kept on the DIFFERENCE d = e - t rather than on e: the noise energy ||e - alpha t||^2 then comes out
+// as Sdd + 2 (1 - alpha) Sdt + (1 - alpha)^2 Stt (ssr_sispec_from_sums), which stays accurate when est is within 1e-6 of
+// target - from (See, Stt, Set) the same quantity is a difference of nearly equal sums, good to ~1e-16 See at best.
 
 template <typename T> struct SsrStftParams {
   const float* a;            // signal buffer A (est, or the only signal in SINGLE mode)
@@ -173,16 +176,18 @@ SSR_DEV void ssr_accumulate_metrics(float e, float t, int mask, double* acc) {
     acc[0] += (double)(d * d);
   }
   if (mask & SSR_M_SISPEC) {
-    acc[1] += (double)e * (double)e;
-    acc[2] += (double)t * (double)t;
-    acc[3] += (double)e * (double)t;
+    const double td = (double)t, d = (double)e - td;
+    acc[1] += d * d;
+    acc[2] += td * td;
+    acc[3] += d * td;
   }
   if (mask & SSR_M_LOG_SISPEC) {
     const float le = FASTM ? ssr_log10f_fast(e + EPSF) : log10f(e + EPSF);
     const float lt = FASTM ? ssr_log10f_fast(t + EPSF) : log10f(t + EPSF);
-    acc[4] += (double)le * (double)le;
-    acc[5] += (double)lt * (double)lt;
-    acc[6] += (double)le * (double)lt;
+    const double td = (double)lt, d = (double)le - td;
+    acc[4] += d * d;
+    acc[5] += td * td;
+    acc[6] += d * td;
   }
 }
 
@@ -200,15 +205,16 @@ SSR_DEV void ssr_accumulate_metrics(double e, float t, int mask, double* acc) {
     acc[0] += d * d;
   }
   if (mask & SSR_M_SISPEC) {
-    acc[1] += e * e;
-    acc[2] += (double)t * (double)t;
-    acc[3] += e * (double)t;
+    const double td = (double)t, d = e - td;
+    acc[1] += d * d;
+    acc[2] += td * td;
+    acc[3] += d * td;
   }
   if (mask & SSR_M_LOG_SISPEC) {
-    const double le = log10(e + EPS), lt = (double)log10f(t + EPSF);
-    acc[4] += le * le;
+    const double le = log10(e + EPS), lt = (double)log10f(t + EPSF), d = le - lt;
+    acc[4] += d * d;
     acc[5] += lt * lt;
-    acc[6] += le * lt;
+    acc[6] += d * lt;
   }
 }
 
@@ -221,15 +227,16 @@ SSR_DEV void ssr_accumulate_metrics(double e, double t, int mask, double* acc) {
     acc[0] += d * d;
   }
   if (mask & SSR_M_SISPEC) {
-    acc[1] += e * e;
+    const double d = e - t;
+    acc[1] += d * d;
     acc[2] += t * t;
-    acc[3] += e * t;
+    acc[3] += d * t;
   }
   if (mask & SSR_M_LOG_SISPEC) {
-    const double le = log10(e + EPS), lt = log10(t + EPS);
-    acc[4] += le * le;
+    const double le = log10(e + EPS), lt = log10(t + EPS), d = le - lt;
+    acc[4] += d * d;
     acc[5] += lt * lt;
-    acc[6] += le * lt;
+    acc[6] += d * lt;
   }
 }
 

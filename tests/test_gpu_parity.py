@@ -717,3 +717,25 @@ def test_partially_silent_signals(n_fft, hop):
     spec = ostft.librosa_stft(t_sil, n_fft, hop).T
     assert np.abs(re[0].cpu().numpy() - spec.real).max() <= 3e-7 * np.abs(spec).max()
     assert np.abs(im[0].cpu().numpy() - spec.imag).max() <= 3e-7 * np.abs(spec).max()
+
+
+def test_sispec_stays_accurate_at_very_high_snr():
+    """An estimate within 1e-6 of its target (identity testee on a negligible degradation): the SISpec sums are
+    kept on the difference e - t, so the noise energy is not a difference of nearly equal sums.  On given spectrograms
+    (identical float32 magnitudes on both sides) against the float64 evaluation of the reference's formula."""
+    from ssr_eval_amd import backend as B
+    from oracle import metrics as om
+    rng = np.random.default_rng(9)
+    t = (np.abs(rng.standard_normal((40, 65))) + 0.1).astype(np.float32)
+    for amp in (1e-2, 1e-4, 1e-6, 1e-7):
+        e = (t * (1 + amp * rng.standard_normal(t.shape))).astype(np.float32)
+        got = B.spectrogram_metrics([e], [t], B.M_SISPEC | B.M_LOG_SISPEC).cpu().numpy()[0]
+        te, tt = torch.tensor(e)[None, None], torch.tensor(t)[None, None]
+        exact = float(om.sispec_exact(te, tt))
+        exact_log = float(om.sispec_exact(om.to_log(te), om.to_log(tt)))
+        assert abs(got[2] - exact) <= 1e-7 * abs(exact), (amp, got[2], exact)
+        # log variant: the GPU library's and torch's float32 log10 differ in the last bit of some elements, and d = le - lt
+        # is only ~1e3 ulp at amp = 1e-4 (below that the log-domain value is round-off defined): 1e-5, amp >= 1e-4 only
+        if amp >= 1e-4:
+            assert abs(got[1] - exact_log) <= 1e-5 * abs(exact_log), (amp, got[1], exact_log)
+    assert exact > 120.0

@@ -43,6 +43,14 @@ CUTOFFS_HZ = [1000, 2000, 4000, 6000, 8000, 12000, 16000]    # sweep labels 2..3
 CUT_BINS = [int(1025 * (c / int(SR / 2))) for c in CUTOFFS_HZ]  # 42 85 170 256 341 512 683
 
 
+def make_inputs(n_pairs, device, seed):
+    """The cfg-2 synthetic pairs: target 0.1 N(0,1), estimate = target + 0.01 N(0,1); [n_pairs, 192000] float32."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    tgt = (0.1 * torch.randn((n_pairs, N_SAMPLES), generator=g, device=device, dtype=torch.float32)).contiguous()
+    est = (tgt + 0.01 * torch.randn((n_pairs, N_SAMPLES), generator=g, device=device, dtype=torch.float32)).contiguous()
+    return est, tgt
+
+
 def event_time_ms(fn, iters):
     """Average duration of fn() in ms, HIP events on the current stream (the one the kernels launch on)."""
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -92,10 +100,8 @@ class Cfg2:
     def __init__(self, a, dev, rank):
         from ssr_eval_amd import backend as B
         self.B, self.a, self.dev = B, a, dev
-        g = torch.Generator(device=dev).manual_seed(20220328 + rank)
         n = a.pairs
-        self.tgt = (0.1 * torch.randn((n, N_SAMPLES), generator=g, device=dev, dtype=torch.float32)).contiguous()
-        self.est = (self.tgt + 0.01 * torch.randn((n, N_SAMPLES), generator=g, device=dev, dtype=torch.float32)).contiguous()
+        self.est, self.tgt = make_inputs(n, dev, 20220328 + rank)
         self.plan = B.get_plan(N_FFT, HOP, a.precision, dev)
         self.batch = B.PairBatch(self.plan, B.Ragged.from_uniform(self.est), B.Ragged.from_uniform(self.tgt))
         self.mask = B.M_LSD | B.M_SSIM

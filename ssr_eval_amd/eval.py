@@ -343,7 +343,8 @@ class SSR_Eval_Helper:
         decoded = decode_batch(files)
         targets = to_rate(decoded, self.evaluationset_sr)           # the reference shells out to `sox -r` here
         inputs = to_rate(decoded, self.model_input_sr)              # librosa.load(file, sr=input_sr), eval.py:242
-        items = list(zip(targets, inputs))
+        # (the reference loads the file twice: target and input never share a buffer, whatever a testee does to its input)
+        items = [(t, x.copy() if x is t else x) for t, x in zip(targets, inputs)]
         res = self.evaluate_arrays(items, files)
         if self.save_processed_result:
             for (i, k), y in self._last_processed.items():

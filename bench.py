@@ -459,10 +459,10 @@ def side_figures(a, dev):
         mask = B.M_LSD | B.M_SSIM
         ms = event_time_ms(lambda: b2.run(mask), 3)
         ms_stft = event_time_ms(lambda: b2.run(mask, stages=1), 3)
-        return {"workload": "AudioMetrics(48000) sizes: n_fft 2229 (radix-3 x Bluestein-743, M = 2048) / hop 480, %d pairs of 4 s @ 48 kHz, "
+        return {"workload": "AudioMetrics(48000) sizes: n_fft 2229 (radix-3 x Bluestein-743, M = 2048, three autonomous waves per frame) / hop 480, %d pairs of 4 s @ 48 kHz, "
                             "LSD + SSIM" % nb,
                 "pairs_per_s": round(nb / (ms * 1e-3), 1),
-                "roofline": hbm_roofline("ssr_stft_pair(k_stft_r3)", (2 * N_SAMPLES * 4 + 32) * nb, ms_stft)}
+                "roofline": hbm_roofline("ssr_stft_pair(k_stft_r3_wave)", (2 * N_SAMPLES * 4 + 32) * nb, ms_stft)}
 
     def other(cfg, steps):
         def run():

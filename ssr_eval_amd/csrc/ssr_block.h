@@ -57,6 +57,8 @@ static inline unsigned ssr_launder_index(unsigned i) { return i; }
     const int any_ = SSR_WAVE_ANY(pred);                    \
     SSR_WAVE_FLAG_STORE(tid, any_, dst);                    \
   } while (0)
+// wave number of a thread as a value the compiler knows to be wave-uniform (scalar register on the device)
+static inline int ssr_wave_of(int tid) { return tid >> 6; }
 static inline float ssr_fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 static inline float ssr_fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 static inline double ssr_fmul_rn(double a, double b) { volatile double r = a * b; return r; }
@@ -117,6 +119,7 @@ template <int W> SSR_DEV double ssr_wave_sum(double v) {
 // wave number as a SCALAR (recomputed where it is used: a per-lane copy would be loop-invariant, get hoisted out of the
 // frame loop and occupy - or spill - a vector register for the whole kernel)
 SSR_DEV int ssr_wave_index(int tid) { return __builtin_amdgcn_readfirstlane(tid) >> 6; }
+SSR_DEV int ssr_wave_of(int tid) { return ssr_wave_index(tid); }
 #define SSR_WAVE_SUM_STORE(tid, NT_, val, dst)                                     \
   do {                                                                             \
     const double s_ = ssr_wave_sum<((NT_) < 64 ? (NT_) : 64)>(val);                \

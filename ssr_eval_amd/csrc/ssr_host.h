@@ -65,6 +65,7 @@ int ssr_units_per_chunk_for(int max_units, int n_items, int target_wgs = 0);
 // Pair transform of this plan on float32 (in64 = false) signals runs the wave-autonomous engine (ssr_stft_wave.h: one
 // wave per workgroup) -> the chunking aims for 4x as many (one-wave) workgroups.
 bool ssr_stft_uses_wave_engine(const ssr_plan* pl, bool in64);
+bool ssr_stft_r3_uses_wave_engine(const ssr_plan* pl);     // n_fft = 3 q over M = 2048, float32 pairs (ssr_stft_r3_wave.h)
 int ssr_pair_units_per_chunk(const ssr_plan* pl, int max_units, int n_items, bool in64);
 
 // ---- launchers defined by the kernel translation units --------------------------------------------------------

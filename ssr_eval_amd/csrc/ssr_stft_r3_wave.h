@@ -1,0 +1,187 @@
+// Kernel body K1-K4 for n_fft = 3 q on the wave engine: the AudioMetrics(48000) size (2229 = 3 * 743, hop 480) - what every
+// user of the reference's default API hits at 48 kHz.
+//
+// Same mathematics as ssr_stft_r3.h: one radix-3 decimation-in-time step over three length-q Bluestein transforms with
+// M = 2048,    X[k + q j] = sum_{r<3} W3^{r j} * ( W_n^{r k} * DFT_q{ x[3 m + r] }[k] ).
+// There a workgroup of four waves walks r = 0, 1, 2 in lock step - six barrier-phased 2048-point transforms per unit on a
+// 35 KB buffer plus 36 KB of parked sub-spectra: two workgroups per CU.  Here a workgroup is THREE AUTONOMOUS WAVES, wave r
+// running the whole chirp-z of sub-sequence r (forward transform -> * filter -> inverse transform, the inverse starting from
+// the registers the forward one ended in, as in ssr_lowpass_wave.h) on its own 17 KB exchange array with no barrier; the
+// three arrays (51 KB) are free once the transforms are done, so the sub-spectra (36 KB) are parked IN them for the
+// epilogue.  Three workgroup barriers per unit (transforms done / parked / epilogue done) instead of ~50, 52 KB per
+// workgroup -> three workgroups = nine waves per CU.
+#pragma once
+#include "ssr_stft_r3.h"
+#include "ssr_stft_wave.h"
+
+template <typename T, bool SUMS> struct SsrR3WaveRegs {
+  cx<T> v[SSR_W_P];
+  T tx[SSR_W_P];
+  float pa[12], pb[12];      // the next unit's decimated samples m = lane + 64 i, i < 12 (q <= 768), requested a unit ahead
+  cx<T> tw1[7];
+  cx<T> tw2[12];
+  double sums[SUMS ? 6 : 1];
+};
+
+template <typename T> struct SsrWaveBuf { T* re; T* im; };
+
+template <typename T> struct SsrR3WaveLds {
+  static constexpr int NW = 3;
+  // scratch (doubles first), then three split-exchange arrays; the parked sub-spectra alias the arrays
+  static constexpr size_t bytes() { return sizeof(double) * (4 + 6 * 4 + 2) + sizeof(int) * 16 + sizeof(T) * NW * SSR_W_PN; }
+  double* sc1; double* wacc; double* res; int* nz; T* x;
+  SSR_MEMBER explicit SsrR3WaveLds(char* base) {
+    sc1 = reinterpret_cast<double*>(base);          // [3] per-wave LSD sums of the current unit (+1 pad)
+    wacc = sc1 + 4;                                 // [6][4] per-wave SISpec sums at the chunk end
+    res = wacc + 6 * 4;                             // [0] running LSD of the chunk
+    nz = reinterpret_cast<int*>(res + 2);           // [2 signals][2 flag sets][3 waves] (+ pad)
+    x = reinterpret_cast<T*>(nz + 16);
+  }
+};
+
+// decimated samples of unit u (frame u of both signals), sub-sequence r: sample 3 m + r of the frame, m = lane + 64 i
+template <typename T, typename REGS>
+SSR_DEV void ssr_r3_wave_prefetch(REGS& R, int lane, int r, const SsrView<float>& va, const SsrView<float>& vb, int u, int hop,
+                                  int n_fft, int q, int n, int n_frames) {
+  const int t_c = (u < n_frames) ? u : n_frames - 1;
+  const int base = t_c * hop - n_fft / 2;
+  const bool interior = base >= 0 && base + n_fft <= n;
+  SSR_UNROLL for (int i = 0; i < 12; ++i) {
+    const int m = lane + 64 * i;
+    const int mc = (m < q) ? m : q - 1;
+    const int s3 = base + 3 * mc + r;
+    const unsigned idx = SSR_UIDX(interior ? s3 : ssr_reflect(s3, n));
+    R.pa[i] = va.at(idx);
+    R.pb[i] = vb.at(idx);
+  }
+}
+
+// grid = n_items * n_chunks workgroups of 192 threads; PAIR mode, float32 signals, M = 2048 (q <= 768).
+template <typename T, bool SUMS, typename BLK>
+SSR_BODY void ssr_stft_r3_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
+  constexpr bool SPLIT = true;
+  constexpr int NT = 192;
+  using Regs = SsrR3WaveRegs<T, SUMS>;
+  SsrR3WaveLds<T> L(lds_base);
+  const int n_fft = p.n_fft, hop = p.hop, F = n_fft / 2 + 1, q = n_fft / 3;
+  T* yre = L.x;                       // parked sub-spectra [3 q] re, [3 q] im: alias the exchange arrays (3 * 2113 >= 6 q)
+  T* yim = L.x + 3 * q;
+  const int n = p.len[item];
+  const int n_frames = ssr_num_frames_dev(n, n_fft, hop);
+  const int u0 = chunk * p.units_per_chunk;
+  const int u1 = (u0 + p.units_per_chunk < n_frames) ? u0 + p.units_per_chunk : n_frames;
+  const int64_t row0 = p.frame_off[item];
+  double* part = p.part ? p.part + ((int64_t)item * p.n_chunks + chunk) * SSR_NPART : nullptr;
+  const int mask = SUMS ? p.metric_mask : (p.metric_mask & SSR_M_LSD);
+  const bool want_lsd = mask & SSR_M_LSD;
+  const SsrView<float> va(p.a + p.a_off[item], n), vb(p.b + p.b_off[item], n);
+  const SsrView<cx<T>> vwc(p.wchirp, n_fft), vbf(p.bfilt, SSR_W_N), vch(p.chirp, n_fft), vt(p.tw, SSR_W_N);
+
+  SSR_REGS(Regs, regs, blk);
+  SSR_PHASE(blk, regs, {
+    for (int i = tid; i < 6 * 4; i += NT) L.wacc[i] = 0.0;
+    if (tid == 0) L.res[0] = 0.0;
+    for (int i = 0; i < (SUMS ? 6 : 1); ++i) R.sums[i] = 0.0;
+    if (u0 < u1) ssr_r3_wave_prefetch<T>(R, tid & 63, ssr_wave_of(tid), va, vb, u0, hop, n_fft, q, n, n_frames);
+  });
+
+  BLK blk0 = blk;
+  for (int u = u0; u < u1; ++u) {
+    blk = blk0; ssr_launder(blk);
+#define SSR_R3_L (SsrWaveBuf<T>{L.x + ssr_wave_of(tid) * SSR_W_PN, L.x + ssr_wave_of(tid) * SSR_W_PN})
+    // ---- wave r: decimated frame * (window * chirp) -> registers (only m < q is non-zero: 12 of the 32 points), first pass
+    SSR_WPHASE(blk, regs, {
+      const int lane = tid & 63, r = ssr_wave_of(tid);
+      unsigned ora = 0u, orb = 0u;
+      SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) {
+        if (i < 12) {
+          const int m = lane + 64 * i;
+          const cx<T> wc = vwc.at(SSR_UIDX(m < q ? m : q - 1), (int64_t)r * q);
+          const cx<T> z = cmul(cx<T>{(T)R.pa[i], (T)R.pb[i]}, wc);
+          R.v[i] = (m < q) ? z : cx<T>{(T)0, (T)0};
+          ora |= (m < q) ? ssr_mag_bits(R.pa[i]) : 0u;
+          orb |= (m < q) ? ssr_mag_bits(R.pb[i]) : 0u;
+        } else {
+          R.v[i] = cx<T>{(T)0, (T)0};
+        }
+      }
+      // non-zero flags of the frame: one slot per wave (three decimated thirds make a frame), two sets (written a unit ahead
+      // of the epilogue that reads them would need no double buffering, but the epilogue of unit u runs before these of u + 1)
+      SSR_WAVE_ANY_STORE(lane, ora != 0u, L.nz + ((u - u0) & 1) * 3 + r);
+      SSR_WAVE_ANY_STORE(lane, orb != 0u, L.nz + 8 + ((u - u0) & 1) * 3 + r);
+      ssr_dft32(R.v);
+      if (want_lsd && u > u0 && tid == 0) L.res[0] += sqrt((L.sc1[0] + L.sc1[1] + L.sc1[2]) / (double)F);
+    });
+#define VT vt
+    SSR_W_FFT_TAIL(blk, blk0, regs, SSR_R3_L, );
+    // spectrum * filter; the inverse transform's input register i takes swap(.) of k = lane + 64 i, i = b + 4 qq
+    SSR_WPHASE(blk, regs, {
+      const int lane = tid & 63;
+      cx<T> z[SSR_W_P];
+      SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int qq = 0; qq < 8; ++qq) {
+        const cx<T> y = cmul(R.v[8 * b + qq], vbf.at(SSR_UIDX(lane + 64 * b + 256 * qq)));
+        z[b + 4 * qq] = {y.y, y.x};
+      }
+      SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) R.v[i] = z[i];
+      ssr_dft32(R.v);
+    });
+    SSR_W_FFT_TAIL(blk, blk0, regs, SSR_R3_L, );
+#undef VT
+    // registers hold swap(IFFT * M): true real part = .y, imaginary = .x, at k = lane + 64 (b + 4 qq); k < q is wanted:
+    // post-multiply (chirp * W_n^{r k} / 2) in place
+    SSR_WPHASE(blk, regs, {
+      const int lane = tid & 63, r = ssr_wave_of(tid);
+      SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int qq = 0; qq < 3; ++qq) {
+        const int k = lane + 64 * (b + 4 * qq);
+        const cx<T> c = vch.at(SSR_UIDX(k < q ? k : q - 1), (int64_t)r * q);
+        R.v[8 * b + qq] = cmul(cx<T>{R.v[8 * b + qq].y, R.v[8 * b + qq].x}, c);
+      }
+    });
+    // ---- all three waves are done with their exchange arrays: park the sub-spectra in them
+    SSR_PHASE(blk, regs, {});
+    SSR_PHASE(blk, regs, {
+      const int lane = tid & 63, r = ssr_wave_of(tid);
+      SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int qq = 0; qq < 3; ++qq) {
+        const int k = lane + 64 * (b + 4 * qq);
+        if (k < q) { yre[r * q + k] = R.v[8 * b + qq].x; yim[r * q + k] = R.v[8 * b + qq].y; }
+      }
+    });
+    // ---- epilogue: X[K] and X[n - K] from the parked thirds, separate, emit, accumulate
+    blk = blk0; ssr_launder(blk);
+    float* ra0 = p.out_a ? p.out_a + (row0 + u) * F : nullptr;
+    float* rb0 = p.out_b ? p.out_b + (row0 + u) * F : nullptr;
+    SSR_PHASE(blk, regs, {
+      ssr_r3_wave_prefetch<T>(R, tid & 63, ssr_wave_of(tid), va, vb, u + 1, hop, n_fft, q, n, n_frames);   // (unconditional)
+      SSR_SCHED_BARRIER();
+      double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      const int par = ((u - u0) & 1) * 3;
+      bool a_nz = false, b_nz = false;
+      for (int w = 0; w < 3; ++w) { a_nz = a_nz || L.nz[par + w] != 0; b_nz = b_nz || L.nz[8 + par + w] != 0; }
+      const bool store = p.out_kind == SSR_OUT_MAG;
+      for (int K = tid; K < F; K += NT) {
+        const int Kn = (K == 0) ? 0 : n_fft - K;
+        const cx<T> zk = ssr_r3_combine<T>(yre, yim, q, K);
+        const cx<T> zn = ssr_r3_combine<T>(yre, yim, q, Kn);
+        float e, t;
+        ssr_pair_bin<T, 0, true>(mask, acc, zk, zn, a_nz, b_nz, e, t);
+        if (store) { ra0[K] = e; rb0[K] = t; }
+      }
+      if (want_lsd) SSR_WAVE_SUM_STORE(tid, NT, acc[0], L.sc1);
+      if constexpr (SUMS)
+        for (int i = 0; i < 6; ++i) R.sums[i] += acc[1 + i];
+    });
+  }
+#undef SSR_R3_L
+
+  if (part == nullptr) return;
+  if constexpr (SUMS) {
+    SSR_PHASE(blk, regs, for (int i = 0; i < 6; ++i) SSR_WAVE_SUM_ADD(tid, NT, R.sums[i], L.wacc + i * 4));
+  }
+  SSR_PHASE(blk, regs, if (tid == 0) {
+    double lsd = L.res[0];
+    if (want_lsd && u1 > u0) lsd += sqrt((L.sc1[0] + L.sc1[1] + L.sc1[2]) / (double)F);
+    part[0] = lsd;
+    for (int i = 0; i < 6; ++i) part[1 + i] = L.wacc[i * 4] + L.wacc[i * 4 + 1] + L.wacc[i * 4 + 2];
+    part[7] = 0.0;
+  });
+}

@@ -145,28 +145,30 @@ SSR_DEV constexpr int ssr_w_off_st1(int i) { return 528 * (i >> 3) + 33 * (i & 7
 // values just written are free at that point, and the loads' latency overlaps the exchange.
 #define SSR_W_EXCHANGE(blk, regs, L, WB, WO, RB, RO, EXTRA)                                               \
   if constexpr (!SPLIT) {                                                                                 \
-    SSR_WPHASE(blk, regs, { const int w_ = ssr_wave_bases(tid).WB;                                        \
+    SSR_WPHASE(blk, regs, { const int w_ = ssr_wave_bases(tid & 63).WB;                                        \
       SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) { (L).re[w_ + WO(i)] = R.v[i].x; (L).im[w_ + WO(i)] = R.v[i].y; } }); \
-    SSR_WPHASE(blk, regs, { SSR_SCHED_BARRIER(); EXTRA; const int r_ = ssr_wave_bases(tid).RB;           \
+    SSR_WPHASE(blk, regs, { SSR_SCHED_BARRIER(); EXTRA; const int r_ = ssr_wave_bases(tid & 63).RB;           \
       SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) R.v[i] = {(L).re[r_ + RO(i)], (L).im[r_ + RO(i)]}; });   \
   } else {                                                                                                \
-    SSR_WPHASE(blk, regs, { const int w_ = ssr_wave_bases(tid).WB;                                        \
+    SSR_WPHASE(blk, regs, { const int w_ = ssr_wave_bases(tid & 63).WB;                                        \
       SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) (L).re[w_ + WO(i)] = R.v[i].x; });                     \
-    SSR_WPHASE(blk, regs, { SSR_SCHED_BARRIER(); EXTRA; const int r_ = ssr_wave_bases(tid).RB;           \
+    SSR_WPHASE(blk, regs, { SSR_SCHED_BARRIER(); EXTRA; const int r_ = ssr_wave_bases(tid & 63).RB;           \
       SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) R.tx[i] = (L).re[r_ + RO(i)]; });                      \
-    SSR_WPHASE(blk, regs, { const int w_ = ssr_wave_bases(tid).WB;                                        \
+    SSR_WPHASE(blk, regs, { const int w_ = ssr_wave_bases(tid & 63).WB;                                        \
       SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) (L).re[w_ + WO(i)] = R.v[i].y; });                     \
-    SSR_WPHASE(blk, regs, { const int r_ = ssr_wave_bases(tid).RB;                                        \
+    SSR_WPHASE(blk, regs, { const int r_ = ssr_wave_bases(tid & 63).RB;                                        \
       SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) R.v[i] = {R.tx[i], (L).re[r_ + RO(i)]}; });            \
   }
 
 // The rest of the transform after the in-register radix-32 pass (ssr_dft32 applied to R.v): exchange, radix-8 pass with the
 // lane's seven twiddles, exchange, radix-8 pass with table twiddles.  On exit register 8 b + q holds Z[tid + 64 b + 256 q].
 // BLK0: the untouched block descriptor (a fresh opaque lane index per stage: addresses are formed where they are used).
+// The lane index is `tid & 63` throughout: a workgroup of several autonomous waves (ssr_stft_r3_wave.h) passes an L whose
+// arrays are the calling wave's own.
 // EXTRA2: further table loads to issue with the last pass's twiddles (the low-pass kernel's synthesis window).
 #define SSR_W_LOAD_TW1 { const unsigned k8 = SSR_UIDX(8 * (tid & 31)); \
                          SSR_UNROLL for (int q = 1; q < 8; ++q) R.tw1[q - 1] = VT.at(k8 * q); }
-#define SSR_W_LOAD_TW2 SSR_UNROLL for (int b = 0; b < 4; ++b) { const unsigned j = SSR_UIDX(tid + 64 * b); \
+#define SSR_W_LOAD_TW2 SSR_UNROLL for (int b = 0; b < 4; ++b) { const unsigned j = SSR_UIDX((tid & 63) + 64 * b); \
                          R.tw2[3 * b] = VT.at(j); R.tw2[3 * b + 1] = VT.at(2 * j); R.tw2[3 * b + 2] = VT.at(4 * j); }
 #define SSR_W_FFT_TAIL(blk, BLK0, regs, L, EXTRA2)                                                                        \
   blk = BLK0; ssr_launder(blk);                                                                                     \

@@ -39,6 +39,14 @@ bool ssr_stft_uses_wave_engine(const ssr_plan* pl, bool in64) {
   return !in64 && !pl->eng.bluestein && pl->eng.radix == 1 && pl->eng.logn == 11;
 }
 
+bool ssr_stft_r3_uses_wave_engine(const ssr_plan* pl) {
+#ifdef SSR_DEV_KNOBS
+  static const int off = getenv("SSR_NO_WAVE") ? atoi(getenv("SSR_NO_WAVE")) : 0;
+  if (off) return false;
+#endif
+  return pl->eng.radix == 3 && pl->eng.logn == 11 && pl->eng.q <= 768;
+}
+
 int ssr_pair_units_per_chunk(const ssr_plan* pl, int max_units, int n_items, bool in64) {
   return ssr_units_per_chunk_for(max_units, n_items, ssr_stft_uses_wave_engine(pl, in64) ? 4 * ssr_target_wgs() : 0);
 }

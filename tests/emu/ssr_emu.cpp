@@ -16,6 +16,7 @@
 #include "../../ssr_eval_amd/csrc/ssr_stft_r3.h"
 #include "../../ssr_eval_amd/csrc/ssr_stft_wave.h"
 #include "../../ssr_eval_amd/csrc/ssr_lowpass_wave.h"
+#include "../../ssr_eval_amd/csrc/ssr_stft_r3_wave.h"
 #include "../../ssr_eval_amd/csrc/ssr_tables.h"
 
 static std::vector<char> poisoned(size_t bytes) { return std::vector<char>(bytes + 64, (char)0xFF); }
@@ -148,6 +149,42 @@ extern "C" int emu_stft_wave(int precision, int hop, int out_kind, int mask, int
                                    n_chunks, out_a, out_b, part);
   return emu_stft_wave_t<float>(hop, out_kind, mask, split, a, b, a_off, b_off, len, frame_off, n_items, units_per_chunk,
                                 n_chunks, out_a, out_b, part);
+}
+
+// radix-3 x Bluestein pair engine on three autonomous waves (ssr_stft_r3_wave.h): n_fft = 3 q, M = 2048
+template <typename T>
+static int emu_stft_r3_wave_t(int n_fft, int hop, int out_kind, int mask, const float* a, const float* b, const int64_t* a_off,
+                              const int64_t* b_off, const int32_t* len, const int64_t* frame_off, int n_items,
+                              int units_per_chunk, int n_chunks, float* out_a, float* out_b, double* part) {
+  SsrTables<T> t;
+  if (!ssr_build_tables<T>(n_fft, t)) return -3;
+  if (t.eng.radix != 3 || t.eng.logn != 11) return -4;
+  SsrStftParams<T> p{};
+  p.a = a; p.b = b; p.a_off = a_off; p.b_off = b_off; p.len = len; p.frame_off = frame_off;
+  p.mode = SSR_MODE_PAIR; p.out_kind = out_kind; p.metric_mask = mask;
+  p.n_fft = n_fft; p.hop = hop; p.n_bins = n_fft / 2 + 1;
+  p.units_per_chunk = units_per_chunk; p.n_chunks = n_chunks;
+  p.window = t.window_h.data(); p.tw = t.tw.data();
+  p.wchirp = t.wchirp.data(); p.bfilt = t.bfilt.data(); p.chirp = t.chirp.data();
+  p.out_a = out_a; p.out_b = out_b; p.part = part;
+  SsrBlk blk{192};
+  const bool sums = mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC);
+  for (int item = 0; item < n_items; ++item)
+    for (int c = 0; c < n_chunks; ++c) {
+      auto lds = poisoned(SsrR3WaveLds<T>::bytes());
+      if (sums) ssr_stft_r3_wave_body<T, true>(p, blk, c, item, lds.data());
+      else ssr_stft_r3_wave_body<T, false>(p, blk, c, item, lds.data());
+    }
+  return 0;
+}
+extern "C" int emu_stft_r3_wave(int precision, int n_fft, int hop, int out_kind, int mask, const float* a, const float* b,
+                                const int64_t* a_off, const int64_t* b_off, const int32_t* len, const int64_t* frame_off,
+                                int n_items, int units_per_chunk, int n_chunks, float* out_a, float* out_b, double* part) {
+  if (precision == 1)
+    return emu_stft_r3_wave_t<double>(n_fft, hop, out_kind, mask, a, b, a_off, b_off, len, frame_off, n_items, units_per_chunk,
+                                      n_chunks, out_a, out_b, part);
+  return emu_stft_r3_wave_t<float>(n_fft, hop, out_kind, mask, a, b, a_off, b_off, len, frame_off, n_items, units_per_chunk,
+                                   n_chunks, out_a, out_b, part);
 }
 
 // pair mode with a float64 estimate and a float32 (b) or float64 (b64) target (IN64 kernel variants)

@@ -321,3 +321,28 @@ def test_sispec_stays_accurate_at_very_high_snr():
         if amp >= 1e-4:
             assert abs(out[1] - exact_log) <= 1e-5 * abs(exact_log), (amp, out[1], exact_log)
     assert exact > 120.0
+
+
+@pytest.mark.parametrize("n_fft,hop", [(2229, 480), (2100, 500)])
+def test_radix3_wave_engine_matches_oracle_and_block_engine(n_fft, hop):
+    """ssr_stft_r3_wave.h (n_fft = 3 q over M = 2048 - AudioMetrics(48000)'s 2229 - on three autonomous waves per workgroup,
+    sub-spectra parked in the exchange arrays) against the oracle and the four-waves-per-frame radix-3 engine."""
+    rng = np.random.default_rng(n_fft)
+    lens = [9000, n_fft * 3 + 77, 4000, 6000]
+    tg = [(0.1 * rng.standard_normal(n)).astype(np.float32) for n in lens]
+    es = [(t + 0.02 * rng.standard_normal(len(t))).astype(np.float32) for t in tg]
+    es[3][1000:5500] = 0.0
+    mags_e, mags_t, _ = E.stft(es, tg, n_fft, hop, 1, 0, 1, 15, 3, wave="r3")
+    for x, m in zip(es + tg, mags_e + mags_t):
+        ref = ostft.stft_mag_TF(x, n_fft, hop)
+        assert np.abs(m - ref).max() <= 2e-7 * ref.max()
+        assert ((m == 0) == (ref == 0)).all()
+    assert (mags_e[3] == 0).all(axis=1).any()
+    got = E.pair_metrics(es, tg, n_fft, hop, 1, wave="r3", units_per_chunk=3)
+    blk = E.pair_metrics(es, tg, n_fft, hop, 1, units_per_chunk=3)
+    for e, t, g, b in zip(es, tg, got, blk):
+        w = om.evaluation(e, t, n_fft=n_fft, hop=hop)
+        np.testing.assert_allclose(g, [w[k] for k in ("lsd", "log_sispec", "sispec", "ssim")], rtol=1e-5)
+        np.testing.assert_allclose(g, b, rtol=1e-7)
+    lsd_only = E.pair_metrics(es, tg, n_fft, hop, 1, mask=E.M_LSD | E.M_SSIM, wave="r3", units_per_chunk=5)
+    np.testing.assert_allclose(lsd_only[:, [0, 3]], got[:, [0, 3]], rtol=1e-12)

@@ -37,3 +37,19 @@ def test_more_gpus_than_devices_fails_loudly():
 def test_world_size_mismatch_fails_loudly():
     r = _bench("--gpus", "2", "--_cpu-skeleton", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE is 1" in (r.stderr + r.stdout)
+
+
+def test_torchrun_launch_two_ranks_gloo():
+    """The driver's own launch line for N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N."""
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    port = 29600 + os.getpid() % 300
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--_cpu-skeleton"], capture_output=True, text=True, timeout=300, env=e)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["extra"]["job_means"] == [1.5]

@@ -489,9 +489,10 @@ def side_figures(a, dev):
         root = tempfile.mkdtemp(prefix="ssr_e2e_")
         try:
             n_files = 0
-            for s in range(8):
+            counts = [53, 53, 15, 52, 38, 53, 53, 50]           # cfg-4's per-speaker file counts (424 ... 398), one eighth
+            for s, c in enumerate(counts):
                 os.makedirs(os.path.join(root, "p%03d" % (360 + s)))
-                for i in range(8):
+                for i in range(c):
                     n = int(rng.integers(int(1.5 * 44100), 9 * 44100))
                     write_wav(os.path.join(root, "p%03d" % (360 + s), "u%03d.wav" % i), 0.1 * rng.standard_normal(n), 44100)
                     n_files += 1
@@ -501,8 +502,8 @@ def side_figures(a, dev):
             t0 = time.perf_counter()
             res = h.evaluate(save_json=False)
             dt = time.perf_counter() - t0
-            return {"workload": "SSR_Eval_Helper.evaluate() on %d PCM .wav files (8 speakers, 1.5-9 s @ 44.1 kHz, cfg-4's length "
-                                "distribution), identity testee, setting_fft cutoff 12 kHz, evaluation_sr 48000: host decode + H2D + "
+            return {"workload": "SSR_Eval_Helper.evaluate() on %d PCM .wav files (8 speakers with cfg-4's file-count proportions, "
+                                "1.5-9 s @ 44.1 kHz), identity testee, setting_fft cutoff 12 kHz, evaluation_sr 48000: host decode + H2D + "
                                 "resample + low-pass + 4 metrics + aggregation" % n_files,
                     "files_per_s": round(n_files / dt, 1), "seconds": round(dt, 3),
                     "averaged_lsd": float(res["averaged"]["proc_fft_24000_44100"]["lsd"])}

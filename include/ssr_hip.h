@@ -86,6 +86,11 @@ int ssr_magphase(const float* re, const float* im, int64_t n, float eps, float* 
  * (metrics.py:89-90).  out: double [n_items][4].  total_rows = sum_i T_i, frame_off = exclusive prefix
  * sum of T_i.  workspace: at least ssr_pair_metrics_workspace_bytes(...) bytes of device memory. */
 size_t ssr_pair_metrics_workspace_bytes(const ssr_plan* plan, int n_items, int max_len, int64_t total_rows);
+/* The same for a given metric_mask: without SSIM the two [total_rows, n_bins] magnitude images are never materialised and the
+ * workspace shrinks from 8 bytes per bin of the batch to the partial records (a few hundred bytes per item).  A workspace
+ * sized for a mask serves every call whose mask is a subset of it. */
+size_t ssr_pair_metrics_workspace_bytes_for(const ssr_plan* plan, int n_items, int max_len, int64_t total_rows,
+                                            unsigned metric_mask);
 int ssr_pair_metrics(const ssr_plan* plan, const float* est, const int64_t* est_off, const float* tgt,
                      const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off, int n_items, int max_len,
                      int64_t total_rows, unsigned metric_mask, double* out, void* workspace, size_t workspace_bytes,

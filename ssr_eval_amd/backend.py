@@ -176,15 +176,25 @@ class PairBatch:
             self.est = est
         self.plan, self.est, self.tgt = plan, est, tgt
         self.rows = _Rows(plan, est.lens_host, est.device)
-        lib = plan.lib
-        self.ws_bytes = int(lib.ssr_pair_metrics_workspace_bytes(plan.handle, est.n, est.max_len, self.rows.total))
-        self.ws = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=est.device)
+        # the workspace is allocated on first use for the mask at hand: without SSIM no magnitude image is materialised
+        # (8 bytes per bin of the batch otherwise), and it only grows when a later call asks for more
+        self.ws_bytes, self.ws, self._ws_mask = 0, None, 0
         self.out = torch.empty((est.n, 4), dtype=torch.float64, device=est.device)
+
+    def _workspace(self, mask):
+        if self.ws is None or (mask & ~self._ws_mask):
+            want = mask | self._ws_mask
+            p, e = self.plan, self.est
+            self.ws_bytes = int(p.lib.ssr_pair_metrics_workspace_bytes_for(p.handle, e.n, e.max_len, self.rows.total, want))
+            self.ws = None                                          # release before the larger allocation
+            self.ws = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=e.device)
+            self._ws_mask = want
 
     def run(self, mask=M_ALL, stages=7):
         p, e, t = self.plan, self.est, self.tgt
         if e.n == 0:
             return self.out
+        self._workspace(mask)
         if (mask & M_SSIM) and (self.rows.T.min() < 7 or p.n_bins < 7):
             raise ValueError("win_size exceeds image extent")  # what skimage raises for images smaller than 7x7
         if e.data.dtype == torch.float64:

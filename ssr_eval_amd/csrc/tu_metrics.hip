@@ -50,15 +50,17 @@ struct PairWs {
   int units_per_chunk, n_chunks;
   SsimGeom sg;
 };
-static PairWs pair_ws(const ssr_plan* pl, int n_items, int max_len, int64_t total_rows, bool in64) {
+// want_mag: the two magnitude images are only materialised when SSIM is asked for (8 bytes per bin of the batch - 38 GB for
+// 12,500 utterances of 4 s - against a few hundred bytes per item for the partial records)
+static PairWs pair_ws(const ssr_plan* pl, int n_items, int max_len, int64_t total_rows, bool in64, bool want_mag) {
   PairWs w;
   const int max_T = (int)ssr_num_frames(pl, max_len);
   w.units_per_chunk = ssr_pair_units_per_chunk(pl, max_T, n_items, in64);     // depends on the engine that will run
   w.n_chunks = ssr_ceil_div(max_T, w.units_per_chunk);
   w.sg = ssim_geom(max_T, pl->n_bins, n_items);
   size_t o = 0;
-  w.off_est = o; o += ssr_align256((size_t)total_rows * pl->n_bins * sizeof(float));
-  w.off_tgt = o; o += ssr_align256((size_t)total_rows * pl->n_bins * sizeof(float));
+  w.off_est = o; o += want_mag ? ssr_align256((size_t)total_rows * pl->n_bins * sizeof(float)) : 0;
+  w.off_tgt = o; o += want_mag ? ssr_align256((size_t)total_rows * pl->n_bins * sizeof(float)) : 0;
   w.off_part = o; o += ssr_align256((size_t)n_items * w.n_chunks * SSR_NPART * sizeof(double));
   w.off_ssim = o; o += ssr_align256((size_t)n_items * w.sg.n_row_tiles * w.sg.n_strips * sizeof(double));
   w.total = o;
@@ -66,11 +68,17 @@ static PairWs pair_ws(const ssr_plan* pl, int n_items, int max_len, int64_t tota
 }
 
 // ----------------------------------------------------------------------------------------------------
-extern "C" size_t ssr_pair_metrics_workspace_bytes(const ssr_plan* pl, int n_items, int max_len, int64_t total_rows) {
+extern "C" size_t ssr_pair_metrics_workspace_bytes_for(const ssr_plan* pl, int n_items, int max_len, int64_t total_rows,
+                                                        unsigned metric_mask) {
   if (!pl || n_items <= 0) return 0;
+  const bool mag = metric_mask & SSR_METRIC_SSIM;
   // the float32 and float64-signal entry points may chunk differently (different engines): cover both
-  const size_t a = pair_ws(pl, n_items, max_len, total_rows, false).total, b = pair_ws(pl, n_items, max_len, total_rows, true).total;
+  const size_t a = pair_ws(pl, n_items, max_len, total_rows, false, mag).total, b = pair_ws(pl, n_items, max_len, total_rows, true, mag).total;
   return (a > b ? a : b) + ssr_align256((size_t)n_items * sizeof(int32_t));
+}
+
+extern "C" size_t ssr_pair_metrics_workspace_bytes(const ssr_plan* pl, int n_items, int max_len, int64_t total_rows) {
+  return ssr_pair_metrics_workspace_bytes_for(pl, n_items, max_len, total_rows, SSR_METRIC_ALL);
 }
 
 template <int CPT> static int launch_ssim_inst(const SsrSsimParams& p, int grid, hipStream_t s) {
@@ -142,7 +150,7 @@ static int pair_metrics_impl(const ssr_plan* pl, const float* est, const double*
   if (want_ssim && (int64_t)max_T * pl->n_bins >= ((int64_t)1 << 30))
     return ssr_fail(SSR_ERR_UNSUPPORTED, "spectrogram of 2^30 elements or more (4 GiB buffer views)");
   if (want_ssim && (max_T < 7 || pl->n_bins < 7)) return ssr_fail(SSR_ERR_INVALID_ARG, "win_size exceeds image extent");
-  const PairWs w = pair_ws(pl, n_items, max_len, total_rows, est64 != nullptr);
+  const PairWs w = pair_ws(pl, n_items, max_len, total_rows, est64 != nullptr, want_ssim);
   // rows array lives at the tail of the ssim partial area's alignment slack: allocate it explicitly
   const size_t rows_bytes = ssr_align256((size_t)n_items * sizeof(int32_t));
   if (!workspace || workspace_bytes < w.total + rows_bytes) return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small");

@@ -198,6 +198,50 @@ template <typename E> struct SsrView {
 #endif
 };
 
+// A read-WRITE device array with predicated, range-checked element access: ld returns 0 and st is dropped when `ok` is
+// false or idx >= n_elems.  Device: raw buffer resource; a false predicate selects an out-of-range offset, so the
+// hardware's bounds check does the masking (no branch, no exec-mask change).  idx may be a NEGATIVE int cast to unsigned
+// (it stays out of range after the scaling by sizeof(E) as long as |idx| * sizeof(E) < 2^31).
+template <typename E> struct SsrRwView {
+#ifdef SSR_HOST_EMU
+  E* base; int64_t n;
+  SSR_MEMBER SsrRwView(E* p, int64_t n_elems) : base(p), n(n_elems) {}
+  SSR_MEMBER E ld(unsigned idx, bool ok) const { return (ok && (int64_t)idx < n) ? base[idx] : (E)0; }
+  SSR_MEMBER void st(unsigned idx, E v, bool ok) const { if (ok && (int64_t)idx < n) base[idx] = v; }
+  // the same by BYTE offset; any negative offset is out of range (callers OR an all-ones mask into it to switch a lane off)
+  SSR_MEMBER E ld_raw(int off) const { return ld((unsigned)off / (unsigned)sizeof(E), off >= 0); }
+  SSR_MEMBER void st_raw(int off, E v) const { st((unsigned)off / (unsigned)sizeof(E), v, off >= 0); }
+  SSR_MEMBER void st_raw_nt(int off, E v) const { st_raw(off, v); }
+#else
+  __amdgpu_buffer_rsrc_t rsrc;
+  SSR_MEMBER SsrRwView(E* p, int64_t n_elems)
+      : rsrc(__builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(unsigned)(n_elems * (int64_t)sizeof(E)), 0x00020000)) {}
+  SSR_MEMBER E ld(unsigned idx, bool ok) const {
+    const int vo = ok ? (int)(idx * (unsigned)sizeof(E)) : -1;
+    if constexpr (sizeof(E) == 4) return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vo, 0, 0));
+    else return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b64(rsrc, vo, 0, 0));
+  }
+  SSR_MEMBER void st(unsigned idx, E v, bool ok) const {
+    const int vo = ok ? (int)(idx * (unsigned)sizeof(E)) : -1;
+    if constexpr (sizeof(E) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, vo, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, v), rsrc, vo, 0, 0);
+  }
+  SSR_MEMBER E ld_raw(int off) const {
+    if constexpr (sizeof(E) == 4) return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+    else return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+  }
+  SSR_MEMBER void st_raw(int off, E v) const {
+    if constexpr (sizeof(E) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, v), rsrc, off, 0, 0);
+  }
+  // streaming store (nt): written once, not read again by this kernel - do not displace what the caches are kept for
+  SSR_MEMBER void st_raw_nt(int off, E v) const {
+    if constexpr (sizeof(E) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, off, 0, 2);
+    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, v), rsrc, off, 0, 2);
+  }
+#endif
+};
+
 // ------------------------------------------------------------------------------------------------
 // complex helpers
 template <typename T> struct cx { T x, y; };

@@ -34,6 +34,7 @@ struct ssr_plan {
   DevTables<float> f32;
   DevTables<double> f64;
   double* window64 = nullptr;  // always present (OLA normalisation)
+  double* wss_tab = nullptr;   // [hop] overlap-added squared window where every overlapping frame exists (hop <= n_fft)
   std::vector<void*> allocs;
 };
 

@@ -25,7 +25,8 @@ template <typename T> struct SsrLowpassParams {
   const cx<T>* tw;
   const float* spec_re;      // ISTFT mode: [rows, F] real parts (null in analysis mode)
   const float* spec_im;
-  float* frames;             // [rows, n_fft] windowed inverse frames
+  float* frames;             // [rows, n_fft] windowed inverse frames; PAIRED (ssr_lowpass_wave.h): per item ceil(T / 2)
+                             // segments of n_fft + hop samples in the same region (frames 2g and 2g+1 already added up)
 };
 
 // grid = (n_chunks, n_items), block = n_fft / 8
@@ -116,14 +117,30 @@ SSR_BODY void ssr_lowpass_frames_body(const SsrLowpassParams<T>& p, BLK& blk, in
 }
 
 struct SsrOlaParams {
-  const float* frames;       // [rows, n_fft]
+  const float* frames;       // [rows, n_fft], or paired segments (see SsrLowpassParams)
   const int64_t* frame_off;  // [n_items]
   const int32_t* len;        // [n_items] output samples
   const int64_t* out_off;    // [n_items]
   int n_fft, hop;
   const double* window;      // [n_fft]
   float* out;
+  const double* wss_tab;     // [hop] overlap-added squared window where every overlapping frame exists (paired kernel)
+  float inv_hop, inv_2hop;   // 1 / hop, 1 / (2 hop) rounded to float32 (quotient estimates, corrected exactly)
 };
+
+// Overlap-added squared window at padded position `pos` (= sample + n_fft/2): the frames t with 0 <= pos - t hop < n_fft
+// that exist, added in ascending t; clamped like torchlibrosa's ISTFT (1e-11).
+SSR_DEV double ssr_ola_wss(const double* window, int N, int hop, int n_frames, int pos) {
+  int t_hi = pos / hop;
+  if (t_hi > n_frames - 1) t_hi = n_frames - 1;
+  const int t_lo = (pos < N) ? 0 : (pos - N) / hop + 1;
+  double wss = 0.0;
+  for (int t = t_lo; t <= t_hi; ++t) {
+    const int m = pos - t * hop;
+    wss += window[m] * window[m];
+  }
+  return wss < 1e-11 ? 1e-11 : wss;
+}
 
 SSR_DEV void ssr_ola_sample(const SsrOlaParams& p, int item, int s) {
   const int n = p.len[item];
@@ -135,12 +152,75 @@ SSR_DEV void ssr_ola_sample(const SsrOlaParams& p, int item, int s) {
   if (t_hi > n_frames - 1) t_hi = n_frames - 1;
   const int t_lo = (pos < N) ? 0 : (pos - N) / hop + 1;
   const float* fr = p.frames + p.frame_off[item] * (int64_t)N;
-  double acc = 0.0, wss = 0.0;
-  for (int t = t_lo; t <= t_hi; ++t) {
-    const int m = pos - t * hop;
-    acc += (double)fr[(int64_t)t * N + m];
-    wss += p.window[m] * p.window[m];
+  double acc = 0.0;
+  for (int t = t_lo; t <= t_hi; ++t) acc += (double)fr[(int64_t)t * N + (pos - t * hop)];
+  p.out[p.out_off[item] + s] = (float)(acc / ssr_ola_wss(p.window, N, hop, n_frames, pos));
+}
+
+// floor(a / d) for 0 <= a < 2^24 from the float32 reciprocal of d (one multiply + an exact correction instead of the
+// ~40-instruction integer division)
+SSR_DEV int ssr_fast_div(int a, int d, float inv_d) {
+  int q = (int)((float)a * inv_d);
+  if ((q + 1) * d <= a) ++q;
+  if (q * d > a) --q;
+  return q;
+}
+
+// PAIRED segments: unit u = frames 2u, 2u+1 starts at padded position 2 u hop and is n_fft + hop long.  Segment rows are
+// ssr_seg_stride floats apart and row u is shifted right by (2 u hop) mod 4 elements, so that the element of padded
+// position pos sits at u stride + pos - ((2 u hop) & ~3): 16-byte aligned whenever pos is a multiple of 4 (the quad loads of
+// ssr_ola_paired_quad; a dwordx4 access that is only 4-byte aligned costs several times an aligned one).
+SSR_HD int ssr_seg_stride(int n_fft, int hop) { return (n_fft + hop + ((hop & 1) ? 2 : 0) + 3) & ~3; }
+
+SSR_DEV void ssr_ola_paired_sample(const SsrOlaParams& p, int item, int s) {
+  const int n = p.len[item];
+  if (s >= n) return;
+  const int N = p.n_fft, hop = p.hop, SEG = N + hop, two = 2 * hop, stride = ssr_seg_stride(N, hop);
+  const int n_frames = ssr_num_frames_dev(n, N, hop);
+  const int n_units = (n_frames + 1) / 2;
+  const int pos = s + N / 2;
+  int u_hi = pos / two;
+  if (u_hi > n_units - 1) u_hi = n_units - 1;
+  const int u_lo = (pos < SEG) ? 0 : (pos - SEG) / two + 1;
+  const float* sg = p.frames + p.frame_off[item] * (int64_t)N;
+  double acc = 0.0;
+  for (int u = u_lo; u <= u_hi; ++u) acc += (double)sg[(int64_t)u * stride + (pos - ((u * two) & ~3))];
+  p.out[p.out_off[item] + s] = (float)(acc / ssr_ola_wss(p.window, N, hop, n_frames, pos));
+}
+
+// Four consecutive samples s0 .. s0+3 (s0 a multiple of 4) per thread.  Where every frame that overlaps them exists (all but
+// the first and last few frames of a signal) the quotients are formed once (float32 reciprocal estimate, corrected
+// exactly), every unit that reaches ANY of the four contributes one aligned 16-byte load - elements outside the unit are
+// replaced by 0.0, which leaves the sample's sum bit-identical - and the window sums come from the table; otherwise sample
+// by sample as above.  No lane of a wave leaves the fast path because a unit or a frame starts inside its quad (with hop
+// 441 that would be most waves).
+SSR_DEV void ssr_ola_paired_quad(const SsrOlaParams& p, int item, int s0) {
+  const int n = p.len[item];
+  if (s0 >= n) return;
+  const int N = p.n_fft, hop = p.hop, SEG = N + hop, two = 2 * hop, stride = ssr_seg_stride(N, hop);
+  const int pos0 = s0 + N / 2, pos3 = pos0 + 3;
+  if (s0 + 3 < n && pos3 < (1 << 24) && hop >= 4) {
+    const int n_frames = ssr_num_frames_dev(n, N, hop);
+    const int n_units = (n_frames + 1) / 2;
+    const int t0 = ssr_fast_div(pos0, hop, p.inv_hop);
+    if (t0 >= (N - 1) / hop && t0 + 1 <= n_frames - 1) {
+      int u_hi = ssr_fast_div(pos3, two, p.inv_2hop);
+      if (u_hi > n_units - 1) u_hi = n_units - 1;
+      const int u_lo = (pos0 < SEG) ? 0 : ssr_fast_div(pos0 - SEG, two, p.inv_2hop) + 1;
+      const float* sg = p.frames + p.frame_off[item] * (int64_t)N;
+      double a[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int u = u_lo; u <= u_hi; ++u) {
+        float v[4];
+        memcpy(v, sg + (int64_t)u * stride + (pos0 - ((u * two) & ~3)), 16);
+        const int j0 = pos0 - u * two;                             // index of the quad's first sample in unit u
+        for (int k = 0; k < 4; ++k) a[k] += ((unsigned)(j0 + k) < (unsigned)SEG) ? (double)v[k] : 0.0;
+      }
+      const int m0 = pos0 - t0 * hop;
+      float o[4];
+      for (int k = 0; k < 4; ++k) o[k] = (float)(a[k] / p.wss_tab[(m0 + k < hop) ? m0 + k : m0 + k - hop]);
+      memcpy(p.out + p.out_off[item] + s0, o, 16);
+      return;
+    }
   }
-  if (wss < 1e-11) wss = 1e-11;
-  p.out[p.out_off[item] + s] = (float)(acc / wss);
+  for (int k = 0; k < 4; ++k) ssr_ola_paired_sample(p, item, s0 + k);
 }

@@ -8,6 +8,12 @@
 // the set the in-register first pass of the NEXT transform wants: the inverse transform starts from the registers the
 // forward one ended in (a compile-time renaming), with no exchange in between.  The inverse is the forward engine on
 // exchanged (im, re) parts.  ISTFT mode builds the Hermitian-extended packed spectrum straight into those registers.
+//
+// PAIRED = true (hop <= n_fft / 2) adds the unit's two frames up before they leave the wave: frame 2g is parked in the
+// exchange array and read back hop samples further on, so the unit writes ONE segment of n_fft + hop samples
+//     seg[j] = frame_2g[j] (j < n_fft)  +  frame_2g+1[j - hop] (j >= hop)
+// instead of two frames of n_fft (61 % of the bytes at hop 441, for k_ola_paired to read back: <= 3 terms per sample
+// instead of <= 5).  The sum is formed in T and rounded to float32 once.  Row layout: ssr_seg_stride (ssr_lowpass.h).
 #pragma once
 #include "ssr_lowpass.h"
 #include "ssr_stft_wave.h"
@@ -21,6 +27,22 @@ template <typename T> struct SsrLowpassWaveRegs {
   cx<T> tw1[7];
   cx<T> tw2[12];
 };
+
+SSR_DEV int ssr_neg_mask(int x) { return x >> 31; }               // all ones iff x < 0
+SSR_DEV double ssr_and_not(double v, int mask) {                  // v with its bits cleared where mask is all ones
+  unsigned long long u;
+  memcpy(&u, &v, 8);
+  u &= ~(((unsigned long long)(unsigned)mask << 32) | (unsigned)mask);
+  memcpy(&v, &u, 8);
+  return v;
+}
+SSR_DEV float ssr_and_not(float v, int mask) {
+  unsigned u;
+  memcpy(&u, &v, 4);
+  u &= ~(unsigned)mask;
+  memcpy(&v, &u, 4);
+  return v;
+}
 
 // samples of frames 2g / 2g+1 (reflect-padded the torch way: callers guarantee len > N/2) into the prefetch registers
 template <typename T, typename REGS>
@@ -42,7 +64,7 @@ SSR_DEV void ssr_lowpass_wave_prefetch(REGS& R, int tid, const SsrView<float>& v
 }
 
 // grid = n_items * n_chunks workgroups of one wave; 2048-point plans only.
-template <typename T, bool SPLIT, bool ANALYSIS, typename BLK>
+template <typename T, bool SPLIT, bool ANALYSIS, bool PAIRED, typename BLK>
 SSR_BODY void ssr_lowpass_wave_body(const SsrLowpassParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
   constexpr int N = SSR_W_N, F = N / 2 + 1;
   using Regs = SsrLowpassWaveRegs<T>;
@@ -120,10 +142,36 @@ SSR_BODY void ssr_lowpass_wave_body(const SsrLowpassParams<T>& p, BLK& blk, int 
     }
 #define SSR_W_LOAD_WIN ; SSR_UNROLL for (int r = 0; r < SSR_W_P / 2; ++r) R.wl[r] = vw.at(SSR_UIDX(tid + 64 * r));
 #define VT vt
-    SSR_W_FFT_TAIL(blk, blk0, regs, L, SSR_W_LOAD_WIN);
+    // (paired: the outputs of the last pass all stay live until frame ta is parked, so the window is requested after it)
+    if constexpr (PAIRED) { SSR_W_FFT_TAIL(blk, blk0, regs, L, ); } else { SSR_W_FFT_TAIL(blk, blk0, regs, L, SSR_W_LOAD_WIN); }
 #undef VT
     // registers: swap(N * IFFT): frame ta = .y, frame tb = .x at sample m = tid + 64 (b + 4 q).  Window, scale, write.
     blk = blk0; ssr_launder(blk);
+    if constexpr (PAIRED) {
+      const int stride = ssr_seg_stride(N, hop), shift = (2 * g * hop) & 3;           // row layout: ssr_lowpass.h
+      const SsrRwView<float> vseg(p.frames + row0 * N + (int64_t)g * stride + shift, N + hop);
+      // window; frame ta to the exchange array (its first hop samples stay in .y), frame tb stays in .x
+      SSR_WPHASE(blk, regs, {
+        SSR_SCHED_BARRIER() SSR_W_LOAD_WIN;
+        SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int q = 0; q < 8; ++q) {
+          const int r = b + 4 * q, i = 8 * b + q;
+          const T w = ((r < SSR_W_P / 2) ? R.wl[r] : (T)1 - R.wl[r - SSR_W_P / 2]) * inv_n;
+          const T av = R.v[i].y * w;
+          R.v[i] = {b_valid ? R.v[i].x * w : (T)0, av};
+          L.re[tid + 64 * r] = av;
+        }
+      });
+      SSR_WPHASE(blk, regs, {
+        // per-lane conditions as all-ones masks (no compare: 64 lane masks in scalar registers do not fit): a lane beyond
+        // the frame contributes +0.0 (its bits ANDed away), a lane beyond the head stores out of range
+        SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int q = 0; q < 8; ++q) {
+          const int r = b + 4 * q, i = 8 * b + q, m = tid + 64 * r;
+          const T tail = ssr_and_not(L.re[(m + hop) & (N - 1)], ssr_neg_mask(N - 1 - (m + hop)));
+          vseg.st_raw((m + hop) * 4, (float)(R.v[i].x + tail));
+          if (r < SSR_W_P / 2) vseg.st_raw((m * 4) | ssr_neg_mask(hop - 1 - m), (float)R.v[i].y);   // hop <= n_fft / 2
+        }
+      });
+    } else {
     float* fa = p.frames + (row0 + ta) * (int64_t)N;
     float* fb = p.frames + (row0 + tb) * (int64_t)N;
     SSR_WPHASE(blk, regs, {
@@ -134,6 +182,7 @@ SSR_BODY void ssr_lowpass_wave_body(const SsrLowpassParams<T>& p, BLK& blk, int 
         if (b_valid) fb[SSR_UIDX(tid + 64 * r)] = (float)(R.v[8 * b + q].x * w);
       }
     });
+    }
     // the analysis window of the next unit (the same values; requested again rather than kept)
     if constexpr (analysis) {
       SSR_WPHASE(blk, regs, SSR_UNROLL for (int r = 0; r < SSR_W_P / 2; ++r) R.wl[r] = vw.at(SSR_UIDX(tid + 64 * r)));

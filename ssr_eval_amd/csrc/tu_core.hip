@@ -125,6 +125,17 @@ extern "C" int ssr_plan_create(int n_fft, int hop, int precision, ssr_plan** out
     SsrTables<double> t;
     ssr_build_tables<double>(n_fft, t);
     rc = upload(pl, t.window, &pl->window64);
+    if (!rc && hop <= n_fft) {
+      // position pos with every overlapping frame present sees window[m + k hop]^2, m = pos mod hop, for every k with
+      // m + k hop < n_fft - added from the largest k down (= ascending frame index, the order of ssr_ola_wss), clamped like it
+      std::vector<double> tab((size_t)hop);
+      for (int m = 0; m < hop; ++m) {
+        double wss = 0.0;
+        for (int mm = m + ((n_fft - 1 - m) / hop) * hop; mm >= m; mm -= hop) wss += t.window[mm] * t.window[mm];
+        tab[m] = wss < 1e-11 ? 1e-11 : wss;
+      }
+      rc = upload(pl, tab, &pl->wss_tab);
+    }
   }
   if (rc) { ssr_plan_destroy(pl); return rc; }
   *out = pl;

@@ -19,6 +19,12 @@ __global__ __launch_bounds__(256) void k_ola(SsrOlaParams p, int blocks_per_item
   ssr_ola_sample(p, item, s);
 }
 
+__global__ __launch_bounds__(256) void k_ola_paired(SsrOlaParams p, int blocks_per_item) {
+  const int item = blockIdx.x / blocks_per_item;
+  const int s0 = ((blockIdx.x % blocks_per_item) * 256 + threadIdx.x) * 4;
+  ssr_ola_paired_quad(p, item, s0);
+}
+
 template <typename T, int LOGN> static int launch_lowpass_inst(SsrLowpassParams<T>& p, int grid, hipStream_t s) {
   const size_t lds = SsrStftLds<T, LOGN>::bytes();
   static thread_local int slot = 0;
@@ -29,12 +35,12 @@ template <typename T, int LOGN> static int launch_lowpass_inst(SsrLowpassParams<
 }
 
 // Wave-autonomous engine for 2048-point plans (ssr_lowpass_wave.h): one wave per workgroup, 17 KB of LDS, 2 waves / SIMD.
-template <typename T, bool ANALYSIS>
+template <typename T, bool ANALYSIS, bool PAIRED>
 __global__ __launch_bounds__(64, 2) void k_lowpass_wave(SsrLowpassParams<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SsrBlk blk{(int)threadIdx.x};
   const int item = blockIdx.x / p.n_chunks, chunk = blockIdx.x % p.n_chunks;
-  ssr_lowpass_wave_body<T, true, ANALYSIS>(p, blk, chunk, item, smem);
+  ssr_lowpass_wave_body<T, true, ANALYSIS, PAIRED>(p, blk, chunk, item, smem);
 }
 
 bool ssr_lowpass_uses_wave_engine(const ssr_plan* pl) {
@@ -45,14 +51,30 @@ bool ssr_lowpass_uses_wave_engine(const ssr_plan* pl) {
   return !pl->eng.bluestein && pl->eng.logn == 11;
 }
 
+// The wave engine hands k_ola one segment per frame PAIR (ssr_lowpass_wave.h) when the segments of every item fit the
+// item's frame rows: ceil(T / 2) (n_fft + hop) <= T n_fft for every T a signal longer than n_fft / 2 can have.
+bool ssr_lowpass_pairs_frames(const ssr_plan* pl) {
+#ifdef SSR_DEV_KNOBS
+  static const int off = getenv("SSR_NO_PAIRED") ? atoi(getenv("SSR_NO_PAIRED")) : 0;
+  if (off) return false;
+#endif
+  if (!ssr_lowpass_uses_wave_engine(pl) || pl->hop > pl->n_fft / 2 || pl->wss_tab == nullptr) return false;
+  int64_t t = 1 + (pl->n_fft / 2 + 1) / pl->hop;          // fewest frames of a signal that passes the reflect-pad check ...
+  if (t % 2 == 0) ++t;                                     // ... the tightest case is the smallest odd count from there
+  return (t + 1) / 2 * ssr_seg_stride(pl->n_fft, pl->hop) <= t * pl->n_fft;
+}
+
 template <typename T> int ssr_launch_lowpass(const ssr_plan* pl, SsrLowpassParams<T>& p, int grid, hipStream_t s) {
   const DevTables<T>& d = ssr_tables_of<T>(pl);
   p.window = d.window; p.tw = d.tw;
   if (pl->eng.bluestein) return ssr_fail(SSR_ERR_UNSUPPORTED, "inverse STFT needs a power-of-two n_fft in [256, 4096]");
   if (ssr_lowpass_uses_wave_engine(pl)) {
     typedef SsrWaveLds<T, true> WaveLds;
-    if (p.spec_re == nullptr) hipLaunchKernelGGL((k_lowpass_wave<T, true>), dim3(grid), dim3(64), WaveLds::bytes(), s, p);
-    else hipLaunchKernelGGL((k_lowpass_wave<T, false>), dim3(grid), dim3(64), WaveLds::bytes(), s, p);
+    const bool analysis = p.spec_re == nullptr, paired = ssr_lowpass_pairs_frames(pl);
+    if (analysis && paired) hipLaunchKernelGGL((k_lowpass_wave<T, true, true>), dim3(grid), dim3(64), WaveLds::bytes(), s, p);
+    else if (analysis) hipLaunchKernelGGL((k_lowpass_wave<T, true, false>), dim3(grid), dim3(64), WaveLds::bytes(), s, p);
+    else if (paired) hipLaunchKernelGGL((k_lowpass_wave<T, false, true>), dim3(grid), dim3(64), WaveLds::bytes(), s, p);
+    else hipLaunchKernelGGL((k_lowpass_wave<T, false, false>), dim3(grid), dim3(64), WaveLds::bytes(), s, p);
     HIP_TRY(hipGetLastError());
     return SSR_OK;
   }
@@ -99,9 +121,11 @@ static int run_inverse(const ssr_plan* pl, const float* in, const int64_t* in_of
     rc = ssr_launch_lowpass<float>(pl, p, n_items * n_chunks, s);
   }
   if (rc) return rc;
-  SsrOlaParams q{(const float*)workspace, frame_off, len, out_off, pl->n_fft, pl->hop, pl->window64, out};
-  const int bpi = ssr_ceil_div(max_len, 256);
-  hipLaunchKernelGGL(k_ola, dim3((unsigned)((int64_t)n_items * bpi)), dim3(256), 0, s, q, bpi);
+  SsrOlaParams q{(const float*)workspace, frame_off, len, out_off, pl->n_fft, pl->hop, pl->window64, out, pl->wss_tab,
+                 1.0f / (float)pl->hop, 1.0f / (float)(2 * pl->hop)};
+  const int bpi = ssr_ceil_div(max_len, 256), bpi4 = ssr_ceil_div(max_len, 1024);
+  if (ssr_lowpass_pairs_frames(pl)) hipLaunchKernelGGL(k_ola_paired, dim3((unsigned)((int64_t)n_items * bpi4)), dim3(256), 0, s, q, bpi4);
+  else hipLaunchKernelGGL(k_ola, dim3((unsigned)((int64_t)n_items * bpi)), dim3(256), 0, s, q, bpi);
   HIP_TRY(hipGetLastError());
   return SSR_OK;
 }

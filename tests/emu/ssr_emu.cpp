@@ -286,11 +286,11 @@ extern "C" int emu_lowpass_frames(int precision, int n_fft, int hop, const float
                                      re_in, im_in, frames);
 }
 
-// wave-autonomous low-pass / ISTFT frames kernel (ssr_lowpass_wave.h; 2048-point plans)
+// wave-autonomous low-pass / ISTFT frames kernel (ssr_lowpass_wave.h; 2048-point plans); paired: one segment per frame pair
 template <typename T>
-static int emu_lowpass_wave_t(int hop, int split, const float* in, const int64_t* in_off, const int32_t* len, const int32_t* cut,
-                              const int64_t* frame_off, int n_items, int pairs_per_chunk, int n_chunks, const float* re_in,
-                              const float* im_in, float* frames) {
+static int emu_lowpass_wave_t(int hop, int split, int paired, const float* in, const int64_t* in_off, const int32_t* len,
+                              const int32_t* cut, const int64_t* frame_off, int n_items, int pairs_per_chunk, int n_chunks,
+                              const float* re_in, const float* im_in, float* frames) {
   SsrTables<T> t;
   if (!ssr_build_tables<T>(2048, t)) return -3;
   SsrLowpassParams<T> p{};
@@ -301,35 +301,48 @@ static int emu_lowpass_wave_t(int hop, int split, const float* in, const int64_t
   SsrBlk blk{64};
   for (int item = 0; item < n_items; ++item)
     for (int c = 0; c < n_chunks; ++c) {
-      if (split) {
+      if (split && paired) {
         auto lds = poisoned(SsrWaveLds<T, true>::bytes());
-        if (re_in) ssr_lowpass_wave_body<T, true, false>(p, blk, c, item, lds.data());
-        else ssr_lowpass_wave_body<T, true, true>(p, blk, c, item, lds.data());
+        if (re_in) ssr_lowpass_wave_body<T, true, false, true>(p, blk, c, item, lds.data());
+        else ssr_lowpass_wave_body<T, true, true, true>(p, blk, c, item, lds.data());
+      } else if (split) {
+        auto lds = poisoned(SsrWaveLds<T, true>::bytes());
+        if (re_in) ssr_lowpass_wave_body<T, true, false, false>(p, blk, c, item, lds.data());
+        else ssr_lowpass_wave_body<T, true, true, false>(p, blk, c, item, lds.data());
       } else {
         auto lds = poisoned(SsrWaveLds<T, false>::bytes());
-        if (re_in) ssr_lowpass_wave_body<T, false, false>(p, blk, c, item, lds.data());
-        else ssr_lowpass_wave_body<T, false, true>(p, blk, c, item, lds.data());
+        if (re_in) ssr_lowpass_wave_body<T, false, false, false>(p, blk, c, item, lds.data());
+        else ssr_lowpass_wave_body<T, false, true, false>(p, blk, c, item, lds.data());
       }
     }
   return 0;
 }
-extern "C" int emu_lowpass_wave(int precision, int hop, int split, const float* in, const int64_t* in_off, const int32_t* len,
-                                const int32_t* cut, const int64_t* frame_off, int n_items, int pairs_per_chunk, int n_chunks,
-                                const float* re_in, const float* im_in, float* frames) {
+extern "C" int emu_lowpass_wave(int precision, int hop, int split, int paired, const float* in, const int64_t* in_off,
+                                const int32_t* len, const int32_t* cut, const int64_t* frame_off, int n_items,
+                                int pairs_per_chunk, int n_chunks, const float* re_in, const float* im_in, float* frames) {
   if (precision == 1)
-    return emu_lowpass_wave_t<double>(hop, split, in, in_off, len, cut, frame_off, n_items, pairs_per_chunk, n_chunks, re_in,
-                                      im_in, frames);
-  return emu_lowpass_wave_t<float>(hop, split, in, in_off, len, cut, frame_off, n_items, pairs_per_chunk, n_chunks, re_in, im_in,
-                                   frames);
+    return emu_lowpass_wave_t<double>(hop, split, paired, in, in_off, len, cut, frame_off, n_items, pairs_per_chunk, n_chunks,
+                                      re_in, im_in, frames);
+  return emu_lowpass_wave_t<float>(hop, split, paired, in, in_off, len, cut, frame_off, n_items, pairs_per_chunk, n_chunks, re_in,
+                                   im_in, frames);
 }
 
-extern "C" int emu_ola(int n_fft, int hop, const float* frames, const int64_t* frame_off, const int32_t* len,
+extern "C" int emu_ola(int n_fft, int hop, int paired, const float* frames, const int64_t* frame_off, const int32_t* len,
                        const int64_t* out_off, int n_items, int max_len, float* out) {
   SsrTables<double> t;
   if (!ssr_build_tables<double>(n_fft, t)) return -3;
-  SsrOlaParams p{frames, frame_off, len, out_off, n_fft, hop, t.window.data(), out};
-  for (int item = 0; item < n_items; ++item)
-    for (int s = 0; s < max_len; ++s) ssr_ola_sample(p, item, s);
+  std::vector<double> tab((size_t)hop);
+  for (int m = 0; m < hop && hop <= n_fft; ++m) {
+    double wss = 0.0;
+    for (int mm = m + ((n_fft - 1 - m) / hop) * hop; mm >= m; mm -= hop) wss += t.window[mm] * t.window[mm];
+    tab[m] = wss < 1e-11 ? 1e-11 : wss;
+  }
+  SsrOlaParams p{frames, frame_off, len, out_off, n_fft, hop, t.window.data(), out, tab.data(), 1.0f / (float)hop,
+                 1.0f / (float)(2 * hop)};
+  for (int item = 0; item < n_items; ++item) {
+    if (paired) for (int s = 0; s < max_len; s += 4) ssr_ola_paired_quad(p, item, s);
+    else for (int s = 0; s < max_len; ++s) ssr_ola_sample(p, item, s);
+  }
   return 0;
 }
 

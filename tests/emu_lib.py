@@ -150,7 +150,7 @@ def lowpass(sigs, cuts, n_fft=2048, hop=441, precision=1, pairs_per_chunk=4, wav
     n_chunks = int(-(-((T.max() + 1) // 2) // pairs_per_chunk))
     if wave is not None:
         assert n_fft == 2048
-        rc = lib().emu_lowpass_wave(precision, hop, 1 if wave == "split" else 0, _p(a, C.c_float), _p(off, C.c_int64),
+        rc = lib().emu_lowpass_wave(precision, hop, 0 if wave == "full" else 1, 1 if wave == "paired" else 0, _p(a, C.c_float), _p(off, C.c_int64),
                                     _p(lens, C.c_int32), _p(cuts, C.c_int32), _p(frame_off, C.c_int64), len(lens), pairs_per_chunk,
                                     n_chunks, None, None, _p(frames, C.c_float))
     else:
@@ -159,7 +159,7 @@ def lowpass(sigs, cuts, n_fft=2048, hop=441, precision=1, pairs_per_chunk=4, wav
                                       None, None, _p(frames, C.c_float))
     assert rc == 0
     out = np.full(int(lens.sum()), np.nan, np.float32)
-    rc = lib().emu_ola(n_fft, hop, _p(frames, C.c_float), _p(frame_off, C.c_int64), _p(lens, C.c_int32),
+    rc = lib().emu_ola(n_fft, hop, 1 if wave == "paired" else 0, _p(frames, C.c_float), _p(frame_off, C.c_int64), _p(lens, C.c_int32),
                        _p(off, C.c_int64), len(lens), int(lens.max()), _p(out, C.c_float))
     assert rc == 0
     return [out[off[i]:off[i] + lens[i]] for i in range(len(lens))]
@@ -175,7 +175,7 @@ def istft(res, ims, lengths, n_fft=2048, hop=441, precision=1, pairs_per_chunk=4
     n_chunks = int(-(-((T.max() + 1) // 2) // pairs_per_chunk))
     if wave is not None:
         assert n_fft == 2048
-        rc = lib().emu_lowpass_wave(precision, hop, 1 if wave == "split" else 0, None, None, _p(lens, C.c_int32), None,
+        rc = lib().emu_lowpass_wave(precision, hop, 0 if wave == "full" else 1, 1 if wave == "paired" else 0, None, None, _p(lens, C.c_int32), None,
                                     _p(frame_off, C.c_int64), len(lens), pairs_per_chunk, n_chunks, _p(re, C.c_float),
                                     _p(im, C.c_float), _p(frames, C.c_float))
     else:
@@ -184,7 +184,7 @@ def istft(res, ims, lengths, n_fft=2048, hop=441, precision=1, pairs_per_chunk=4
                                       _p(frames, C.c_float))
     assert rc == 0
     out = np.full(int(lens.sum()), np.nan, np.float32)
-    rc = lib().emu_ola(n_fft, hop, _p(frames, C.c_float), _p(frame_off, C.c_int64), _p(lens, C.c_int32),
+    rc = lib().emu_ola(n_fft, hop, 1 if wave == "paired" else 0, _p(frames, C.c_float), _p(frame_off, C.c_int64), _p(lens, C.c_int32),
                        _p(off, C.c_int64), len(lens), int(lens.max()), _p(out, C.c_float))
     assert rc == 0
     return [out[off[i]:off[i] + lens[i]] for i in range(len(lens))]

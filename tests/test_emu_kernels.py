@@ -94,6 +94,34 @@ def test_fft_lowpass_and_istft(golden):
     np.testing.assert_allclose(y, golden["fd_roundtrip"], atol=2e-8)
 
 
+@pytest.mark.parametrize("hop", [441, 512, 300, 64, 1000, 1024])
+def test_lowpass_wave_engine_frames_and_paired_segments(hop):
+    """ssr_lowpass_wave.h: one wave per frame pair, (a) writing two frames for k_ola and (b) PAIRED - the pair added up
+    through the exchange array into one segment of n_fft + hop samples for k_ola_paired - against the oracle's ISTFT
+    definition and against the block engine: ragged lengths (odd and even frame counts, a signal barely longer than the
+    reflect pad), chunk boundaries, hops with 2 to 32 overlapping frames."""
+    rng = np.random.default_rng(hop)
+    sigs = [(0.3 * rng.standard_normal(n)).astype(np.float32) for n in (9000, 5 * hop + 1030, 1025, 4 * hop + 1100, 6 * hop + 1029)]
+    cuts = [300, 1025, 77, 512, 900]
+    want = [olp.stft_hard_lowpass(x, (c + 0.5) / 1025, n_fft=2048, hop=hop) for x, c in zip(sigs, cuts)]
+    blk = E.lowpass(sigs, cuts, hop=hop, pairs_per_chunk=3)
+    # float32 frames / segments: half an ulp of each term, divided by the window sum (>= 1.5 up to hop 512, 0.5 at hop 1000)
+    atol = 5e-8 if hop <= 512 else 2.5e-7
+    for wave, ppc in (("split", 3), ("full", 4), ("paired", 2), ("paired", 64)):
+        got = E.lowpass(sigs, cuts, hop=hop, pairs_per_chunk=ppc, wave=wave)
+        for w, b, v in zip(want, blk, got):
+            assert np.isfinite(v).all()
+            np.testing.assert_allclose(b, w, atol=atol)
+            np.testing.assert_allclose(v, w, atol=atol)
+    # ISTFT mode on given spectra
+    re, im = ostft.tl_stft(sigs[0][None], n_fft=2048, hop=hop)
+    ref = E.istft([re[0, 0]], [im[0, 0]], [len(sigs[0])], hop=hop)[0]
+    for wave in ("split", "paired"):
+        got = E.istft([re[0, 0]], [im[0, 0]], [len(sigs[0])], hop=hop, pairs_per_chunk=5, wave=wave)[0]
+        np.testing.assert_allclose(got, ref, atol=atol)
+        np.testing.assert_allclose(got, sigs[0], atol=2e-6)
+
+
 @pytest.mark.parametrize("up,down", [(441, 160), (160, 147), (160, 441), (80, 147), (147, 80), (3, 1), (1, 2)])
 def test_resampler_bit_exact_vs_scipy(golden, up, down):
     x = golden["rs_x16k"]

@@ -17,14 +17,22 @@ import wave
 import numpy as np
 
 
+try:
+    import soundfile as _sf  # optional (WAV / FLAC / OGG)
+except ImportError:
+    _sf = None
+
+
+def _mono(x, nch):
+    """Channel mean of interleaved samples [n * nch] (librosa.load's mono=True); a mono file passes through."""
+    return x if nch == 1 else np.ascontiguousarray(x.reshape(-1, nch).mean(axis=1), dtype=np.float32)
+
+
 def read_audio(path):
     """-> (float32 mono [n], sample_rate)."""
-    try:
-        import soundfile as sf  # optional
-        x, sr = sf.read(path, dtype="float32", always_2d=True)
-        return np.ascontiguousarray(x.mean(axis=1), dtype=np.float32), int(sr)
-    except ImportError:
-        pass
+    if _sf is not None:
+        x, sr = _sf.read(path, dtype="float32", always_2d=True)
+        return _mono(np.ascontiguousarray(x, dtype=np.float32).reshape(-1), x.shape[1]), int(sr)
     if not path.lower().endswith(".wav"):
         raise RuntimeError("decoding %s needs the `soundfile` package (only PCM .wav is readable without it)"
                            % os.path.basename(path))
@@ -32,7 +40,8 @@ def read_audio(path):
         sr, nch, sw, n = f.getframerate(), f.getnchannels(), f.getsampwidth(), f.getnframes()
         raw = f.readframes(n)
     if sw == 2:
-        x = np.frombuffer(raw, "<i2").astype(np.float32) / 32768.0
+        x = np.frombuffer(raw, "<i2").astype(np.float32)
+        x *= np.float32(1.0 / 32768.0)                             # a power of two: the same values as the division
     elif sw == 4:
         x = np.frombuffer(raw, "<i4").astype(np.float32) / 2147483648.0
     elif sw == 3:
@@ -43,7 +52,7 @@ def read_audio(path):
         x = (np.frombuffer(raw, np.uint8).astype(np.float32) - 128.0) / 128.0
     else:
         raise RuntimeError("unsupported sample width %d" % sw)
-    return np.ascontiguousarray(x.reshape(-1, nch).mean(axis=1), dtype=np.float32), int(sr)
+    return _mono(x, nch), int(sr)
 
 
 def write_wav(path, x, sr):
@@ -60,14 +69,23 @@ def load_audio(path, sr=None, res_type="kaiser_best"):
     return load_audio_batch([path], sr, res_type)[0]
 
 
+_POOL = {}
+
+
+def _decode_pool(threads):
+    """One pool per worker count for the life of the process (starting 16 threads per batch cost more than decoding it)."""
+    from concurrent.futures import ThreadPoolExecutor
+    if threads not in _POOL:
+        _POOL[threads] = ThreadPoolExecutor(max_workers=threads, thread_name_prefix="ssr-decode")
+    return _POOL[threads]
+
+
 def decode_batch(paths, threads=None):
     """[(float32 mono waveform, file rate)] for a list of files; decoding fans out over host threads."""
-    from concurrent.futures import ThreadPoolExecutor
     paths = list(paths)
     if len(paths) <= 1:
         return [read_audio(p) for p in paths]
-    with ThreadPoolExecutor(max_workers=threads or min(16, os.cpu_count() or 1)) as ex:
-        return list(ex.map(read_audio, paths))
+    return list(_decode_pool(threads or min(16, os.cpu_count() or 1)).map(read_audio, paths))
 
 
 def to_rate(decoded, sr, res_type="kaiser_best"):
@@ -83,8 +101,8 @@ def to_rate(decoded, sr, res_type="kaiser_best"):
         from . import backend as B
         for file_sr, idx in groups.items():
             ys = B.resample_sinc([decoded[i][0] for i in idx], file_sr, int(sr), res_type)
-            for i, y in zip(idx, ys):
-                out[i] = y.cpu().numpy()
+            for i, y in zip(idx, B.to_host_list(ys)):
+                out[i] = y
     return out
 
 

@@ -1,0 +1,26 @@
+"""Developer experiment: cProfile of SSR_Eval_Helper.evaluate() on the bench's end-to-end file set (where does the host time go)."""
+import cProfile, os, pstats, shutil, sys, tempfile, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ssr_eval_amd import SSR_Eval_Helper, BasicTestee
+from ssr_eval_amd.io import write_wav
+
+rng = np.random.default_rng(4)
+root = tempfile.mkdtemp(prefix="ssr_e2e_")
+try:
+    n_files = 0
+    for s, c in enumerate([53, 53, 15, 52, 38, 53, 53, 50]):
+        os.makedirs(os.path.join(root, "p%03d" % (360 + s)))
+        for i in range(c):
+            n = int(rng.integers(int(1.5 * 44100), 9 * 44100))
+            write_wav(os.path.join(root, "p%03d" % (360 + s), "u%03d.wav" % i), 0.1 * rng.standard_normal(n), 44100)
+            n_files += 1
+    h = SSR_Eval_Helper(BasicTestee(), input_sr=44100, output_sr=44100, evaluation_sr=48000, test_data_root=root,
+                        setting_fft={"cutoff_freq": [12000]})
+    h.evaluate(limit_test_nums=2, limit_test_speaker=1, save_json=False)
+    t0 = time.perf_counter(); h.evaluate(save_json=False); print("plain run: %.3f s, %d files" % (time.perf_counter() - t0, n_files))
+    pr = cProfile.Profile(); pr.enable(); h.evaluate(save_json=False); pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+finally:
+    shutil.rmtree(root, ignore_errors=True)

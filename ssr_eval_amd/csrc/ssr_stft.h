@@ -518,8 +518,8 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
               const int m = ssr_fft_first_index<LOGN, PPT>(tid, r0 + r);
               const cx<T> z = cmul(cx<T>{a_ok ? (T)fa[r] : (T)0, b_ok ? (T)fb[r] : (T)0}, wc[r]);
               R.v[r0 + r] = (m < n_fft) ? z : cx<T>{(T)0, (T)0};
-              nza = nza || (m < n_fft && fa[r] != 0);
-              nzb = nzb || (m < n_fft && fb[r] != 0);
+              nza = nza || (m < n_fft && m != 0 && fa[r] != 0);      // sample m = 0: window weight exactly 0 (periodic Hann)
+              nzb = nzb || (m < n_fft && m != 0 && fb[r] != 0);
             }
           } else {
             SSR_UNROLL for (int r = 0; r < 4; ++r) R.v[r0 + r] = cx<T>{(T)0, (T)0};

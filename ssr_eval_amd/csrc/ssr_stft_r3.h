@@ -97,8 +97,8 @@ SSR_BODY void ssr_stft_r3_body(const SsrStftParams<T>& p, BLK& blk, int chunk, i
             const SB fb = vb.at(SSR_UIDX(ib));
             const cx<T> z = cmul(cx<T>{a_ok ? (T)fa : (T)0, b_ok ? (T)fb : (T)0}, vwc.at(SSR_UIDX(mc), wch_off));
             R.v[g] = (m < q) ? z : cx<T>{(T)0, (T)0};
-            nza = nza || (m < q && fa != 0);
-            nzb = nzb || (m < q && fb != 0);
+            nza = nza || (m < q && s3 != 0 && fa != 0);             // frame sample 0: window weight exactly 0 (periodic Hann)
+            nzb = nzb || (m < q && s3 != 0 && fb != 0);
           } else {
             R.v[g] = cx<T>{(T)0, (T)0};
           }

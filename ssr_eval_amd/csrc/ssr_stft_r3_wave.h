@@ -99,8 +99,9 @@ SSR_BODY void ssr_stft_r3_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
           const cx<T> wc = vwc.at(SSR_UIDX(m < q ? m : q - 1), (int64_t)r * q);
           const cx<T> z = cmul(cx<T>{(T)R.pa[i], (T)R.pb[i]}, wc);
           R.v[i] = (m < q) ? z : cx<T>{(T)0, (T)0};
-          ora |= (m < q) ? ssr_mag_bits(R.pa[i]) : 0u;
-          orb |= (m < q) ? ssr_mag_bits(R.pb[i]) : 0u;
+          const bool counts = (m < q) && (m + r != 0);            // frame sample 0: window weight exactly 0 (periodic Hann)
+          ora |= counts ? ssr_mag_bits(R.pa[i]) : 0u;
+          orb |= counts ? ssr_mag_bits(R.pb[i]) : 0u;
         } else {
           R.v[i] = cx<T>{(T)0, (T)0};
         }

@@ -351,6 +351,29 @@ def test_sispec_stays_accurate_at_very_high_snr():
     assert exact > 120.0
 
 
+@pytest.mark.parametrize("n_fft,hop", [(771, 100), (743, 160), (2229, 480), (2048, 512)])
+def test_frame_whose_only_nonzero_sample_has_window_weight_zero_is_silent(n_fft, hop):
+    """tools/stress_parity.py, seed 12: a frame that is all zeros except its sample 0 is multiplied by periodic Hann's
+    w[0] = 0, so the reference's spectrum is exactly 0 there; the packed transforms of the Bluestein / radix-3 engines left
+    ~1e-18 of the neighbouring frame instead (their silent-frame vote counted sample 0)."""
+    rng = np.random.default_rng(n_fft)
+    n = 12 * hop + n_fft
+    for t in (5, 6):                                            # both slots of a frame pair
+        x = (0.1 * rng.standard_normal(n)).astype(np.float32)
+        p0 = t * hop - n_fft // 2
+        x[p0 + 1:p0 + n_fft] = 0.0                              # frame t: only sample 0 survives
+        ref = ostft.stft_mag_TF(x, n_fft, hop)
+        assert (ref[t] == 0).all() and (ref[t - 1] != 0).any()
+        m, _, _ = E.stft([x], None, n_fft, hop, precision=1, mode=1, units_per_chunk=4)         # frame pairs of one signal
+        assert ((m[0] == 0) == (ref == 0)).all()
+        other = (0.1 * rng.standard_normal(n)).astype(np.float32)
+        for wave in ((None, "split") if n_fft == 2048 else (None, "r3") if n_fft == 2229 else (None,)):
+            me, mt, _ = E.stft([x], [other], n_fft, hop, 1, 0, 1, 15, 4, wave=wave)              # (estimate, target) pairs
+            assert ((me[0] == 0) == (ref == 0)).all() and (mt[0] != 0).any(axis=1).all()
+            mo, mx, _ = E.stft([other], [x], n_fft, hop, 1, 0, 1, 15, 4, wave=wave)
+            assert ((mx[0] == 0) == (ref == 0)).all()
+
+
 @pytest.mark.parametrize("n_fft,hop", [(2229, 480), (2100, 500)])
 def test_radix3_wave_engine_matches_oracle_and_block_engine(n_fft, hop):
     """ssr_stft_r3_wave.h (n_fft = 3 q over M = 2048 - AudioMetrics(48000)'s 2229 - on three autonomous waves per workgroup,

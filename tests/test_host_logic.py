@@ -145,3 +145,39 @@ def test_cabi_argument_validation_needs_no_gpu():
     assert lib.ssr_plan_destroy(None) == 0
     assert lib.ssr_num_frames(None, 100) == -1
     assert lib.ssr_pair_metrics_workspace_bytes(None, 4, 4096, 36) == 0
+
+
+def test_batched_transfers_keep_values_and_dtypes(tmp_path):
+    """backend.to_host_list (one device-to-host copy for a list of results) and the packed host path of Ragged.from_list:
+    consecutive views of one buffer, scattered tensors, mixed dtypes; io.read_audio on 16-bit mono / stereo PCM."""
+    import torch
+    from ssr_eval_amd import backend as B
+    from ssr_eval_amd.io import read_audio, write_wav, decode_batch
+    flat = torch.arange(20, dtype=torch.float32)
+    views = [flat[0:5], flat[5:5], flat[5:12], flat[12:20]]
+    for got, want in zip(B.to_host_list(views), views):
+        assert got.dtype == np.float32 and np.array_equal(got, want.numpy())
+    scattered = [flat[3:7], flat[0:2], torch.ones(3)]
+    for got, want in zip(B.to_host_list(scattered), scattered):
+        assert np.array_equal(got, want.numpy())
+    mixed = [flat[:3], torch.ones(2, dtype=torch.float64)]
+    got = B.to_host_list(mixed)
+    assert got[0].dtype == np.float32 and got[1].dtype == np.float64
+    assert B.to_host_list([]) == []
+    r = B.Ragged.from_list([np.arange(4, dtype=np.float64), torch.arange(3, dtype=torch.float32), np.zeros(0, np.float32)], "cpu")
+    assert r.data.dtype == torch.float32 and list(r.lens_host) == [4, 3, 0] and r.off.tolist() == [0, 4, 7]
+    assert r.data.tolist() == [0, 1, 2, 3, 0, 1, 2]
+    with pytest.raises(ValueError):
+        B.Ragged.from_list([np.zeros((2, 2), np.float32)], "cpu")
+    x = (0.25 * np.sin(np.arange(1000) / 7.0)).astype(np.float32)
+    write_wav(str(tmp_path / "m.wav"), x, 16000)
+    y, sr = read_audio(str(tmp_path / "m.wav"))
+    assert sr == 16000 and y.dtype == np.float32 and np.abs(y - x).max() <= 1.0 / 32768
+    import wave
+    with wave.open(str(tmp_path / "s.wav"), "wb") as f:
+        f.setnchannels(2); f.setsampwidth(2); f.setframerate(8000)
+        f.writeframes(np.stack([np.full(10, 1000), np.full(10, 3000)], 1).astype("<i2").tobytes())
+    ys, sr = read_audio(str(tmp_path / "s.wav"))
+    assert sr == 8000 and np.allclose(ys, 2000 / 32768.0)
+    both = decode_batch([str(tmp_path / "m.wav"), str(tmp_path / "s.wav")])
+    assert np.array_equal(both[0][0], y) and both[1][1] == 8000

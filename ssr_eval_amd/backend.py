@@ -101,28 +101,16 @@ class Ragged:
     @staticmethod
     def from_list(arrays, device=None, dtype=torch.float32):
         dev = torch.device(device) if device is not None else default_device()
-        arrays = list(arrays)
+        ts = []
         for a in arrays:
-            if (a.dim() if isinstance(a, torch.Tensor) else np.ndim(a)) != 1:
-                raise ValueError("expected 1-D signals, got shape %s" % (tuple(np.shape(a)),))
-        if arrays and not any(isinstance(a, torch.Tensor) and a.device.type != "cpu" for a in arrays):
-            # host signals: packed on the host, ONE transfer (a transfer per signal costs ~35 us each in launch overhead)
-            npdt = np.float64 if dtype == torch.float64 else np.float32
-            host = np.concatenate([(a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)).astype(npdt, copy=False)
-                                   for a in arrays])
-            lens = np.array([a.shape[0] for a in arrays], dtype=np.int64)
-            if lens.max() >= 2 ** 31:
-                raise ValueError("signal too long")
-            data = torch.from_numpy(host).to(dev)
-            ts = arrays
-        else:
-            ts = [(a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(device=dev, dtype=dtype,
-                                                                                                     non_blocking=True)
-                  for a in arrays]
-            lens = np.array([t.shape[0] for t in ts], dtype=np.int64)
-            if len(ts) and lens.max() >= 2 ** 31:
-                raise ValueError("signal too long")
-            data = torch.cat(ts) if len(ts) else torch.empty(0, dtype=dtype, device=dev)
+            t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+            if t.dim() != 1:
+                raise ValueError("expected 1-D signals, got shape %s" % (tuple(t.shape),))
+            ts.append(t.to(device=dev, dtype=dtype, non_blocking=True))
+        lens = np.array([t.shape[0] for t in ts], dtype=np.int64)
+        if len(ts) and lens.max() >= 2 ** 31:
+            raise ValueError("signal too long")
+        data = torch.cat(ts) if len(ts) else torch.empty(0, dtype=dtype, device=dev)
         off = np.concatenate(([0], np.cumsum(lens)[:-1])) if len(ts) else np.zeros(0, np.int64)
         return Ragged(data, torch.from_numpy(off.astype(np.int64)).to(dev),
                       torch.from_numpy(lens.astype(np.int32)).to(dev), lens)
@@ -147,31 +135,6 @@ class Ragged:
         flat = self.data if flat is None else flat
         o = np.concatenate(([0], np.cumsum(self.lens_host)))
         return [flat[o[i]:o[i + 1]] for i in range(self.n)]
-
-
-def to_host_list(tensors):
-    """[ndarray] for a list of 1-D device tensors with ONE device-to-host transfer (the pieces are packed on the device
-    unless they already are consecutive views of one buffer, as the results of Ragged.split are)."""
-    tensors = list(tensors)
-    if not tensors:
-        return []
-    if any(t.dtype != tensors[0].dtype or t.device != tensors[0].device or t.dim() != 1 for t in tensors):
-        return [t.cpu().numpy() for t in tensors]
-    lens = [int(t.shape[0]) for t in tensors]
-    base, es = tensors[0], tensors[0].element_size()
-    consecutive = all(t.is_contiguous() and t.untyped_storage().data_ptr() == base.untyped_storage().data_ptr() for t in tensors)
-    if consecutive:
-        want = base.storage_offset()
-        for t, n in zip(tensors, lens):
-            consecutive = consecutive and t.storage_offset() == want
-            want += n
-    if consecutive:
-        flat = torch.as_strided(base, (sum(lens),), (1,), base.storage_offset())
-    else:
-        flat = torch.cat(tensors)
-    host = flat.cpu().numpy()
-    o = np.concatenate(([0], np.cumsum(lens)))
-    return [host[o[i]:o[i + 1]] for i in range(len(lens))]
 
 
 class _Rows:

@@ -325,8 +325,8 @@ class SSR_Eval_Helper:
                 idx = [i for i, o in enumerate(all_proc) if (o.dtype == np.float64) == want64]
                 if idx:
                     ys = B.resample_poly([all_proc[i] for i in idx], self.evaluationset_sr, self.model_output_sr, self._device)
-                    for i, y in zip(idx, B.to_host_list(ys)):
-                        all_proc[i] = y
+                    for i, y in zip(idx, ys):
+                        all_proc[i] = y.cpu().numpy()
         results = [dict() for _ in items]
         if all_proc:
             vals = self.audio_metrics.evaluation_batch(all_proc, all_tgt)

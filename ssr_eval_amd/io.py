@@ -101,8 +101,8 @@ def to_rate(decoded, sr, res_type="kaiser_best"):
         from . import backend as B
         for file_sr, idx in groups.items():
             ys = B.resample_sinc([decoded[i][0] for i in idx], file_sr, int(sr), res_type)
-            for i, y in zip(idx, B.to_host_list(ys)):
-                out[i] = y
+            for i, y in zip(idx, ys):
+                out[i] = y.cpu().numpy()
     return out
 
 

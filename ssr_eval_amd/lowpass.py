@@ -34,7 +34,7 @@ def stft_hard_lowpass_batch(datas, ratios, device=None):
     plan = B.get_plan(N_FFT, HOP, _precision, device)
     ys = B.fft_lowpass(plan, [d if isinstance(d, torch.Tensor) else np.asarray(d, np.float32) for d in datas],
                        [cut_bin(r) for r in ratios])
-    return B.to_host_list(ys)
+    return [y.cpu().numpy() for y in ys]
 
 
 def align_length(x, y):
@@ -60,8 +60,8 @@ def _subsample_batch(xs, fs_down, fs_ori=44100):
             continue
         sel = [xs[i] if want64 else xs[i].astype(np.float32) for i in idx]
         up = B.resample_poly(B.resample_poly(sel, fs_down, fs_ori), fs_ori, fs_down)
-        for i, u in zip(idx, B.to_host_list(up)):
-            outs[i] = align_length(xs[i], u)
+        for i, u in zip(idx, up):
+            outs[i] = align_length(xs[i], u.cpu().numpy())
     return outs
 
 
@@ -94,8 +94,8 @@ def _iir_batch(xs, highcut, fs, order, ftype, lowcut=None):
         idx = [i for i, x in enumerate(xs) if (x.dtype == np.float64) == want64]
         if idx:
             ys = B.sosfiltfilt(sos, [xs[i] if want64 else xs[i].astype(np.float32) for i in idx])
-            for i, y in zip(idx, B.to_host_list(ys)):
-                outs[i] = align_length(xs[i], y)
+            for i, y in zip(idx, ys):
+                outs[i] = align_length(xs[i], y.cpu().numpy())
     return outs
 
 

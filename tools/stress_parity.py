@@ -33,9 +33,17 @@ def main():
         mags = B.stft(plan, ests)
         re, im = B.stft(plan, tgts, kind="complex")
         for i, (e, t) in enumerate(zip(ests, tgts)):
-            w = om.evaluation(e, t, n_fft=n_fft, hop=hop)
+            w, ex = om.evaluation_with_exact(e, t, n_fft=n_fft, hop=hop)
             want = np.array([w["lsd"], w["log_sispec"], w["sispec"], w["ssim"]])
             rel = np.abs(got[i] - want) / np.maximum(np.abs(want), np.array([1e-3, 1.0, 1.0, 1e-3]))   # dB values near 0: absolute
+            # SISpec pair: where the reference's float32 sums are themselves off the float64 evaluation of its formula by more
+            # than the bar, the kernel is held to that evaluation and to the band the reference's round-off spans
+            # (tests/test_gpu_parity.py::assert_sispec_parity)
+            for j, key in ((1, "log_sispec"), (2, "sispec")):
+                scale = max(abs(ex[key]), 1.0)
+                band = abs(want[j] - ex[key])
+                if band > 3e-6 * scale and abs(got[i][j] - ex[key]) <= 1e-6 * scale + 1e-6 and abs(got[i][j] - want[j]) <= band + 2e-6 * scale:
+                    rel[j] = abs(got[i][j] - ex[key]) / scale
             worst = np.maximum(worst, rel)
             ref = ostft.stft_mag_TF(e, n_fft, hop)
             dm = np.abs(mags[i].cpu().numpy() - ref).max() / ref.max()

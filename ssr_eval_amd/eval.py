@@ -245,11 +245,12 @@ class SSR_Eval_Helper:
             ret.update(self.lowpass_stft_hard(file, x, sr))
         return ret
 
-    def preprocess_arrays(self, xs, sr, files=None):
+    def preprocess_arrays(self, xs, sr, files=None, resident=None):
         """preprocess_array for a list of waveforms with every degradation batched over the list (one launch
         sequence per (filter, cutoff, order) instead of one per file).  Key order per item is the reference's
         (eval.py:243-269: butter, cheby, ellip, bessel, subsampling, mp3, fft).  `files`: the source paths, needed
-        by the mp3 degradation only (sox encodes the file itself)."""
+        by the mp3 degradation only (sox encodes the file itself).  `resident`: the same waveforms as device tensors when the
+        caller has uploaded them already (used by the degradations that take float32 device input)."""
         rets = [dict() for _ in xs]
         if not xs:
             return rets
@@ -282,7 +283,8 @@ class SSR_Eval_Helper:
                 ret.update(self.mp3_encoding(f, x, sr))
         if self.setting_fft is not None:
             keys, ratios = self._fft_plan_keys(sr)
-            ys = stft_hard_lowpass_batch([x for x in xs for _ in keys], ratios * len(xs), self._device)
+            src = xs if resident is None else resident
+            ys = stft_hard_lowpass_batch([x for x in src for _ in keys], ratios * len(xs), self._device)
             for i, ret in enumerate(rets):
                 for j, k in enumerate(keys):
                     ret[k] = ys[i * len(keys) + j]
@@ -306,18 +308,19 @@ class SSR_Eval_Helper:
             extras.append(add)
         return keys, outs, extras
 
-    def evaluate_arrays(self, items, files=None):
+    def evaluate_arrays(self, items, files=None, resident_inputs=None):
         """items: list of (target waveform @ evaluation_sr, input waveform @ input_sr).
-        -> list of {key: {metric: float}} (one dict per item), everything batched on the GPU."""
+        -> list of {key: {metric: float}} (one dict per item), everything batched on the GPU.
+        resident_inputs: the input waveforms as device tensors, if already uploaded."""
         all_keys, all_proc, all_tgt, all_extra, owner = [], [], [], [], []
-        degraded = self.preprocess_arrays([np.asarray(x) for _, x in items], self.model_input_sr, files)
+        degraded = self.preprocess_arrays([np.asarray(x) for _, x in items], self.model_input_sr, files, resident_inputs)
         for i, (target, x) in enumerate(items):
             keys, outs, extras = self._infer_and_collect(degraded[i])
             for k, o, e in zip(keys, outs, extras):
                 # a float64 output (IIR-degraded input through a pass-through testee) stays float64, as in the
                 # reference: librosa.resample and AudioMetrics.evaluation keep the dtype they are given
                 all_keys.append(k); all_proc.append(o if o.dtype == np.float64 else o.astype(np.float32))
-                all_tgt.append(np.asarray(target, np.float32))
+                all_tgt.append(target if isinstance(target, torch.Tensor) else np.asarray(target, np.float32))
                 all_extra.append(e); owner.append(i)
         if self.model_output_sr != self.evaluationset_sr and all_proc:
             # eval.py:144-150; float64 and float32 outputs are resampled in their own dtype
@@ -326,26 +329,35 @@ class SSR_Eval_Helper:
                 if idx:
                     ys = B.resample_poly([all_proc[i] for i in idx], self.evaluationset_sr, self.model_output_sr, self._device)
                     for i, y in zip(idx, ys):
-                        all_proc[i] = y.cpu().numpy()
+                        all_proc[i] = y                             # stays in HBM: the metric stage is the only consumer
         results = [dict() for _ in items]
         if all_proc:
-            vals = self.audio_metrics.evaluation_batch(all_proc, all_tgt)
+            vals = self.audio_metrics.evaluation_batch(all_proc, all_tgt, resident=True)
             for i, k, v, e in zip(owner, all_keys, vals, all_extra):
                 v.update(e)
                 results[i][k] = v
-        self._last_processed = dict(zip(zip(owner, all_keys), all_proc)) if self.save_processed_result else None
+        self._last_processed = None
+        if self.save_processed_result:
+            self._last_processed = {(i, k): (y.cpu().numpy() if isinstance(y, torch.Tensor) else y)
+                                    for i, k, y in zip(owner, all_keys, all_proc)}
         return results
 
-    def evaluate_files(self, files):
-        """eval.py:128-156 for a LIST of files in one batched pass (decode on the host, everything else on the GPU)."""
+    def evaluate_files(self, files, decoded=None):
+        """eval.py:128-156 for a LIST of files in one batched pass (decode on the host, everything else on the GPU).
+        decoded: the files' io.decode_batch result if the caller already has it."""
         from .io import decode_batch, to_rate, write_wav
         # decode once on host threads, one ragged resampling launch per (file rate -> rate) group (ssr_eval_amd.io, N2)
-        decoded = decode_batch(files)
-        targets = to_rate(decoded, self.evaluationset_sr)           # the reference shells out to `sox -r` here
-        inputs = to_rate(decoded, self.model_input_sr)              # librosa.load(file, sr=input_sr), eval.py:242
+        if decoded is None:
+            decoded = decode_batch(files)
+        # the decoded waveforms cross the bus once: target resampling and the float32 degradations read the same upload
+        on_dev = B.Ragged.from_list([x for x, _ in decoded], self._device).split() if decoded else []
+        # the reference shells out to `sox -r` here; resampled targets stay in HBM for the metric stage
+        targets = to_rate(decoded, self.evaluationset_sr, keep_on_device=True, resident=on_dev)
+        inputs = to_rate(decoded, self.model_input_sr, resident=on_dev)         # librosa.load(file, sr=input_sr), eval.py:242
+        same_rate = all(file_sr == int(self.model_input_sr) for _, file_sr in decoded)
         # (the reference loads the file twice: target and input never share a buffer, whatever a testee does to its input)
         items = [(t, x.copy() if x is t else x) for t, x in zip(targets, inputs)]
-        res = self.evaluate_arrays(items, files)
+        res = self.evaluate_arrays(items, files, on_dev if same_rate else None)
         if self.save_processed_result:
             for (i, k), y in self._last_processed.items():
                 write_wav(files[i] + k + "_processed_" + self.test_name + ".wav", y, self.evaluationset_sr)
@@ -379,9 +391,15 @@ class SSR_Eval_Helper:
         rank, world = D.rank_world()
         mine = D.shard_indices(len(work), rank, world)
         paths = [os.path.join(self.test_data_root, *work[i]) for i in mine]
+        from .io import decode_async
         local = []
-        for b in range(0, len(paths), max(1, int(batch_files))):   # ragged batches of files per launch sequence
-            local += self.evaluate_files(paths[b:b + max(1, int(batch_files))])
+        step = max(1, int(batch_files))                            # ragged batches of files per launch sequence
+        batches = [paths[b:b + step] for b in range(0, len(paths), step)]
+        ahead = decode_async(batches[0]) if batches else None      # host decode of batch k+1 runs under the GPU work of batch k
+        for k, batch in enumerate(batches):
+            decoded = ahead()
+            ahead = decode_async(batches[k + 1]) if k + 1 < len(batches) else None
+            local += self.evaluate_files(batch, decoded)
         return self._assemble(work, speakers, mine, local, save_json, datetime.now())
 
     def _assemble(self, work, speakers, mine, local, save_json, now):

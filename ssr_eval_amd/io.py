@@ -88,8 +88,17 @@ def decode_batch(paths, threads=None):
     return list(_decode_pool(threads or min(16, os.cpu_count() or 1)).map(read_audio, paths))
 
 
-def to_rate(decoded, sr, res_type="kaiser_best"):
-    """The rate change of librosa.load for decoded [(x, file_sr)] items: one ragged GPU launch per distinct file rate."""
+def decode_async(paths, threads=None):
+    """Start decoding `paths` on the pool; -> a function that waits for and returns the decode_batch result."""
+    futures = [_decode_pool(threads or min(16, os.cpu_count() or 1)).submit(read_audio, p) for p in paths]
+    return lambda: [f.result() for f in futures]
+
+
+def to_rate(decoded, sr, res_type="kaiser_best", keep_on_device=False, resident=None):
+    """The rate change of librosa.load for decoded [(x, file_sr)] items: one ragged GPU launch per distinct file rate.
+    keep_on_device: resampled items are returned as device tensors (views of the launch's output) instead of ndarrays -
+    for a consumer that is another GPU stage; items already at `sr` stay the host arrays they are.
+    resident: the same waveforms as device tensors, if the caller has uploaded them already (no second transfer)."""
     out = [None] * len(decoded)
     groups = {}
     for i, (x, file_sr) in enumerate(decoded):
@@ -100,9 +109,9 @@ def to_rate(decoded, sr, res_type="kaiser_best"):
     if groups:
         from . import backend as B
         for file_sr, idx in groups.items():
-            ys = B.resample_sinc([decoded[i][0] for i in idx], file_sr, int(sr), res_type)
+            ys = B.resample_sinc([decoded[i][0] if resident is None else resident[i] for i in idx], file_sr, int(sr), res_type)
             for i, y in zip(idx, ys):
-                out[i] = y.cpu().numpy()
+                out[i] = y if keep_on_device else y.cpu().numpy()
     return out
 
 

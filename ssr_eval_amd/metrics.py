@@ -45,8 +45,9 @@ class AudioMetrics:
         sp = B.stft(plan, [np.asarray(wav) if not isinstance(wav, torch.Tensor) else wav])[0][None, None]
         return sp if keep_on_device else sp.cpu()
 
-    def _prepare_pair(self, est, target):
-        if type(est) != type(target):
+    def _prepare_pair(self, est, target, resident=False):
+        # resident (internal callers): the signals may be device tensors the previous stage left in HBM, next to ndarrays
+        if type(est) != type(target) and not (resident and not isinstance(est, str) and not isinstance(target, str)):
             raise ValueError("The input value should either both be numpy array or strings")
         if isinstance(est, str):
             est, target = self.read(est, target)
@@ -61,9 +62,9 @@ class AudioMetrics:
         """{lsd, log_sispec, sispec, ssim} for one (estimate, target) pair (metrics.py:51-107)."""
         return self.evaluation_batch([est], [target])[0]
 
-    def evaluation_batch(self, ests, targets, mask=B.M_ALL):
+    def evaluation_batch(self, ests, targets, mask=B.M_ALL, resident=False):
         """The same four metrics for lists of pairs, one fused launch sequence for the whole batch."""
-        pairs = [self._prepare_pair(e, t) for e, t in zip(ests, targets)]
+        pairs = [self._prepare_pair(e, t, resident) for e, t in zip(ests, targets)]
         # A float64 estimate (IIR-degraded input passed through a testee, eval.py:138-150) makes the reference's est
         # spectrogram - and with it every metric - float64; float64 targets (arrays decoded as float64 by the caller)
         # likewise.  Pairs are grouped by dtype combination and each group runs its own launch sequence:

@@ -23,9 +23,26 @@ try:
     h.evaluate(limit_test_nums=2, limit_test_speaker=1, save_json=False)
     for rep in range(5):
         t0 = time.perf_counter(); h.evaluate(save_json=False); print("plain run: %.3f s, %d files" % (time.perf_counter() - t0, n_files), flush=True)
+    if os.environ.get("STAGES"):          # wall-clock per stage (wrappers around the stage functions; GPU work is synchronised)
+        import torch, collections
+        from ssr_eval_amd import io as IO, backend as B, eval as EV, metrics as M
+        acc = collections.OrderedDict()
+
+        def timed(mod, name, label=None):
+            f = getattr(mod, name)
+            def g(*a, **k):
+                torch.cuda.synchronize(); t = time.perf_counter(); r = f(*a, **k); torch.cuda.synchronize()
+                acc[label or name] = acc.get(label or name, 0.0) + time.perf_counter() - t
+                return r
+            setattr(mod, name, g)
+        timed(IO, "to_rate"); timed(EV.SSR_Eval_Helper, "preprocess_arrays"); timed(EV.SSR_Eval_Helper, "_infer_and_collect")
+        timed(B, "resample_poly"); timed(M.AudioMetrics, "evaluation_batch"); timed(EV.SSR_Eval_Helper, "evaluate_files")
+        timed(EV.SSR_Eval_Helper, "_assemble")
+        t0 = time.perf_counter(); h.evaluate(save_json=False); tot = time.perf_counter() - t0
+        print("stages (s):", {k: round(v, 4) for k, v in acc.items()}, "total", round(tot, 4))
     if os.environ.get("NO_PROFILE"):
         raise SystemExit(0)
     pr = cProfile.Profile(); pr.enable(); h.evaluate(save_json=False); pr.disable()
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(18)
 finally:
     shutil.rmtree(root, ignore_errors=True)

@@ -182,9 +182,10 @@ SSR_DEV unsigned ssr_mag_bits(double v) {
 // add every loop trip).  Host emulation: a plain pointer.  Arrays are limited to 4 GiB (checked on the host).
 template <typename E> struct SsrView {
 #ifdef SSR_HOST_EMU
-  const E* base;
-  SSR_MEMBER SsrView(const E* p, int64_t) : base(p) {}
+  const E* base; int64_t n;
+  SSR_MEMBER SsrView(const E* p, int64_t n_elems) : base(p), n(n_elems) {}
   SSR_MEMBER E at(unsigned idx, int64_t uniform_off = 0) const { return base[uniform_off + idx]; }
+  SSR_MEMBER E at_or_zero(unsigned idx) const { return ((int64_t)idx < n) ? base[idx] : (E)0; }
 #else
   __amdgpu_buffer_rsrc_t rsrc;
   SSR_MEMBER SsrView(const E* p, int64_t n_elems)
@@ -195,6 +196,9 @@ template <typename E> struct SsrView {
     else if constexpr (sizeof(E) == 8) return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b64(rsrc, vo, so, 0));
     else return __builtin_bit_cast(E, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, so, 0));
   }
+  // element idx, or 0 where idx >= n_elems (the hardware's range check; idx may be a negative int cast to unsigned as
+  // long as |idx| * sizeof(E) < 2^31)
+  SSR_MEMBER E at_or_zero(unsigned idx) const { return at(idx); }
 #endif
 };
 

@@ -45,18 +45,28 @@ template <typename S> SSR_HD size_t ssr_resample_lds_bytes(const SsrResamplePara
   return sizeof(S) * (taps + ssr_resample_win(p) + 8);
 }
 // host-side geometry.  A block's work items are (phase r < up, group g < G), J outputs each, dealt to the NT threads in
-// rounds: G is chosen for full rounds (441 phases x 1 group = 1.72 rounds -> a quarter of the lanes idle; x 4 = 6.9) under
-// a cap on the input window (which lives in LDS next to the tap table).
-SSR_HD int ssr_resample_pick_groups(int up, int down) {
+// rounds.  G is chosen for (lane efficiency of the rounds) x (workgroups a CU holds at the resulting LDS footprint, at most
+// `max_wg_per_cu`, the register-file limit): 441 phases x 4 groups fill 98 % of 7 rounds but their 20 KB window next to the
+// 37 KB tap table lets only two workgroups share a CU; x 3 fills 86 % of 6 rounds and three fit.  Caps: the input window
+// must fit the prefetch registers, a block at most 16384 outputs.
+SSR_HD int ssr_resample_max_wg_per_cu(size_t elem_size) { return elem_size == 4 ? 3 : 2; }   // k_resample's launch bounds
+SSR_HD int ssr_resample_pick_groups(int up, int down, int n_taps = 0, size_t elem_size = 4) {
+  const int hpp = n_taps > 0 ? (n_taps + up - 1) / up : 21, cap = ssr_resample_max_wg_per_cu(elem_size);
   int best = 1;
-  double best_eff = 0.0;
-  for (int g = 1; g <= 16; ++g) {
+  double best_score = 0.0;
+  for (int g = 1; g <= 2048; ++g) {                                     // (small `up`: many groups make a full round)
     const int64_t opb = (int64_t)up * SSR_RESAMPLE_J * g;
-    const int64_t win = opb * down / up + 64;
-    if (g > 1 && (win > 10240 || opb > 16384)) break;
+    const int64_t win = opb * down / up + hpp + 2;
+    if (g > 1 && (win + 62 > 10240 || opb > 16384)) break;
     const int64_t items = (int64_t)up * g, rounds = (items + SSR_RESAMPLE_NT - 1) / SSR_RESAMPLE_NT;
     const double eff = (double)items / (double)(rounds * SSR_RESAMPLE_NT);
-    if (eff > best_eff + 0.02) { best_eff = eff; best = g; }
+    size_t lds = elem_size * (size_t)((int64_t)hpp * up + win + 8);
+    if (lds > 96 * 1024) lds = elem_size * (size_t)(win + 8);          // tap table left in HBM / L2 (resample_poly_t)
+    int per_cu = (int)((160 * 1024) / (lds + 512));
+    per_cu = per_cu < 1 ? 1 : (per_cu > cap ? cap : per_cu);
+    const double score = eff * per_cu;
+    if (score > best_score * 1.02) { best_score = score; best = g; }
+    else if (score >= best_score * 0.999) best = g;                     // as good: the larger block (less halo per output)
   }
   return best;
 }
@@ -168,12 +178,12 @@ SSR_BODY void ssr_resample_persistent_body(const SsrResampleParamsT<S>& p, BLK& 
     SSR_PHASE(blk, regs, {
       const int n_in_n = p.in_len[nitem];
       const SsrView<S> vn(p.in + p.in_off[nitem], n_in_n);       // (scalar base + 32-bit lane offset per load)
-      SSR_UNROLL for (int u = 0; u < PF; ++u) {                 // next window -> registers (in flight across the arithmetic)
-        const int i = tid + u * NT;
-        const int64_t j = nb.q_lo + i;
-        const bool ok = i < nb.win && j >= 0 && j < n_in_n;
-        R.nx[u] = ok ? vn.at((unsigned)(ok ? j : 0)) : (S)0;
-      }
+      // next window -> registers (in flight across the arithmetic).  No per-lane condition: an index outside [0, n_in) - a
+      // negative one included, as an unsigned offset - is out of the view's range and loads 0, which IS the signal's zero
+      // extension; slots beyond the window load something that is never written to LDS.  (44 lane masks kept in scalar
+      // registers across the multiply-adds - for the select after the load - were 98 spilled SGPRs.)
+      const int q_lo_n = (int)nb.q_lo + tid;
+      SSR_UNROLL for (int u = 0; u < PF; ++u) R.nx[u] = vn.at_or_zero((unsigned)(q_lo_n + u * NT));
       if (b.live) ssr_resample_compute<S>(p, tid, item, b, xw, h, h_len);
     });
     SSR_PHASE(blk, regs, {

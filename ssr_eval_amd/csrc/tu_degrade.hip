@@ -18,8 +18,12 @@ __global__ __launch_bounds__(64) void k_xcorr_pick(const double* best_val, const
   if (item < n_items) ssr_xcorr_pick(best_val, best_idx, n_lag_blocks, item, argmax_out);
 }
 
+#ifndef SSR_RESAMPLE_WPE
+#define SSR_RESAMPLE_WPE 3
+#endif
+// float32 signals: 3 workgroups per CU (<= 168 VGPRs; the LDS footprint allows three) - float64 accumulators need the 256
 template <typename S>
-__global__ __launch_bounds__(SSR_RESAMPLE_NT) void k_resample(SsrResampleParamsT<S> p, int blocks_per_item, int total) {
+__global__ __launch_bounds__(SSR_RESAMPLE_NT, sizeof(S) == 4 ? SSR_RESAMPLE_WPE : 2) void k_resample(SsrResampleParamsT<S> p, int blocks_per_item, int total) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SsrBlk blk{(int)threadIdx.x};
   ssr_resample_persistent_body<S>(p, blk, (int)blockIdx.x, (int)gridDim.x, total, blocks_per_item, smem);
@@ -71,7 +75,7 @@ static int resample_poly_t(const S* in, const int64_t* in_off, const int32_t* in
   if (up < 1 || down < 1 || n_taps < 1) return ssr_fail(SSR_ERR_INVALID_ARG, "bad resampling plan");
   if (n_items <= 0 || max_out_len <= 0) return SSR_OK;
   SsrResampleParamsT<S> p{in, in_off, in_len, out_off, out_len, up, down, taps, n_taps, n_pre_remove,
-                          ssr_resample_pick_groups(up, down), 1, out};
+                          ssr_resample_pick_groups(up, down, n_taps, sizeof(S)), 1, out};
   if (ssr_resample_lds_bytes(p) > 96 * 1024) p.taps_in_lds = 0;      // huge tap tables stay in HBM / L2
   const size_t lds = ssr_resample_lds_bytes(p);
   if (lds > 160 * 1024) {           // huge reduced `up`: the phase-blocked kernel's window does not fit LDS
@@ -96,7 +100,7 @@ static int resample_poly_t(const S* in, const int64_t* in_off, const int32_t* in
   HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
   int per_cu = (int)((160 * 1024) / (lds + 512));
   if (per_cu < 1) per_cu = 1;
-  if (per_cu > 8) per_cu = 8;
+  if (per_cu > ssr_resample_max_wg_per_cu(sizeof(S))) per_cu = ssr_resample_max_wg_per_cu(sizeof(S));   // registers: launch bounds
   int64_t wgs = (int64_t)n_cu * per_cu;
   if (wgs > total) wgs = total;
   hipLaunchKernelGGL((k_resample<S>), dim3((unsigned)wgs), dim3(SSR_RESAMPLE_NT), lds, (hipStream_t)stream, p, bpi, (int)total);

@@ -352,7 +352,7 @@ static int emu_resample_t(const S* in, const int64_t* in_off, const int32_t* in_
                           const int32_t* out_len, int n_items, int max_out_len, int up, int down, const S* taps, int n_taps,
                           int n_pre_remove, int groups, int taps_in_lds, S* out) {
   SsrResampleParamsT<S> p{in, in_off, in_len, out_off, out_len, up, down, taps, n_taps, n_pre_remove,
-                          groups > 0 ? groups : ssr_resample_pick_groups(up, down), taps_in_lds, out};
+                          groups > 0 ? groups : ssr_resample_pick_groups(up, down, n_taps, sizeof(S)), taps_in_lds, out};
   if (groups < 0) {      // the window-free fallback (one output per thread)
     for (int item = 0; item < n_items; ++item)
       for (int64_t m = 0; m < max_out_len; ++m) ssr_resample_direct_output<S>(p, item, m);

@@ -216,6 +216,17 @@ int ssr_sosfiltfilt_f64(const double* x, const int64_t* off, const int32_t* len,
                     const double* sos, const double* zi, int n_sections, int edge, double* y, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* A12 / SURVEY 8(e).  The path's one collective: the per-speaker [metric sums ..., count] buffer summed over ranks in
+ * float64 (what SSR_Eval_Helper.evaluate's mean-of-speaker-means needs from the other shards, ssr_eval/eval.py:200-216) -
+ * ncclAllReduce(sum, double) over RCCL / xGMI, in place, on `stream`.  RCCL is resolved with dlopen at the first call
+ * (SSR_ERR_UNSUPPORTED when it is absent); one communicator per rank / GPU:
+ *   rank 0: ssr_comm_unique_id(uid) -> hand the 128 bytes to every rank (any side channel) -> all: ssr_comm_init_rank.
+ * The Python mirror uses torch.distributed (the same RCCL) instead: ssr_eval_amd/dist.py. */
+int ssr_comm_unique_id(void* uid128);
+int ssr_comm_init_rank(const void* uid128, int n_ranks, int rank, void** comm);
+int ssr_comm_destroy(void* comm);
+int ssr_allreduce_sums(double* buf, int n, void* comm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

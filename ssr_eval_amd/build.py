@@ -74,7 +74,7 @@ def build(force=False, verbose=False, extra=(), jobs=None, out=None):
 
     with ThreadPoolExecutor(max_workers=jobs or max(1, (os.cpu_count() or 2))) as ex:
         list(ex.map(one, todo))
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [_obj_of(u) for u in units()]
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [_obj_of(u) for u in units()] + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -286,3 +286,26 @@ def test_load_audio_is_librosa_load_shaped(tmp_path):
         np.testing.assert_array_equal(load_audio(p, 48000), y)
     x, sr = read_audio(paths[0])
     np.testing.assert_array_equal(load_audio(paths[0]), x)                          # sr=None: native rate
+
+
+@pytest.mark.gpu
+def test_cabi_allreduce_sums_single_rank_communicator():
+    """ssr_allreduce_sums (the path's one collective behind the C ABI, RCCL resolved with dlopen): a one-rank communicator
+    on this GPU - unique id, init, in-place float64 sum (identity with one rank), destroy."""
+    import ctypes as C
+    import torch
+    from ssr_eval_amd import _lib
+    lib = _lib.load()
+    torch.cuda.set_device(0)
+    uid = (C.c_char * 128)()
+    _lib.check(lib.ssr_comm_unique_id(uid))
+    comm = C.c_void_p()
+    _lib.check(lib.ssr_comm_init_rank(uid, 1, 0, C.byref(comm)))
+    assert comm.value
+    buf = torch.tensor([1.5, -2.0, 1e-300, 3.0], dtype=torch.float64, device="cuda")
+    want = buf.cpu().clone()
+    _lib.check(lib.ssr_allreduce_sums(buf.data_ptr(), buf.numel(), comm, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(buf.cpu(), want)
+    assert lib.ssr_allreduce_sums(buf.data_ptr(), 0, comm, None) == 0
+    _lib.check(lib.ssr_comm_destroy(comm))

@@ -145,6 +145,12 @@ def test_cabi_argument_validation_needs_no_gpu():
     assert lib.ssr_plan_destroy(None) == 0
     assert lib.ssr_num_frames(None, 100) == -1
     assert lib.ssr_pair_metrics_workspace_bytes(None, 4, 4096, 36) == 0
+    comm = C.c_void_p()
+    assert lib.ssr_comm_unique_id(None) == -1 and lib.ssr_allreduce_sums(None, 4, None, None) == -1
+    assert lib.ssr_comm_init_rank(None, 1, 0, C.byref(comm)) == -1
+    uid = (C.c_char * 128)()
+    assert lib.ssr_comm_init_rank(uid, 2, 2, C.byref(comm)) == -1 and b"rank" in lib.ssr_last_error()
+    assert lib.ssr_comm_destroy(None) == 0
 
 
 def test_wav_decode_mono_stereo_and_batch(tmp_path):

@@ -33,6 +33,9 @@ struct ssr_plan {
   SsrEngine eng;
   DevTables<float> f32;
   DevTables<double> f64;
+  SsrEngine weng;              // the wave engine's variant for float32 pairs (ssr_pick_wave_engine; !ok: none)
+  DevTables<float> f32w;       // its tables where they differ from the block engine's (radix 2), else copies of the pointers
+  DevTables<double> f64w;
   double* window64 = nullptr;  // always present (OLA normalisation)
   double* wss_tab = nullptr;   // [hop] overlap-added squared window where every overlapping frame exists (hop <= n_fft)
   std::vector<void*> allocs;
@@ -41,6 +44,9 @@ struct ssr_plan {
 template <typename T> inline const DevTables<T>& ssr_tables_of(const ssr_plan* pl);
 template <> inline const DevTables<float>& ssr_tables_of<float>(const ssr_plan* pl) { return pl->f32; }
 template <> inline const DevTables<double>& ssr_tables_of<double>(const ssr_plan* pl) { return pl->f64; }
+template <typename T> inline const DevTables<T>& ssr_wave_tables_of(const ssr_plan* pl);
+template <> inline const DevTables<float>& ssr_wave_tables_of<float>(const ssr_plan* pl) { return pl->f32w; }
+template <> inline const DevTables<double>& ssr_wave_tables_of<double>(const ssr_plan* pl) { return pl->f64w; }
 
 // Every entry point that takes a plan runs on the plan's device: its tables live there.  (The Python mirror selects
 // the device before calling in; a C caller that forgot gets an error instead of an illegal address.)
@@ -66,7 +72,7 @@ int ssr_units_per_chunk_for(int max_units, int n_items, int target_wgs = 0);
 // Pair transform of this plan on float32 (in64 = false) signals runs the wave-autonomous engine (ssr_stft_wave.h: one
 // wave per workgroup) -> the chunking aims for 4x as many (one-wave) workgroups.
 bool ssr_stft_uses_wave_engine(const ssr_plan* pl, bool in64);
-bool ssr_stft_r3_uses_wave_engine(const ssr_plan* pl);     // n_fft = 3 q over M = 2048, float32 pairs (ssr_stft_r3_wave.h)
+int ssr_stft_rn_wave_radix(const ssr_plan* pl);            // 1 / 2 / 3: n_fft = R q over M = 2048, float32 pairs (ssr_stft_rn_wave.h); 0: none
 int ssr_pair_units_per_chunk(const ssr_plan* pl, int max_units, int n_items, bool in64);
 
 // ---- launchers defined by the kernel translation units --------------------------------------------------------
@@ -78,6 +84,8 @@ template <typename T> int ssr_launch_stft_pair64(const ssr_plan*, SsrStftParams<
 template <typename T> int ssr_launch_stft_single(const ssr_plan*, SsrStftParams<T>&, int grid, hipStream_t);
 // radix-3 engine (n_fft = 3q)
 template <typename T> int ssr_launch_stft_r3(const ssr_plan*, SsrStftParams<T>&, int grid, hipStream_t);
+// R autonomous waves per workgroup (n_fft = R q, float32 pairs); defined next to the radix-3 engine
+template <typename T> int ssr_launch_stft_rn_wave(const ssr_plan*, SsrStftParams<T>&, int grid, hipStream_t);
 template <typename T> int ssr_launch_stft_r3_64(const ssr_plan*, SsrStftParams<T>&, int grid, hipStream_t);
 // dispatcher (tu_core.hip): fills the plan tables into p and picks the unit
 template <typename T> int ssr_launch_stft(const ssr_plan*, SsrStftParams<T>&, int grid, hipStream_t);

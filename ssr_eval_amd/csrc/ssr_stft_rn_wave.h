@@ -1,23 +1,27 @@
-// Kernel body K1-K4 for n_fft = 3 q on the wave engine: the AudioMetrics(48000) size (2229 = 3 * 743, hop 480) - what every
-// user of the reference's default API hits at 48 kHz.
+// Kernel body K1-K4 for n_fft = R q (R = 1, 2, 3; q <= 1024) on the wave engine: the AudioMetrics(rate) sizes that are not a
+// power of two - 2229 = 3 * 743 (48 kHz: what every user of the reference's default API hits), 1486 = 2 * 743 (32 kHz),
+// 1114 = 2 * 557 (24 kHz), 743 (16 kHz) - ssr_eval/metrics.py:16-19.
 //
-// Same mathematics as ssr_stft_r3.h: one radix-3 decimation-in-time step over three length-q Bluestein transforms with
-// M = 2048,    X[k + q j] = sum_{r<3} W3^{r j} * ( W_n^{r k} * DFT_q{ x[3 m + r] }[k] ).
-// There a workgroup of four waves walks r = 0, 1, 2 in lock step - six barrier-phased 2048-point transforms per unit on a
-// 35 KB buffer plus 36 KB of parked sub-spectra: two workgroups per CU.  Here a workgroup is THREE AUTONOMOUS WAVES, wave r
-// running the whole chirp-z of sub-sequence r (forward transform -> * filter -> inverse transform, the inverse starting from
-// the registers the forward one ended in, as in ssr_lowpass_wave.h) on its own 17 KB exchange array with no barrier; the
-// three arrays (51 KB) are free once the transforms are done, so the sub-spectra (36 KB) are parked IN them for the
-// epilogue.  Three workgroup barriers per unit (transforms done / parked / epilogue done) instead of ~50, 52 KB per
-// workgroup -> three workgroups = nine waves per CU.
+// One radix-R decimation-in-time step over R length-q Bluestein transforms with M = 2048,
+//     X[k + q j] = sum_{r<R} W_R^{r j} * ( W_n^{r k} * DFT_q{ x[R m + r] }[k] )        (R = 1: the plain chirp-z transform).
+// The block engines walk the sub-sequences in lock step on four waves (ssr_stft_r3.h: six barrier-phased 2048-point
+// transforms per unit on a 35 KB buffer plus 36 KB of parked sub-spectra; R = 2 and 1 ran as ONE Bluestein transform of 4096 /
+// 2048 points, ssr_stft.h).  Here a workgroup is R AUTONOMOUS WAVES, wave r running the whole chirp-z of sub-sequence r
+// (forward transform -> * filter -> inverse transform, the inverse starting from the registers the forward one ended in, as in
+// ssr_lowpass_wave.h) on its own 17 KB exchange array with no barrier; the arrays are free once the transforms are done, so
+// the sub-spectra (2 R q values) are parked IN them for the epilogue.  Three workgroup barriers per unit (transforms done /
+// parked / epilogue done), 17 KB per wave -> eight or nine waves per CU whatever R.
 #pragma once
 #include "ssr_stft_r3.h"
 #include "ssr_stft_wave.h"
 
-template <typename T, bool SUMS> struct SsrR3WaveRegs {
+// rows of 64 sub-sequence samples / sub-spectrum bins a wave handles: q <= 768 under R = 3 (n_fft <= 2304), else q <= 1024
+SSR_HD constexpr int ssr_rn_rows(int R) { return R == 3 ? 12 : 16; }
+
+template <typename T, bool SUMS, int NW> struct SsrRnWaveRegs {
   cx<T> v[SSR_W_P];
   T tx[SSR_W_P];
-  float pa[12], pb[12];      // the next unit's decimated samples m = lane + 64 i, i < 12 (q <= 768), requested a unit ahead
+  float pa[ssr_rn_rows(NW)], pb[ssr_rn_rows(NW)];   // the next unit's decimated samples m = lane + 64 i, requested a unit ahead
   cx<T> tw1[7];
   cx<T> tw2[12];
   double sums[SUMS ? 6 : 1];
@@ -25,12 +29,11 @@ template <typename T, bool SUMS> struct SsrR3WaveRegs {
 
 template <typename T> struct SsrWaveBuf { T* re; T* im; };
 
-template <typename T> struct SsrR3WaveLds {
-  static constexpr int NW = 3;
-  // scratch (doubles first), then three split-exchange arrays; the parked sub-spectra alias the arrays
+template <typename T, int NW> struct SsrRnWaveLds {
+  // scratch (doubles first), then NW split-exchange arrays; the parked sub-spectra alias the arrays
   static constexpr size_t bytes() { return sizeof(double) * (4 + 6 * 4 + 2) + sizeof(int) * 16 + sizeof(T) * NW * SSR_W_PN; }
   double* sc1; double* wacc; double* res; int* nz; T* x;
-  SSR_MEMBER explicit SsrR3WaveLds(char* base) {
+  SSR_MEMBER explicit SsrRnWaveLds(char* base) {
     sc1 = reinterpret_cast<double*>(base);          // [3] per-wave LSD sums of the current unit (+1 pad)
     wacc = sc1 + 4;                                 // [6][4] per-wave SISpec sums at the chunk end
     res = wacc + 6 * 4;                             // [0] running LSD of the chunk
@@ -39,33 +42,44 @@ template <typename T> struct SsrR3WaveLds {
   }
 };
 
-// decimated samples of unit u (frame u of both signals), sub-sequence r: sample 3 m + r of the frame, m = lane + 64 i
-template <typename T, typename REGS>
-SSR_DEV void ssr_r3_wave_prefetch(REGS& R, int lane, int r, const SsrView<float>& va, const SsrView<float>& vb, int u, int hop,
+// decimated samples of unit u (frame u of both signals), sub-sequence r: sample NW m + r of the frame, m = lane + 64 i
+template <typename T, int NW, typename REGS>
+SSR_DEV void ssr_rn_wave_prefetch(REGS& R, int lane, int r, const SsrView<float>& va, const SsrView<float>& vb, int u, int hop,
                                   int n_fft, int q, int n, int n_frames) {
   const int t_c = (u < n_frames) ? u : n_frames - 1;
   const int base = t_c * hop - n_fft / 2;
   const bool interior = base >= 0 && base + n_fft <= n;
-  SSR_UNROLL for (int i = 0; i < 12; ++i) {
+  SSR_UNROLL for (int i = 0; i < ssr_rn_rows(NW); ++i) {
     const int m = lane + 64 * i;
     const int mc = (m < q) ? m : q - 1;
-    const int s3 = base + 3 * mc + r;
+    const int s3 = base + NW * mc + r;
     const unsigned idx = SSR_UIDX(interior ? s3 : ssr_reflect(s3, n));
     R.pa[i] = va.at(idx);
     R.pb[i] = vb.at(idx);
   }
 }
 
-// grid = n_items * n_chunks workgroups of 192 threads; PAIR mode, float32 signals, M = 2048 (q <= 768).
-template <typename T, bool SUMS, typename BLK>
-SSR_BODY void ssr_stft_r3_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
+// X[K] (already carrying the factor 1/2) from the NW parked sub-spectra
+template <typename T, int NW> SSR_DEV cx<T> ssr_rn_combine(const T* yre, const T* yim, int q, int K) {
+  if constexpr (NW == 3) return ssr_r3_combine<T>(yre, yim, q, K);
+  else if constexpr (NW == 1) return {yre[K], yim[K]};
+  else {
+    const int j = (K >= q) ? 1 : 0, k = K - j * q;                  // X[k + q j] = y0[k] + (-1)^j y1[k]
+    const cx<T> y0 = {yre[k], yim[k]}, y1 = {yre[q + k], yim[q + k]};
+    return j ? cx<T>{y0.x - y1.x, y0.y - y1.y} : cx<T>{y0.x + y1.x, y0.y + y1.y};
+  }
+}
+
+// grid = n_items * n_chunks workgroups of 64 NW threads; PAIR mode, float32 signals, M = 2048.
+template <typename T, bool SUMS, int NW, typename BLK>
+SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
   constexpr bool SPLIT = true;
-  constexpr int NT = 192;
-  using Regs = SsrR3WaveRegs<T, SUMS>;
-  SsrR3WaveLds<T> L(lds_base);
-  const int n_fft = p.n_fft, hop = p.hop, F = n_fft / 2 + 1, q = n_fft / 3;
-  T* yre = L.x;                       // parked sub-spectra [3 q] re, [3 q] im: alias the exchange arrays (3 * 2113 >= 6 q)
-  T* yim = L.x + 3 * q;
+  constexpr int NT = 64 * NW, NI = ssr_rn_rows(NW), NQ = NI / 4;     // rows i = b + 4 qq, b < 4, qq < NQ
+  using Regs = SsrRnWaveRegs<T, SUMS, NW>;
+  SsrRnWaveLds<T, NW> L(lds_base);
+  const int n_fft = p.n_fft, hop = p.hop, F = n_fft / 2 + 1, q = n_fft / NW;
+  T* yre = L.x;                       // parked sub-spectra [NW q] re, [NW q] im: alias the exchange arrays (2113 >= 2 q)
+  T* yim = L.x + NW * q;
   const int n = p.len[item];
   const int n_frames = ssr_num_frames_dev(n, n_fft, hop);
   const int u0 = chunk * p.units_per_chunk;
@@ -82,19 +96,19 @@ SSR_BODY void ssr_stft_r3_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
     for (int i = tid; i < 6 * 4; i += NT) L.wacc[i] = 0.0;
     if (tid == 0) L.res[0] = 0.0;
     for (int i = 0; i < (SUMS ? 6 : 1); ++i) R.sums[i] = 0.0;
-    if (u0 < u1) ssr_r3_wave_prefetch<T>(R, tid & 63, ssr_wave_of(tid), va, vb, u0, hop, n_fft, q, n, n_frames);
+    if (u0 < u1) ssr_rn_wave_prefetch<T, NW>(R, tid & 63, ssr_wave_of(tid), va, vb, u0, hop, n_fft, q, n, n_frames);
   });
 
   BLK blk0 = blk;
   for (int u = u0; u < u1; ++u) {
     blk = blk0; ssr_launder(blk);
 #define SSR_R3_L (SsrWaveBuf<T>{L.x + ssr_wave_of(tid) * SSR_W_PN, L.x + ssr_wave_of(tid) * SSR_W_PN})
-    // ---- wave r: decimated frame * (window * chirp) -> registers (only m < q is non-zero: 12 of the 32 points), first pass
+    // ---- wave r: decimated frame * (window * chirp) -> registers (only m < q is non-zero: NI of the 32 points), first pass
     SSR_WPHASE(blk, regs, {
       const int lane = tid & 63, r = ssr_wave_of(tid);
       unsigned ora = 0u, orb = 0u;
       SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) {
-        if (i < 12) {
+        if (i < NI) {
           const int m = lane + 64 * i;
           const cx<T> wc = vwc.at(SSR_UIDX(m < q ? m : q - 1), (int64_t)r * q);
           const cx<T> z = cmul(cx<T>{(T)R.pa[i], (T)R.pb[i]}, wc);
@@ -111,7 +125,11 @@ SSR_BODY void ssr_stft_r3_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
       SSR_WAVE_ANY_STORE(lane, ora != 0u, L.nz + ((u - u0) & 1) * 3 + r);
       SSR_WAVE_ANY_STORE(lane, orb != 0u, L.nz + 8 + ((u - u0) & 1) * 3 + r);
       ssr_dft32(R.v);
-      if (want_lsd && u > u0 && tid == 0) L.res[0] += sqrt((L.sc1[0] + L.sc1[1] + L.sc1[2]) / (double)F);
+      if (want_lsd && u > u0 && tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < NW; ++w) s += L.sc1[w];
+        L.res[0] += sqrt(s / (double)F);
+      }
     });
 #define VT vt
     SSR_W_FFT_TAIL(blk, blk0, regs, SSR_R3_L, );
@@ -132,17 +150,17 @@ SSR_BODY void ssr_stft_r3_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
     // post-multiply (chirp * W_n^{r k} / 2) in place
     SSR_WPHASE(blk, regs, {
       const int lane = tid & 63, r = ssr_wave_of(tid);
-      SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int qq = 0; qq < 3; ++qq) {
+      SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int qq = 0; qq < NQ; ++qq) {
         const int k = lane + 64 * (b + 4 * qq);
         const cx<T> c = vch.at(SSR_UIDX(k < q ? k : q - 1), (int64_t)r * q);
         R.v[8 * b + qq] = cmul(cx<T>{R.v[8 * b + qq].y, R.v[8 * b + qq].x}, c);
       }
     });
-    // ---- all three waves are done with their exchange arrays: park the sub-spectra in them
+    // ---- all waves are done with their exchange arrays: park the sub-spectra in them
     SSR_PHASE(blk, regs, {});
     SSR_PHASE(blk, regs, {
       const int lane = tid & 63, r = ssr_wave_of(tid);
-      SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int qq = 0; qq < 3; ++qq) {
+      SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int qq = 0; qq < NQ; ++qq) {
         const int k = lane + 64 * (b + 4 * qq);
         if (k < q) { yre[r * q + k] = R.v[8 * b + qq].x; yim[r * q + k] = R.v[8 * b + qq].y; }
       }
@@ -152,17 +170,17 @@ SSR_BODY void ssr_stft_r3_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
     float* ra0 = p.out_a ? p.out_a + (row0 + u) * F : nullptr;
     float* rb0 = p.out_b ? p.out_b + (row0 + u) * F : nullptr;
     SSR_PHASE(blk, regs, {
-      ssr_r3_wave_prefetch<T>(R, tid & 63, ssr_wave_of(tid), va, vb, u + 1, hop, n_fft, q, n, n_frames);   // (unconditional)
+      ssr_rn_wave_prefetch<T, NW>(R, tid & 63, ssr_wave_of(tid), va, vb, u + 1, hop, n_fft, q, n, n_frames);   // (unconditional)
       SSR_SCHED_BARRIER();
       double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       const int par = ((u - u0) & 1) * 3;
       bool a_nz = false, b_nz = false;
-      for (int w = 0; w < 3; ++w) { a_nz = a_nz || L.nz[par + w] != 0; b_nz = b_nz || L.nz[8 + par + w] != 0; }
+      for (int w = 0; w < NW; ++w) { a_nz = a_nz || L.nz[par + w] != 0; b_nz = b_nz || L.nz[8 + par + w] != 0; }
       const bool store = p.out_kind == SSR_OUT_MAG;
       for (int K = tid; K < F; K += NT) {
         const int Kn = (K == 0) ? 0 : n_fft - K;
-        const cx<T> zk = ssr_r3_combine<T>(yre, yim, q, K);
-        const cx<T> zn = ssr_r3_combine<T>(yre, yim, q, Kn);
+        const cx<T> zk = ssr_rn_combine<T, NW>(yre, yim, q, K);
+        const cx<T> zn = ssr_rn_combine<T, NW>(yre, yim, q, Kn);
         float e, t;
         ssr_pair_bin<T, 0, true>(mask, acc, zk, zn, a_nz, b_nz, e, t);
         if (store) { ra0[K] = e; rb0[K] = t; }
@@ -180,9 +198,17 @@ SSR_BODY void ssr_stft_r3_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
   }
   SSR_PHASE(blk, regs, if (tid == 0) {
     double lsd = L.res[0];
-    if (want_lsd && u1 > u0) lsd += sqrt((L.sc1[0] + L.sc1[1] + L.sc1[2]) / (double)F);
+    if (want_lsd && u1 > u0) {
+      double s = 0.0;
+      for (int w = 0; w < NW; ++w) s += L.sc1[w];
+      lsd += sqrt(s / (double)F);
+    }
     part[0] = lsd;
-    for (int i = 0; i < 6; ++i) part[1 + i] = L.wacc[i * 4] + L.wacc[i * 4 + 1] + L.wacc[i * 4 + 2];
+    for (int i = 0; i < 6; ++i) {
+      double s = 0.0;
+      for (int w = 0; w < NW; ++w) s += L.wacc[i * 4 + w];
+      part[1 + i] = s;
+    }
     part[7] = 0.0;
   });
 }

@@ -163,7 +163,7 @@ SSR_DEV constexpr int ssr_w_off_st1(int i) { return 528 * (i >> 3) + 33 * (i & 7
 // The rest of the transform after the in-register radix-32 pass (ssr_dft32 applied to R.v): exchange, radix-8 pass with the
 // lane's seven twiddles, exchange, radix-8 pass with table twiddles.  On exit register 8 b + q holds Z[tid + 64 b + 256 q].
 // BLK0: the untouched block descriptor (a fresh opaque lane index per stage: addresses are formed where they are used).
-// The lane index is `tid & 63` throughout: a workgroup of several autonomous waves (ssr_stft_r3_wave.h) passes an L whose
+// The lane index is `tid & 63` throughout: a workgroup of several autonomous waves (ssr_stft_rn_wave.h) passes an L whose
 // arrays are the calling wave's own.
 // EXTRA2: further table loads to issue with the last pass's twiddles (the low-pass kernel's synthesis window).
 #define SSR_W_LOAD_TW1 { const unsigned k8 = SSR_UIDX(8 * (tid & 31)); \

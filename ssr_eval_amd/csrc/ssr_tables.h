@@ -40,6 +40,21 @@ inline SsrEngine ssr_pick_engine(int n_fft) {
   return e;
 }
 
+// The wave engine's variant for float32 pairs (ssr_stft_rn_wave.h): n_fft = R q over M = 2048 on R autonomous waves.
+//  * R = 3 where the block engine already splits by three (2229);
+//  * R = 1 where plain Bluestein runs at M = 2048 (513 <= n_fft <= 1024, not a power of two: 743);
+//  * R = 2 for even n_fft whose plain Bluestein length is 4096 (1026 <= n_fft <= 2048: 1114, 1486) - its tables differ from
+//    the block engine's (chirp of length q = n_fft / 2, filter spectrum of 2048 points) and are built separately.
+inline SsrEngine ssr_pick_wave_engine(int n_fft) {
+  const SsrEngine e = ssr_pick_engine(n_fft);
+  SsrEngine none{false, false, 0, 1, 0};
+  if (!e.ok || !e.bluestein) return none;
+  if (e.radix == 3) return (e.logn == 11 && e.q <= 768) ? e : none;
+  if (e.logn == 11) return e;                                              // R = 1, q = n_fft
+  if (e.logn == 12 && n_fft % 2 == 0 && n_fft / 2 <= 1024) return SsrEngine{true, true, 11, 2, n_fft / 2};
+  return none;
+}
+
 template <typename T> struct SsrTables {
   SsrEngine eng;
   int n_fft;
@@ -70,8 +85,11 @@ inline void ssr_host_fft_ld(std::vector<long double>& re, std::vector<long doubl
   }
 }
 
-template <typename T> bool ssr_build_tables(int n_fft, SsrTables<T>& t) {
-  t.eng = ssr_pick_engine(n_fft);
+template <typename T> bool ssr_build_tables_for(int n_fft, SsrEngine eng, SsrTables<T>& t);
+template <typename T> bool ssr_build_tables(int n_fft, SsrTables<T>& t) { return ssr_build_tables_for<T>(n_fft, ssr_pick_engine(n_fft), t); }
+
+template <typename T> bool ssr_build_tables_for(int n_fft, SsrEngine eng, SsrTables<T>& t) {
+  t.eng = eng;
   t.n_fft = n_fft;
   if (!t.eng.ok) return false;
   const int N = 1 << t.eng.logn;
@@ -89,7 +107,7 @@ template <typename T> bool ssr_build_tables(int n_fft, SsrTables<T>& t) {
     t.tw[i] = {(T)cosl(ang), (T)sinl(ang)};
   }
   if (t.eng.bluestein) {
-    // inner (Bluestein) length q: n_fft itself, or n_fft / 3 under the radix-3 outer step
+    // inner (Bluestein) length q: n_fft itself, or n_fft / R under a radix-R outer step
     const int q = t.eng.q, R = t.eng.radix;
     std::vector<long double> cr(q), ci(q);
     for (int k = 0; k < q; ++k) {

@@ -39,16 +39,20 @@ bool ssr_stft_uses_wave_engine(const ssr_plan* pl, bool in64) {
   return !in64 && !pl->eng.bluestein && pl->eng.radix == 1 && pl->eng.logn == 11;
 }
 
-bool ssr_stft_r3_uses_wave_engine(const ssr_plan* pl) {
+int ssr_stft_rn_wave_radix(const ssr_plan* pl) {
 #ifdef SSR_DEV_KNOBS
   static const int off = getenv("SSR_NO_WAVE") ? atoi(getenv("SSR_NO_WAVE")) : 0;
-  if (off) return false;
+  if (off) return 0;
 #endif
-  return pl->eng.radix == 3 && pl->eng.logn == 11 && pl->eng.q <= 768;
+  return pl->weng.ok ? pl->weng.radix : 0;
 }
 
 int ssr_pair_units_per_chunk(const ssr_plan* pl, int max_units, int n_items, bool in64) {
-  return ssr_units_per_chunk_for(max_units, n_items, ssr_stft_uses_wave_engine(pl, in64) ? 4 * ssr_target_wgs() : 0);
+  // aim for the same number of WAVES per launch whatever the workgroup size: 4096 four-wave workgroups
+  int per_wg = 4;
+  if (ssr_stft_uses_wave_engine(pl, in64)) per_wg = 1;
+  else if (!in64 && ssr_stft_rn_wave_radix(pl)) per_wg = ssr_stft_rn_wave_radix(pl) == 3 ? 4 : ssr_stft_rn_wave_radix(pl);
+  return ssr_units_per_chunk_for(max_units, n_items, per_wg < 4 ? (4 / per_wg) * ssr_target_wgs() : 0);
 }
 
 int ssr_units_per_chunk_for(int max_units, int n_items, int target_wgs) {
@@ -85,16 +89,25 @@ template <typename V> static int upload(ssr_plan* pl, const std::vector<V>& h, V
   return SSR_OK;
 }
 
-template <typename T> static int build_dev_tables(ssr_plan* pl, DevTables<T>& d) {
+template <typename T> static int build_dev_tables(ssr_plan* pl, DevTables<T>& d, DevTables<T>& dw) {
   SsrTables<T> t;
   if (!ssr_build_tables<T>(pl->n_fft, t)) return ssr_fail(SSR_ERR_UNSUPPORTED, "unsupported n_fft");
   int rc;
+  if (pl->weng.ok && pl->weng.radix != pl->eng.radix) {        // the wave engine splits differently: its own chirps and filter
+    SsrTables<T> w;
+    if (!ssr_build_tables_for<T>(pl->n_fft, pl->weng, w)) return ssr_fail(SSR_ERR_UNSUPPORTED, "unsupported n_fft");
+    if ((rc = upload(pl, w.tw, &dw.tw))) return rc;
+    if ((rc = upload(pl, w.wchirp, &dw.wchirp))) return rc;
+    if ((rc = upload(pl, w.bfilt, &dw.bfilt))) return rc;
+    if ((rc = upload(pl, w.chirp, &dw.chirp))) return rc;
+  }
   if ((rc = upload(pl, t.window, &d.window))) return rc;
   if ((rc = upload(pl, t.window_h, &d.window_h))) return rc;
   if ((rc = upload(pl, t.tw, &d.tw))) return rc;
   if ((rc = upload(pl, t.wchirp, &d.wchirp))) return rc;
   if ((rc = upload(pl, t.bfilt, &d.bfilt))) return rc;
   if ((rc = upload(pl, t.chirp, &d.chirp))) return rc;
+  if (pl->weng.ok && pl->weng.radix == pl->eng.radix) dw = d;
   return SSR_OK;
 }
 
@@ -102,6 +115,11 @@ template <typename T> int ssr_launch_stft(const ssr_plan* pl, SsrStftParams<T>& 
   const DevTables<T>& d = ssr_tables_of<T>(pl);
   p.window = d.window_h; p.tw = d.tw; p.wchirp = d.wchirp; p.bfilt = d.bfilt; p.chirp = d.chirp;
   const bool in64 = p.a64 != nullptr;
+  if (!in64 && p.mode == SSR_MODE_PAIR && ssr_stft_rn_wave_radix(pl)) {
+    const DevTables<T>& w = ssr_wave_tables_of<T>(pl);
+    p.tw = w.tw; p.wchirp = w.wchirp; p.bfilt = w.bfilt; p.chirp = w.chirp;
+    return ssr_launch_stft_rn_wave<T>(pl, p, grid, s);
+  }
   if (pl->eng.radix == 3) return in64 ? ssr_launch_stft_r3_64<T>(pl, p, grid, s) : ssr_launch_stft_r3<T>(pl, p, grid, s);
   if (p.mode != SSR_MODE_PAIR) return ssr_launch_stft_single<T>(pl, p, grid, s);
   return in64 ? ssr_launch_stft_pair64<T>(pl, p, grid, s) : ssr_launch_stft_pair<T>(pl, p, grid, s);
@@ -118,9 +136,10 @@ extern "C" int ssr_plan_create(int n_fft, int hop, int precision, ssr_plan** out
   if (!eng.ok) return ssr_fail(SSR_ERR_UNSUPPORTED, "n_fft too large: Bluestein length would exceed 8192 (n_fft <= 4096)");
   ssr_plan* pl = new ssr_plan();
   pl->n_fft = n_fft; pl->hop = hop; pl->n_bins = n_fft / 2 + 1; pl->precision = precision; pl->eng = eng;
+  pl->weng = ssr_pick_wave_engine(n_fft);
   int rc = SSR_OK;
   if (hipGetDevice(&pl->device) != hipSuccess) rc = ssr_fail(SSR_ERR_HIP, "hipGetDevice failed (no HIP device?)");
-  if (!rc) rc = (precision == SSR_F64) ? build_dev_tables<double>(pl, pl->f64) : build_dev_tables<float>(pl, pl->f32);
+  if (!rc) rc = (precision == SSR_F64) ? build_dev_tables<double>(pl, pl->f64, pl->f64w) : build_dev_tables<float>(pl, pl->f32, pl->f32w);
   if (!rc) {
     SsrTables<double> t;
     ssr_build_tables<double>(n_fft, t);

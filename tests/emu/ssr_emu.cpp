@@ -16,7 +16,7 @@
 #include "../../ssr_eval_amd/csrc/ssr_stft_r3.h"
 #include "../../ssr_eval_amd/csrc/ssr_stft_wave.h"
 #include "../../ssr_eval_amd/csrc/ssr_lowpass_wave.h"
-#include "../../ssr_eval_amd/csrc/ssr_stft_r3_wave.h"
+#include "../../ssr_eval_amd/csrc/ssr_stft_rn_wave.h"
 #include "../../ssr_eval_amd/csrc/ssr_tables.h"
 
 static std::vector<char> poisoned(size_t bytes) { return std::vector<char>(bytes + 64, (char)0xFF); }
@@ -151,14 +151,26 @@ extern "C" int emu_stft_wave(int precision, int hop, int out_kind, int mask, int
                                 n_chunks, out_a, out_b, part);
 }
 
-// radix-3 x Bluestein pair engine on three autonomous waves (ssr_stft_r3_wave.h): n_fft = 3 q, M = 2048
+// radix-R x Bluestein pair engine on R autonomous waves (ssr_stft_rn_wave.h): n_fft = R q, M = 2048, R = 1 / 2 / 3 as
+// ssr_pick_wave_engine decides
+template <typename T, int NW>
+static void emu_rn_wave_run(const SsrStftParams<T>& p, int n_items, int n_chunks, bool sums) {
+  SsrBlk blk{64 * NW};
+  for (int item = 0; item < n_items; ++item)
+    for (int c = 0; c < n_chunks; ++c) {
+      auto lds = poisoned(SsrRnWaveLds<T, NW>::bytes());
+      if (sums) ssr_stft_rn_wave_body<T, true, NW>(p, blk, c, item, lds.data());
+      else ssr_stft_rn_wave_body<T, false, NW>(p, blk, c, item, lds.data());
+    }
+}
 template <typename T>
 static int emu_stft_r3_wave_t(int n_fft, int hop, int out_kind, int mask, const float* a, const float* b, const int64_t* a_off,
                               const int64_t* b_off, const int32_t* len, const int64_t* frame_off, int n_items,
                               int units_per_chunk, int n_chunks, float* out_a, float* out_b, double* part) {
+  const SsrEngine we = ssr_pick_wave_engine(n_fft);
+  if (!we.ok) return -4;
   SsrTables<T> t;
-  if (!ssr_build_tables<T>(n_fft, t)) return -3;
-  if (t.eng.radix != 3 || t.eng.logn != 11) return -4;
+  if (!ssr_build_tables_for<T>(n_fft, we, t)) return -3;
   SsrStftParams<T> p{};
   p.a = a; p.b = b; p.a_off = a_off; p.b_off = b_off; p.len = len; p.frame_off = frame_off;
   p.mode = SSR_MODE_PAIR; p.out_kind = out_kind; p.metric_mask = mask;
@@ -167,14 +179,10 @@ static int emu_stft_r3_wave_t(int n_fft, int hop, int out_kind, int mask, const 
   p.window = t.window_h.data(); p.tw = t.tw.data();
   p.wchirp = t.wchirp.data(); p.bfilt = t.bfilt.data(); p.chirp = t.chirp.data();
   p.out_a = out_a; p.out_b = out_b; p.part = part;
-  SsrBlk blk{192};
   const bool sums = mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC);
-  for (int item = 0; item < n_items; ++item)
-    for (int c = 0; c < n_chunks; ++c) {
-      auto lds = poisoned(SsrR3WaveLds<T>::bytes());
-      if (sums) ssr_stft_r3_wave_body<T, true>(p, blk, c, item, lds.data());
-      else ssr_stft_r3_wave_body<T, false>(p, blk, c, item, lds.data());
-    }
+  if (we.radix == 1) emu_rn_wave_run<T, 1>(p, n_items, n_chunks, sums);
+  else if (we.radix == 2) emu_rn_wave_run<T, 2>(p, n_items, n_chunks, sums);
+  else emu_rn_wave_run<T, 3>(p, n_items, n_chunks, sums);
   return 0;
 }
 extern "C" int emu_stft_r3_wave(int precision, int n_fft, int hop, int out_kind, int mask, const float* a, const float* b,

@@ -69,8 +69,8 @@ def stft(sigs_a, sigs_b, n_fft, hop, precision=1, mode=0, out_kind=1, mask=0, un
     part = np.full((len(lens), n_chunks, 8), np.nan, np.float64) if mode == 0 else None
     tail = (_p(a_off, C.c_int64), _p(b_off, C.c_int64), _p(lens, C.c_int32), _p(frame_off, C.c_int64), len(lens),
             units_per_chunk, n_chunks, _p(out_a, C.c_float), _p(out_b, C.c_float), _p(part, C.c_double))
-    if wave == "r3":                # radix-3 x Bluestein on three autonomous waves (pair mode, n_fft = 3 q, M = 2048)
-        assert mode == 0 and n_fft % 3 == 0 and not est64
+    if wave == "r3":                # radix-R x Bluestein on R autonomous waves (pair mode, n_fft = R q, M = 2048; R = 1, 2, 3)
+        assert mode == 0 and not est64
         rc = lib().emu_stft_r3_wave(precision, n_fft, hop, out_kind, mask, _p(a, C.c_float), _p(b, C.c_float), *tail)
     elif wave is not None:          # wave-autonomous engine: "full" or "split" exchange (pair mode, n_fft 2048, float32 signals)
         assert mode == 0 and n_fft == 2048 and not est64

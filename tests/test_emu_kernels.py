@@ -367,17 +367,18 @@ def test_frame_whose_only_nonzero_sample_has_window_weight_zero_is_silent(n_fft,
         m, _, _ = E.stft([x], None, n_fft, hop, precision=1, mode=1, units_per_chunk=4)         # frame pairs of one signal
         assert ((m[0] == 0) == (ref == 0)).all()
         other = (0.1 * rng.standard_normal(n)).astype(np.float32)
-        for wave in ((None, "split") if n_fft == 2048 else (None, "r3") if n_fft == 2229 else (None,)):
+        for wave in ((None, "split") if n_fft == 2048 else (None, "r3")):
             me, mt, _ = E.stft([x], [other], n_fft, hop, 1, 0, 1, 15, 4, wave=wave)              # (estimate, target) pairs
             assert ((me[0] == 0) == (ref == 0)).all() and (mt[0] != 0).any(axis=1).all()
             mo, mx, _ = E.stft([other], [x], n_fft, hop, 1, 0, 1, 15, 4, wave=wave)
             assert ((mx[0] == 0) == (ref == 0)).all()
 
 
-@pytest.mark.parametrize("n_fft,hop", [(2229, 480), (2100, 500)])
-def test_radix3_wave_engine_matches_oracle_and_block_engine(n_fft, hop):
-    """ssr_stft_r3_wave.h (n_fft = 3 q over M = 2048 - AudioMetrics(48000)'s 2229 - on three autonomous waves per workgroup,
-    sub-spectra parked in the exchange arrays) against the oracle and the four-waves-per-frame radix-3 engine."""
+@pytest.mark.parametrize("n_fft,hop", [(2229, 480), (2100, 500), (1486, 320), (1114, 240), (743, 160), (1000, 250), (2048 - 2, 500)])
+def test_radix_n_wave_engine_matches_oracle_and_block_engine(n_fft, hop):
+    """ssr_stft_rn_wave.h (n_fft = R q over M = 2048 on R autonomous waves per workgroup, sub-spectra parked in the exchange
+    arrays: AudioMetrics(48000)'s 2229 = 3 * 743, (32000)'s 1486 = 2 * 743, (24000)'s 1114 = 2 * 557, (16000)'s 743, the
+    largest even size 2046 = 2 * 1023) against the oracle and the four-waves-per-frame engines."""
     rng = np.random.default_rng(n_fft)
     lens = [9000, n_fft * 3 + 77, 4000, 6000]
     tg = [(0.1 * rng.standard_normal(n)).astype(np.float32) for n in lens]

@@ -459,10 +459,27 @@ def side_figures(a, dev):
         mask = B.M_LSD | B.M_SSIM
         ms = event_time_ms(lambda: b2.run(mask), 3)
         ms_stft = event_time_ms(lambda: b2.run(mask, stages=1), 3)
-        return {"workload": "AudioMetrics(48000) sizes: n_fft 2229 (radix-3 x Bluestein-743, M = 2048, three autonomous waves per frame) / hop 480, %d pairs of 4 s @ 48 kHz, "
+        return {"workload": "AudioMetrics(48000) sizes: n_fft 2229 (radix-3 x Bluestein-743, M = 2048, three autonomous waves per frame pair) / hop 480, %d pairs of 4 s @ 48 kHz, "
                             "LSD + SSIM" % nb,
                 "pairs_per_s": round(nb / (ms * 1e-3), 1),
-                "roofline": hbm_roofline("ssr_stft_pair(k_stft_r3_wave)", (2 * N_SAMPLES * 4 + 32) * nb, ms_stft)}
+                "roofline": hbm_roofline("ssr_stft_pair(k_stft_rn_wave<3>)", (2 * N_SAMPLES * 4 + 32) * nb, ms_stft)}
+
+    def rates():
+        """Every AudioMetrics(rate) size of the reference (ssr_eval/metrics.py:16-19), 4 s signals at that rate, four metrics."""
+        out = {}
+        nb = min(a.pairs, 512)
+        for rate in (16000, 24000, 32000, 44100, 48000):
+            hop, n_fft = int(rate / 100), int(2048 / (44100 / rate))
+            g = torch.Generator(device=dev).manual_seed(rate)
+            tgt = (0.1 * torch.randn((nb, 4 * rate), generator=g, device=dev)).contiguous()
+            est = (tgt + 0.01 * torch.randn((nb, 4 * rate), generator=g, device=dev)).contiguous()
+            b2 = B.PairBatch(B.get_plan(n_fft, hop, a.precision, dev), B.Ragged.from_uniform(est), B.Ragged.from_uniform(tgt))
+            b2.run(B.M_ALL)
+            ms = event_time_ms(lambda: b2.run(B.M_ALL), 3)
+            out[str(rate)] = {"n_fft": n_fft, "hop": hop, "pairs_per_s": round(nb / (ms * 1e-3), 1)}
+            del b2, est, tgt
+            torch.cuda.empty_cache()
+        return {"workload": "%d pairs of 4 s per rate, LSD + log-SISpec + SISpec + SSIM" % nb, "rates": out}
 
     def other(cfg, steps):
         def run():
@@ -511,6 +528,7 @@ def side_figures(a, dev):
             shutil.rmtree(root, ignore_errors=True)
 
     guarded("api_true_2229_480", api_true)
+    guarded("audio_metrics_rates", rates)
     guarded("cfg3", other("cfg3", 2))
     guarded("cfg5", other("cfg5", 2))
     guarded("evaluate_end_to_end", e2e)

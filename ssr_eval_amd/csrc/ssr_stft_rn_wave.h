@@ -15,13 +15,13 @@
 #include "ssr_stft_r3.h"
 #include "ssr_stft_wave.h"
 
-// rows of 64 sub-sequence samples / sub-spectrum bins a wave handles: q <= 768 under R = 3 (n_fft <= 2304), else q <= 1024
-SSR_HD constexpr int ssr_rn_rows(int R) { return R == 3 ? 12 : 16; }
-
-template <typename T, bool SUMS, int NW> struct SsrRnWaveRegs {
+// NQ: rows of 64 sub-sequence samples / sub-spectrum bins a wave handles, in fours: 3 for q <= 768 (every AudioMetrics
+// size: 743, 557), 4 for q <= 1024.  Twelve rows instead of sixteen is eight fewer prefetch registers and eight fewer
+// conditions per phase (the sixteen-row variants spill 18-40 VGPRs).
+template <typename T, bool SUMS, int NQ> struct SsrRnWaveRegs {
   cx<T> v[SSR_W_P];
   T tx[SSR_W_P];
-  float pa[ssr_rn_rows(NW)], pb[ssr_rn_rows(NW)];   // the next unit's decimated samples m = lane + 64 i, requested a unit ahead
+  float pa[4 * NQ], pb[4 * NQ];   // the next unit's decimated samples m = lane + 64 i, requested a unit ahead
   cx<T> tw1[7];
   cx<T> tw2[12];
   double sums[SUMS ? 6 : 1];
@@ -43,13 +43,13 @@ template <typename T, int NW> struct SsrRnWaveLds {
 };
 
 // decimated samples of unit u (frame u of both signals), sub-sequence r: sample NW m + r of the frame, m = lane + 64 i
-template <typename T, int NW, typename REGS>
+template <typename T, int NW, int NQ, typename REGS>
 SSR_DEV void ssr_rn_wave_prefetch(REGS& R, int lane, int r, const SsrView<float>& va, const SsrView<float>& vb, int u, int hop,
                                   int n_fft, int q, int n, int n_frames) {
   const int t_c = (u < n_frames) ? u : n_frames - 1;
   const int base = t_c * hop - n_fft / 2;
   const bool interior = base >= 0 && base + n_fft <= n;
-  SSR_UNROLL for (int i = 0; i < ssr_rn_rows(NW); ++i) {
+  SSR_UNROLL for (int i = 0; i < 4 * NQ; ++i) {
     const int m = lane + 64 * i;
     const int mc = (m < q) ? m : q - 1;
     const int s3 = base + NW * mc + r;
@@ -70,12 +70,13 @@ template <typename T, int NW> SSR_DEV cx<T> ssr_rn_combine(const T* yre, const T
   }
 }
 
-// grid = n_items * n_chunks workgroups of 64 NW threads; PAIR mode, float32 signals, M = 2048.
-template <typename T, bool SUMS, int NW, typename BLK>
+// grid = n_items * n_chunks workgroups of 64 NW threads; PAIR mode, float32 signals, M = 2048, q = n_fft / NW <= 256 NQ.
+template <typename T, bool SUMS, int NW, int NQ, typename BLK>
 SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
   constexpr bool SPLIT = true;
-  constexpr int NT = 64 * NW, NI = ssr_rn_rows(NW), NQ = NI / 4;     // rows i = b + 4 qq, b < 4, qq < NQ
-  using Regs = SsrRnWaveRegs<T, SUMS, NW>;
+  constexpr int NT = 64 * NW, NI = 4 * NQ;                           // rows i = b + 4 qq, b < 4, qq < NQ
+  static_assert(NQ == 3 || NQ == 4, "q <= 768 or q <= 1024");
+  using Regs = SsrRnWaveRegs<T, SUMS, NQ>;
   SsrRnWaveLds<T, NW> L(lds_base);
   const int n_fft = p.n_fft, hop = p.hop, F = n_fft / 2 + 1, q = n_fft / NW;
   T* yre = L.x;                       // parked sub-spectra [NW q] re, [NW q] im: alias the exchange arrays (2113 >= 2 q)
@@ -96,7 +97,7 @@ SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
     for (int i = tid; i < 6 * 4; i += NT) L.wacc[i] = 0.0;
     if (tid == 0) L.res[0] = 0.0;
     for (int i = 0; i < (SUMS ? 6 : 1); ++i) R.sums[i] = 0.0;
-    if (u0 < u1) ssr_rn_wave_prefetch<T, NW>(R, tid & 63, ssr_wave_of(tid), va, vb, u0, hop, n_fft, q, n, n_frames);
+    if (u0 < u1) ssr_rn_wave_prefetch<T, NW, NQ>(R, tid & 63, ssr_wave_of(tid), va, vb, u0, hop, n_fft, q, n, n_frames);
   });
 
   BLK blk0 = blk;
@@ -170,7 +171,7 @@ SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
     float* ra0 = p.out_a ? p.out_a + (row0 + u) * F : nullptr;
     float* rb0 = p.out_b ? p.out_b + (row0 + u) * F : nullptr;
     SSR_PHASE(blk, regs, {
-      ssr_rn_wave_prefetch<T, NW>(R, tid & 63, ssr_wave_of(tid), va, vb, u + 1, hop, n_fft, q, n, n_frames);   // (unconditional)
+      ssr_rn_wave_prefetch<T, NW, NQ>(R, tid & 63, ssr_wave_of(tid), va, vb, u + 1, hop, n_fft, q, n, n_frames);   // (unconditional)
       SSR_SCHED_BARRIER();
       double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       const int par = ((u - u0) & 1) * 3;

@@ -153,14 +153,14 @@ extern "C" int emu_stft_wave(int precision, int hop, int out_kind, int mask, int
 
 // radix-R x Bluestein pair engine on R autonomous waves (ssr_stft_rn_wave.h): n_fft = R q, M = 2048, R = 1 / 2 / 3 as
 // ssr_pick_wave_engine decides
-template <typename T, int NW>
+template <typename T, int NW, int NQ>
 static void emu_rn_wave_run(const SsrStftParams<T>& p, int n_items, int n_chunks, bool sums) {
   SsrBlk blk{64 * NW};
   for (int item = 0; item < n_items; ++item)
     for (int c = 0; c < n_chunks; ++c) {
       auto lds = poisoned(SsrRnWaveLds<T, NW>::bytes());
-      if (sums) ssr_stft_rn_wave_body<T, true, NW>(p, blk, c, item, lds.data());
-      else ssr_stft_rn_wave_body<T, false, NW>(p, blk, c, item, lds.data());
+      if (sums) ssr_stft_rn_wave_body<T, true, NW, NQ>(p, blk, c, item, lds.data());
+      else ssr_stft_rn_wave_body<T, false, NW, NQ>(p, blk, c, item, lds.data());
     }
 }
 template <typename T>
@@ -180,9 +180,10 @@ static int emu_stft_r3_wave_t(int n_fft, int hop, int out_kind, int mask, const 
   p.wchirp = t.wchirp.data(); p.bfilt = t.bfilt.data(); p.chirp = t.chirp.data();
   p.out_a = out_a; p.out_b = out_b; p.part = part;
   const bool sums = mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC);
-  if (we.radix == 1) emu_rn_wave_run<T, 1>(p, n_items, n_chunks, sums);
-  else if (we.radix == 2) emu_rn_wave_run<T, 2>(p, n_items, n_chunks, sums);
-  else emu_rn_wave_run<T, 3>(p, n_items, n_chunks, sums);
+  const bool wide = we.q > 768;
+  if (we.radix == 1) { if (wide) emu_rn_wave_run<T, 1, 4>(p, n_items, n_chunks, sums); else emu_rn_wave_run<T, 1, 3>(p, n_items, n_chunks, sums); }
+  else if (we.radix == 2) { if (wide) emu_rn_wave_run<T, 2, 4>(p, n_items, n_chunks, sums); else emu_rn_wave_run<T, 2, 3>(p, n_items, n_chunks, sums); }
+  else emu_rn_wave_run<T, 3, 3>(p, n_items, n_chunks, sums);
   return 0;
 }
 extern "C" int emu_stft_r3_wave(int precision, int n_fft, int hop, int out_kind, int mask, const float* a, const float* b,

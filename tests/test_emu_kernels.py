@@ -113,6 +113,11 @@ def test_lowpass_wave_engine_frames_and_paired_segments(hop):
             assert np.isfinite(v).all()
             np.testing.assert_allclose(b, w, atol=atol)
             np.testing.assert_allclose(v, w, atol=atol)
+    if hop == 441:                                             # the float32-transform instantiations of the same bodies
+        for wave in ("split", "paired"):
+            got32 = E.lowpass(sigs, cuts, hop=hop, precision=0, pairs_per_chunk=3, wave=wave)
+            for w, v in zip(want, got32):
+                np.testing.assert_allclose(v, w, atol=2e-5)
     # ISTFT mode on given spectra
     re, im = ostft.tl_stft(sigs[0][None], n_fft=2048, hop=hop)
     ref = E.istft([re[0, 0]], [im[0, 0]], [len(sigs[0])], hop=hop)[0]
@@ -398,3 +403,7 @@ def test_radix_n_wave_engine_matches_oracle_and_block_engine(n_fft, hop):
         np.testing.assert_allclose(g, b, rtol=1e-7)
     lsd_only = E.pair_metrics(es, tg, n_fft, hop, 1, mask=E.M_LSD | E.M_SSIM, wave="r3", units_per_chunk=5)
     np.testing.assert_allclose(lsd_only[:, [0, 3]], got[:, [0, 3]], rtol=1e-12)
+    if n_fft in (1486, 743):                                   # the float32-transform instantiation: magnitudes to float32 accuracy
+        m32, _, _ = E.stft(es[:1], tg[:1], n_fft, hop, 0, 0, 1, 15, 3, wave="r3")
+        ref = ostft.stft_mag_TF(es[0], n_fft, hop)
+        assert np.abs(m32[0] - ref).max() <= 2e-4 * ref.max()

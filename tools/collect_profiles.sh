@@ -19,6 +19,10 @@ if [ "${PMC:-0}" = "1" ]; then
   for P in FETCH_SIZE WRITE_SIZE; do
     rm -rf $OUT/pmc_$P
     timeout 400 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pmc_$P -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-side > $OUT/pmc_$P.log 2>&1; echo "$P rc=$?"
+    for C in ${PMC_CFGS:-}; do          # the same two passes for further configs (their own kernels: low-pass, resampler)
+      rm -rf $OUT/pmc_${P}_$C
+      timeout 400 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pmc_${P}_$C -o p -- python $R/bench.py --config $C --steps 2 --warmup 1 --no-cpu-baseline --no-side > $OUT/pmc_${P}_$C.log 2>&1; echo "$P $C rc=$?"
+    done
   done
 fi
 find $OUT -name "*kernel_stats.csv" | head

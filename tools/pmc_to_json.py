@@ -23,19 +23,21 @@ for stats in sorted(glob.glob(src + "/stats_*/*kernel_stats.csv")):
     if os.path.exists(bj) and os.path.getsize(bj):
         summary.setdefault("bench_line_under_rocprof", {})[cfg] = json.load(open(bj))
 KEYS = ("k_stft_wave<double, false", "k_stft_wave<double, true", "k_ssim", "k_stft<double, 11")
+MORE = {"cfg3": ("k_lowpass_wave", "k_ola_paired", "k_ola("), "cfg5": ("k_resample",)}     # kernels only these configs run
 pm = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(src + "/pmc_%s/*counter_collection.csv" % c)
-    if not f:
-        continue
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f[0])):
-        for k in KEYS:
-            if k in r["Kernel_Name"] and r["Counter_Name"] == c:
-                agg[k].append(float(r["Counter_Value"]))
-    for k, v in agg.items():
-        v = sorted(v)
-        pm.setdefault(k, {})[c] = v[len(v) // 2]
+    for sub, keys in [("", KEYS)] + [("_" + cfg, ks) for cfg, ks in MORE.items()]:
+        f = glob.glob(src + "/pmc_%s%s/*counter_collection.csv" % (c, sub))
+        if not f:
+            continue
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f[0])):
+            for k in keys:
+                if k in r["Kernel_Name"] and r["Counter_Name"] == c:
+                    agg[k].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            v = sorted(v)
+            pm.setdefault(k, {})[c] = v[len(v) // 2]
 summary["pmc_kb_per_launch"] = pm
 # gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reads exactly 1/2 of a coalesced streaming read: x2.
 # WRITE_SIZE is taken as reported (it matches the 3.16 GB of magnitudes the STFT kernel is known to write).  Both in KiB.

@@ -65,15 +65,20 @@ def event_time_ms(fn, iters):
 
 
 def pmc_traffic(kernel_key):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/rNN_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, corrected per MI355X_MICROARCH.md)."""
+    """HBM bytes per launch of a kernel (or of several: keys joined by "+", summed) from the committed rocprofv3 PMC passes
+    of this same command (profiles/rNN_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, corrected per
+    MI355X_MICROARCH.md)."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
         try:
             d = json.load(open(f))["traffic_bytes_per_launch"]
-            for k, v in d.items():
-                if kernel_key in k:
-                    return v["total_bytes"], os.path.basename(f)
+            total = 0.0
+            for key in kernel_key.split("+"):
+                hit = [v["total_bytes"] for k, v in d.items() if key in k]
+                if not hit:
+                    raise KeyError(key)
+                total += hit[0]
+            return total, os.path.basename(f)
         except Exception:
             continue
     return None, None
@@ -213,8 +218,9 @@ class Cfg3:
         stages = {"fft_lowpass": (ms_lp, 2 * N_SAMPLES * 4 * n), "stft+lsd+sispec": (ms_stft, (2 * N_SAMPLES * 4 + 32) * n),
                   "ssim": (ms_ssim, (2 * N_SAMPLES * 4 + 32) * n)}
         dom = max(stages, key=lambda k: stages[k][0])
-        roof = hbm_roofline("ssr_pair_metrics:" + dom if dom != "fft_lowpass" else "ssr_fft_lowpass(k_lowpass_frames+k_ola)",
-                            stages[dom][1], stages[dom][0], None,
+        tkey = {"fft_lowpass": "k_lowpass_wave+k_ola_paired", "stft+lsd+sispec": "k_stft_wave<double, true", "ssim": "k_ssim"}[dom]
+        roof = hbm_roofline("ssr_pair_metrics:" + dom if dom != "fft_lowpass" else "ssr_fft_lowpass(k_lowpass_wave+k_ola_paired)",
+                            stages[dom][1], stages[dom][0], tkey if a.pairs == 1024 and a.precision == "f64" else None,
                             "per cutoff and 1024 utterances; algorithmic bytes: low-pass 2*n*4 per (utterance, cutoff), pair metrics "
                             "2*n*4+32 per pair (SURVEY 8(d))")
         extra = {"stage_ms_per_cutoff": {k: round(v[0], 4) for k, v in stages.items()},

@@ -309,3 +309,44 @@ def test_cabi_allreduce_sums_single_rank_communicator():
     assert torch.equal(buf.cpu(), want)
     assert lib.ssr_allreduce_sums(buf.data_ptr(), 0, comm, None) == 0
     _lib.check(lib.ssr_comm_destroy(comm))
+
+
+def test_full_size_properties_of_the_path():
+    """Size-independent properties at BASELINE's full sizes (4 s @ 48 kHz; 512 / 1024 items per launch), where the oracle is
+    too slow to cover every item: STFT -> ISTFT round trip and the low-pass with a cut beyond Nyquist are the identity,
+    scaling by a power of two commutes with the low-pass bit for bit, a pair's metrics do not depend on where it sits in
+    the batch, LSD(c t, t) = 2 |log10 c|, SISpec ignores the target's scale, SSIM(x, x) = 1."""
+    from ssr_eval_amd import backend as B
+    dev = torch.device("cuda", 0)
+    n, n_s = 512, 192000
+    g = torch.Generator(device=dev).manual_seed(99)
+    x = (0.1 * torch.randn((n, n_s), generator=g, device=dev)).contiguous()
+    # FDomainHelper sizes (2048 / 441): forward complex STFT, inverse STFT (the paired-segment overlap-add at full scale)
+    plan_fd = B.get_plan(2048, 441, "f64", dev)
+    sub = [x[i] for i in range(0, n, 4)]                              # 128 items: 0.9 GB of spectra
+    re, im = B.stft(plan_fd, sub, kind="complex", torch_style_pad=True)
+    back = B.istft(plan_fd, re, im, [n_s] * len(sub))
+    worst = max(float((b - s).abs().max()) for b, s in zip(back, sub))
+    assert worst <= 2e-6, worst
+    del re, im, back
+    rag = B.Ragged.from_uniform(x)
+    ident = B.LowpassBatch(plan_fd, rag, [1025] * n).run().clone()
+    assert float((ident - x.view(-1)).abs().max()) <= 2e-6
+    lp = B.LowpassBatch(plan_fd, rag, [256] * n).run().clone()
+    half = B.LowpassBatch(plan_fd, B.Ragged.from_uniform((0.5 * x).contiguous()), [256] * n).run()
+    assert torch.equal(half, 0.5 * lp)                                 # exact: a power of two scales every intermediate
+    assert float(lp.abs().max()) > 0.01 and float((lp - x.view(-1)).abs().max()) > 0.01
+    # pair metrics (2048 / 512): position independence, closed forms
+    plan = B.get_plan(2048, 512, "f64", dev)
+    est = lp.view(n, n_s)
+    fwd = B.PairBatch(plan, B.Ragged.from_uniform(est), rag).run(B.M_ALL).clone()
+    rev = B.PairBatch(plan, B.Ragged.from_uniform(est.flip(0).contiguous()), B.Ragged.from_uniform(x.flip(0).contiguous())).run(B.M_ALL)
+    assert torch.equal(fwd, rev.flip(0))
+    scaled = B.PairBatch(plan, B.Ragged.from_uniform((0.25 * x).contiguous()), rag).run(B.M_ALL).cpu().numpy()
+    np.testing.assert_allclose(scaled[:, 0], 2 * abs(np.log10(0.25)), rtol=1e-6)          # LSD(c t, t)
+    assert (scaled[:, 2] > 100).all()                                 # est = c t: SISpec is round-off defined, but huge
+    tgt2 = B.PairBatch(plan, B.Ragged.from_uniform(est), B.Ragged.from_uniform((3.0 * x).contiguous())).run(B.M_SISPEC).cpu().numpy()
+    np.testing.assert_allclose(tgt2[:, 2], fwd[:, 2].cpu().numpy(), rtol=2e-6)            # target scale does not matter
+    same = B.PairBatch(plan, rag, rag).run(B.M_SSIM | B.M_LSD).cpu().numpy()
+    # (the two SSIM ratios are float32: 1 - 3e-8; LSD's 1e-12 guards leave ~1e-12 where a frame holds a tiny bin)
+    assert (np.abs(same[:, 3] - 1.0) <= 1e-7).all() and (same[:, 0] <= 1e-9).all()

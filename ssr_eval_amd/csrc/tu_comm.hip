@@ -4,6 +4,8 @@
 // link-time dependency on it and loads on a box without RCCL.
 #include <dlfcn.h>
 
+#include <mutex>
+
 #include "ssr_host.h"
 
 namespace {
@@ -20,8 +22,9 @@ struct Rccl {
 };
 int rccl(Rccl** out) {
   static Rccl r;
-  static int state = 0;                                       // 0 untried, 1 ok, -1 unavailable
-  if (state == 0) {
+  static bool ok = false;
+  static std::once_flag once;                                 // entry points may be called from several host threads
+  std::call_once(once, [] {
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
       if (!r.h) r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     if (r.h) {
@@ -31,9 +34,9 @@ int rccl(Rccl** out) {
       r.allreduce = (fn_allreduce)dlsym(r.h, "ncclAllReduce");
       r.errstr = (fn_errstr)dlsym(r.h, "ncclGetErrorString");
     }
-    state = (r.h && r.get_uid && r.init_rank && r.destroy && r.allreduce) ? 1 : -1;
-  }
-  if (state < 0) return ssr_fail(SSR_ERR_UNSUPPORTED, "RCCL (librccl.so) could not be loaded");
+    ok = r.h && r.get_uid && r.init_rank && r.destroy && r.allreduce;
+  });
+  if (!ok) return ssr_fail(SSR_ERR_UNSUPPORTED, "RCCL (librccl.so) could not be loaded");
   *out = &r;
   return SSR_OK;
 }

@@ -38,14 +38,16 @@ struct SsrSsimParams {
   int F;
   int rows_per_tile, n_row_tiles, n_strips;
   double* part;              // [n_items, n_row_tiles * n_strips] sum of S over the tile
+  int pitch;                 // floats between rows (0: F).  A multiple of 4 on a 16-byte-aligned base selects CONTIG.
 };
+SSR_DEV int ssr_ssim_pitch(const SsrSsimParams& p) { return p.pitch ? p.pitch : p.F; }
 
 // Only four window sums are needed: S depends on vx and vy through vx + vy alone, so x^2 and y^2 are
 // accumulated together:  q0 = sum x, q1 = sum y, q2 = sum (x^2 + y^2), q3 = sum x*y.
 template <int CPT> struct SsrSsimRegs {
   double cs[CPT + 1][4];  // running 7-row sums for the thread's (strided) input columns tid + NT*i
   double s;               // sum of S over the thread's outputs
-  float px[4][CPT + 1];   // row values in flight: entering row (x, y), leaving row (x, y) - loaded one row step ahead
+  float px[2][4][CPT + 1];   // row values in flight, two row steps deep: [step parity][entering x, y, leaving x, y][column slot]
 };
 
 // Column-sum index in LDS.  The horizontal pass reads with a lane stride of CPT doubles; for even CPT that is a
@@ -73,6 +75,7 @@ struct SsrImage {
   const float* base;
   SSR_MEMBER SsrImage(const float* p, int64_t) : base(p) {}
   SSR_MEMBER float at(int64_t row_elems, unsigned col) const { return base[row_elems + col]; }
+  SSR_MEMBER void at4(int64_t row_elems, unsigned col, float* o) const { memcpy(o, base + row_elems + col, 16); }
 #else
   __amdgpu_buffer_rsrc_t rsrc;
   SSR_MEMBER SsrImage(const float* p, int64_t n_elems)
@@ -80,44 +83,79 @@ struct SsrImage {
   SSR_MEMBER float at(int64_t row_elems, unsigned col) const {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(col * 4u), (int)(row_elems * 4), 0));
   }
+  // four consecutive pixels, (row_elems + col) a multiple of 4 on a 16-byte-aligned image: one aligned 16-byte load
+  SSR_MEMBER void at4(int64_t row_elems, unsigned col, float* o) const {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(col * 4u), (int)(row_elems * 4), 0));
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
 #endif
 };
+
+// Which input column of the strip a thread's register slot i holds.  Strided (the general kernel): tid + NT i - every load
+// instruction reads 64 consecutive pixels.  CONTIG (CPT = 4, rows 16-byte aligned): slots 0..3 are the thread's own four
+// consecutive columns 4 tid .. 4 tid + 3 (ONE 16-byte load per image row; the wave reads 1 KB contiguous) and slot 4 is one of
+// the strip's six extra columns, 256 + tid.  The thread's outputs are columns 4 tid .. 4 tid + 3 either way; under CONTIG
+// their window sums take the first four column sums from the thread's own registers and only six from LDS.
+template <int CPT, bool CONTIG> SSR_DEV int ssr_ssim_col(int tid, int i) {
+  if constexpr (CONTIG) return (i < CPT) ? CPT * tid + i : SSR_SSIM_NT * CPT + tid;
+  else return tid + SSR_SSIM_NT * i;
+}
 
 // Row step, split in two so that the loads of the NEXT step are in flight while the current one is consumed:
 // ssr_ssim_row_load issues the loads of the row entering the 7-row window (row_add) and of the row leaving
 // it (row_sub; re-reads row_add when there is none) with clamped, always valid column indices;
 // ssr_ssim_row_apply folds the loaded values into the thread's running column sums.
-template <int CPT>
+template <int CPT, bool CONTIG, int SET>
 SSR_DEV void ssr_ssim_row_load(const SsrSsimParams& p, SsrSsimRegs<CPT>& R, int tid, const SsrImage& x, const SsrImage& y,
                                int row_add, int row_sub, int c_in0, int ncol_in) {
   constexpr int VC = CPT + 1;
   const bool sub = row_sub >= 0;
-  const int64_t ea = (int64_t)row_add * p.F + c_in0;                       // block-uniform element offsets of the rows
-  const int64_t es = (int64_t)(sub ? row_sub : row_add) * p.F + c_in0;
+  const int pitch = ssr_ssim_pitch(p);
+  const int64_t ea = (int64_t)row_add * pitch + c_in0;                     // block-uniform element offsets of the rows
+  const int64_t es = (int64_t)(sub ? row_sub : row_add) * pitch + c_in0;
+  if constexpr (CONTIG) {
+    static_assert(!CONTIG || CPT == 4, "four consecutive columns per thread");
+    // (a quad past the strip's last column - narrow last strip - is clamped to the last aligned quad: never used, see apply)
+    const int last4 = (ncol_in - 1) & ~3;
+    const unsigned c4 = (unsigned)((4 * tid < last4) ? 4 * tid : last4);
+    float q[4][4];
+    x.at4(ea, c4, q[0]); y.at4(ea, c4, q[1]); x.at4(es, c4, q[2]); y.at4(es, c4, q[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) R.px[SET][k][i] = q[k][i];
+    int ce = SSR_SSIM_NT * CPT + tid;
+    if (ce >= ncol_in) ce = ncol_in - 1;
+    R.px[SET][0][4] = x.at(ea, (unsigned)ce); R.px[SET][1][4] = y.at(ea, (unsigned)ce);
+    R.px[SET][2][4] = x.at(es, (unsigned)ce); R.px[SET][3][4] = y.at(es, (unsigned)ce);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < VC; ++i) {
     int c = tid + SSR_SSIM_NT * i;
     if (c >= ncol_in) c = ncol_in - 1;
     const unsigned uc = (unsigned)c;
-    R.px[0][i] = x.at(ea, uc);
-    R.px[1][i] = y.at(ea, uc);
-    R.px[2][i] = x.at(es, uc);
-    R.px[3][i] = y.at(es, uc);
+    R.px[SET][0][i] = x.at(ea, uc);
+    R.px[SET][1][i] = y.at(ea, uc);
+    R.px[SET][2][i] = x.at(es, uc);
+    R.px[SET][3][i] = y.at(es, uc);
   }
 }
 
-template <int CPT>
+template <int CPT, bool CONTIG, int SET>
 SSR_DEV void ssr_ssim_row_apply(SsrSsimRegs<CPT>& R, int tid, bool sub, int ncol_in) {
   constexpr int VC = CPT + 1;
 #pragma unroll
   for (int i = 0; i < VC; ++i) {
-    if (tid + SSR_SSIM_NT * i < ncol_in) {
-      const double a = (double)R.px[0][i], b = (double)R.px[1][i];
-      const double c = sub ? (double)R.px[2][i] : 0.0, d = sub ? (double)R.px[3][i] : 0.0;
-      R.cs[i][0] += a - c;
-      R.cs[i][1] += b - d;
-      R.cs[i][2] += (a * a + b * b) - (c * c + d * d);
-      R.cs[i][3] += a * b - c * d;
+    if (ssr_ssim_col<CPT, CONTIG>(tid, i) < ncol_in) {
+      const double a = (double)R.px[SET][0][i], b = (double)R.px[SET][1][i];
+      const double c = sub ? (double)R.px[SET][2][i] : 0.0, d = sub ? (double)R.px[SET][3][i] : 0.0;
+      // every product goes into its running sum with one fused multiply-add (10 operations per column instead of 13)
+      R.cs[i][0] = (R.cs[i][0] + a) - c;
+      R.cs[i][1] = (R.cs[i][1] + b) - d;
+      R.cs[i][2] = fma(-d, d, fma(-c, c, fma(b, b, fma(a, a, R.cs[i][2]))));
+      R.cs[i][3] = fma(-c, d, fma(a, b, R.cs[i][3]));
     }
   }
 }
@@ -136,25 +174,21 @@ SSR_DEV double ssr_ssim_value(double sx, double sy, double sq, double sxy) {
   const double a2 = (2.0 * cov) * (n * sxy - pxy) + C2n;
   const double b1 = pp + C1n;
   const double b2 = cov * (n * sq - pp) + C2n;
-  // The two ratios are O(1) (|a1/b1| <= 1, |a2/b2| <= 1) and carry no cancellation any more, so they are
-  // formed in float32 with the hardware reciprocal (v_rcp_f32, 1 ulp): ~2e-7 per pixel, unbiased, against a 1e-5 bar
-  // on the MEAN of ~4e5 pixels (measured on the test vectors: < 2e-7 on the mean; k_ssim -8 % against two IEEE
-  // divisions).  All moment arithmetic above (where the cancellation lives) stays in float64.
+  // The ratio (a1 a2) / (b1 b2) is O(1) and carries no cancellation any more, so it is formed in float32 with the hardware
+  // reciprocal (v_rcp_f32, 1 ulp): ~2e-7 per pixel, unbiased, against a 1e-5 bar on the MEAN of ~4e5 pixels (measured on the
+  // test vectors: < 2e-7 on the mean).  All moment arithmetic above (where the cancellation lives) stays in float64.
 #ifndef SSR_HOST_EMU
-  const float q1 = (float)a1 * __builtin_amdgcn_rcpf((float)b1);
-  const float q2 = (float)a2 * __builtin_amdgcn_rcpf((float)b2);
+  return (double)((float)(a1 * a2) * __builtin_amdgcn_rcpf((float)(b1 * b2)));       // one reciprocal for both ratios
 #else
-  const float q1 = (float)a1 / (float)b1;
-  const float q2 = (float)a2 / (float)b2;
+  return (double)((float)(a1 * a2) / (float)(b1 * b2));
 #endif
-  return (double)(q1 * q2);
 }
 
 // grid = (n_row_tiles * n_strips, n_items); block = SSR_SSIM_NT.
 // Vertical pass: thread owns STRIDED input columns (coalesced loads, running 7-row sums in registers) and
 // publishes the four column sums through LDS.  Horizontal pass: thread owns CPT CONTIGUOUS outputs, reads
 // CPT+6 column sums per quantity once and slides the 7-wide window across them.
-template <int CPT, typename BLK>
+template <int CPT, bool CONTIG, typename BLK>
 SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item, char* lds_base) {
   constexpr int NT = SSR_SSIM_NT, PW = SsrSsimLds<CPT>::PW, VC = CPT + 1, W = SSR_SSIM_WIN;
   using Regs = SsrSsimRegs<CPT>;
@@ -168,59 +202,76 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
   const int ncol_in = (p.F - c_in0 < NT * CPT + (W - 1)) ? p.F - c_in0 : NT * CPT + (W - 1);
   const int ncol_out = ncol_in - (W - 1);
   double* part = p.part + (int64_t)item * p.n_row_tiles * p.n_strips + tile;
-  const SsrImage x(p.x + p.frame_off[item] * p.F, (int64_t)T * p.F);
-  const SsrImage y(p.y + p.frame_off[item] * p.F, (int64_t)T * p.F);
+  const int pitch = ssr_ssim_pitch(p);
+  const SsrImage x(p.x + p.frame_off[item] * pitch, (int64_t)T * pitch);
+  const SsrImage y(p.y + p.frame_off[item] * pitch, (int64_t)T * pitch);
 
   SSR_REGS(Regs, regs, blk);
   if (r0 >= r1 || ncol_out <= 0) {
     SSR_PHASE(blk, regs, if (tid == 0) *part = 0.0);
     return;
   }
-  // warm-up: rows r0 .. r0+5
+  // Row steps s = 0 .. n_steps-1: step s adds row r0 + s to the running 7-row column sums and (s >= 7) subtracts row
+  // r0 + s - 7; from s = 6 on the sums are those of output row r0 + s - 6.  The rows of step s + 2 are requested as soon as
+  // step s has consumed its own (two steps in flight: one was not enough to cover the load latency - each wave sat idle
+  // ~80 % of its life, and neither fewer LDS bytes nor fewer instructions moved the kernel).
+  const int n_steps = (W - 1) + (r1 - r0);
+#if defined(SSR_DEV_KNOBS) && defined(SSR_ABL_SSIM)   // timing-only ablations (wrong results): 1 no ssim_value, 2 no LDS, 4 no row loads
+#define SSR_SABL(bit) ((SSR_ABL_SSIM) & (bit))
+#else
+#define SSR_SABL(bit) 0
+#endif
+#define SSR_SSIM_STEP(s_, SET)                                                                                               \
+  SSR_PHASE(blk, regs, {                                                                                                    \
+    ssr_ssim_row_apply<CPT, CONTIG, SET>(R, tid, (s_) >= W, ncol_in);                                                        \
+    if ((s_) + 2 < n_steps && !SSR_SABL(4))                                                                                 \
+      ssr_ssim_row_load<CPT, CONTIG, SET>(p, R, tid, x, y, r0 + (s_) + 2, ((s_) + 2 >= W) ? r0 + (s_) + 2 - W : -1, c_in0, ncol_in); \
+    if ((s_) >= W - 1 && !SSR_SABL(2)) {                                                                                    \
+      for (int i = 0; i < VC; ++i) {                                                                                        \
+        const int c = ssr_ssim_col<CPT, CONTIG>(tid, i);                                                                    \
+        if (c < ncol_in)                                                                                                    \
+          for (int q = 0; q < 4; ++q) L.col[q * PW + ssr_ssim_slot<CPT>(c)] = R.cs[i][q];                                    \
+      }                                                                                                                     \
+    }                                                                                                                       \
+  });                                                                                                                       \
+  if ((s_) >= W - 1) {                                                                                                      \
+    SSR_PHASE(blk, regs, {                                                                                                  \
+      const int j0 = tid * CPT;                                                                                             \
+      if (j0 < ncol_out) {                                                                                                  \
+        double w[4][CPT];                            /* window sums, one quantity at a time (register pressure) */          \
+        for (int q = 0; q < 4; ++q) {                                                                                       \
+          double v[CPT + W - 1];                                                                                            \
+          for (int d = 0; d < CPT + W - 1; ++d) {                                                                           \
+            int c = j0 + d;                                                                                                 \
+            if (c >= ncol_in) c = ncol_in - 1;      /* only feeds outputs that are masked below */                          \
+            if ((CONTIG && d < CPT) || SSR_SABL(2)) v[d] = R.cs[d % VC][q];   /* the thread's own columns: already in its registers */ \
+            else v[d] = L.col[q * PW + ssr_ssim_slot<CPT>(c)];                                                              \
+          }                                                                                                                 \
+          double sw = v[0];                                                                                                 \
+          for (int d = 1; d < W; ++d) sw += v[d];                                                                           \
+          w[q][0] = sw;                                                                                                     \
+          for (int i = 1; i < CPT; ++i) {                                                                                   \
+            sw += v[i + W - 1] - v[i - 1];                                                                                  \
+            w[q][i] = sw;                                                                                                   \
+          }                                                                                                                 \
+        }                                                                                                                   \
+        for (int i = 0; i < CPT; ++i)                                                                                       \
+          if (j0 + i < ncol_out) R.s += SSR_SABL(1) ? w[0][i] + w[1][i] + w[2][i] + w[3][i] : ssr_ssim_value(w[0][i], w[1][i], w[2][i], w[3][i]); \
+      }                                                                                                                     \
+    });                                                                                                                     \
+  }
   SSR_PHASE(blk, regs, {
     for (int i = 0; i < VC; ++i)
       for (int q = 0; q < 4; ++q) R.cs[i][q] = 0.0;
     R.s = 0.0;
-    for (int rr = r0; rr < r0 + W - 1; ++rr) {
-      ssr_ssim_row_load<CPT>(p, R, tid, x, y, rr, -1, c_in0, ncol_in);
-      ssr_ssim_row_apply<CPT>(R, tid, false, ncol_in);
-    }
-    ssr_ssim_row_load<CPT>(p, R, tid, x, y, r0 + W - 1, -1, c_in0, ncol_in);   // first step of the row loop
+    ssr_ssim_row_load<CPT, CONTIG, 0>(p, R, tid, x, y, r0, -1, c_in0, ncol_in);
+    if (n_steps > 1) ssr_ssim_row_load<CPT, CONTIG, 1>(p, R, tid, x, y, r0 + 1, -1, c_in0, ncol_in);
   });
-  for (int r = r0; r < r1; ++r) {
-    SSR_PHASE(blk, regs, {
-      ssr_ssim_row_apply<CPT>(R, tid, r > r0, ncol_in);
-      if (r + 1 < r1) ssr_ssim_row_load<CPT>(p, R, tid, x, y, r + W, r, c_in0, ncol_in);   // next step, one row ahead
-      for (int i = 0; i < VC; ++i) {
-        const int c = tid + NT * i;
-        if (c < ncol_in)
-          for (int q = 0; q < 4; ++q) L.col[q * PW + ssr_ssim_slot<CPT>(c)] = R.cs[i][q];
-      }
-    });
-    SSR_PHASE(blk, regs, {
-      const int j0 = tid * CPT;
-      if (j0 < ncol_out) {
-        double w[4][CPT];                            // window sums, one quantity at a time (register pressure)
-        for (int q = 0; q < 4; ++q) {
-          double v[CPT + W - 1];
-          for (int d = 0; d < CPT + W - 1; ++d) {
-            int c = j0 + d;
-            if (c >= ncol_in) c = ncol_in - 1;      // only feeds outputs that are masked below
-            v[d] = L.col[q * PW + ssr_ssim_slot<CPT>(c)];
-          }
-          double s = v[0];
-          for (int d = 1; d < W; ++d) s += v[d];
-          w[q][0] = s;
-          for (int i = 1; i < CPT; ++i) {
-            s += v[i + W - 1] - v[i - 1];
-            w[q][i] = s;
-          }
-        }
-        for (int i = 0; i < CPT; ++i)
-          if (j0 + i < ncol_out) R.s += ssr_ssim_value(w[0][i], w[1][i], w[2][i], w[3][i]);
-      }
-    });
+  for (int s0 = 0; s0 < n_steps; s0 += 2) {
+    SSR_SSIM_STEP(s0, 0)
+    if (s0 + 1 < n_steps) { SSR_SSIM_STEP(s0 + 1, 1) }
   }
+#undef SSR_SSIM_STEP
 #define SSR_GET_S(q) R.s
   SSR_BLOCK_SUM(blk, regs, NT, 1, L.sc0, L.sc1, L.res, SSR_GET_S);
 #undef SSR_GET_S

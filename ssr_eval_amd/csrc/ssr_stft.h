@@ -65,6 +65,8 @@ template <typename T> struct SsrStftParams {
   const cx<T>* chirp;        // [n_fft]  0.5 * exp(-i*pi*k^2/n_fft)
   float* out_a;              // PAIR: est magnitudes [frames, F]; SINGLE: mag or re
   float* out_b;              // PAIR: target magnitudes;          SINGLE: im (COMPLEX) or unused
+  int out_pitch;             // floats between output rows (0: F).  The pair pipeline pads its magnitude rows to a multiple of 4
+                             // so that k_ssim reads them with aligned 16-byte loads (ssr_metrics.h, CONTIG)
   double* part;              // [n_items, n_chunks, SSR_NPART] or null
 };
 
@@ -584,10 +586,11 @@ SSR_BODY void ssr_stft_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int 
     }
 
     // ---- epilogue: separate the two spectra, emit, accumulate; leave per-wave LSD sums in sc1.
-    float* ra0 = p.out_a ? p.out_a + (row0 + ta) * F : nullptr;   // block-uniform row pointers
-    float* ra1 = p.out_a ? p.out_a + (row0 + tb) * F : nullptr;
-    float* rb0 = p.out_b ? p.out_b + (row0 + ta) * F : nullptr;
-    float* rb1 = p.out_b ? p.out_b + (row0 + tb) * F : nullptr;
+    const int64_t OP = p.out_pitch ? p.out_pitch : F;      // floats between output rows
+    float* ra0 = p.out_a ? p.out_a + (row0 + ta) * OP : nullptr;   // block-uniform row pointers
+    float* ra1 = p.out_a ? p.out_a + (row0 + tb) * OP : nullptr;
+    float* rb0 = p.out_b ? p.out_b + (row0 + ta) * OP : nullptr;
+    float* rb1 = p.out_b ? p.out_b + (row0 + tb) * OP : nullptr;
     if (MODE == SSR_MODE_PAIR) { ra1 = ra0; rb1 = rb0; }
     SSR_PHASE(blk, regs, {
       if constexpr (!BLUESTEIN)

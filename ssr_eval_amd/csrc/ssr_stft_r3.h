@@ -143,10 +143,11 @@ SSR_BODY void ssr_stft_r3_body(const SsrStftParams<T>& p, BLK& blk, int chunk, i
       });
     }
 
-    float* ra0 = p.out_a ? p.out_a + (row0 + ta) * F : nullptr;
-    float* ra1 = p.out_a ? p.out_a + (row0 + tb) * F : nullptr;
-    float* rb0 = p.out_b ? p.out_b + (row0 + ta) * F : nullptr;
-    float* rb1 = p.out_b ? p.out_b + (row0 + tb) * F : nullptr;
+    const int64_t OP = p.out_pitch ? p.out_pitch : F;      // floats between output rows
+    float* ra0 = p.out_a ? p.out_a + (row0 + ta) * OP : nullptr;
+    float* ra1 = p.out_a ? p.out_a + (row0 + tb) * OP : nullptr;
+    float* rb0 = p.out_b ? p.out_b + (row0 + ta) * OP : nullptr;
+    float* rb1 = p.out_b ? p.out_b + (row0 + tb) * OP : nullptr;
     if (MODE == SSR_MODE_PAIR) { ra1 = ra0; rb1 = rb0; }
     SSR_PHASE(blk, regs, {
       double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};

@@ -168,8 +168,9 @@ SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
     });
     // ---- epilogue: X[K] and X[n - K] from the parked thirds, separate, emit, accumulate
     blk = blk0; ssr_launder(blk);
-    float* ra0 = p.out_a ? p.out_a + (row0 + u) * F : nullptr;
-    float* rb0 = p.out_b ? p.out_b + (row0 + u) * F : nullptr;
+    const int64_t OP = p.out_pitch ? p.out_pitch : F;      // floats between output rows
+    float* ra0 = p.out_a ? p.out_a + (row0 + u) * OP : nullptr;
+    float* rb0 = p.out_b ? p.out_b + (row0 + u) * OP : nullptr;
     SSR_PHASE(blk, regs, {
       ssr_rn_wave_prefetch<T, NW, NQ>(R, tid & 63, ssr_wave_of(tid), va, vb, u + 1, hop, n_fft, q, n, n_frames);   // (unconditional)
       SSR_SCHED_BARRIER();

@@ -298,8 +298,9 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
 
     // ---- epilogue: four groups of four bins (partner values in, magnitudes out per group: few registers live at once)
     blk = blk0; ssr_launder(blk);
-    float* ra0 = p.out_a ? p.out_a + (row0 + u) * F : nullptr;   // wave-uniform row pointers
-    float* rb0 = p.out_b ? p.out_b + (row0 + u) * F : nullptr;
+    const int64_t OP = p.out_pitch ? p.out_pitch : F;      // floats between output rows
+    float* ra0 = p.out_a ? p.out_a + (row0 + u) * OP : nullptr;   // wave-uniform row pointers
+    float* rb0 = p.out_b ? p.out_b + (row0 + u) * OP : nullptr;
     SSR_WPHASE(blk, regs, {
       // UNCONDITIONAL (the last frame of a chunk re-requests a clamped, valid frame that nobody consumes): under a condition
       // the previous contents of the 64 + 32 registers would stay live through all three passes for the path not taken

@@ -6,13 +6,16 @@
 #ifndef SSR_SSIM_WAVES_PER_EU
 #define SSR_SSIM_WAVES_PER_EU 1
 #endif
-template <int CPT>
+template <int CPT, bool CONTIG>
 __global__ __launch_bounds__(SSR_SSIM_NT, SSR_SSIM_WAVES_PER_EU) void k_ssim(SsrSsimParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SsrBlk blk{(int)threadIdx.x};
   const int tiles = p.n_row_tiles * p.n_strips;
-  ssr_ssim_body<CPT>(p, blk, blockIdx.x % tiles, blockIdx.x / tiles, smem);
+  ssr_ssim_body<CPT, CONTIG>(p, blk, blockIdx.x % tiles, blockIdx.x / tiles, smem);
 }
+
+// row pitch of the pair pipeline's magnitude images: rows padded to 16 bytes (k_ssim's aligned loads, ssr_metrics.h CONTIG)
+static int mag_pitch(int n_bins) { return (n_bins + 3) & ~3; }
 
 __global__ __launch_bounds__(256) void k_specred(SsrSpecRedParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -59,8 +62,8 @@ static PairWs pair_ws(const ssr_plan* pl, int n_items, int max_len, int64_t tota
   w.n_chunks = ssr_ceil_div(max_T, w.units_per_chunk);
   w.sg = ssim_geom(max_T, pl->n_bins, n_items);
   size_t o = 0;
-  w.off_est = o; o += want_mag ? ssr_align256((size_t)total_rows * pl->n_bins * sizeof(float)) : 0;
-  w.off_tgt = o; o += want_mag ? ssr_align256((size_t)total_rows * pl->n_bins * sizeof(float)) : 0;
+  w.off_est = o; o += want_mag ? ssr_align256((size_t)total_rows * mag_pitch(pl->n_bins) * sizeof(float)) : 0;
+  w.off_tgt = o; o += want_mag ? ssr_align256((size_t)total_rows * mag_pitch(pl->n_bins) * sizeof(float)) : 0;
   w.off_part = o; o += ssr_align256((size_t)n_items * w.n_chunks * SSR_NPART * sizeof(double));
   w.off_ssim = o; o += ssr_align256((size_t)n_items * w.sg.n_row_tiles * w.sg.n_strips * sizeof(double));
   w.total = o;
@@ -81,19 +84,33 @@ extern "C" size_t ssr_pair_metrics_workspace_bytes(const ssr_plan* pl, int n_ite
   return ssr_pair_metrics_workspace_bytes_for(pl, n_items, max_len, total_rows, SSR_METRIC_ALL);
 }
 
-template <int CPT> static int launch_ssim_inst(const SsrSsimParams& p, int grid, hipStream_t s) {
-  const size_t lds = SsrSsimLds<CPT>::bytes();
+template <int CPT, bool CONTIG = false> static int launch_ssim_inst(const SsrSsimParams& p, int grid, hipStream_t s) {
+#ifdef SSR_DEV_KNOBS
+  static const size_t extra = getenv("SSR_SSIM_LDS_EXTRA") ? (size_t)atoi(getenv("SSR_SSIM_LDS_EXTRA")) : 0;   // caps workgroups / CU
+#else
+  const size_t extra = 0;
+#endif
+  const size_t lds = SsrSsimLds<CPT>::bytes() + extra;
   static thread_local int slot = 0;
-  if (int rc = ssr_allow_lds((const void*)k_ssim<CPT>, lds, &slot)) return rc;
-  hipLaunchKernelGGL((k_ssim<CPT>), dim3(grid), dim3(SSR_SSIM_NT), lds, s, p);
+  if (int rc = ssr_allow_lds((const void*)k_ssim<CPT, CONTIG>, lds, &slot)) return rc;
+  hipLaunchKernelGGL((k_ssim<CPT, CONTIG>), dim3(grid), dim3(SSR_SSIM_NT), lds, s, p);
   HIP_TRY(hipGetLastError());
   return SSR_OK;
 }
 
+// pitch: floats between image rows (0: F, the caller's own [T, F] tensors)
 static int launch_ssim(const float* x, const float* y, const int64_t* frame_off, const int32_t* n_rows, int n_items,
-                       int F, const SsimGeom& g, double* part, hipStream_t s) {
-  SsrSsimParams p{x, y, frame_off, n_rows, F, g.rows_per_tile, g.n_row_tiles, g.n_strips, part};
+                       int F, int pitch, const SsimGeom& g, double* part, hipStream_t s) {
+  SsrSsimParams p{x, y, frame_off, n_rows, F, g.rows_per_tile, g.n_row_tiles, g.n_strips, part, pitch};
   const int grid = n_items * g.n_row_tiles * g.n_strips;
+#ifdef SSR_DEV_KNOBS
+  static const int no_contig = getenv("SSR_SSIM_NO_CONTIG") ? atoi(getenv("SSR_SSIM_NO_CONTIG")) : 0;
+#else
+  const int no_contig = 0;
+#endif
+  // four consecutive columns per thread through aligned 16-byte loads: rows and both bases 16-byte aligned
+  if (g.cpt == 4 && !no_contig && pitch > 0 && pitch % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
+    return launch_ssim_inst<4, true>(p, grid, s);
   switch (g.cpt) {
     case 1: return launch_ssim_inst<1>(p, grid, s);
     case 2: return launch_ssim_inst<2>(p, grid, s);
@@ -128,7 +145,7 @@ static int pair_stage_stft(const ssr_plan* pl, const float* est, const double* e
   p.mode = SSR_MODE_PAIR; p.out_kind = need_mag ? SSR_OUT_MAG : SSR_OUT_NONE; p.metric_mask = (int)mask;
   p.n_fft = pl->n_fft; p.hop = pl->hop; p.n_bins = pl->n_bins;
   p.units_per_chunk = w.units_per_chunk; p.n_chunks = w.n_chunks;
-  p.out_a = (float*)(ws + w.off_est); p.out_b = (float*)(ws + w.off_tgt);
+  p.out_a = (float*)(ws + w.off_est); p.out_b = (float*)(ws + w.off_tgt); p.out_pitch = mag_pitch(pl->n_bins);
   p.part = (double*)(ws + w.off_part);
   return ssr_launch_stft<T>(pl, p, n_items * w.n_chunks, s);
 }
@@ -168,7 +185,7 @@ static int pair_metrics_impl(const ssr_plan* pl, const float* est, const double*
   }
   if ((stages & 2) && want_ssim) {
     rc = launch_ssim((const float*)(ws + w.off_est), (const float*)(ws + w.off_tgt), frame_off, rows, n_items,
-                     pl->n_bins, w.sg, (double*)(ws + w.off_ssim), s);
+                     pl->n_bins, mag_pitch(pl->n_bins), w.sg, (double*)(ws + w.off_ssim), s);
     if (rc) return rc;
   }
   if (stages & 4) {
@@ -252,7 +269,7 @@ extern "C" int ssr_spectrogram_metrics(const float* est_sp, const float* tgt_sp,
     HIP_TRY(hipGetLastError());
   }
   if (want_ssim) {
-    int rc = launch_ssim(est_sp, tgt_sp, frame_off, n_rows, n_items, n_bins, w.sg, (double*)(ws + w.off_ssim), s);
+    int rc = launch_ssim(est_sp, tgt_sp, frame_off, n_rows, n_items, n_bins, 0, w.sg, (double*)(ws + w.off_ssim), s);
     if (rc) return rc;
   }
   return launch_finalize(want_red ? (const double*)(ws + w.off_part) : nullptr, w.n_chunks,

@@ -208,13 +208,13 @@ extern "C" int emu_stft_in64(int precision, int n_fft, int hop, int out_kind, in
                            n_items, units_per_chunk, n_chunks, out_a, out_b, part);
 }
 
-template <int CPT>
+template <int CPT, bool CONTIG = false>
 static void run_ssim(const SsrSsimParams& p, int n_items) {
   SsrBlk blk{SSR_SSIM_NT};
   for (int item = 0; item < n_items; ++item)
     for (int t = 0; t < p.n_row_tiles * p.n_strips; ++t) {
       auto lds = poisoned(SsrSsimLds<CPT>::bytes());
-      ssr_ssim_body<CPT>(p, blk, t, item, lds.data());
+      ssr_ssim_body<CPT, CONTIG>(p, blk, t, item, lds.data());
     }
 }
 
@@ -225,9 +225,15 @@ extern "C" int emu_ssim_geom(int F, int* cpt, int* n_strips) {
   return 0;
 }
 
+// pitch: floats between image rows (0: F); contig: the CPT = 4 variant on 16-byte-aligned rows (pitch a multiple of 4)
 extern "C" int emu_ssim(const float* x, const float* y, const int64_t* frame_off, const int32_t* n_rows, int n_items,
-                        int F, int rows_per_tile, int n_row_tiles, int n_strips, int cpt, double* part) {
-  SsrSsimParams p{x, y, frame_off, n_rows, F, rows_per_tile, n_row_tiles, n_strips, part};
+                        int F, int pitch, int contig, int rows_per_tile, int n_row_tiles, int n_strips, int cpt, double* part) {
+  SsrSsimParams p{x, y, frame_off, n_rows, F, rows_per_tile, n_row_tiles, n_strips, part, pitch};
+  if (contig) {
+    if (cpt != 4 || pitch % 4 != 0 || pitch < F) return -2;
+    run_ssim<4, true>(p, n_items);
+    return 0;
+  }
   switch (cpt) {
     case 1: run_ssim<1>(p, n_items); return 0;
     case 2: run_ssim<2>(p, n_items); return 0;

@@ -93,10 +93,17 @@ def spectro_desc(sps):
     return np.ascontiguousarray(np.concatenate(sps).astype(np.float32)), frame_off, T
 
 
-def ssim_parts(xs, ys, rows_per_tile=16, cpt=None):
+def ssim_parts(xs, ys, rows_per_tile=16, cpt=None, contig=False):
+    """contig: the pair pipeline's layout - rows padded to a multiple of 4 floats (NaN in the padding) - and the CPT = 4
+    kernel variant that reads them with aligned 16-byte loads."""
     x, frame_off, T = spectro_desc(xs)
     y, _, _ = spectro_desc(ys)
     F = xs[0].shape[1]
+    pitch = 0
+    if contig:
+        pitch = (F + 3) & ~3
+        x = np.ascontiguousarray(np.pad(x, ((0, 0), (0, pitch - F)), constant_values=np.nan))
+        y = np.ascontiguousarray(np.pad(y, ((0, 0), (0, pitch - F)), constant_values=np.nan))
     n_row_tiles = int(-(-(T.max() - 6) // rows_per_tile))
     c, ns = C.c_int(), C.c_int()
     lib().emu_ssim_geom(F, C.byref(c), C.byref(ns))
@@ -106,7 +113,7 @@ def ssim_parts(xs, ys, rows_per_tile=16, cpt=None):
         n_strips = int(-(-(F - 6) // (64 * cpt)))
     part = np.full((len(xs), n_row_tiles * n_strips), np.nan)
     rc = lib().emu_ssim(_p(x, C.c_float), _p(y, C.c_float), _p(frame_off, C.c_int64), _p(T, C.c_int32), len(xs), F,
-                        rows_per_tile, n_row_tiles, n_strips, cpt, _p(part, C.c_double))
+                        pitch, 1 if contig else 0, rows_per_tile, n_row_tiles, n_strips, cpt, _p(part, C.c_double))
     assert rc == 0
     return part, T
 

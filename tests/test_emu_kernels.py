@@ -81,6 +81,25 @@ def test_ssim_tiles_and_strips(shape, cpt):
     assert abs(out[1, 3] - ossim.structural_similarity(a[:max(7, shape[0] - 3)], b[:max(7, shape[0] - 3)])) < 2e-7
 
 
+@pytest.mark.parametrize("shape", [(9, 1025), (30, 1025), (8, 263), (12, 256 * 3 + 6), (10, 700), (7, 7 + 250), (11, 1028)])
+def test_ssim_contiguous_columns_variant(shape):
+    """The pair pipeline's SSIM kernel (CPT = 4, rows padded to 16 bytes - NaN in the padding here): a thread loads its four
+    consecutive columns with one aligned 16-byte read per image row, publishes their sums, and slides the 7-wide window over
+    its own four sums (registers) + six neighbours' (LDS).  Against the oracle and the strided kernel; strips of every
+    fill (full, one column into the next strip, narrow last strip, widths not a multiple of 4)."""
+    rng = np.random.default_rng(shape[1])
+    a = np.abs(rng.standard_normal(shape)).astype(np.float32) * 50
+    b = (a * (1 + 0.2 * rng.standard_normal(shape))).astype(np.float32)
+    xs, ys = [a, a[:max(7, shape[0] - 2)]], [b, b[:max(7, shape[0] - 2)]]
+    sp_c, T = E.ssim_parts(xs, ys, rows_per_tile=4, cpt=4, contig=True)
+    sp_s, _ = E.ssim_parts(xs, ys, rows_per_tile=4, cpt=4)
+    assert np.isfinite(sp_c).all()
+    out_c, out_s = E.finalize(None, sp_c, T, shape[1], 8), E.finalize(None, sp_s, T, shape[1], 8)
+    for i in range(2):
+        assert abs(out_c[i, 3] - ossim.structural_similarity(xs[i], ys[i])) < 2e-7
+        assert abs(out_c[i, 3] - out_s[i, 3]) < 1e-12                   # the same sums in a different order
+
+
 def test_fft_lowpass_and_istft(golden):
     x = golden["lp_x"]
     for hc, fs in [(4000, 44100), (12000, 44100), (6000, 48000)]:

@@ -48,6 +48,9 @@ template <int CPT> struct SsrSsimRegs {
   double cs[CPT + 1][4];  // running 7-row sums for the thread's (strided) input columns tid + NT*i
   double s;               // sum of S over the thread's outputs
   float px[2][4][CPT + 1];   // row values in flight, two row steps deep: [step parity][entering x, y, leaving x, y][column slot]
+  float ring[SSR_SSIM_WIN][CPT + 1];   // CONTIG: the x pixels of the last seven rows, slot = row step mod 7 - the leaving x row is
+                                       // not fetched again.  (A second ring for y: 172 VGPRs -> two waves per SIMD, or five spilled
+                                       // registers at three; or 168 with the loads only one step ahead - all measured slower.)
 };
 
 // Column-sum index in LDS.  The horizontal pass reads with a lane stride of CPT doubles; for even CPT that is a
@@ -119,16 +122,15 @@ SSR_DEV void ssr_ssim_row_load(const SsrSsimParams& p, SsrSsimRegs<CPT>& R, int 
     // (a quad past the strip's last column - narrow last strip - is clamped to the last aligned quad: never used, see apply)
     const int last4 = (ncol_in - 1) & ~3;
     const unsigned c4 = (unsigned)((4 * tid < last4) ? 4 * tid : last4);
+    // (the leaving x row comes from the thread's seven-row register ring: R.px[SET][2] is not loaded)
     float q[4][4];
-    x.at4(ea, c4, q[0]); y.at4(ea, c4, q[1]); x.at4(es, c4, q[2]); y.at4(es, c4, q[3]);
+    x.at4(ea, c4, q[0]); y.at4(ea, c4, q[1]); y.at4(es, c4, q[3]);
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) R.px[SET][k][i] = q[k][i];
+    for (int i = 0; i < 4; ++i) { R.px[SET][0][i] = q[0][i]; R.px[SET][1][i] = q[1][i]; R.px[SET][3][i] = q[3][i]; }
     int ce = SSR_SSIM_NT * CPT + tid;
     if (ce >= ncol_in) ce = ncol_in - 1;
     R.px[SET][0][4] = x.at(ea, (unsigned)ce); R.px[SET][1][4] = y.at(ea, (unsigned)ce);
-    R.px[SET][2][4] = x.at(es, (unsigned)ce); R.px[SET][3][4] = y.at(es, (unsigned)ce);
+    R.px[SET][3][4] = y.at(es, (unsigned)ce);
     return;
   }
 #pragma unroll
@@ -143,20 +145,21 @@ SSR_DEV void ssr_ssim_row_load(const SsrSsimParams& p, SsrSsimRegs<CPT>& R, int 
   }
 }
 
-template <int CPT, bool CONTIG, int SET>
+template <int CPT, bool CONTIG, int SET, int SLOT>
 SSR_DEV void ssr_ssim_row_apply(SsrSsimRegs<CPT>& R, int tid, bool sub, int ncol_in) {
   constexpr int VC = CPT + 1;
 #pragma unroll
   for (int i = 0; i < VC; ++i) {
     if (ssr_ssim_col<CPT, CONTIG>(tid, i) < ncol_in) {
       const double a = (double)R.px[SET][0][i], b = (double)R.px[SET][1][i];
-      const double c = sub ? (double)R.px[SET][2][i] : 0.0, d = sub ? (double)R.px[SET][3][i] : 0.0;
+      const double c = sub ? (double)(CONTIG ? R.ring[SLOT][i] : R.px[SET][2][i]) : 0.0, d = sub ? (double)R.px[SET][3][i] : 0.0;
       // every product goes into its running sum with one fused multiply-add (10 operations per column instead of 13)
       R.cs[i][0] = (R.cs[i][0] + a) - c;
       R.cs[i][1] = (R.cs[i][1] + b) - d;
       R.cs[i][2] = fma(-d, d, fma(-c, c, fma(b, b, fma(a, a, R.cs[i][2]))));
       R.cs[i][3] = fma(-c, d, fma(a, b, R.cs[i][3]));
     }
+    if constexpr (CONTIG) R.ring[SLOT][i] = R.px[SET][0][i];    // the x row just added leaves seven steps from now (same slot)
   }
 }
 
@@ -221,9 +224,9 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
 #else
 #define SSR_SABL(bit) 0
 #endif
-#define SSR_SSIM_STEP(s_, SET)                                                                                               \
+#define SSR_SSIM_STEP(s_, SET, SLOT)                                                                                         \
   SSR_PHASE(blk, regs, {                                                                                                    \
-    ssr_ssim_row_apply<CPT, CONTIG, SET>(R, tid, (s_) >= W, ncol_in);                                                        \
+    ssr_ssim_row_apply<CPT, CONTIG, SET, SLOT>(R, tid, (s_) >= W, ncol_in);                                                  \
     if ((s_) + 2 < n_steps && !SSR_SABL(4))                                                                                 \
       ssr_ssim_row_load<CPT, CONTIG, SET>(p, R, tid, x, y, r0 + (s_) + 2, ((s_) + 2 >= W) ? r0 + (s_) + 2 - W : -1, c_in0, ncol_in); \
     if ((s_) >= W - 1 && !SSR_SABL(2)) {                                                                                    \
@@ -267,9 +270,18 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
     ssr_ssim_row_load<CPT, CONTIG, 0>(p, R, tid, x, y, r0, -1, c_in0, ncol_in);
     if (n_steps > 1) ssr_ssim_row_load<CPT, CONTIG, 1>(p, R, tid, x, y, r0 + 1, -1, c_in0, ncol_in);
   });
-  for (int s0 = 0; s0 < n_steps; s0 += 2) {
-    SSR_SSIM_STEP(s0, 0)
-    if (s0 + 1 < n_steps) { SSR_SSIM_STEP(s0 + 1, 1) }
+  if constexpr (CONTIG) {          // ring slot = step mod 7, prefetch set = step mod 2: fourteen steps per trip, all indices static
+    for (int s0 = 0; s0 < n_steps; s0 += 14) {
+#define SSR_SSIM_STEP_K(k) if (s0 + (k) < n_steps) { SSR_SSIM_STEP(s0 + (k), (k) % 2, (k) % 7) }
+      SSR_SSIM_STEP_K(0) SSR_SSIM_STEP_K(1) SSR_SSIM_STEP_K(2) SSR_SSIM_STEP_K(3) SSR_SSIM_STEP_K(4) SSR_SSIM_STEP_K(5) SSR_SSIM_STEP_K(6)
+      SSR_SSIM_STEP_K(7) SSR_SSIM_STEP_K(8) SSR_SSIM_STEP_K(9) SSR_SSIM_STEP_K(10) SSR_SSIM_STEP_K(11) SSR_SSIM_STEP_K(12) SSR_SSIM_STEP_K(13)
+#undef SSR_SSIM_STEP_K
+    }
+  } else {
+    for (int s0 = 0; s0 < n_steps; s0 += 2) {
+      SSR_SSIM_STEP(s0, 0, 0)
+      if (s0 + 1 < n_steps) { SSR_SSIM_STEP(s0 + 1, 1, 0) }
+    }
   }
 #undef SSR_SSIM_STEP
 #define SSR_GET_S(q) R.s

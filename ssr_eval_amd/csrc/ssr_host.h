@@ -74,6 +74,9 @@ int ssr_units_per_chunk_for(int max_units, int n_items, int target_wgs = 0);
 bool ssr_stft_uses_wave_engine(const ssr_plan* pl, bool in64);
 int ssr_stft_rn_wave_radix(const ssr_plan* pl);            // 1 / 2 / 3: n_fft = R q over M = 2048, float32 pairs (ssr_stft_rn_wave.h); 0: none
 int ssr_pair_units_per_chunk(const ssr_plan* pl, int max_units, int n_items, bool in64);
+// chunks per interleaving group of the pair transform (1: none).  The wave engine's chunks interleave in groups of 8 so that
+// the frames whose samples overlap are transformed at the same time on one XCD (ssr_stft_wave.h); n_chunks is a multiple of it.
+int ssr_pair_interleave(const ssr_plan* pl, bool in64);
 
 // ---- launchers defined by the kernel translation units --------------------------------------------------------
 template <typename T> struct SsrStftParams;

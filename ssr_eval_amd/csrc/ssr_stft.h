@@ -57,6 +57,8 @@ template <typename T> struct SsrStftParams {
   int n_fft, hop, n_bins;
   int units_per_chunk;       // frames (PAIR) or frame pairs (SINGLE) per workgroup
   int n_chunks;              // gridDim.x
+  int interleave;            // wave engine (ssr_stft_wave.h): S chunks of a group take every S-th unit of the group's span
+                             // (0 / 1: a chunk's units are consecutive); n_chunks is then a multiple of S
   const T* window;           // [n_fft] 0.5 * periodic Hann (direct engine; the 1/2 belongs to the separation)
   const cx<T>* tw;           // [N or M] twiddles
   // bluestein tables (null for the direct engine)

@@ -238,8 +238,14 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
   SsrWaveLds<T, SPLIT> L(lds_base);
   const int n = p.len[item], hop = p.hop;
   const int n_frames = ssr_num_frames_dev(n, N, hop);
-  const int u0 = chunk * p.units_per_chunk;
-  const int u1 = (u0 + p.units_per_chunk < n_frames) ? u0 + p.units_per_chunk : n_frames;
+  // Units of this chunk: u0, u0 + S, u0 + 2 S, ... (< u1).  S = 1: consecutive frames.  S > 1: the S chunks of a group
+  // interleave over the group's span of S * units_per_chunk frames - they run at the same time on the same XCD (k_stft_wave's
+  // block mapping), so the 75 % overlap of neighbouring frames is found in that XCD's L2 instead of being fetched again by the
+  // same wave 13 us later, when it has long been evicted (2048 waves x 16 KB of live signal = the whole L2).
+  const int S = p.interleave > 1 ? p.interleave : 1;
+  const int span0 = (chunk / S) * S * p.units_per_chunk;
+  const int u0 = span0 + chunk % S;
+  const int u1 = (span0 + S * p.units_per_chunk < n_frames) ? span0 + S * p.units_per_chunk : n_frames;
   const float* sa = p.a + p.a_off[item];
   const float* sb = p.b + p.b_off[item];
   const int64_t row0 = p.frame_off[item];
@@ -264,7 +270,7 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
   });
 
   BLK blk0 = blk;
-  for (int u = u0; u < u1; ++u) {
+  for (int u = u0, it = 0; u < u1; u += S, ++it) {
     // The lane's table values (window, twiddles) and addresses are loop-invariant, and 128 + 64 registers of data and
     // prefetched samples leave no room to keep them: with the lane index opaque the optimiser cannot hoist them out of the
     // loop (it would, and then shuffle some 250 values through the accumulator registers every frame).  Table values are
@@ -278,7 +284,7 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
         R.v[r] = {(T)R.pa[r] * w, (T)R.pb[r] * w};
       }
       ssr_dft32(R.v);
-      if (want_lsd && u > u0 && tid == 0) R.lsd_total += sqrt(L.sc1[0] / (double)F);
+      if (want_lsd && it > 0 && tid == 0) R.lsd_total += sqrt(L.sc1[0] / (double)F);
     });
 #define VT vt
     SSR_W_FFT_TAIL(blk, blk0, regs, L, );
@@ -304,11 +310,11 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
     SSR_WPHASE(blk, regs, {
       // UNCONDITIONAL (the last frame of a chunk re-requests a clamped, valid frame that nobody consumes): under a condition
       // the previous contents of the 64 + 32 registers would stay live through all three passes for the path not taken
-      ssr_wave_prefetch<T>(p, R, tid, va, vb, u + 1, n, n_frames);
+      ssr_wave_prefetch<T>(p, R, tid, va, vb, u + S, n, n_frames);
       SSR_UNROLL for (int r = 0; r < SSR_W_P / 2; ++r) R.wl[r] = vw.at(SSR_UIDX(tid + 64 * r));
       SSR_SCHED_BARRIER();
       double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      const int par = (u - u0) & 1;
+      const int par = it & 1;
       const bool a_nz = L.nonzero(0, par), b_nz = L.nonzero(1, par);
       const bool both = a_nz && b_nz;                             // wave-uniform: the common case carries no selects
       const int im_off = SPLIT ? SSR_W_IMOFF : 0;

@@ -55,6 +55,16 @@ int ssr_pair_units_per_chunk(const ssr_plan* pl, int max_units, int n_items, boo
   return ssr_units_per_chunk_for(max_units, n_items, per_wg < 4 ? (4 / per_wg) * ssr_target_wgs() : 0);
 }
 
+int ssr_pair_interleave(const ssr_plan* pl, bool in64) {
+  if (!ssr_stft_uses_wave_engine(pl, in64)) return 1;
+#ifdef SSR_DEV_KNOBS
+  static const int v = getenv("SSR_WAVE_INTERLEAVE") ? atoi(getenv("SSR_WAVE_INTERLEAVE")) : 8;
+  return v > 1 ? v : 1;
+#else
+  return 8;
+#endif
+}
+
 int ssr_units_per_chunk_for(int max_units, int n_items, int target_wgs) {
   const int target = target_wgs > 0 ? target_wgs : ssr_target_wgs();
   int64_t u = ((int64_t)max_units * n_items + target - 1) / target;

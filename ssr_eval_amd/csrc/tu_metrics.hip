@@ -60,6 +60,8 @@ static PairWs pair_ws(const ssr_plan* pl, int n_items, int max_len, int64_t tota
   const int max_T = (int)ssr_num_frames(pl, max_len);
   w.units_per_chunk = ssr_pair_units_per_chunk(pl, max_T, n_items, in64);     // depends on the engine that will run
   w.n_chunks = ssr_ceil_div(max_T, w.units_per_chunk);
+  const int S = ssr_pair_interleave(pl, in64);                                 // whole interleaving groups (empty chunks write zeros)
+  w.n_chunks = ssr_ceil_div(w.n_chunks, S) * S;
   w.sg = ssim_geom(max_T, pl->n_bins, n_items);
   size_t o = 0;
   w.off_est = o; o += want_mag ? ssr_align256((size_t)total_rows * mag_pitch(pl->n_bins) * sizeof(float)) : 0;
@@ -144,7 +146,7 @@ static int pair_stage_stft(const ssr_plan* pl, const float* est, const double* e
   p.a = est; p.a64 = est64; p.b = tgt; p.b64 = tgt64; p.a_off = est_off; p.b_off = tgt_off; p.len = len; p.frame_off = frame_off;
   p.mode = SSR_MODE_PAIR; p.out_kind = need_mag ? SSR_OUT_MAG : SSR_OUT_NONE; p.metric_mask = (int)mask;
   p.n_fft = pl->n_fft; p.hop = pl->hop; p.n_bins = pl->n_bins;
-  p.units_per_chunk = w.units_per_chunk; p.n_chunks = w.n_chunks;
+  p.units_per_chunk = w.units_per_chunk; p.n_chunks = w.n_chunks; p.interleave = ssr_pair_interleave(pl, est64 != nullptr);
   p.out_a = (float*)(ws + w.off_est); p.out_b = (float*)(ws + w.off_tgt); p.out_pitch = mag_pitch(pl->n_bins);
   p.part = (double*)(ws + w.off_part);
   return ssr_launch_stft<T>(pl, p, n_items * w.n_chunks, s);

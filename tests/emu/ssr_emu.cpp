@@ -113,7 +113,7 @@ extern "C" int emu_stft(int precision, int n_fft, int hop, int mode, int out_kin
 
 // wave-autonomous 2048-point pair engine (ssr_stft_wave.h): one 64-lane "workgroup" per (item, chunk)
 template <typename T>
-static int emu_stft_wave_t(int hop, int out_kind, int mask, int split, const float* a, const float* b, const int64_t* a_off,
+static int emu_stft_wave_t(int hop, int out_kind, int mask, int split, int interleave, const float* a, const float* b, const int64_t* a_off,
                            const int64_t* b_off, const int32_t* len, const int64_t* frame_off, int n_items,
                            int units_per_chunk, int n_chunks, float* out_a, float* out_b, double* part) {
   SsrTables<T> t;
@@ -122,7 +122,8 @@ static int emu_stft_wave_t(int hop, int out_kind, int mask, int split, const flo
   p.a = a; p.b = b; p.a_off = a_off; p.b_off = b_off; p.len = len; p.frame_off = frame_off;
   p.mode = SSR_MODE_PAIR; p.out_kind = out_kind; p.metric_mask = mask;
   p.n_fft = 2048; p.hop = hop; p.n_bins = 1025;
-  p.units_per_chunk = units_per_chunk; p.n_chunks = n_chunks;
+  p.units_per_chunk = units_per_chunk; p.n_chunks = n_chunks; p.interleave = interleave;
+  if (interleave > 1 && n_chunks % interleave) return -5;
   p.window = t.window_h.data(); p.tw = t.tw.data();
   p.out_a = out_a; p.out_b = out_b; p.part = part;
   SsrBlk blk{64};
@@ -141,13 +142,13 @@ static int emu_stft_wave_t(int hop, int out_kind, int mask, int split, const flo
     }
   return 0;
 }
-extern "C" int emu_stft_wave(int precision, int hop, int out_kind, int mask, int split, const float* a, const float* b,
+extern "C" int emu_stft_wave(int precision, int hop, int out_kind, int mask, int split, int interleave, const float* a, const float* b,
                              const int64_t* a_off, const int64_t* b_off, const int32_t* len, const int64_t* frame_off,
                              int n_items, int units_per_chunk, int n_chunks, float* out_a, float* out_b, double* part) {
   if (precision == 1)
-    return emu_stft_wave_t<double>(hop, out_kind, mask, split, a, b, a_off, b_off, len, frame_off, n_items, units_per_chunk,
+    return emu_stft_wave_t<double>(hop, out_kind, mask, split, interleave, a, b, a_off, b_off, len, frame_off, n_items, units_per_chunk,
                                    n_chunks, out_a, out_b, part);
-  return emu_stft_wave_t<float>(hop, out_kind, mask, split, a, b, a_off, b_off, len, frame_off, n_items, units_per_chunk,
+  return emu_stft_wave_t<float>(hop, out_kind, mask, split, interleave, a, b, a_off, b_off, len, frame_off, n_items, units_per_chunk,
                                 n_chunks, out_a, out_b, part);
 }
 

@@ -46,7 +46,7 @@ def ragged(arrs):
 
 
 def stft(sigs_a, sigs_b, n_fft, hop, precision=1, mode=0, out_kind=1, mask=0, units_per_chunk=8, est64=False,
-         tgt64=False, wave=None):
+         tgt64=False, wave=None, interleave=1):
     """mode 0 (pair): returns (mag_a list, mag_b list, part); mode 1 (single): (out_a list, out_b list, None).
     est64 / tgt64 (pair mode): the signals are float64 and run through the IN64 kernel variants."""
     a, a_off, lens = ragged(sigs_a)
@@ -64,6 +64,8 @@ def stft(sigs_a, sigs_b, n_fft, hop, precision=1, mode=0, out_kind=1, mask=0, un
     frame_off = np.concatenate(([0], np.cumsum(T)[:-1])).astype(np.int64)
     units = T if mode == 0 else (T + 1) // 2
     n_chunks = int(-(-units.max() // units_per_chunk))
+    if interleave > 1:                               # whole groups of `interleave` chunks (wave engine)
+        n_chunks = -(-n_chunks // interleave) * interleave
     out_a = np.full((int(T.sum()), F), np.nan, np.float32)
     out_b = np.full((int(T.sum()), F), np.nan, np.float32)
     part = np.full((len(lens), n_chunks, 8), np.nan, np.float64) if mode == 0 else None
@@ -74,8 +76,8 @@ def stft(sigs_a, sigs_b, n_fft, hop, precision=1, mode=0, out_kind=1, mask=0, un
         rc = lib().emu_stft_r3_wave(precision, n_fft, hop, out_kind, mask, _p(a, C.c_float), _p(b, C.c_float), *tail)
     elif wave is not None:          # wave-autonomous engine: "full" or "split" exchange (pair mode, n_fft 2048, float32 signals)
         assert mode == 0 and n_fft == 2048 and not est64
-        rc = lib().emu_stft_wave(precision, hop, out_kind, mask, 1 if wave == "split" else 0, _p(a, C.c_float), _p(b, C.c_float),
-                                 *tail)
+        rc = lib().emu_stft_wave(precision, hop, out_kind, mask, 1 if wave == "split" else 0, interleave, _p(a, C.c_float),
+                                 _p(b, C.c_float), *tail)
     elif est64:
         b64 = np.concatenate(sigs_b).astype(np.float64) if tgt64 else None
         rc = lib().emu_stft_in64(precision, n_fft, hop, out_kind, mask, _p(a, C.c_double),
@@ -142,8 +144,9 @@ def finalize(part, ssim_part, T, F, mask):
 
 
 def pair_metrics(ests, tgts, n_fft, hop, precision=1, mask=M_ALL, units_per_chunk=8, rows_per_tile=16, est64=False,
-                 tgt64=False, wave=None):
-    ea, tb, part = stft(ests, tgts, n_fft, hop, precision, 0, 1, mask, units_per_chunk, est64=est64, tgt64=tgt64, wave=wave)
+                 tgt64=False, wave=None, interleave=1):
+    ea, tb, part = stft(ests, tgts, n_fft, hop, precision, 0, 1, mask, units_per_chunk, est64=est64, tgt64=tgt64, wave=wave,
+                        interleave=interleave)
     sp, T = ssim_parts(ea, tb, rows_per_tile) if mask & M_SSIM else (None, np.array([e.shape[0] for e in ea]))
     return finalize(part, sp, T, n_fft // 2 + 1, mask)
 

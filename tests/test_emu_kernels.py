@@ -338,6 +338,14 @@ def test_wave_autonomous_engine_matches_oracle_and_block_engine(wave):
     # LSD-only variant (no running SISpec sums) gives the same LSD
     lsd_only = E.pair_metrics(es, tg, 2048, 512, 1, mask=E.M_LSD | E.M_SSIM, wave=wave, units_per_chunk=7)
     np.testing.assert_allclose(lsd_only[:, [0, 3]], got[:, [0, 3]], rtol=1e-12)
+    # interleaved chunks (groups of S chunks take every S-th frame of the group's span): same magnitudes bit for bit, same
+    # metrics up to the order of the per-chunk sums; group sizes that do and do not divide the frame count, empty chunks
+    for S, upc in ((8, 2), (3, 5), (8, 1)):
+        mi_e, mi_t, _ = E.stft(es, tg, 2048, 512, 1, 0, 1, 15, upc, wave=wave, interleave=S)
+        for m0, m1 in zip(mags_e + mags_t, mi_e + mi_t):
+            np.testing.assert_array_equal(m0, m1)
+        gi = E.pair_metrics(es, tg, 2048, 512, 1, wave=wave, units_per_chunk=upc, interleave=S)
+        np.testing.assert_allclose(gi, got, rtol=1e-12)
 
 
 @pytest.mark.parametrize("sr_orig,sr_new", [(44100, 48000), (48000, 44100), (48000, 16000), (16000, 44100), (22050, 48000)])

@@ -21,6 +21,8 @@ template <typename T> struct SsrLowpassParams {
   const int32_t* cut;        // [n_items] first zeroed bin (analysis mode)
   const int64_t* frame_off;  // [n_items] first row of item i in `frames` / spec_re / spec_im
   int n_fft, hop, pairs_per_chunk, n_chunks;
+  int interleave;            // wave engine: S chunks of a group take every S-th frame pair of the group's span (0 / 1: consecutive
+                             // pairs per chunk); n_chunks is then a multiple of S - see ssr_stft_wave.h
   const T* window;
   const cx<T>* tw;
   const float* spec_re;      // ISTFT mode: [rows, F] real parts (null in analysis mode)

@@ -72,8 +72,12 @@ SSR_BODY void ssr_lowpass_wave_body(const SsrLowpassParams<T>& p, BLK& blk, int 
   const int n = p.len[item], hop = p.hop;
   const int n_frames = ssr_num_frames_dev(n, N, hop);
   const int n_pairs = (n_frames + 1) / 2;
-  const int g0 = chunk * p.pairs_per_chunk;
-  const int g1 = (g0 + p.pairs_per_chunk < n_pairs) ? g0 + p.pairs_per_chunk : n_pairs;
+  // this chunk's frame pairs: g0, g0 + S, ... (< g1); S > 1: the S chunks of a group interleave over the group's span and run
+  // at the same time on one XCD, so the 78 % overlap of neighbouring frames comes from its L2 (ssr_stft_wave.h)
+  const int S = p.interleave > 1 ? p.interleave : 1;
+  const int span0 = (chunk / S) * S * p.pairs_per_chunk;
+  const int g0 = span0 + chunk % S;
+  const int g1 = (span0 + S * p.pairs_per_chunk < n_pairs) ? span0 + S * p.pairs_per_chunk : n_pairs;
   const int64_t row0 = p.frame_off[item];
   constexpr bool analysis = ANALYSIS;            // false: ISTFT mode (p.spec_re / p.spec_im given)
   const int cut = analysis ? p.cut[item] : F;
@@ -92,7 +96,7 @@ SSR_BODY void ssr_lowpass_wave_body(const SsrLowpassParams<T>& p, BLK& blk, int 
     }
   });
   BLK blk0 = blk;
-  for (int g = g0; g < g1; ++g) {
+  for (int g = g0; g < g1; g += S) {
     const int ta = 2 * g, tb = 2 * g + 1;
     const bool b_valid = tb < n_frames;
     blk = blk0; ssr_launder(blk);

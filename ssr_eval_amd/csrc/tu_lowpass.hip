@@ -35,11 +35,19 @@ template <typename T, int LOGN> static int launch_lowpass_inst(SsrLowpassParams<
 }
 
 // Wave-autonomous engine for 2048-point plans (ssr_lowpass_wave.h): one wave per workgroup, 17 KB of LDS, 2 waves / SIMD.
+// (block mapping under interleaving: a group's S one-wave workgroups on one XCD, back to back - as k_stft_wave, tu_stft.inc)
 template <typename T, bool ANALYSIS, bool PAIRED>
-__global__ __launch_bounds__(64, 2) void k_lowpass_wave(SsrLowpassParams<T> p) {
+__global__ __launch_bounds__(64, 2) void k_lowpass_wave(SsrLowpassParams<T> p, int n_groups) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SsrBlk blk{(int)threadIdx.x};
-  const int item = blockIdx.x / p.n_chunks, chunk = blockIdx.x % p.n_chunks;
+  int logical = (int)blockIdx.x;
+  if (p.interleave > 1) {
+    const int S = p.interleave, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const int G = (slot / S) * 8 + xcd;
+    if (G >= n_groups) return;
+    logical = G * S + slot % S;
+  }
+  const int item = logical / p.n_chunks, chunk = logical % p.n_chunks;
   ssr_lowpass_wave_body<T, true, ANALYSIS, PAIRED>(p, blk, chunk, item, smem);
 }
 
@@ -71,10 +79,15 @@ template <typename T> int ssr_launch_lowpass(const ssr_plan* pl, SsrLowpassParam
   if (ssr_lowpass_uses_wave_engine(pl)) {
     typedef SsrWaveLds<T, true> WaveLds;
     const bool analysis = p.spec_re == nullptr, paired = ssr_lowpass_pairs_frames(pl);
-    if (analysis && paired) hipLaunchKernelGGL((k_lowpass_wave<T, true, true>), dim3(grid), dim3(64), WaveLds::bytes(), s, p);
-    else if (analysis) hipLaunchKernelGGL((k_lowpass_wave<T, true, false>), dim3(grid), dim3(64), WaveLds::bytes(), s, p);
-    else if (paired) hipLaunchKernelGGL((k_lowpass_wave<T, false, true>), dim3(grid), dim3(64), WaveLds::bytes(), s, p);
-    else hipLaunchKernelGGL((k_lowpass_wave<T, false, false>), dim3(grid), dim3(64), WaveLds::bytes(), s, p);
+    int n_groups = grid;
+    if (p.interleave > 1) {
+      n_groups = grid / p.interleave;
+      grid = ssr_ceil_div(n_groups, 8) * 8 * p.interleave;
+    }
+    if (analysis && paired) hipLaunchKernelGGL((k_lowpass_wave<T, true, true>), dim3(grid), dim3(64), WaveLds::bytes(), s, p, n_groups);
+    else if (analysis) hipLaunchKernelGGL((k_lowpass_wave<T, true, false>), dim3(grid), dim3(64), WaveLds::bytes(), s, p, n_groups);
+    else if (paired) hipLaunchKernelGGL((k_lowpass_wave<T, false, true>), dim3(grid), dim3(64), WaveLds::bytes(), s, p, n_groups);
+    else hipLaunchKernelGGL((k_lowpass_wave<T, false, false>), dim3(grid), dim3(64), WaveLds::bytes(), s, p, n_groups);
     HIP_TRY(hipGetLastError());
     return SSR_OK;
   }
@@ -105,18 +118,25 @@ static int run_inverse(const ssr_plan* pl, const float* in, const int64_t* in_of
   if (!workspace || workspace_bytes < ssr_ola_workspace_bytes(pl, total_rows)) return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small");
   const int max_pairs = (int)((ssr_num_frames(pl, max_len) + 1) / 2);
   const int ppc = ssr_units_per_chunk_for(max_pairs, n_items, ssr_lowpass_uses_wave_engine(pl) ? 4 * ssr_target_wgs() : 0);
-  const int n_chunks = ssr_ceil_div(max_pairs, ppc);
+  int n_chunks = ssr_ceil_div(max_pairs, ppc);
+#ifdef SSR_DEV_KNOBS
+  static const int il_env = getenv("SSR_LP_INTERLEAVE") ? atoi(getenv("SSR_LP_INTERLEAVE")) : 8;
+#else
+  const int il_env = 8;
+#endif
+  const int interleave = ssr_lowpass_uses_wave_engine(pl) && il_env > 1 ? il_env : 1;     // chunks come in whole groups
+  n_chunks = ssr_ceil_div(n_chunks, interleave) * interleave;
   int rc;
   if (pl->precision == SSR_F64) {
     SsrLowpassParams<double> p{};
     p.in = in; p.in_off = in_off; p.len = len; p.cut = cut; p.frame_off = frame_off;
-    p.n_fft = pl->n_fft; p.hop = pl->hop; p.pairs_per_chunk = ppc; p.n_chunks = n_chunks;
+    p.n_fft = pl->n_fft; p.hop = pl->hop; p.pairs_per_chunk = ppc; p.n_chunks = n_chunks; p.interleave = interleave;
     p.spec_re = re; p.spec_im = im; p.frames = (float*)workspace;
     rc = ssr_launch_lowpass<double>(pl, p, n_items * n_chunks, s);
   } else {
     SsrLowpassParams<float> p{};
     p.in = in; p.in_off = in_off; p.len = len; p.cut = cut; p.frame_off = frame_off;
-    p.n_fft = pl->n_fft; p.hop = pl->hop; p.pairs_per_chunk = ppc; p.n_chunks = n_chunks;
+    p.n_fft = pl->n_fft; p.hop = pl->hop; p.pairs_per_chunk = ppc; p.n_chunks = n_chunks; p.interleave = interleave;
     p.spec_re = re; p.spec_im = im; p.frames = (float*)workspace;
     rc = ssr_launch_lowpass<float>(pl, p, n_items * n_chunks, s);
   }

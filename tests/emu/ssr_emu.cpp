@@ -304,14 +304,15 @@ extern "C" int emu_lowpass_frames(int precision, int n_fft, int hop, const float
 
 // wave-autonomous low-pass / ISTFT frames kernel (ssr_lowpass_wave.h; 2048-point plans); paired: one segment per frame pair
 template <typename T>
-static int emu_lowpass_wave_t(int hop, int split, int paired, const float* in, const int64_t* in_off, const int32_t* len,
+static int emu_lowpass_wave_t(int hop, int split, int paired, int interleave, const float* in, const int64_t* in_off, const int32_t* len,
                               const int32_t* cut, const int64_t* frame_off, int n_items, int pairs_per_chunk, int n_chunks,
                               const float* re_in, const float* im_in, float* frames) {
   SsrTables<T> t;
   if (!ssr_build_tables<T>(2048, t)) return -3;
   SsrLowpassParams<T> p{};
   p.in = in; p.in_off = in_off; p.len = len; p.cut = cut; p.frame_off = frame_off;
-  p.n_fft = 2048; p.hop = hop; p.pairs_per_chunk = pairs_per_chunk; p.n_chunks = n_chunks;
+  p.n_fft = 2048; p.hop = hop; p.pairs_per_chunk = pairs_per_chunk; p.n_chunks = n_chunks; p.interleave = interleave;
+  if (interleave > 1 && n_chunks % interleave) return -5;
   p.window = t.window.data(); p.tw = t.tw.data();
   p.spec_re = re_in; p.spec_im = im_in; p.frames = frames;
   SsrBlk blk{64};
@@ -333,13 +334,13 @@ static int emu_lowpass_wave_t(int hop, int split, int paired, const float* in, c
     }
   return 0;
 }
-extern "C" int emu_lowpass_wave(int precision, int hop, int split, int paired, const float* in, const int64_t* in_off,
+extern "C" int emu_lowpass_wave(int precision, int hop, int split, int paired, int interleave, const float* in, const int64_t* in_off,
                                 const int32_t* len, const int32_t* cut, const int64_t* frame_off, int n_items,
                                 int pairs_per_chunk, int n_chunks, const float* re_in, const float* im_in, float* frames) {
   if (precision == 1)
-    return emu_lowpass_wave_t<double>(hop, split, paired, in, in_off, len, cut, frame_off, n_items, pairs_per_chunk, n_chunks,
+    return emu_lowpass_wave_t<double>(hop, split, paired, interleave, in, in_off, len, cut, frame_off, n_items, pairs_per_chunk, n_chunks,
                                       re_in, im_in, frames);
-  return emu_lowpass_wave_t<float>(hop, split, paired, in, in_off, len, cut, frame_off, n_items, pairs_per_chunk, n_chunks, re_in,
+  return emu_lowpass_wave_t<float>(hop, split, paired, interleave, in, in_off, len, cut, frame_off, n_items, pairs_per_chunk, n_chunks, re_in,
                                    im_in, frames);
 }
 

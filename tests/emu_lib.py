@@ -151,16 +151,18 @@ def pair_metrics(ests, tgts, n_fft, hop, precision=1, mask=M_ALL, units_per_chun
     return finalize(part, sp, T, n_fft // 2 + 1, mask)
 
 
-def lowpass(sigs, cuts, n_fft=2048, hop=441, precision=1, pairs_per_chunk=4, wave=None):
+def lowpass(sigs, cuts, n_fft=2048, hop=441, precision=1, pairs_per_chunk=4, wave=None, interleave=1):
     a, off, lens = ragged(sigs)
     T = np.array([num_frames(int(n), n_fft, hop) for n in lens])
     frame_off = np.concatenate(([0], np.cumsum(T)[:-1])).astype(np.int64)
     cuts = np.asarray(cuts, np.int32)
     frames = np.full((int(T.sum()), n_fft), np.nan, np.float32)
     n_chunks = int(-(-((T.max() + 1) // 2) // pairs_per_chunk))
+    if interleave > 1:
+        n_chunks = -(-n_chunks // interleave) * interleave
     if wave is not None:
         assert n_fft == 2048
-        rc = lib().emu_lowpass_wave(precision, hop, 0 if wave == "full" else 1, 1 if wave == "paired" else 0, _p(a, C.c_float), _p(off, C.c_int64),
+        rc = lib().emu_lowpass_wave(precision, hop, 0 if wave == "full" else 1, 1 if wave == "paired" else 0, interleave, _p(a, C.c_float), _p(off, C.c_int64),
                                     _p(lens, C.c_int32), _p(cuts, C.c_int32), _p(frame_off, C.c_int64), len(lens), pairs_per_chunk,
                                     n_chunks, None, None, _p(frames, C.c_float))
     else:
@@ -175,7 +177,7 @@ def lowpass(sigs, cuts, n_fft=2048, hop=441, precision=1, pairs_per_chunk=4, wav
     return [out[off[i]:off[i] + lens[i]] for i in range(len(lens))]
 
 
-def istft(res, ims, lengths, n_fft=2048, hop=441, precision=1, pairs_per_chunk=4, wave=None):
+def istft(res, ims, lengths, n_fft=2048, hop=441, precision=1, pairs_per_chunk=4, wave=None, interleave=1):
     re, frame_off, T = spectro_desc(res)
     im, _, _ = spectro_desc(ims)
     lens = np.asarray(lengths, np.int32)
@@ -183,9 +185,11 @@ def istft(res, ims, lengths, n_fft=2048, hop=441, precision=1, pairs_per_chunk=4
     off = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int64)
     frames = np.full((int(T.sum()), n_fft), np.nan, np.float32)
     n_chunks = int(-(-((T.max() + 1) // 2) // pairs_per_chunk))
+    if interleave > 1:
+        n_chunks = -(-n_chunks // interleave) * interleave
     if wave is not None:
         assert n_fft == 2048
-        rc = lib().emu_lowpass_wave(precision, hop, 0 if wave == "full" else 1, 1 if wave == "paired" else 0, None, None, _p(lens, C.c_int32), None,
+        rc = lib().emu_lowpass_wave(precision, hop, 0 if wave == "full" else 1, 1 if wave == "paired" else 0, interleave, None, None, _p(lens, C.c_int32), None,
                                     _p(frame_off, C.c_int64), len(lens), pairs_per_chunk, n_chunks, _p(re, C.c_float),
                                     _p(im, C.c_float), _p(frames, C.c_float))
     else:

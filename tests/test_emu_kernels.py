@@ -132,6 +132,12 @@ def test_lowpass_wave_engine_frames_and_paired_segments(hop):
             assert np.isfinite(v).all()
             np.testing.assert_allclose(b, w, atol=atol)
             np.testing.assert_allclose(v, w, atol=atol)
+    if hop in (441, 512):                                      # interleaved chunks: the same frames, dealt differently - same bits
+        base = E.lowpass(sigs, cuts, hop=hop, pairs_per_chunk=2, wave="paired")
+        for S, ppc in ((8, 1), (3, 2), (8, 4)):
+            got_i = E.lowpass(sigs, cuts, hop=hop, pairs_per_chunk=ppc, wave="paired", interleave=S)
+            for b0, b1 in zip(base, got_i):
+                np.testing.assert_array_equal(b0, b1)
     if hop == 441:                                             # the float32-transform instantiations of the same bodies
         for wave in ("split", "paired"):
             got32 = E.lowpass(sigs, cuts, hop=hop, precision=0, pairs_per_chunk=3, wave=wave)

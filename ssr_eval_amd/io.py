@@ -56,12 +56,20 @@ def read_audio(path):
 
 
 def write_wav(path, x, sr):
-    x = np.clip(np.asarray(x, np.float32), -1.0, 1.0 - 1.0 / 32768)
+    """``soundfile.write(path, x, sr)`` of a mono signal (ssr_eval/eval.py:153-154).  For a ``.wav`` name soundfile's default
+    subtype is PCM_16, so the reference's artefact files are 16-bit as well: libsndfile scales by 32768, rounds to nearest
+    (ties to even) and - python-soundfile switches clipping on - saturates at -32768 / 32767.  Without the package the same
+    conversion is done here through the standard-library writer."""
+    x = np.asarray(x, np.float32).reshape(-1)
+    if _sf is not None:
+        _sf.write(path, x, int(sr))
+        return
+    q = np.clip(np.rint(x.astype(np.float64) * 32768.0), -32768.0, 32767.0).astype("<i2")
     with wave.open(path, "wb") as f:
         f.setnchannels(1)
         f.setsampwidth(2)
         f.setframerate(int(sr))
-        f.writeframes((x * 32768.0).astype("<i2").tobytes())
+        f.writeframes(q.tobytes())
 
 
 def load_audio(path, sr=None, res_type="kaiser_best"):

@@ -166,7 +166,12 @@ def test_wav_decode_mono_stereo_and_batch(tmp_path):
     x = (0.25 * np.sin(np.arange(1000) / 7.0)).astype(np.float32)
     write_wav(str(tmp_path / "m.wav"), x, 16000)
     y, sr = read_audio(str(tmp_path / "m.wav"))
-    assert sr == 16000 and y.dtype == np.float32 and np.abs(y - x).max() <= 1.0 / 32768
+    assert sr == 16000 and y.dtype == np.float32 and np.abs(y - x).max() <= 0.5 / 32768   # rounded, not truncated
+    # libsndfile's float -> PCM_16 with clipping on (what soundfile.write does for a .wav name): x 32768, nearest-even, saturate
+    edge = np.array([1.5, 1.0, 32766.5 / 32768, 0.5 / 32768, 1.5 / 32768, -0.5 / 32768, -1.0, -2.0], np.float32)
+    write_wav(str(tmp_path / "e.wav"), edge, 8000)
+    q = np.rint(read_audio(str(tmp_path / "e.wav"))[0].astype(np.float64) * 32768).astype(int)
+    assert q.tolist() == [32767, 32767, 32766, 0, 2, 0, -32768, -32768]
     import wave
     with wave.open(str(tmp_path / "s.wav"), "wb") as f:
         f.setnchannels(2); f.setsampwidth(2); f.setframerate(8000)

@@ -24,6 +24,7 @@
 #define SSR_HD static inline
 #define SSR_SCHED_FENCE() do {} while (0)
 #define SSR_SCHED_BARRIER() do {} while (0)
+#define SSR_VMEM_DRAIN() do {} while (0)
 template <typename V> static inline void ssr_touch(V&) {}
 #define SSR_UNROLL
 #define SSR_UNROLL4
@@ -87,6 +88,8 @@ static inline double ssr_fadd_rn(double a, double b) { volatile double r = a + b
 #define SSR_SCHED_FENCE() asm volatile("" ::: "memory")
 // instruction-scheduler barrier: nothing is moved across this point
 #define SSR_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// s_waitcnt vmcnt(0) (expcnt / lgkmcnt untouched): every vector-memory operation of the wave has completed
+#define SSR_VMEM_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70)
 // "this register is needed here": a zero-instruction read-modify-write that makes the compiler place the wait for an
 // outstanding load that fills it at this point - and makes the value a product of this point of the program, no
 // longer of the load (nothing downstream is tied to the memory counters any more)

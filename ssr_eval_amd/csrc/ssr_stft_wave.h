@@ -200,21 +200,23 @@ SSR_DEV constexpr int ssr_w_off_st1(int i) { return 528 * (i >> 3) + 33 * (i & 7
   });
 
 // Request unit u's samples into the prefetch registers (branch-free, always valid addresses, reflection only at the ends).
-template <typename T, typename REGS>
+// WHICH: 1 = the first signal's, 2 = the second's, 3 = both.  A wave can have 63 vector-memory instructions in flight (vmcnt is
+// six bits); the 64th waits at issue for the oldest to return, so the body requests the two signals at different times.
+template <typename T, int WHICH = 3, typename REGS>
 SSR_DEV void ssr_wave_prefetch(const SsrStftParams<T>& p, REGS& R, int tid, const SsrView<float>& va, const SsrView<float>& vb,
                                int u, int n, int n_frames) {
   const int t_c = (u < n_frames) ? u : n_frames - 1;
   const int base = t_c * p.hop - SSR_W_N / 2;
   if (base >= 0 && base + SSR_W_N <= n) {            // wave-uniform: the frame lies fully inside the signal
     SSR_UNROLL for (int r = 0; r < SSR_W_P; ++r) {
-      R.pa[r] = va.at(SSR_UIDX(tid + 64 * r), base);
-      R.pb[r] = vb.at(SSR_UIDX(tid + 64 * r), base);
+      if (WHICH & 1) R.pa[r] = va.at(SSR_UIDX(tid + 64 * r), base);
+      if (WHICH & 2) R.pb[r] = vb.at(SSR_UIDX(tid + 64 * r), base);
     }
   } else {
     SSR_UNROLL for (int r = 0; r < SSR_W_P; ++r) {
       const unsigned m = SSR_UIDX(ssr_reflect(base + tid + 64 * r, n));
-      R.pa[r] = va.at(m);
-      R.pb[r] = vb.at(m);
+      if (WHICH & 1) R.pa[r] = va.at(m);
+      if (WHICH & 2) R.pb[r] = vb.at(m);
     }
   }
 }
@@ -231,7 +233,8 @@ template <typename REGS> SSR_DEV void ssr_wave_flags(REGS& R, int tid, int* nz, 
 }
 
 // grid = n_items * n_chunks workgroups of ONE wave; PAIR mode, direct 2048-point engine, float32 signals.
-template <typename T, bool SUMS, bool SPLIT, typename BLK>
+// MAG: 1 / 0 = magnitude rows are / are not written (p.out_kind == SSR_OUT_MAG known at compile time), -1 = decided at run time.
+template <typename T, bool SUMS, bool SPLIT, int MAG = -1, typename BLK>
 SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
   constexpr int N = SSR_W_N, F = N / 2 + 1;
   using Regs = SsrWaveRegs<T, SUMS>;
@@ -264,9 +267,9 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
     if (tid == 0) L.sc1[0] = 0.0;
     if (u0 < u1) {
       ssr_wave_prefetch<T>(p, R, tid, va, vb, u0, n, n_frames);
-      ssr_wave_flags(R, tid, L.nz, 0);
       SSR_UNROLL for (int r = 0; r < SSR_W_P / 2; ++r) R.wl[r] = vw.at(SSR_UIDX(tid + 64 * r));
     }
+    SSR_VMEM_DRAIN();
   });
 
   BLK blk0 = blk;
@@ -279,6 +282,7 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
     // ---- pass 0: window, radix-32 DFT in registers (Stockham pass with stride 1: no twiddle).  Lane 0 also closes the
     // previous frame's LSD.
     SSR_WPHASE(blk, regs, {
+      ssr_wave_flags(R, tid, L.nz, it & 1);            // silent-frame votes of this unit, read by its epilogue
       SSR_UNROLL for (int r = 0; r < SSR_W_P; ++r) {
         const T w = (r < SSR_W_P / 2) ? R.wl[r] : (T)0.5 - R.wl[r - SSR_W_P / 2];       // w[m + N/2] = 1/2 - w[m]
         R.v[r] = {(T)R.pa[r] * w, (T)R.pb[r] * w};
@@ -310,7 +314,9 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
     SSR_WPHASE(blk, regs, {
       // UNCONDITIONAL (the last frame of a chunk re-requests a clamped, valid frame that nobody consumes): under a condition
       // the previous contents of the 64 + 32 registers would stay live through all three passes for the path not taken
-      ssr_wave_prefetch<T>(p, R, tid, va, vb, u + S, n, n_frames);
+      // The first signal and the window now (32 + 16 requests), the second signal half-way through the bins: 64 + 16 at once
+      // stopped the wave at the 64th request until the oldest ones had returned, i.e. exposed the latency it is here to hide.
+      ssr_wave_prefetch<T, 1>(p, R, tid, va, vb, u + S, n, n_frames);
       SSR_UNROLL for (int r = 0; r < SSR_W_P / 2; ++r) R.wl[r] = vw.at(SSR_UIDX(tid + 64 * r));
       SSR_SCHED_BARRIER();
       double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -320,7 +326,7 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
       const int im_off = SPLIT ? SSR_W_IMOFF : 0;
       const T* lre = L.re;
       const T* lim = SPLIT ? L.re : L.im;
-      const bool store = p.out_kind == SSR_OUT_MAG;
+      const bool store = MAG < 0 ? p.out_kind == SSR_OUT_MAG : MAG != 0;
       const int pr = ssr_wave_bases(tid).pr;
       constexpr int G = SUMS ? 2 : 4;                              // bins in flight (the variant with running sums is tighter)
       SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int q0 = 0; q0 < 4; q0 += G) {
@@ -338,6 +344,11 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
             rb0[SSR_UIDX(tid + 64 * b + 256 * (q0 + q))] = t;
           }
         }
+        if (b == 1 && q0 + G == 4) {
+          SSR_SCHED_BARRIER();
+          ssr_wave_prefetch<T, 2>(p, R, tid, va, vb, u + S, n, n_frames);
+          SSR_SCHED_BARRIER();
+        }
       }
       if (tid == 0) {                                             // the Nyquist bin: Z[1024] pairs with itself
         const cx<T> zq = {lre[0], lim[im_off]};
@@ -345,7 +356,6 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
         ssr_pair_bin<T, 0, true>(mask, acc, zq, zq, a_nz, b_nz, e, t);
         if (store) { ra0[N / 2] = e; rb0[N / 2] = t; }
       }
-      ssr_wave_flags(R, tid, L.nz, par ^ 1);
       if (want_lsd) SSR_WAVE_SUM_STORE(tid, 64, acc[0], L.sc1);
       if constexpr (SUMS)
         for (int q = 0; q < 6; ++q) R.sums[q] += acc[1 + q];

@@ -39,6 +39,14 @@
   SSR_WAVE_SYNC();
 #endif
 
+// Developer build (-DSSR_PHASE_CLOCKS): shader-clock stamps at the phase boundaries of k_stft_wave's frame loop, summed per
+// launch (tu_stft.inc prints them).  SSR_CLK(i) is empty everywhere else.
+#define SSR_CLK(i)
+#if defined(SSR_PHASE_CLOCKS) && !defined(SSR_HOST_EMU)
+static __device__ unsigned long long ssr_dbg_clk[8];
+#define SSR_CLK_NOW(i) do { SSR_SCHED_BARRIER(); clk_[i] = __builtin_readcyclecounter(); SSR_SCHED_BARRIER(); } while (0)
+#endif
+
 constexpr int SSR_W_N = 2048, SSR_W_L = 64, SSR_W_P = 32;     // points, lanes, points per lane
 SSR_DEV int ssr_wpad(int i) { return i + (i >> 5); }            // lane stride 32 -> 33 doubles: conflict-free ds_*_b64
 constexpr int SSR_W_PN = SSR_W_N + (SSR_W_N >> 5) + 1;
@@ -179,6 +187,7 @@ SSR_DEV constexpr int ssr_w_off_st1(int i) { return 528 * (i >> 3) + 33 * (i & 7
       SSR_UNROLL for (int q = 1; q < 8; ++q) R.v[8 * b + q] = cmul(R.v[8 * b + q], R.tw1[q - 1]);                   \
       ssr_bfly8(R.v + 8 * b);                                                                                       \
     }                                                                                                               \
+    SSR_CLK(2);                                                                                                     \
   });                                                                                                               \
   blk = BLK0; ssr_launder(blk);                                                                                     \
   SSR_W_EXCHANGE(blk, regs, L, st1, ssr_w_off_st1, ld8, ssr_w_off_ld8, SSR_W_LOAD_TW2 EXTRA2);                      \
@@ -197,6 +206,7 @@ SSR_DEV constexpr int ssr_w_off_st1(int i) { return 528 * (i >> 3) + 33 * (i & 7
       x[7] = cmul(x[7], cmul(w3, w4));                                                                              \
       ssr_bfly8(x);                                                                                                 \
     }                                                                                                               \
+    SSR_CLK(3);                                                                                                     \
   });
 
 // Request unit u's samples into the prefetch registers (branch-free, always valid addresses, reflection only at the ends).
@@ -273,6 +283,11 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
   });
 
   BLK blk0 = blk;
+#ifdef SSR_CLK_NOW
+#undef SSR_CLK
+#define SSR_CLK(i) SSR_CLK_NOW(i)
+  unsigned long long clk_[6] = {0, 0, 0, 0, 0, 0}, clk_sum[5] = {0, 0, 0, 0, 0}, clk_frames = 0;
+#endif
   for (int u = u0, it = 0; u < u1; u += S, ++it) {
     // The lane's table values (window, twiddles) and addresses are loop-invariant, and 128 + 64 registers of data and
     // prefetched samples leave no room to keep them: with the lane index opaque the optimiser cannot hoist them out of the
@@ -282,6 +297,7 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
     // ---- pass 0: window, radix-32 DFT in registers (Stockham pass with stride 1: no twiddle).  Lane 0 also closes the
     // previous frame's LSD.
     SSR_WPHASE(blk, regs, {
+      SSR_CLK(0);
       ssr_wave_flags(R, tid, L.nz, it & 1);            // silent-frame votes of this unit, read by its epilogue
       SSR_UNROLL for (int r = 0; r < SSR_W_P; ++r) {
         const T w = (r < SSR_W_P / 2) ? R.wl[r] : (T)0.5 - R.wl[r - SSR_W_P / 2];       // w[m + N/2] = 1/2 - w[m]
@@ -289,6 +305,7 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
       }
       ssr_dft32(R.v);
       if (want_lsd && it > 0 && tid == 0) R.lsd_total += sqrt(L.sc1[0] / (double)F);
+      SSR_CLK(1);
     });
 #define VT vt
     SSR_W_FFT_TAIL(blk, blk0, regs, L, );
@@ -319,6 +336,7 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
       ssr_wave_prefetch<T, 1>(p, R, tid, va, vb, u + S, n, n_frames);
       SSR_UNROLL for (int r = 0; r < SSR_W_P / 2; ++r) R.wl[r] = vw.at(SSR_UIDX(tid + 64 * r));
       SSR_SCHED_BARRIER();
+      SSR_CLK(4);
       double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       const int par = it & 1;
       const bool a_nz = L.nonzero(0, par), b_nz = L.nonzero(1, par);
@@ -359,8 +377,21 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
       if (want_lsd) SSR_WAVE_SUM_STORE(tid, 64, acc[0], L.sc1);
       if constexpr (SUMS)
         for (int q = 0; q < 6; ++q) R.sums[q] += acc[1 + q];
+      SSR_CLK(5);
     });
+#ifdef SSR_CLK_NOW
+    for (int q = 0; q < 5; ++q) clk_sum[q] += clk_[q + 1] - clk_[q];
+    ++clk_frames;
+#endif
   }
+#ifdef SSR_CLK_NOW
+#undef SSR_CLK
+#define SSR_CLK(i)
+  if (blk.tid == 0) {
+    for (int q = 0; q < 5; ++q) atomicAdd(&ssr_dbg_clk[q], clk_sum[q]);
+    atomicAdd(&ssr_dbg_clk[5], clk_frames);
+  }
+#endif
 
   if (part == nullptr) return;
   // ---- chunk tail: last frame's LSD and the wave-sums of the SISpec accumulators

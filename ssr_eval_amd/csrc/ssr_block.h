@@ -44,6 +44,8 @@ static inline unsigned ssr_launder_index(unsigned i) { return i; }
     (dst)[(tid) >> 6] += (val);                             \
   } while (0)
 #define SSR_WAVE_SUM_ADD(tid, NT_, val, dst) do { (dst)[(tid) >> 6] += (val); } while (0)
+// lane-private accumulator in LDS: *p += v, nothing returned
+#define SSR_LDS_ACCUM(p, v) do { *(p) += (v); } while (0)
 // inside a phase: SSR_WAVE_ANY(pred) = "pred holds on some lane of this wave" (device: a scalar; host: the lane's own
 // pred, folded over the wave by the store); SSR_WAVE_FLAG_STORE: dst[tid / 64] = that flag
 #define SSR_WAVE_ANY(pred) ((pred) ? 1 : 0)
@@ -128,6 +130,8 @@ SSR_DEV int ssr_wave_of(int tid) { return ssr_wave_index(tid); }
     const double s_ = ssr_wave_sum<((NT_) < 64 ? (NT_) : 64)>(val);                \
     if (((tid) & 63) == 0) (dst)[ssr_wave_index(tid)] = s_;                        \
   } while (0)
+// lane-private accumulator in LDS: *p += v as one ds_add_f64 (nothing comes back: no register, no wait)
+#define SSR_LDS_ACCUM(p, v) ((void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT))
 #define SSR_WAVE_SUM_ADD(tid, NT_, val, dst)                                       \
   do {                                                                             \
     const double s_ = ssr_wave_sum<((NT_) < 64 ? (NT_) : 64)>(val);                \

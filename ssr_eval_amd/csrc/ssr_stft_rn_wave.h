@@ -24,7 +24,6 @@ template <typename T, bool SUMS, int NQ> struct SsrRnWaveRegs {
   float pa[4 * NQ], pb[4 * NQ];   // the next unit's decimated samples m = lane + 64 i, requested a unit ahead
   cx<T> tw1[7];
   cx<T> tw2[12];
-  double sums[SUMS ? 6 : 1];
 };
 
 template <typename T> struct SsrWaveBuf { T* re; T* im; };
@@ -41,6 +40,12 @@ template <typename T, int NW> struct SsrRnWaveLds {
     x = reinterpret_cast<T*>(nz + 16);
   }
 };
+
+// LDS of one workgroup: scratch + exchange arrays, and for the variants with SISpec / log-SISpec running sums one float64
+// accumulator per sum and lane ([6][64 NW], updated with ds_add_f64; see ssr_stft_wave_lds_bytes)
+template <typename T, int NW, bool SUMS> constexpr size_t ssr_stft_rn_wave_lds_bytes() {
+  return SsrRnWaveLds<T, NW>::bytes() + (SUMS ? 6 * 64 * NW * sizeof(double) : 0);
+}
 
 // decimated samples of unit u (frame u of both signals), sub-sequence r: sample NW m + r of the frame, m = lane + 64 i
 template <typename T, int NW, int NQ, typename REGS>
@@ -92,11 +97,12 @@ SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
   const SsrView<float> va(p.a + p.a_off[item], n), vb(p.b + p.b_off[item], n);
   const SsrView<cx<T>> vwc(p.wchirp, n_fft), vbf(p.bfilt, SSR_W_N), vch(p.chirp, n_fft), vt(p.tw, SSR_W_N);
 
+  double* lsum = reinterpret_cast<double*>(lds_base + SsrRnWaveLds<T, NW>::bytes());   // [6][NT], SUMS only
   SSR_REGS(Regs, regs, blk);
   SSR_PHASE(blk, regs, {
     for (int i = tid; i < 6 * 4; i += NT) L.wacc[i] = 0.0;
     if (tid == 0) L.res[0] = 0.0;
-    for (int i = 0; i < (SUMS ? 6 : 1); ++i) R.sums[i] = 0.0;
+    if constexpr (SUMS) for (int i = 0; i < 6; ++i) lsum[NT * i + tid] = 0.0;
     if (u0 < u1) ssr_rn_wave_prefetch<T, NW, NQ>(R, tid & 63, ssr_wave_of(tid), va, vb, u0, hop, n_fft, q, n, n_frames);
   });
 
@@ -189,14 +195,14 @@ SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
       }
       if (want_lsd) SSR_WAVE_SUM_STORE(tid, NT, acc[0], L.sc1);
       if constexpr (SUMS)
-        for (int i = 0; i < 6; ++i) R.sums[i] += acc[1 + i];
+        for (int i = 0; i < 6; ++i) SSR_LDS_ACCUM(lsum + NT * i + tid, acc[1 + i]);
     });
   }
 #undef SSR_R3_L
 
   if (part == nullptr) return;
   if constexpr (SUMS) {
-    SSR_PHASE(blk, regs, for (int i = 0; i < 6; ++i) SSR_WAVE_SUM_ADD(tid, NT, R.sums[i], L.wacc + i * 4));
+    SSR_PHASE(blk, regs, for (int i = 0; i < 6; ++i) SSR_WAVE_SUM_ADD(tid, NT, lsum[NT * i + tid], L.wacc + i * 4));
   }
   SSR_PHASE(blk, regs, if (tid == 0) {
     double lsd = L.res[0];

@@ -109,7 +109,6 @@ template <typename T, bool SUMS> struct SsrWaveRegs {
                              // the stores' acknowledgements)
   cx<T> tw1[7];              // w^(8 (tid mod 32) q), q = 1..7: requested while the first exchange is in flight
   cx<T> tw2[12];             // w^j, w^2j, w^4j of the four third-pass butterflies: requested while the second one is
-  double sums[SUMS ? 6 : 1]; // SISpec / log-SISpec running sums
   double lsd_total;          // lane 0: sum over the chunk's frames of the per-frame LSD
 };
 
@@ -131,6 +130,13 @@ template <typename T, bool SPLIT> struct SsrWaveLds {
     return f != 0;
   }
 };
+
+// LDS of one k_stft_wave wave.  The six SISpec / log-SISpec running sums of a lane live behind the exchange array (6 x 64
+// float64 = 3 KB: 16,968 + 3,072 B still makes eight waves per CU) and are updated with ds_add_f64 - as registers they
+// were twelve more than the variant had (11 spilled to scratch: 0.9 GB of scratch traffic per launch).
+template <typename T, bool SPLIT, bool SUMS> constexpr size_t ssr_stft_wave_lds_bytes() {
+  return SsrWaveLds<T, SPLIT>::bytes() + (SUMS ? 6 * 64 * sizeof(double) : 0);
+}
 
 // LDS slots as (per-lane base) + (compile-time offset): the offsets fold into the DS instructions' immediate fields.
 //  after pass 0 : register rho = frequency q = ssr_dft32_freq(rho) of sub-transform `tid` -> slot 32 tid + q, padded 33 tid + q
@@ -270,10 +276,11 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
   const SsrView<T> vw(p.window, N);
   const SsrView<cx<T>> vt(p.tw, N);
 
+  double* lsum = reinterpret_cast<double*>(lds_base + SsrWaveLds<T, SPLIT>::bytes());   // [6][64], SUMS only
   SSR_REGS(Regs, regs, blk);
   SSR_WPHASE(blk, regs, {
     R.lsd_total = 0.0;
-    for (int q = 0; q < (SUMS ? 6 : 1); ++q) R.sums[q] = 0.0;
+    if constexpr (SUMS) for (int q = 0; q < 6; ++q) lsum[64 * q + tid] = 0.0;
     if (tid == 0) L.sc1[0] = 0.0;
     if (u0 < u1) {
       ssr_wave_prefetch<T>(p, R, tid, va, vb, u0, n, n_frames);
@@ -376,7 +383,7 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
       }
       if (want_lsd) SSR_WAVE_SUM_STORE(tid, 64, acc[0], L.sc1);
       if constexpr (SUMS)
-        for (int q = 0; q < 6; ++q) R.sums[q] += acc[1 + q];
+        for (int q = 0; q < 6; ++q) SSR_LDS_ACCUM(lsum + 64 * q + tid, acc[1 + q]);
       SSR_CLK(5);
     });
 #ifdef SSR_CLK_NOW
@@ -397,7 +404,7 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
   // ---- chunk tail: last frame's LSD and the wave-sums of the SISpec accumulators
   if constexpr (SUMS) {
     for (int q = 0; q < 6; ++q) {
-      SSR_WPHASE(blk, regs, SSR_WAVE_SUM_STORE(tid, 64, R.sums[q], L.sc1 + 1));
+      SSR_WPHASE(blk, regs, SSR_WAVE_SUM_STORE(tid, 64, lsum[64 * q + tid], L.sc1 + 1));
       SSR_WPHASE(blk, regs, if (tid == 0) part[1 + q] = L.sc1[1]);
     }
   } else {

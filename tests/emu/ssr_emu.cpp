@@ -131,11 +131,11 @@ static int emu_stft_wave_t(int hop, int out_kind, int mask, int split, int inter
   for (int item = 0; item < n_items; ++item)
     for (int c = 0; c < n_chunks; ++c) {
       if (split) {
-        auto lds = poisoned(SsrWaveLds<T, true>::bytes());
+        auto lds = poisoned(ssr_stft_wave_lds_bytes<T, true, true>());
         if (sums) ssr_stft_wave_body<T, true, true>(p, blk, c, item, lds.data());
         else ssr_stft_wave_body<T, false, true>(p, blk, c, item, lds.data());
       } else {
-        auto lds = poisoned(SsrWaveLds<T, false>::bytes());
+        auto lds = poisoned(ssr_stft_wave_lds_bytes<T, false, true>());
         if (sums) ssr_stft_wave_body<T, true, false>(p, blk, c, item, lds.data());
         else ssr_stft_wave_body<T, false, false>(p, blk, c, item, lds.data());
       }
@@ -159,7 +159,7 @@ static void emu_rn_wave_run(const SsrStftParams<T>& p, int n_items, int n_chunks
   SsrBlk blk{64 * NW};
   for (int item = 0; item < n_items; ++item)
     for (int c = 0; c < n_chunks; ++c) {
-      auto lds = poisoned(SsrRnWaveLds<T, NW>::bytes());
+      auto lds = poisoned(ssr_stft_rn_wave_lds_bytes<T, NW, true>());
       if (sums) ssr_stft_rn_wave_body<T, true, NW, NQ>(p, blk, c, item, lds.data());
       else ssr_stft_rn_wave_body<T, false, NW, NQ>(p, blk, c, item, lds.data());
     }

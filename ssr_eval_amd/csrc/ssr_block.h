@@ -192,7 +192,7 @@ template <typename E> struct SsrView {
   const E* base; int64_t n;
   SSR_MEMBER SsrView(const E* p, int64_t n_elems) : base(p), n(n_elems) {}
   SSR_MEMBER E at(unsigned idx, int64_t uniform_off = 0) const { return base[uniform_off + idx]; }
-  SSR_MEMBER E at_or_zero(unsigned idx) const { return ((int64_t)idx < n) ? base[idx] : (E)0; }
+  SSR_MEMBER E at_or_zero(unsigned idx) const { return ((int64_t)idx < n) ? base[idx] : E{}; }
 #else
   __amdgpu_buffer_rsrc_t rsrc;
   SSR_MEMBER SsrView(const E* p, int64_t n_elems)

@@ -95,7 +95,7 @@ SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
   const int mask = SUMS ? p.metric_mask : (p.metric_mask & SSR_M_LSD);
   const bool want_lsd = mask & SSR_M_LSD;
   const SsrView<float> va(p.a + p.a_off[item], n), vb(p.b + p.b_off[item], n);
-  const SsrView<cx<T>> vwc(p.wchirp, n_fft), vbf(p.bfilt, SSR_W_N), vch(p.chirp, n_fft), vt(p.tw, SSR_W_N);
+  const SsrView<cx<T>> vbf(p.bfilt, SSR_W_N), vch(p.chirp, n_fft), vt(p.tw, SSR_W_N);
 
   double* lsum = reinterpret_cast<double*>(lds_base + SsrRnWaveLds<T, NW>::bytes());   // [6][NT], SUMS only
   SSR_REGS(Regs, regs, blk);
@@ -113,14 +113,16 @@ SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
     // ---- wave r: decimated frame * (window * chirp) -> registers (only m < q is non-zero: NI of the 32 points), first pass
     SSR_WPHASE(blk, regs, {
       const int lane = tid & 63, r = ssr_wave_of(tid);
+      // this wave's q table values as a view of their own: rows m >= q are out of its range and load 0, which zeroes the
+      // padded points without a lane mask per row (their sample registers hold a repeat of the frame's sample m = q - 1)
+      const SsrView<cx<T>> vwr(p.wchirp + (int64_t)r * q, q);
       unsigned ora = 0u, orb = 0u;
       SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) {
         if (i < NI) {
-          const int m = lane + 64 * i;
-          const cx<T> wc = vwc.at(SSR_UIDX(m < q ? m : q - 1), (int64_t)r * q);
-          const cx<T> z = cmul(cx<T>{(T)R.pa[i], (T)R.pb[i]}, wc);
-          R.v[i] = (m < q) ? z : cx<T>{(T)0, (T)0};
-          const bool counts = (m < q) && (m + r != 0);            // frame sample 0: window weight exactly 0 (periodic Hann)
+          R.v[i] = cmul(cx<T>{(T)R.pa[i], (T)R.pb[i]}, vwr.at_or_zero(SSR_UIDX(lane + 64 * i)));
+          // silent-frame vote: every register holds a sample of this frame (the repeats included); frame sample 0 carries
+          // window weight exactly 0 (periodic Hann) and does not count
+          const bool counts = i > 0 || lane + r != 0;
           ora |= counts ? ssr_mag_bits(R.pa[i]) : 0u;
           orb |= counts ? ssr_mag_bits(R.pb[i]) : 0u;
         } else {
@@ -131,7 +133,7 @@ SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
       // of the epilogue that reads them would need no double buffering, but the epilogue of unit u runs before these of u + 1)
       SSR_WAVE_ANY_STORE(lane, ora != 0u, L.nz + ((u - u0) & 1) * 3 + r);
       SSR_WAVE_ANY_STORE(lane, orb != 0u, L.nz + 8 + ((u - u0) & 1) * 3 + r);
-      ssr_dft32(R.v);
+      ssr_dft32<T, NI>(R.v);
       if (want_lsd && u > u0 && tid == 0) {
         double s = 0.0;
         for (int w = 0; w < NW; ++w) s += L.sc1[w];

@@ -70,11 +70,22 @@ template <typename T> SSR_DEV cx<T> ssr_w32(int m) {
 }
 
 // v[r], r = 8 n1 + n2  (n1 < 4, n2 < 8)   ->   v[8 k1 + k2] = DFT32(v)[k1 + 4 k2]      (in place, registers only)
-template <typename T> SSR_DEV void ssr_dft32(cx<T>* v) {
+// NZ: only v[0 .. NZ) can be non-zero (a zero-padded Bluestein input: NZ = 12 or 16 rows of 64 samples); the first
+// radix-4 stage then skips the additions of zeros - the same values, 96 fewer instructions at NZ = 12.
+template <typename T, int NZ = 32> SSR_DEV void ssr_dft32(cx<T>* v) {
   const T h = (T)0.70710678118654752440;
+  static_assert(NZ == 32 || (NZ > 8 && NZ <= 16), "full, or two non-zero row groups");
   SSR_UNROLL for (int n2 = 0; n2 < 8; ++n2) {
     cx<T> t[4] = {v[n2], v[8 + n2], v[16 + n2], v[24 + n2]};
-    ssr_bfly4(t);
+    if (NZ == 32) {
+      ssr_bfly4(t);
+    } else if (8 + n2 < NZ) {                       // t[2] = t[3] = 0
+      const cx<T> r = cmul_negi(t[1]);
+      t[2] = csub(t[0], t[1]); t[3] = csub(t[0], r);
+      t[1] = cadd(t[0], r);    t[0] = cadd(t[0], v[8 + n2]);
+    } else {                                        // only t[0]
+      t[1] = t[0]; t[2] = t[0]; t[3] = t[0];
+    }
     SSR_UNROLL for (int k1 = 0; k1 < 4; ++k1) {
       const int m = n2 * k1;                       // compile-time after unrolling: the special angles cost no multiply
       cx<T> x = t[k1];

@@ -363,6 +363,10 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
       const T* lre = L.re;
       const T* lim = SPLIT ? L.re : L.im;
       const bool store = MAG < 0 ? p.out_kind == SSR_OUT_MAG : MAG != 0;
+      // the two magnitude rows as buffer views: scalar row base + one lane offset + an immediate per bin (a plain pointer
+      // costs a 64-bit vector add per store)
+      const SsrRwView<float> wa(ra0, store ? F : 0), wb(rb0, store ? F : 0);
+      const int lane4 = 4 * tid;
       const int pr = ssr_wave_bases(tid).pr;
       constexpr int G = SUMS ? 2 : 4;                              // bins in flight (the variant with running sums is tighter)
       SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int q0 = 0; q0 < 4; q0 += G) {
@@ -376,8 +380,8 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
           if (both) ssr_pair_bin<T, 0, true>(mask, acc, zk, zz, true, true, e, t);
           else ssr_pair_bin<T, 0, true>(mask, acc, zk, zz, a_nz, b_nz, e, t);
           if (store) {
-            ra0[SSR_UIDX(tid + 64 * b + 256 * (q0 + q))] = e;
-            rb0[SSR_UIDX(tid + 64 * b + 256 * (q0 + q))] = t;
+            wa.st_raw(lane4 + 4 * (64 * b + 256 * (q0 + q)), e);
+            wb.st_raw(lane4 + 4 * (64 * b + 256 * (q0 + q)), t);
           }
         }
         if (b == 1 && q0 + G == 4) {
@@ -390,7 +394,7 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
         const cx<T> zq = {lre[0], lim[im_off]};
         float e, t;
         ssr_pair_bin<T, 0, true>(mask, acc, zq, zq, a_nz, b_nz, e, t);
-        if (store) { ra0[N / 2] = e; rb0[N / 2] = t; }
+        if (store) { wa.st_raw(4 * (N / 2), e); wb.st_raw(4 * (N / 2), t); }
       }
       if (want_lsd) SSR_WAVE_SUM_STORE(tid, 64, acc[0], L.sc1);
       if constexpr (SUMS)

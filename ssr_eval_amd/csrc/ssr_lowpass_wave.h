@@ -87,7 +87,7 @@ SSR_BODY void ssr_lowpass_wave_body(const SsrLowpassParams<T>& p, BLK& blk, int 
   const SsrView<float> vre(analysis ? nullptr : p.spec_re + row0 * F, analysis ? 0 : (int64_t)n_frames * F);
   const SsrView<float> vim(analysis ? nullptr : p.spec_im + row0 * F, analysis ? 0 : (int64_t)n_frames * F);
   const SsrView<T> vw(p.window, N);
-  const SsrView<cx<T>> vt(p.tw, N);
+  const SsrView<cx<T>> vt(p.tw, N + SSR_W_TWP);
 
   SSR_REGS(Regs, regs, blk);
   SSR_WPHASE(blk, regs, {

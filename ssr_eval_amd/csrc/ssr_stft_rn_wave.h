@@ -95,7 +95,7 @@ SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
   const int mask = SUMS ? p.metric_mask : (p.metric_mask & SSR_M_LSD);
   const bool want_lsd = mask & SSR_M_LSD;
   const SsrView<float> va(p.a + p.a_off[item], n), vb(p.b + p.b_off[item], n);
-  const SsrView<cx<T>> vbf(p.bfilt, SSR_W_N), vch(p.chirp, n_fft), vt(p.tw, SSR_W_N);
+  const SsrView<cx<T>> vbf(p.bfilt, SSR_W_N), vch(p.chirp, n_fft), vt(p.tw, SSR_W_N + SSR_W_TWP);
 
   double* lsum = reinterpret_cast<double*>(lds_base + SsrRnWaveLds<T, NW>::bytes());   // [6][NT], SUMS only
   SSR_REGS(Regs, regs, blk);

@@ -48,6 +48,7 @@ static __device__ unsigned long long ssr_dbg_clk[8];
 #endif
 
 constexpr int SSR_W_N = 2048, SSR_W_L = 64, SSR_W_P = 32;     // points, lanes, points per lane
+constexpr int SSR_W_TWP = 7 * 32 + 12 * 64;                   // lane-ordered twiddle copies behind the table (= SSR_WAVE_TWP)
 SSR_DEV int ssr_wpad(int i) { return i + (i >> 5); }            // lane stride 32 -> 33 doubles: conflict-free ds_*_b64
 constexpr int SSR_W_PN = SSR_W_N + (SSR_W_N >> 5) + 1;
 constexpr int SSR_W_IMOFF = 1024 + 32;    // SPLIT: the upper-half imaginary parts of the final exchange sit behind the real parts
@@ -191,10 +192,12 @@ SSR_DEV constexpr int ssr_w_off_st1(int i) { return 528 * (i >> 3) + 33 * (i & 7
 // The lane index is `tid & 63` throughout: a workgroup of several autonomous waves (ssr_stft_rn_wave.h) passes an L whose
 // arrays are the calling wave's own.
 // EXTRA2: further table loads to issue with the last pass's twiddles (the low-pass kernel's synthesis window).
-#define SSR_W_LOAD_TW1 { const unsigned k8 = SSR_UIDX(8 * (tid & 31)); \
-                         SSR_UNROLL for (int q = 1; q < 8; ++q) R.tw1[q - 1] = VT.at(k8 * q); }
-#define SSR_W_LOAD_TW2 SSR_UNROLL for (int b = 0; b < 4; ++b) { const unsigned j = SSR_UIDX((tid & 63) + 64 * b); \
-                         R.tw2[3 * b] = VT.at(j); R.tw2[3 * b + 1] = VT.at(2 * j); R.tw2[3 * b + 2] = VT.at(4 * j); }
+// (VT: a view of the plan's twiddle table INCLUDING the lane-ordered copies behind it, SSR_W_N + SSR_W_TWP entries -
+// ssr_tables.h: every load below is one contiguous run of 32 / 64 table entries)
+#define SSR_W_LOAD_TW1 { const unsigned l_ = SSR_UIDX(tid & 31); \
+                         SSR_UNROLL for (int q = 1; q < 8; ++q) R.tw1[q - 1] = VT.at(l_ + (SSR_W_N + 32 * (q - 1))); }
+#define SSR_W_LOAD_TW2 { const unsigned l_ = SSR_UIDX(tid & 63); \
+                         SSR_UNROLL for (int i = 0; i < 12; ++i) R.tw2[i] = VT.at(l_ + (SSR_W_N + 224 + 64 * i)); }
 #define SSR_W_FFT_TAIL(blk, BLK0, regs, L, EXTRA2)                                                                        \
   blk = BLK0; ssr_launder(blk);                                                                                     \
   SSR_W_EXCHANGE(blk, regs, L, st0, ssr_w_off_st0, ld8, ssr_w_off_ld8, SSR_W_LOAD_TW1);                             \
@@ -285,7 +288,7 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
   const bool want_lsd = mask & SSR_M_LSD;
   const SsrView<float> va(sa, n), vb(sb, n);
   const SsrView<T> vw(p.window, N);
-  const SsrView<cx<T>> vt(p.tw, N);
+  const SsrView<cx<T>> vt(p.tw, N + SSR_W_TWP);
 
   double* lsum = reinterpret_cast<double*>(lds_base + SsrWaveLds<T, SPLIT>::bytes());   // [6][64], SUMS only
   SSR_REGS(Regs, regs, blk);

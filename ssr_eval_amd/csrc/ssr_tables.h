@@ -55,6 +55,8 @@ inline SsrEngine ssr_pick_wave_engine(int n_fft) {
   return none;
 }
 
+constexpr int SSR_WAVE_N = 2048, SSR_WAVE_TWP = 7 * 32 + 12 * 64;   // wave engines: transform length, lane-ordered twiddle copies
+
 template <typename T> struct SsrTables {
   SsrEngine eng;
   int n_fft;
@@ -105,6 +107,18 @@ template <typename T> bool ssr_build_tables_for(int n_fft, SsrEngine eng, SsrTab
   for (int i = 0; i < N; ++i) {
     const long double ang = -2.0L * SSR_PI_L * i / N;
     t.tw[i] = {(T)cosl(ang), (T)sinl(ang)};
+  }
+  if (N == SSR_WAVE_N) {
+    // Lane-ordered copies of the twiddles the wave engines read (ssr_stft_wave.h: SSR_W_LOAD_TW1 / TW2), behind the table:
+    //   [N + 32 (q - 1) + l]          = tw[8 l q],          q = 1..7, l < 32   (pass 1: the lane's seven)
+    //   [N + 224 + 64 (3 b + k) + l]  = tw[(l + 64 b) 2^k], b < 4, k < 3, l < 64 (pass 2: w^j, w^2j, w^4j of butterfly b)
+    // A wave's load of one of them is 512 B / 1 KB contiguous instead of 32 / 64 lines 128..512 B apart.
+    t.tw.resize(N + SSR_WAVE_TWP);
+    for (int q = 1; q < 8; ++q)
+      for (int l = 0; l < 32; ++l) t.tw[N + 32 * (q - 1) + l] = t.tw[8 * l * q];
+    for (int b = 0; b < 4; ++b)
+      for (int k = 0; k < 3; ++k)
+        for (int l = 0; l < 64; ++l) t.tw[N + 224 + 64 * (3 * b + k) + l] = t.tw[(l + 64 * b) << k];
   }
   if (t.eng.bluestein) {
     // inner (Bluestein) length q: n_fft itself, or n_fft / R under a radix-R outer step

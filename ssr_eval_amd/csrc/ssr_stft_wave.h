@@ -251,7 +251,8 @@ SSR_DEV void ssr_wave_prefetch(const SsrStftParams<T>& p, REGS& R, int tid, cons
   }
 }
 
-// Silent-frame flags of the PREFETCHED unit into flag set `par` (see ssr_stft_prefetched_flags).
+// Silent-frame votes of the unit whose samples sit in the prefetch registers, into flag set `par` (the body calls it at
+// the top of the frame that consumes them; cf. ssr_stft_prefetched_flags).
 template <typename REGS> SSR_DEV void ssr_wave_flags(REGS& R, int tid, int* nz, int par) {
   SSR_UNROLL for (int r = 0; r < SSR_W_P; ++r) { ssr_touch(R.pa[r]); ssr_touch(R.pb[r]); }
   unsigned ora = 0u, orb = 0u;

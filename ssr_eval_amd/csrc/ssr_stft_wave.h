@@ -384,13 +384,8 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
           if (both) ssr_pair_bin<T, 0, true>(mask, acc, zk, zz, true, true, e, t);
           else ssr_pair_bin<T, 0, true>(mask, acc, zk, zz, a_nz, b_nz, e, t);
           if (store) {
-            if constexpr (SUMS) {        // (two more buffer descriptors are four spilled registers in this variant)
-              ra0[SSR_UIDX(tid + 64 * b + 256 * (q0 + q))] = e;
-              rb0[SSR_UIDX(tid + 64 * b + 256 * (q0 + q))] = t;
-            } else {
-              wa.st_raw(lane4 + 4 * (64 * b + 256 * (q0 + q)), e);
-              wb.st_raw(lane4 + 4 * (64 * b + 256 * (q0 + q)), t);
-            }
+            wa.st_raw(lane4 + 4 * (64 * b + 256 * (q0 + q)), e);
+            wb.st_raw(lane4 + 4 * (64 * b + 256 * (q0 + q)), t);
           }
         }
         if (b == 1 && q0 + G == 4) {
@@ -403,7 +398,7 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
         const cx<T> zq = {lre[0], lim[im_off]};
         float e, t;
         ssr_pair_bin<T, 0, true>(mask, acc, zq, zq, a_nz, b_nz, e, t);
-        if (store) { if constexpr (SUMS) { ra0[N / 2] = e; rb0[N / 2] = t; } else { wa.st_raw(4 * (N / 2), e); wb.st_raw(4 * (N / 2), t); } }
+        if (store) { wa.st_raw(4 * (N / 2), e); wb.st_raw(4 * (N / 2), t); }
       }
       if (want_lsd) SSR_WAVE_SUM_STORE(tid, 64, acc[0], L.sc1);
       if constexpr (SUMS)

@@ -140,7 +140,9 @@ class Cfg2:
         default_wl = a.pairs == 1024 and a.precision == "f64"
         roof = hbm_roofline(dom[0], alg, dom[1], dom[2] if default_wl else None,
                             "fused path is compute-side (f64 FFT + f64 SSIM moments); secondary: STFT kernel runs at %.2f TFLOP/s "
-                            "of real-FFT work = %.3f of the f64 vector peak" % (fft_tflops, fft_tflops / FP64_PEAK_TFLOPS))
+                            "of real-FFT work = %.3f of the f64 vector peak at 2.4 GHz (the chip sustains 1.7-2.0 GHz under FP64 "
+                            "load; by instruction count the kernel issues FP64 at 70 %% of that rate: DESIGN.md section 3)"
+                            % (fft_tflops, fft_tflops / FP64_PEAK_TFLOPS))
         extra = {"stage_ms": {"stft+lsd": round(ms_stft, 4), "ssim": round(ms_ssim, 4), "finalize": round(ms_fin, 4)},
                  "full_metric_set_pairs_per_s_per_gpu": round(a.pairs / (ms_all4 * 1e-3), 1)}
         return roof, extra

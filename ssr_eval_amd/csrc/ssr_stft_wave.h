@@ -308,7 +308,7 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
 #ifdef SSR_CLK_NOW
 #undef SSR_CLK
 #define SSR_CLK(i) SSR_CLK_NOW(i)
-  unsigned long long clk_[6] = {0, 0, 0, 0, 0, 0}, clk_sum[5] = {0, 0, 0, 0, 0}, clk_frames = 0;
+  unsigned long long clk_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, clk_sum[5] = {0, 0, 0, 0, 0}, clk_top[2] = {0, 0}, clk_frames = 0;
 #endif
   for (int u = u0, it = 0; u < u1; u += S, ++it) {
     // The lane's table values (window, twiddles) and addresses are loop-invariant, and 128 + 64 registers of data and
@@ -321,10 +321,12 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
     SSR_WPHASE(blk, regs, {
       SSR_CLK(0);
       ssr_wave_flags(R, tid, L.nz, it & 1);            // silent-frame votes of this unit, read by its epilogue
+      SSR_CLK(6);
       SSR_UNROLL for (int r = 0; r < SSR_W_P; ++r) {
         const T w = (r < SSR_W_P / 2) ? R.wl[r] : (T)0.5 - R.wl[r - SSR_W_P / 2];       // w[m + N/2] = 1/2 - w[m]
         R.v[r] = {(T)R.pa[r] * w, (T)R.pb[r] * w};
       }
+      SSR_CLK(7);
       ssr_dft32(R.v);
       if (want_lsd && it > 0 && tid == 0) R.lsd_total += sqrt(L.sc1[0] / (double)F);
       SSR_CLK(1);
@@ -407,6 +409,7 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
     });
 #ifdef SSR_CLK_NOW
     for (int q = 0; q < 5; ++q) clk_sum[q] += clk_[q + 1] - clk_[q];
+    clk_top[0] += clk_[6] - clk_[0]; clk_top[1] += clk_[7] - clk_[6];
     ++clk_frames;
 #endif
   }
@@ -416,6 +419,7 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
   if (blk.tid == 0) {
     for (int q = 0; q < 5; ++q) atomicAdd(&ssr_dbg_clk[q], clk_sum[q]);
     atomicAdd(&ssr_dbg_clk[5], clk_frames);
+    atomicAdd(&ssr_dbg_clk[6], clk_top[0]); atomicAdd(&ssr_dbg_clk[7], clk_top[1]);
   }
 #endif
 

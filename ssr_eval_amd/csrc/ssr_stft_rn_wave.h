@@ -43,8 +43,9 @@ template <typename T, int NW> struct SsrRnWaveLds {
 
 // LDS of one workgroup: scratch + exchange arrays, and for the variants with SISpec / log-SISpec running sums one float64
 // accumulator per sum and lane ([6][64 NW], updated with ds_add_f64; see ssr_stft_wave_lds_bytes)
+template <typename T, int NW> constexpr size_t ssr_stft_rn_wave_sums_offset() { return (SsrRnWaveLds<T, NW>::bytes() + 7) & ~(size_t)7; }
 template <typename T, int NW, bool SUMS> constexpr size_t ssr_stft_rn_wave_lds_bytes() {
-  return SsrRnWaveLds<T, NW>::bytes() + (SUMS ? 6 * 64 * NW * sizeof(double) : 0);
+  return SUMS ? ssr_stft_rn_wave_sums_offset<T, NW>() + 6 * 64 * NW * sizeof(double) : SsrRnWaveLds<T, NW>::bytes();
 }
 
 // decimated samples of unit u (frame u of both signals), sub-sequence r: sample NW m + r of the frame, m = lane + 64 i
@@ -97,7 +98,7 @@ SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
   const SsrView<float> va(p.a + p.a_off[item], n), vb(p.b + p.b_off[item], n);
   const SsrView<cx<T>> vbf(p.bfilt, SSR_W_N), vch(p.chirp, n_fft), vt(p.tw, SSR_W_N + SSR_W_TWP);
 
-  double* lsum = reinterpret_cast<double*>(lds_base + SsrRnWaveLds<T, NW>::bytes());   // [6][NT], SUMS only
+  double* lsum = reinterpret_cast<double*>(lds_base + ssr_stft_rn_wave_sums_offset<T, NW>());   // [6][NT], SUMS only
   SSR_REGS(Regs, regs, blk);
   SSR_PHASE(blk, regs, {
     for (int i = tid; i < 6 * 4; i += NT) L.wacc[i] = 0.0;

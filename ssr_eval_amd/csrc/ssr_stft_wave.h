@@ -146,8 +146,10 @@ template <typename T, bool SPLIT> struct SsrWaveLds {
 // LDS of one k_stft_wave wave.  The six SISpec / log-SISpec running sums of a lane live behind the exchange array (6 x 64
 // float64 = 3 KB: 16,968 + 3,072 B still makes eight waves per CU) and are updated with ds_add_f64 - as registers they
 // were twelve more than the variant had (11 spilled to scratch: 0.9 GB of scratch traffic per launch).
+// (offset of the accumulators: the float32 engine's arrays end on a 4-byte boundary, ds_add_f64 needs 8)
+template <typename T, bool SPLIT> constexpr size_t ssr_stft_wave_sums_offset() { return (SsrWaveLds<T, SPLIT>::bytes() + 7) & ~(size_t)7; }
 template <typename T, bool SPLIT, bool SUMS> constexpr size_t ssr_stft_wave_lds_bytes() {
-  return SsrWaveLds<T, SPLIT>::bytes() + (SUMS ? 6 * 64 * sizeof(double) : 0);
+  return SUMS ? ssr_stft_wave_sums_offset<T, SPLIT>() + 6 * 64 * sizeof(double) : SsrWaveLds<T, SPLIT>::bytes();
 }
 
 // LDS slots as (per-lane base) + (compile-time offset): the offsets fold into the DS instructions' immediate fields.
@@ -291,7 +293,7 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
   const SsrView<T> vw(p.window, N);
   const SsrView<cx<T>> vt(p.tw, N + SSR_W_TWP);
 
-  double* lsum = reinterpret_cast<double*>(lds_base + SsrWaveLds<T, SPLIT>::bytes());   // [6][64], SUMS only
+  double* lsum = reinterpret_cast<double*>(lds_base + ssr_stft_wave_sums_offset<T, SPLIT>());   // [6][64], SUMS only
   SSR_REGS(Regs, regs, blk);
   SSR_WPHASE(blk, regs, {
     R.lsd_total = 0.0;

@@ -350,3 +350,26 @@ def test_full_size_properties_of_the_path():
     same = B.PairBatch(plan, rag, rag).run(B.M_SSIM | B.M_LSD).cpu().numpy()
     # (the two SSIM ratios are float32: 1 - 3e-8; LSD's 1e-12 guards leave ~1e-12 where a frame holds a tiny bin)
     assert (np.abs(same[:, 3] - 1.0) <= 1e-7).all() and (same[:, 0] <= 1e-9).all()
+
+
+# ---- float32 transform precision: every pair engine with all four metrics ---------------------------------------------------
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (2048, 441), (2229, 480), (1486, 320), (1114, 240), (743, 160), (1024, 256)])
+def test_float32_precision_plans_all_metrics(n_fft, hop):
+    """precision="f32" plans (float32 transform: not the reference's arithmetic, offered for speed) run the same engines with
+    float32 exchange arrays; the running-sum accumulators behind those arrays are float64 and need their own alignment
+    (a misaligned ds_add_f64 is a memory violation, which only this precision could hit).  Against the oracle (float64
+    transform) the float32 transform stays within 5e-5 on these signals."""
+    from ssr_eval_amd import backend as B
+    from oracle import metrics as om
+    rng = np.random.default_rng(n_fft * 7 + hop)
+    plan = B.get_plan(n_fft, hop, "f32")
+    ests, tgts = [], []
+    for _ in range(3):
+        n = int(rng.integers(20 * hop, 60 * hop))
+        t = (0.1 * rng.standard_normal(n)).astype(np.float32)
+        ests.append((t + 0.02 * rng.standard_normal(n)).astype(np.float32))
+        tgts.append(t)
+    got = B.pair_metrics(plan, ests, tgts)
+    for i, (e, t) in enumerate(zip(ests, tgts)):
+        want = _vec(om.evaluation(e, t, n_fft=n_fft, hop=hop))
+        np.testing.assert_allclose(got[i], want, rtol=5e-5, atol=5e-5)

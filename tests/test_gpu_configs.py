@@ -373,3 +373,22 @@ def test_float32_precision_plans_all_metrics(n_fft, hop):
     for i, (e, t) in enumerate(zip(ests, tgts)):
         want = _vec(om.evaluation(e, t, n_fft=n_fft, hop=hop))
         np.testing.assert_allclose(got[i], want, rtol=5e-5, atol=5e-5)
+
+
+@pytest.mark.parametrize("hop", [441, 512])
+def test_float32_precision_lowpass_and_istft(hop):
+    """The wave low-pass / inverse-STFT kernels at precision="f32": the same signal as the float64 transform to float32
+    round-off (the reference's FDomainHelper itself is a float32 torch pipeline, ssr_eval/dsp.py:107-119)."""
+    from ssr_eval_amd import backend as B
+    rng = np.random.default_rng(hop)
+    dev = torch.device("cuda", 0)
+    xs = [(0.1 * rng.standard_normal(int(rng.integers(30000, 90000)))).astype(np.float32) for _ in range(4)]
+    out = {}
+    for prec in ("f64", "f32"):
+        plan = B.get_plan(2048, hop, prec, dev)
+        out[prec] = B.LowpassBatch(plan, B.Ragged.from_list(xs, dev), [256] * len(xs)).run().clone()
+        re, im = B.stft(plan, xs, kind="complex", torch_style_pad=True)
+        back = B.istft(plan, re, im, [len(x) for x in xs])
+        for b, x in zip(back, xs):
+            assert float((b.cpu() - torch.from_numpy(x)).abs().max()) <= (2e-7 if prec == "f64" else 6e-7)
+    assert float((out["f64"] - out["f32"]).abs().max()) <= 3e-7

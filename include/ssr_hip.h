@@ -142,11 +142,24 @@ int ssr_energy_sums(const float* a, const float* b, int n_items, int64_t per_ite
 int ssr_scale_items(const float* x, const float* mul, const float* div, int n_items, int64_t per_item, float* out,
                     void* stream);
 
+/* A5 on [B, C, T, F] tensors with C > 1: AudioMetrics.sispec / its to_log variant (ssr_eval/metrics.py:114-121 with
+ * energy_unify, utils.py:79-82).  pow_norm (utils.py:85-92) is per (b, c), pow_p_norm (utils.py:68-76) over every dimension
+ * but the batch, so the per-channel projections share one all-channel target energy and there is one ratio per batch item.
+ * est / tgt: contiguous [n_batch, n_channels, per_image] float32; log_domain != 0 applies to_log (utils.py:43-44) to both
+ * first.  out: [n_batch + 1] float64 = the per-item values, then their mean (metrics.py:121: sum / B).  Energies are
+ * accumulated in float64 on the difference est - tgt (accurate at any SNR).  workspace: n_batch * n_channels * 24 bytes. */
+int ssr_sispec_multichannel(const float* est, const float* tgt, int n_batch, int n_channels, int64_t per_image,
+                            int log_domain, double* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* K6.  STFT-domain hard low-pass: stft_hard_lowpass_v0 (ssr_eval/lowpass.py:17-28) through
  * FDomainHelper.wav_to_spectrogram_phase / spectrogram_phase_to_wav (ssr_eval/dsp.py:83-119).
  * cut[i] = first zeroed bin = int(n_bins * highcut / int(fs/2)) (lowpass.py:24,193-194; computed by the
  * caller, bit-exact integer).  Output has the input's layout (same off / len).  Power-of-two n_fft only.
- * workspace: ssr_ola_workspace_bytes(plan, total_rows). */
+ * workspace: ssr_ola_workspace_bytes(plan, total_rows).
+ * Precondition, PER ITEM: len[i] > n_fft / 2 (torch's reflect padding inside torchlibrosa's STFT refuses anything
+ * shorter, dsp.py:21-59).  max_len <= n_fft / 2 is SSR_ERR_INVALID_ARG; lengths live on the device, so a short item in a
+ * batch whose max_len passes cannot be reported - it is skipped and its output samples are set to 0 (no out-of-range
+ * access); the Python mirror checks every item on the host and raises ValueError.  Same for ssr_istft. */
 size_t ssr_ola_workspace_bytes(const ssr_plan* plan, int64_t total_rows);
 int ssr_fft_lowpass(const ssr_plan* plan, const float* in, const int64_t* off, const int32_t* len, const int32_t* cut,
                     const int64_t* frame_off, int n_items, int max_len, int64_t total_rows, float* out,

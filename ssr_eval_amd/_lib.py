@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SSR_HIP_LIB") or os.path.join(_HERE, "libssrhip.so")   # env override: developer A/B builds
+LIB_PATH = os.path.join(_HERE, "libssrhip.so")
 
 SSR_F32, SSR_F64 = 0, 1
 M_LSD, M_LOG_SISPEC, M_SISPEC, M_SSIM, M_ALL = 1, 2, 4, 8, 15
@@ -38,6 +38,7 @@ SIGNATURES = {
     "ssr_from_log": (_i, [_vp, _i64, _vp, _vp]),
     "ssr_energy_sums": (_i, [_vp, _vp, _i, _i64, _vp, _vp]),
     "ssr_scale_items": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp]),
+    "ssr_sispec_multichannel": (_i, [_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _sz, _vp]),
     "ssr_ola_workspace_bytes": (_sz, [_vp, _i64]),
     "ssr_fft_lowpass": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _vp, _vp, _sz, _vp]),
     "ssr_istft": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _vp, _vp, _sz, _vp]),

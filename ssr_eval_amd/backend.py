@@ -292,6 +292,21 @@ def scale_items(x, mul, div):
     return out
 
 
+def sispec_multichannel(est, target, log_domain):
+    """SISpec (or its to_log variant) of [B, C, T, F] tensors with C > 1 -> 0-dim float64 device tensor (the batch mean)."""
+    require_gpu()
+    e = _dev_f32(est)
+    t = _dev_f32(target, e.device)
+    Bn, Cn = int(e.shape[0]), int(e.shape[1])
+    per = e[0, 0].numel()
+    out = torch.empty(Bn + 1, dtype=torch.float64, device=e.device)
+    ws = torch.empty(Bn * Cn * 3, dtype=torch.float64, device=e.device)
+    with torch.cuda.device(e.device):
+        _lib.check(_lib.load().ssr_sispec_multichannel(_vp(e), _vp(t), Bn, Cn, per, 1 if log_domain else 0, _vp(out), _vp(ws),
+                                                       ws.numel() * 8, _stream()))
+    return out[Bn]
+
+
 def spectrogram_metrics(est_sps, tgt_sps, mask=M_ALL):
     """Metrics on lists of [T_i, F] float32 magnitude spectrograms -> [n, 4] float64 device tensor."""
     require_gpu()

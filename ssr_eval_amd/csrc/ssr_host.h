@@ -52,15 +52,18 @@ template <> inline const DevTables<double>& ssr_wave_tables_of<double>(const ssr
 // the device before calling in; a C caller that forgot gets an error instead of an illegal address.)
 int ssr_check_plan_device(const ssr_plan* pl);
 
-// Opt a kernel into more than 48 KiB of dynamic LDS, once per (kernel, device) instead of once per launch.
-// `slot` is a per-kernel static the caller owns (one per template instantiation).
-inline int ssr_allow_lds(const void* fn, size_t lds, int* slot) {
+// Opt a kernel into more than 48 KiB of dynamic LDS, once per (kernel, device, largest size so far) instead of once per
+// launch.  `slot` is a per-kernel static the caller owns (one per template instantiation): the largest size each device has
+// been opted into - a kernel whose LDS size depends on the call (resampler rate pair, radix-3 q) grows it per device.
+struct SsrLdsSlot { enum { MAX_DEV = 32 }; size_t opted[MAX_DEV] = {}; };
+inline int ssr_allow_lds(const void* fn, size_t lds, SsrLdsSlot* slot) {
   if (lds <= 48 * 1024) return SSR_OK;
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
-  if (*slot == dev + 1) return SSR_OK;
+  const bool tracked = dev >= 0 && dev < SsrLdsSlot::MAX_DEV;
+  if (tracked && slot->opted[dev] >= lds) return SSR_OK;
   HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  *slot = dev + 1;
+  if (tracked) slot->opted[dev] = lds;
   return SSR_OK;
 }
 

@@ -39,6 +39,7 @@ SSR_BODY void ssr_lowpass_frames_body(const SsrLowpassParams<T>& p, BLK& blk, in
   using Regs = SsrStftRegs<T, false>;
   SsrStftLds<T, LOGN> L(lds_base);
   const int n = p.len[item], hop = p.hop;
+  if (n <= N / 2) return;     // precondition (include/ssr_hip.h): len > n_fft / 2; such an item is skipped (k_ola* zero its output)
   const int n_frames = ssr_num_frames_dev(n, N, hop);
   const int n_pairs = (n_frames + 1) / 2;
   const int g0 = chunk * p.pairs_per_chunk;
@@ -148,6 +149,7 @@ SSR_DEV void ssr_ola_sample(const SsrOlaParams& p, int item, int s) {
   const int n = p.len[item];
   if (s >= n) return;
   const int N = p.n_fft, hop = p.hop;
+  if (n <= N / 2) { p.out[p.out_off[item] + s] = 0.0f; return; }   // item skipped by the frame kernel (reflect padding undefined)
   const int n_frames = ssr_num_frames_dev(n, N, hop);
   const int pos = s + N / 2;
   int t_hi = pos / hop;
@@ -178,6 +180,7 @@ SSR_DEV void ssr_ola_paired_sample(const SsrOlaParams& p, int item, int s) {
   const int n = p.len[item];
   if (s >= n) return;
   const int N = p.n_fft, hop = p.hop, SEG = N + hop, two = 2 * hop, stride = ssr_seg_stride(N, hop);
+  if (n <= N / 2) { p.out[p.out_off[item] + s] = 0.0f; return; }   // item skipped by the frame kernel: its rows hold no segment
   const int n_frames = ssr_num_frames_dev(n, N, hop);
   const int n_units = (n_frames + 1) / 2;
   const int pos = s + N / 2;

@@ -70,6 +70,7 @@ SSR_BODY void ssr_lowpass_wave_body(const SsrLowpassParams<T>& p, BLK& blk, int 
   using Regs = SsrLowpassWaveRegs<T>;
   SsrWaveLds<T, SPLIT> L(lds_base);
   const int n = p.len[item], hop = p.hop;
+  if (n <= N / 2) return;     // precondition (include/ssr_hip.h): len > n_fft / 2; such an item is skipped (k_ola* zero its output)
   const int n_frames = ssr_num_frames_dev(n, N, hop);
   const int n_pairs = (n_frames + 1) / 2;
   // this chunk's frame pairs: g0, g0 + S, ... (< g1); S > 1: the S chunks of a group interleave over the group's span and run

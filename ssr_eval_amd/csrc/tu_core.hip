@@ -266,6 +266,54 @@ __global__ __launch_bounds__(256) void k_energy_sums(const float* a, const float
   if (threadIdx.x < 3) sums[(int64_t)blockIdx.x * 3 + threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
 }
 
+// Multi-channel SISpec (metrics.py:114-121 on [B, C, T, F] tensors with C > 1), stage 1: per image the sums on the
+// DIFFERENCE d = e - t (exact in float64): {Sdd, Stt, Sdt}; log_domain applies to_log (utils.py:43-44, float32) first.
+__global__ __launch_bounds__(256) void k_mc_diff_sums(const float* a, const float* b, int64_t per_item, int log_domain, double* sums) {
+  __shared__ double sh[3][4];
+  const float* pa = a + (int64_t)blockIdx.x * per_item;
+  const float* pb = b + (int64_t)blockIdx.x * per_item;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int64_t i = threadIdx.x; i < per_item; i += 256) {
+    float e = pa[i], t = pb[i];
+    if (log_domain) { e = log10f(e + 1e-12f); t = log10f(t + 1e-12f); }
+    const double td = (double)t, d = (double)e - td;
+    s0 += d * d; s1 += td * td; s2 += d * td;
+  }
+  s0 = ssr_wave_sum<64>(s0); s1 = ssr_wave_sum<64>(s1); s2 = ssr_wave_sum<64>(s2);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s0; sh[1][threadIdx.x >> 6] = s1; sh[2][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x < 3) sums[(int64_t)blockIdx.x * 3 + threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+
+// Stage 2 (one thread; B and C are tiny): pow_norm is per (b, c), pow_p_norm over every dimension but the batch
+// (utils.py:68-92) - the per-channel projections alpha_c = <e_c, t_c> / (sum_c ||t_c||^2 + EPS) share ONE all-channel
+// target energy.  With d = e - t:  e - alpha t = d + (1 - alpha) t, so the noise energy of a channel is
+// Sdd + 2 (1 - alpha) Sdt + (1 - alpha)^2 Stt - no difference of nearly equal sums however close est is to target.
+// out[b] = 10 log10(||scaled||^2 / (||noise||^2 + EPS) + EPS), out[n_batch] = sum_b out[b] / n_batch  (metrics.py:120-121).
+__global__ void k_mc_finalize(const double* sums, int n_batch, int n_ch, double* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double EPS = 1e-12;
+  double total = 0.0;
+  for (int b = 0; b < n_batch; ++b) {
+    const double* s = sums + (int64_t)b * n_ch * 3;
+    double stt_all = 0.0;
+    for (int c = 0; c < n_ch; ++c) stt_all += s[3 * c + 1];
+    double tt = 0.0, nn = 0.0;
+    for (int c = 0; c < n_ch; ++c) {
+      const double sdd = s[3 * c], stt = s[3 * c + 1], sdt = s[3 * c + 2];
+      const double alpha = (sdt + stt) / (stt_all + EPS);
+      const double om = ((stt_all - stt) + EPS - sdt) / (stt_all + EPS);        // 1 - alpha
+      tt += alpha * alpha * stt;
+      nn += sdd + 2.0 * om * sdt + om * om * stt;
+    }
+    if (nn < 0.0) nn = 0.0;
+    const double v = 10.0 * log10(tt / (nn + EPS) + EPS);
+    out[b] = v;
+    total += v;
+  }
+  out[n_batch] = total / (double)n_batch;
+}
+
 // out[item][j] = (x[item][j] * mul[item]) / div[item], two float32 roundings as in energy_unify (utils.py:79-82)
 __global__ __launch_bounds__(256) void k_scale_items(const float* x, const float* mul, const float* div, int64_t per_item,
                                                      int64_t n, float* out) {
@@ -301,6 +349,21 @@ extern "C" int ssr_energy_sums(const float* a, const float* b, int n_items, int6
   if (n_items <= 0) return SSR_OK;
   if (per_item < 0) return ssr_fail(SSR_ERR_INVALID_ARG, "negative item size");
   hipLaunchKernelGGL(k_energy_sums, dim3((unsigned)n_items), dim3(256), 0, (hipStream_t)stream, a, b, per_item, sums);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+
+extern "C" int ssr_sispec_multichannel(const float* est, const float* tgt, int n_batch, int n_channels, int64_t per_image,
+                                       int log_domain, double* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!est || !tgt || !out) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n_batch <= 0 || n_channels <= 0 || per_image < 0) return ssr_fail(SSR_ERR_INVALID_ARG, "bad tensor shape");
+  const size_t need = (size_t)n_batch * n_channels * 3 * sizeof(double);
+  if (!workspace || workspace_bytes < need) return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small (n_batch * n_channels * 24 bytes)");
+  double* sums = (double*)workspace;
+  hipLaunchKernelGGL(k_mc_diff_sums, dim3((unsigned)(n_batch * n_channels)), dim3(256), 0, (hipStream_t)stream, est, tgt, per_image,
+                     log_domain, sums);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_mc_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)sums, n_batch, n_channels, out);
   HIP_TRY(hipGetLastError());
   return SSR_OK;
 }

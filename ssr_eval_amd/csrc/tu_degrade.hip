@@ -80,17 +80,15 @@ static int resample_poly_t(const S* in, const int64_t* in_off, const int32_t* in
   const size_t lds = ssr_resample_lds_bytes(p);
   if (lds > 160 * 1024) {           // huge reduced `up`: the phase-blocked kernel's window does not fit LDS
     const int bpi = ssr_ceil_div(max_out_len, 256);
+    if ((int64_t)n_items * bpi > 0x7fffffff) return ssr_fail(SSR_ERR_UNSUPPORTED, "batch too large for one launch");
     hipLaunchKernelGGL((k_resample_direct<S>), dim3((unsigned)((int64_t)n_items * bpi)), dim3(256), 0, (hipStream_t)stream, p, bpi);
     HIP_TRY(hipGetLastError());
     return SSR_OK;
   }
   if ((size_t)ssr_resample_win(p) > (size_t)SSR_RESAMPLE_MAXPF * SSR_RESAMPLE_NT)
     return ssr_fail(SSR_ERR_UNSUPPORTED, "input window exceeds the prefetch registers");     // (geometry keeps it below)
-  static thread_local int slot = 0;
-  static thread_local size_t slot_lds = 0;          // the LDS size depends on the rate pair: remember the largest one
-  if (lds > slot_lds) slot = 0;
+  static thread_local SsrLdsSlot slot;
   if (int rc = ssr_allow_lds((const void*)k_resample<S>, lds, &slot)) return rc;
-  if (lds > slot_lds) slot_lds = lds;
   const int bpi = ssr_ceil_div(max_out_len, ssr_resample_opb(p));
   const int64_t total = (int64_t)n_items * bpi;
   if (total > 0x7fffffff) return ssr_fail(SSR_ERR_UNSUPPORTED, "batch too large for one launch");
@@ -189,7 +187,7 @@ static int sosfiltfilt_t(const X* x, const int64_t* off, const int32_t* len, int
   if (n_sections <= 8) {
     const int per_wave = 8 * SSR_IIR_U;                           // utterances per one-wave workgroup
     const size_t lds = (size_t)per_wave * 4 * SSR_IIR_CH * sizeof(double);
-    static thread_local int slot = 0;
+    static thread_local SsrLdsSlot slot;
     if (int rc = ssr_allow_lds((const void*)k_sosfiltfilt<8, X>, lds, &slot)) return rc;
     hipLaunchKernelGGL((k_sosfiltfilt<8, X>), dim3(ssr_ceil_div(n_items, per_wave)), dim3(64), lds, s, p);
   } else {

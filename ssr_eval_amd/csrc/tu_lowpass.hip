@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k_ola_paired(SsrOlaParams p, int blocks_p
 
 template <typename T, int LOGN> static int launch_lowpass_inst(SsrLowpassParams<T>& p, int grid, hipStream_t s) {
   const size_t lds = SsrStftLds<T, LOGN>::bytes();
-  static thread_local int slot = 0;
+  static thread_local SsrLdsSlot slot;
   if (int rc = ssr_allow_lds((const void*)k_lowpass_frames<T, LOGN>, lds, &slot)) return rc;
   hipLaunchKernelGGL((k_lowpass_frames<T, LOGN>), dim3(grid), dim3((1 << LOGN) / 8), lds, s, p);
   HIP_TRY(hipGetLastError());

@@ -69,13 +69,20 @@ def allgather_rows(local_rows, global_index, n_total):
         out = np.full((n_total, K), np.nan)
         out[np.asarray(global_index, dtype=np.int64)] = local_rows
         return out
-    kk = torch.tensor([K], dtype=torch.int64, device=_comm_device())
+    # Width agreement: only a rank that owns NO row takes its width from the others.  Ranks that own rows must agree - a
+    # key / metric mismatch between shards is an error on EVERY rank (all of them see the same MAX / MIN), never NaN rows.
+    owns = len(global_index) > 0
+    kk = torch.tensor([K if owns else -1, -K if owns else -(1 << 60)], dtype=torch.int64, device=_comm_device())
     dist.all_reduce(kk, op=dist.ReduceOp.MAX)
-    K = int(kk.item())
+    k_max, k_min = int(kk[0].item()), -int(kk[1].item())
+    if k_max >= 0 and k_min != k_max:
+        raise ValueError("allgather_rows: ranks disagree on the row width (%d .. %d columns): the shards were evaluated with "
+                         "different keys or metrics" % (k_min, k_max))
+    K = max(k_max, 0)
     cap = -(-n_total // world)
     pack = torch.full((cap, K + 1), float("nan"), dtype=torch.float64)
     pack[:, 0] = -1.0
-    if len(global_index) and local_rows.shape[1] == K:
+    if owns:
         pack[:len(global_index), 0] = torch.as_tensor(np.asarray(global_index, dtype=np.float64))
         pack[:len(global_index), 1:] = torch.as_tensor(local_rows)
     pack = pack.to(_comm_device())

@@ -104,18 +104,10 @@ class AudioMetrics:
         return v.to(torch.float32).to(est.device).reshape(est.shape[0], est.shape[1], 1, 1)
 
     def _sispec_multichannel(self, est, target, log_domain):
-        """metrics.py:114-121 for C > 1: pow_norm (utils.py:85-92) is per (b, c), pow_p_norm (utils.py:68-76) is over
-        every dimension but the batch - so the per-channel projections share ONE all-channel target energy and the ratio
-        is formed per batch item.  The image energies come from ssr_energy_sums (float64 accumulation)."""
-        Bn, Cn = est.shape[0], est.shape[1]
-        e, t = (B.elementwise("to_log", est), B.elementwise("to_log", target)) if log_domain else (est, target)
-        s = B.energy_sums(e, t, Bn * Cn).reshape(Bn, Cn, 3)                 # see, stt, set per image
-        see, stt, set_ = s[..., 0], s[..., 1], s[..., 2]
-        alpha = set_ / (stt.sum(dim=1, keepdim=True) + EPS)
-        tt = (alpha * alpha * stt).sum(dim=1)
-        nn = torch.clamp((see - 2.0 * alpha * set_ + alpha * alpha * stt).sum(dim=1), min=0.0)
-        v = 10.0 * torch.log10(tt / (nn + EPS) + EPS)
-        return (v.sum() / Bn).to(torch.float32).to(est.device)
+        """metrics.py:114-121 for C > 1 (one ratio per batch item over an all-channel target energy): ssr_sispec_multichannel."""
+        if est.shape != target.shape:
+            raise ValueError("spectrogram shape mismatch: %s vs %s" % (tuple(est.shape), tuple(target.shape)))
+        return B.sispec_multichannel(est, target, log_domain).to(torch.float32).to(est.device)
 
     def sispec(self, est, target):
         """Scale-invariant spectrogram-to-noise ratio, mean over the batch, 0-dim float32 (metrics.py:114-121)."""

@@ -84,3 +84,33 @@ def test_single_process_primitives():
     buf = D.speaker_sums(rows, [0, 0, 1, 1], 3)
     means, avg = D.mean_of_speaker_means(buf)
     assert means.shape == (2, 3) and np.allclose(avg, rows.reshape(2, 2, 3).mean(1).mean(0))
+
+
+def _worker_width_mismatch(rank, world, port, out_dir):
+    """Both ranks own rows but disagree on their width: every rank must raise (the narrower rank's rows used
+    to be dropped silently and came back as NaN aggregates)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from ssr_eval_amd import dist as D
+    D.init_from_env(backend="gloo")
+    rows = np.ones((2, 4 if rank == 0 else 8))
+    try:
+        D.allgather_rows(rows, [2 * rank, 2 * rank + 1], 4)
+        got = "no error"
+    except ValueError as e:
+        got = "ValueError" if "disagree" in str(e) else repr(e)
+    # a zero-width shard that owns rows is a mismatch too, not an idle rank
+    try:
+        D.allgather_rows(np.empty((1, 0)) if rank == 0 else np.ones((1, 4)), [rank], 2)
+        got2 = "no error"
+    except ValueError:
+        got2 = "ValueError"
+    open(os.path.join(out_dir, "w%d" % rank), "w").write(got + "," + got2)
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_allgather_rows_width_mismatch_raises_on_every_rank(tmp_path):
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_worker_width_mismatch, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / "w0").read() == "ValueError,ValueError" and open(tmp_path / "w1").read() == "ValueError,ValueError"

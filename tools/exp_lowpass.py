@@ -3,6 +3,7 @@ LIBS (comma-separated paths, A/B of kernel variants; each runs in its own proces
 import os, sys, json, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools')); import devlib; devlib.select()   # SSR_DEV_LIB: alternative build
 
 
 def one():
@@ -17,7 +18,7 @@ def one():
     plan = B.get_plan(2048, hop, "f64", dev)
     lb = B.LowpassBatch(plan, B.Ragged.from_uniform(x), [256] * n)
     ms = bench.event_time_ms(lambda: lb.run(), 10)
-    print(json.dumps({"lib": os.path.basename(os.environ.get("SSR_HIP_LIB", "default")), "hop": hop, "fft_lowpass_ms": round(ms, 4)}), flush=True)
+    print(json.dumps({"lib": os.path.basename(os.environ.get("SSR_DEV_LIB", "default")), "hop": hop, "fft_lowpass_ms": round(ms, 4)}), flush=True)
 
 
 if __name__ == "__main__":
@@ -27,5 +28,5 @@ if __name__ == "__main__":
         for lib in os.environ.get("LIBS", "").split(",") or [""]:
             env = dict(os.environ, _ONE="1")
             if lib:
-                env["SSR_HIP_LIB"] = os.path.join(ROOT, lib)
+                env["SSR_DEV_LIB"] = os.path.join(ROOT, lib)
             subprocess.call([sys.executable, os.path.abspath(__file__)], env=env)

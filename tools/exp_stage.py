@@ -1,10 +1,11 @@
 """Developer experiment: time the stages of ssr_pair_metrics under different metric masks / precisions, and check the
-first pairs against the oracle.  SSR_HIP_LIB selects the library build (A/B of kernel variants)."""
+first pairs against the oracle.  SSR_DEV_LIB selects the library build (A/B of kernel variants)."""
 import os, sys, json
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools')); import devlib; devlib.select()   # SSR_DEV_LIB: alternative build
 import bench
 from ssr_eval_amd import backend as B
 
@@ -16,7 +17,7 @@ def main():
     amp = float(os.environ.get("AMP", "0.1"))          # e.g. 1e30: magnitudes overflow float32 - is any kernel's time data-dependent?
     tgt = (amp * torch.randn((n, bench.N_SAMPLES), generator=g, device=dev)).contiguous()
     est = (tgt + 0.1 * amp * torch.randn((n, bench.N_SAMPLES), generator=g, device=dev)).contiguous()
-    res = {"lib": os.environ.get("SSR_HIP_LIB", "default")}
+    res = {"lib": os.environ.get("SSR_DEV_LIB", "default")}
     for prec in os.environ.get("PRECS", "f64").split(","):
         plan = B.get_plan(2048, 512, prec, dev)
         b = B.PairBatch(plan, B.Ragged.from_uniform(est), B.Ragged.from_uniform(tgt))

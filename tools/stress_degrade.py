@@ -5,6 +5,7 @@ import numpy as np, torch
 from scipy import signal
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools')); import devlib; devlib.select()   # SSR_DEV_LIB: alternative build
 from ssr_eval_amd import backend as B
 from ssr_eval_amd.lowpass import lowpass, lowpass_batch
 from oracle import lowpass as olp, metrics as om

@@ -170,6 +170,22 @@ SSR_DEV double ssr_fadd_rn(double a, double b) {
 }
 #endif
 
+// Two float32 values in a 64-bit register pair, processed by ONE packed instruction (v_pk_mul_f32 / v_pk_add_f32 /
+// v_pk_fma_f32: a wave-wide packed float32 instruction takes the same issue slot as a scalar-per-lane one).  Host emulation: a
+// plain pair with elementwise operators.
+#ifdef SSR_HOST_EMU
+struct f2 { float x, y; };
+static inline f2 operator+(f2 a, f2 b) { return {a.x + b.x, a.y + b.y}; }
+static inline f2 operator-(f2 a, f2 b) { return {a.x - b.x, a.y - b.y}; }
+static inline f2 operator*(f2 a, f2 b) { return {a.x * b.x, a.y * b.y}; }
+static inline f2 f2_fma(f2 a, f2 b, f2 c) { return {fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+#else
+typedef float f2 __attribute__((ext_vector_type(2)));
+SSR_DEV f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
+SSR_DEV f2 f2_make(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
+SSR_DEV f2 f2_splat(float v) { return f2_make(v, v); }
+
 // magnitude bits of a sample (sign dropped): non-zero iff the sample is not +-0 (NaN and Inf count as non-zero)
 SSR_DEV unsigned ssr_mag_bits(float v) {
   unsigned u;

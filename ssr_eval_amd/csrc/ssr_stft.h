@@ -166,6 +166,37 @@ SSR_DEV float ssr_log10f_fast(float x) {
 #endif
 }
 
+// The same three sequences on two values at a time: every multiply / add / fused multiply-add is one packed instruction for
+// the pair (the square root, reciprocal and logarithm units take one value per instruction).  Component for component the
+// arithmetic - and so every bit of the result - is that of the scalar versions.
+SSR_DEV f2 ssr_cabsf_fast2(f2 re, f2 im) {
+  const f2 s = f2_fma(re, re, im * im);
+#ifdef SSR_HOST_EMU
+  return f2_make(sqrtf(s.x), sqrtf(s.y));
+#else
+  return f2_make(__builtin_amdgcn_sqrtf(s.x), __builtin_amdgcn_sqrtf(s.y));
+#endif
+}
+SSR_DEV f2 ssr_divf_fast2(f2 a, f2 b) {
+#ifdef SSR_HOST_EMU
+  return f2_make(a.x / b.x, a.y / b.y);
+#else
+  const f2 r = f2_make(__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y));
+  const f2 q = a * r;
+  return f2_fma(f2_fma(f2_make(-q.x, -q.y), b, a), r, q);
+#endif
+}
+SSR_DEV f2 ssr_log10f_fast2(f2 x) {
+#ifdef SSR_HOST_EMU
+  return f2_make(log10f(x.x), log10f(x.y));
+#else
+  const f2 y = f2_make(__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y));
+  const f2 c = f2_splat(0x1.344134p-2f), cc = f2_splat(0x1.09f79ep-26f);
+  const f2 r = y * c;
+  return r + f2_fma(y, cc, f2_fma(y, c, f2_make(-r.x, -r.y)));
+#endif
+}
+
 // LSD term and SISpec sums for one (est, target) magnitude pair, float32 elementwise arithmetic in
 // the order of ssr_eval/metrics.py:110 and ssr_eval/utils.py:43-44; accumulation in float64.
 template <bool FASTM = false>
@@ -271,6 +302,43 @@ SSR_DEV void ssr_pair_bin(int mask, double* acc, cx<T> zk, cx<T> zn, bool a_nz, 
     const float t = FASTABS ? ssr_cabsf_fast(o.br, o.bi) : ssr_cabsf(o.br, o.bi);
     e_out = e; t_out = t;
     ssr_accumulate_metrics<FASTABS>(e, t, mask, acc);
+  }
+}
+
+// Two bins of a pair whose frames both hold signal (no zero forcing), float32 signals, the wave engine's ~1-ulp sequences:
+// the fast path of ssr_stft_wave.h's epilogue.  Bin for bin the values and the order in which they reach the accumulators are
+// those of ssr_pair_bin<T, 0, true>(mask, ...) with mask = LSD (SUMS false) or LSD | SISPEC | LOG_SISPEC (SUMS true); the
+// float32 arithmetic runs on (bin 0, bin 1) register pairs.  e_out / t_out: the two estimate / target magnitudes.
+template <typename T, bool SUMS>
+SSR_DEV void ssr_pair_bins2_fast(double* acc, cx<T> zk0, cx<T> zn0, cx<T> zk1, cx<T> zn1, f2& e_out, f2& t_out) {
+  const f2 EPS2 = f2_splat(1e-12f);
+  const f2 ar = f2_make((float)(zk0.x + zn0.x), (float)(zk1.x + zn1.x)), ai = f2_make((float)(zk0.y - zn0.y), (float)(zk1.y - zn1.y));
+  const f2 br = f2_make((float)(zk0.y + zn0.y), (float)(zk1.y + zn1.y)), bi = f2_make((float)(zn0.x - zk0.x), (float)(zn1.x - zk1.x));
+  const f2 e = ssr_cabsf_fast2(ar, ai), t = ssr_cabsf_fast2(br, bi);
+  e_out = e; t_out = t;
+  {
+    const f2 ee = e + EPS2;
+    const f2 d = ssr_log10f_fast2(ssr_divf_fast2(t * t, ee * ee) + EPS2);
+    const f2 dd = d * d;
+    acc[0] += (double)dd.x;
+    if constexpr (!SUMS) acc[0] += (double)dd.y;
+    if constexpr (SUMS) {
+      // (bin 0's six sums, then bin 1's LSD term and sums: the order of the scalar path)
+      const f2 le = ssr_log10f_fast2(e + EPS2), lt = ssr_log10f_fast2(t + EPS2);
+      {
+        const double td = (double)t.x, d0 = (double)e.x - td;
+        acc[1] += d0 * d0; acc[2] += td * td; acc[3] += d0 * td;
+        const double ld = (double)lt.x, l0 = (double)le.x - ld;
+        acc[4] += l0 * l0; acc[5] += ld * ld; acc[6] += l0 * ld;
+      }
+      acc[0] += (double)dd.y;
+      {
+        const double td = (double)t.y, d0 = (double)e.y - td;
+        acc[1] += d0 * d0; acc[2] += td * td; acc[3] += d0 * td;
+        const double ld = (double)lt.y, l0 = (double)le.y - ld;
+        acc[4] += l0 * l0; acc[5] += ld * ld; acc[6] += l0 * ld;
+      }
+    }
   }
 }
 

@@ -112,6 +112,9 @@ template <typename T, int NZ = 32> SSR_DEV void ssr_dft32(cx<T>* v) {
 // frequency held by register rho after ssr_dft32
 SSR_DEV constexpr int ssr_dft32_freq(int rho) { return (rho >> 3) + 4 * (rho & 7); }
 
+struct SsrTrue { static constexpr bool value = true; };
+struct SsrFalse { static constexpr bool value = false; };
+
 template <typename T, bool SUMS> struct SsrWaveRegs {
   cx<T> v[SSR_W_P];          // the lane's 32 points
   T tx[SSR_W_P];             // SPLIT exchange: real parts read back while the imaginary parts are still to be written
@@ -377,27 +380,45 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
       const int lane4 = 4 * tid;
       const int pr = ssr_wave_bases(tid).pr;
       constexpr int G = SUMS ? 2 : 4;                              // bins in flight (the variant with running sums is tighter)
-      SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int q0 = 0; q0 < 4; q0 += G) {
-        cx<T> zn[G];
-        SSR_UNROLL for (int q = 0; q < G; ++q)                    // Z[2048 - k] sits at upper-half slot 1024 - k
-          zn[q] = {lre[pr - 66 * b - 264 * (q0 + q)], lim[im_off + pr - 66 * b - 264 * (q0 + q)]};
-        SSR_UNROLL for (int q = 0; q < G; ++q) {
-          const cx<T> zk = R.v[8 * b + q0 + q];
-          const cx<T> zz = (b == 0 && q0 + q == 0 && tid == 0) ? zk : zn[q];   // bin 0 pairs with itself
-          float e, t;
-          if (both) ssr_pair_bin<T, 0, true>(mask, acc, zk, zz, true, true, e, t);
-          else ssr_pair_bin<T, 0, true>(mask, acc, zk, zz, a_nz, b_nz, e, t);
-          if (store) {
-            wa.st_raw(lane4 + 4 * (64 * b + 256 * (q0 + q)), e);
-            wb.st_raw(lane4 + 4 * (64 * b + 256 * (q0 + q)), t);
+      // The sixteen bins, two at a time.  FAST (a compile-time fact inside each copy of the loop): both frames hold signal and
+      // the mask is the variant's full set - no zero forcing, no per-bin test of the mask, and the float32 arithmetic of a
+      // bin pair runs as packed instructions (ssr_pair_bins2_fast).  The wave-uniform choice is made ONCE per frame, outside
+      // the loop: taken per bin it split the epilogue into 48 basic blocks with two scalar branches each.
+      auto bins = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int q0 = 0; q0 < 4; q0 += G) {
+          cx<T> zn[G];
+          SSR_UNROLL for (int q = 0; q < G; ++q)                    // Z[2048 - k] sits at upper-half slot 1024 - k
+            zn[q] = {lre[pr - 66 * b - 264 * (q0 + q)], lim[im_off + pr - 66 * b - 264 * (q0 + q)]};
+          if (b == 0 && q0 == 0 && tid == 0) zn[0] = R.v[0];       // bin 0 pairs with itself
+          SSR_UNROLL for (int q = 0; q < G; q += 2) {
+            const cx<T> zk0 = R.v[8 * b + q0 + q], zk1 = R.v[8 * b + q0 + q + 1];
+            f2 e, t;
+            if constexpr (FAST) {
+              ssr_pair_bins2_fast<T, SUMS>(acc, zk0, zn[q], zk1, zn[q + 1], e, t);
+            } else {
+              float e0, t0, e1, t1;
+              ssr_pair_bin<T, 0, true>(mask, acc, zk0, zn[q], a_nz, b_nz, e0, t0);
+              ssr_pair_bin<T, 0, true>(mask, acc, zk1, zn[q + 1], a_nz, b_nz, e1, t1);
+              e = f2_make(e0, e1); t = f2_make(t0, t1);
+            }
+            if (store) {
+              wa.st_raw(lane4 + 4 * (64 * b + 256 * (q0 + q)), e.x);
+              wb.st_raw(lane4 + 4 * (64 * b + 256 * (q0 + q)), t.x);
+              wa.st_raw(lane4 + 4 * (64 * b + 256 * (q0 + q + 1)), e.y);
+              wb.st_raw(lane4 + 4 * (64 * b + 256 * (q0 + q + 1)), t.y);
+            }
+          }
+          if (b == 1 && q0 + G == 4) {
+            SSR_SCHED_BARRIER();
+            ssr_wave_prefetch<T, 2>(p, R, tid, va, vb, u + S, n, n_frames);
+            SSR_SCHED_BARRIER();
           }
         }
-        if (b == 1 && q0 + G == 4) {
-          SSR_SCHED_BARRIER();
-          ssr_wave_prefetch<T, 2>(p, R, tid, va, vb, u + S, n, n_frames);
-          SSR_SCHED_BARRIER();
-        }
-      }
+      };
+      constexpr int FULL = SUMS ? (SSR_M_LSD | SSR_M_LOG_SISPEC | SSR_M_SISPEC) : SSR_M_LSD;
+      if (both && (mask & 7) == FULL) bins(SsrTrue{});
+      else bins(SsrFalse{});
       if (tid == 0) {                                             // the Nyquist bin: Z[1024] pairs with itself
         const cx<T> zq = {lre[0], lim[im_off]};
         float e, t;

@@ -25,6 +25,11 @@ def select():
     if not os.path.exists(path):
         raise FileNotFoundError(path)
     _lib.LIB_PATH = path
+    # an older build (the baseline of an A/B) may lack entry points added since: the tools bind what it has
+    import ctypes
+    probe = ctypes.CDLL(path)
+    for name in [k for k in _lib.SIGNATURES if not hasattr(probe, k)]:
+        del _lib.SIGNATURES[name]
     return path
 
 
@@ -41,3 +46,21 @@ if __name__ == "__main__":
         print(build(sys.argv[2], sys.argv[3:]))
     else:
         print(__doc__)
+
+
+def build_ref(ref, tag):
+    """Build the library as of git revision `ref` (sources extracted to a scratch directory) into
+    tools/_build/libssrhip_<tag>.so - the baseline of a same-box A/B."""
+    import shutil
+    import subprocess
+    import tempfile
+    from ssr_eval_amd import build as b
+    tmp = tempfile.mkdtemp(prefix="ssr_ref_")
+    try:
+        subprocess.check_call("git -C %s archive %s ssr_eval_amd/csrc include | tar -x -C %s" % (ROOT, ref, tmp), shell=True)
+        os.makedirs(BUILD_DIR, exist_ok=True)
+        b.CSRC = os.path.join(tmp, "ssr_eval_amd", "csrc")
+        b.OBJ = os.path.join(tmp, "obj")
+        return b.build(force=True, verbose=False, out=os.path.join(BUILD_DIR, "libssrhip_%s.so" % tag))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

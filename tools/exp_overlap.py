@@ -15,7 +15,7 @@ def main():
     mask = B.M_LSD | B.M_SSIM
     whole = B.PairBatch(plan, B.Ragged.from_uniform(est), B.Ragged.from_uniform(tgt))
     print("serial 1024:", round(bench.event_time_ms(lambda: whole.run(mask), 10), 3), "ms")
-    for nsub in (2, 4, 8):
+    for nsub in (2, 8, 16, 32, 64):
         k = n // nsub
         subs = [B.PairBatch(plan, B.Ragged.from_uniform(est[i * k:(i + 1) * k].contiguous()),
                             B.Ragged.from_uniform(tgt[i * k:(i + 1) * k].contiguous())) for i in range(nsub)]
@@ -31,7 +31,13 @@ def main():
                     sb.run(mask, stages=6)                   # SSIM + finalize on the side stream
             done = torch.cuda.Event(); done.record(s2); s_main.wait_event(done)
         ms = bench.event_time_ms(run, 10)
-        print("pipelined %d sub-batches: %.3f ms" % (nsub, ms))
+        def serial():
+            for sb in subs:
+                sb.run(mask)
+        ms_serial = bench.event_time_ms(serial, 10)
+        ms_ssim = bench.event_time_ms(lambda: [sb.run(mask, stages=2) for sb in subs], 10)
+        print("%d slices of %d pairs (%.0f MB of magnitudes each): pipelined on two streams %.3f ms, same slices on one stream %.3f ms, their k_ssim launches alone %.3f ms"
+              % (nsub, k, k * 376 * 1028 * 8 / 1e6, ms, ms_serial, ms_ssim))
         torch.cuda.synchronize()
         ref = whole.run(mask).clone()
         got = torch.cat([sb.out for sb in subs])

@@ -209,6 +209,8 @@ template <typename E> struct SsrView {
   SSR_MEMBER SsrView(const E* p, int64_t n_elems) : base(p), n(n_elems) {}
   SSR_MEMBER E at(unsigned idx, int64_t uniform_off = 0) const { return base[uniform_off + idx]; }
   SSR_MEMBER E at_or_zero(unsigned idx) const { return ((int64_t)idx < n) ? base[idx] : E{}; }
+  // four consecutive elements from (16-byte aligned) element idx
+  SSR_MEMBER void at4(unsigned idx, int64_t uniform_off, E* out) const { for (int j = 0; j < 4; ++j) out[j] = base[uniform_off + idx + j]; }
 #else
   __amdgpu_buffer_rsrc_t rsrc;
   SSR_MEMBER SsrView(const E* p, int64_t n_elems)
@@ -222,6 +224,14 @@ template <typename E> struct SsrView {
   // element idx, or 0 where idx >= n_elems (the hardware's range check; idx may be a negative int cast to unsigned as
   // long as |idx| * sizeof(E) < 2^31)
   SSR_MEMBER E at_or_zero(unsigned idx) const { return at(idx); }
+  // four consecutive 4-byte elements from (16-byte aligned) element idx: one buffer_load_dwordx4
+  SSR_MEMBER void at4(unsigned idx, int64_t uniform_off, E* out) const {
+    static_assert(sizeof(E) == 4, "dword elements");
+    const int vo = (int)(idx * 4u), so = (int)(unsigned)(uniform_off * 4);
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, so, 0);
+    out[0] = __builtin_bit_cast(E, v.x); out[1] = __builtin_bit_cast(E, v.y); out[2] = __builtin_bit_cast(E, v.z); out[3] = __builtin_bit_cast(E, v.w);
+  }
 #endif
 };
 
@@ -239,6 +249,8 @@ template <typename E> struct SsrRwView {
   SSR_MEMBER E ld_raw(int off) const { return ld((unsigned)off / (unsigned)sizeof(E), off >= 0); }
   SSR_MEMBER void st_raw(int off, E v) const { st((unsigned)off / (unsigned)sizeof(E), v, off >= 0); }
   SSR_MEMBER void st_raw_nt(int off, E v) const { st_raw(off, v); }
+  SSR_MEMBER void st_raw2(int off, E a, E b) const { st_raw(off, a); st_raw(off + (int)sizeof(E), b); }
+  SSR_MEMBER void st_raw4(int off, E a, E b, E c, E d) const { st_raw2(off, a, b); st_raw2(off + 2 * (int)sizeof(E), c, d); }
 #else
   __amdgpu_buffer_rsrc_t rsrc;
   SSR_MEMBER SsrRwView(E* p, int64_t n_elems)
@@ -260,6 +272,19 @@ template <typename E> struct SsrRwView {
   SSR_MEMBER void st_raw(int off, E v) const {
     if constexpr (sizeof(E) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, off, 0, 0);
     else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, v), rsrc, off, 0, 0);
+  }
+  // two / four consecutive 4-byte elements with one buffer_store_dwordx2 / x4 (off: 8- / 16-byte aligned)
+  SSR_MEMBER void st_raw2(int off, E a, E b) const {
+    static_assert(sizeof(E) == 4, "dword elements");
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u2 v; v.x = __builtin_bit_cast(unsigned, a); v.y = __builtin_bit_cast(unsigned, b);
+    __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, off, 0, 0);
+  }
+  SSR_MEMBER void st_raw4(int off, E a, E b, E c, E d) const {
+    static_assert(sizeof(E) == 4, "dword elements");
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 v; v.x = __builtin_bit_cast(unsigned, a); v.y = __builtin_bit_cast(unsigned, b); v.z = __builtin_bit_cast(unsigned, c); v.w = __builtin_bit_cast(unsigned, d);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 0);
   }
   // streaming store (nt): written once, not read again by this kernel - do not displace what the caches are kept for
   SSR_MEMBER void st_raw_nt(int off, E v) const {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py - throughput of the ssr_eval DSP / metric hot path on MI355X.
 
-    python bench.py [--config cfg2|cfg3|cfg5] [--gpus N --steps K --warmup W]
+    python bench.py [--config cfg2|cfg3|cfg4|cfg5] [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 `--gpus N` with N > 1 and no torchrun environment spawns the N ranks itself (one process per GPU, RCCL) and fails if
@@ -16,6 +16,10 @@ is one float64 all-reduce of the per-rank metric sums per step - the final mean 
   cfg3: 1024 targets per GPU x the cutoff sweep {2,4,8,12,16,24,32 kHz} (cut bins 42..683 at fs 48 kHz):
         est = ssr_fft_lowpass(target, cut) (FDomainHelper 2048/441), then the full metric set.  Unit: pairs/s,
         a pair = (utterance, cutoff).
+  cfg4: the full VCTK-shaped test set - 2,937 ragged utterances (1.5-9 s @ 48 kHz) of 8 speakers with the reference's file
+        counts - STRONG scaling: the fixed set is sharded round-robin over the ranks, every step ends with the path's two
+        real exchanges (ssr_eval/eval.py:200-216): one float64 SUM all-reduce of the [speakers, 4 metrics + count] buffer and
+        one padded all-gather of the per-utterance rows.  Unit: pairs/s over the whole job.
   cfg5: 12,500 utterances of 64,000 samples @ 16 kHz per GPU (100 k on 8 GPUs): ssr_resample_poly 441/160 then
         160/147, then LSD (2048/512) against a 48 kHz target.  Unit: resampled samples/s (192,000 per utterance).
 
@@ -242,7 +246,19 @@ class Cfg3:
         return r["lsd"], r["ssim"]
 
     cpu_desc = "(utterance, cutoff) pairs of the same workload (oracle stft_hard low-pass 2048/441 + 4 metrics at 2048/512)"
-    parity = None
+
+    def parity(self, out_vals, n, first):
+        """max relative error of (LSD, SSIM) of CPU-baseline items first .. first + n - 1 (item i = target i mod pairs at
+        cutoff i mod 7) against the values the oracle produced for exactly those items."""
+        B, worst = self.B, 0.0
+        for i, v in zip(range(first, first + n), out_vals[:n]):
+            j, c = i % self.a.pairs, i % 7
+            t = B.Ragged.from_uniform(self.tgt[j:j + 1])
+            lp = B.LowpassBatch(self.lp_plan, t, [CUT_BINS[c]])
+            lp.run()
+            got = B.PairBatch(self.plan, lp.out_ragged(), t).run(B.M_ALL)[0].cpu().numpy()
+            worst = max(worst, abs(got[0] - v[0]) / abs(v[0]), abs(got[3] - v[1]) / abs(v[1]))
+        return worst
 
 
 class Cfg5:
@@ -293,7 +309,8 @@ class Cfg5:
                   "stft+lsd": (ms3, (2 * N_SAMPLES * 4 + 32) * n)}
         # the fused resampling chain's algorithmic bytes are 4*(n_in + n_out_final) = 1,024,000 B / utterance
         chain_alg = 4 * (64000 + 192000) * n
-        roof = hbm_roofline("ssr_resample_poly x2 (k_resample, both stages)", chain_alg, ms1 + ms2, None,
+        roof = hbm_roofline("ssr_resample_poly x2 (k_resample, both stages)", chain_alg, ms1 + ms2,
+                            "k_resample stage 1+k_resample stage 2" if a.utterances == 12500 else None,
                             "the resampling chain is the HBM-side kernel of this config; per-stage read+write rates and the LSD "
                             "stage are under extra.stage_ms / extra.stage_GBs")
         extra = {"stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
@@ -314,7 +331,140 @@ class Cfg5:
 
     cpu_desc = "utterances of the same workload (scipy.signal.resample_poly 441/160 + 160/147, oracle STFT 2048/512 + LSD)"
     cpu_scale = N_SAMPLES          # value unit = output samples
-    parity = None
+
+    def parity(self, out_vals, n, first):
+        """max relative LSD error of utterances first .. first + n - 1 of the full 12,500-utterance launch against the
+        SciPy + oracle values of the CPU baseline for exactly those utterances."""
+        self.step()
+        got = self.batch.out[first:first + n, 0].cpu().numpy()
+        return max(abs(got[i] - v[0]) / abs(v[0]) for i, v in enumerate(out_vals[:n]))
+
+
+class Cfg4:
+    name = "cfg4"
+    metric = "utterance-pairs/sec (utterance-sharded VCTK-shaped test set: 2,937 ragged utterances, 8 speakers, full metric set, 48kHz, n_fft=2048)"
+    unit = "pairs/s"
+    scaling = "strong"
+    own_collectives = True
+    SPEAKER_COUNTS = [424, 424, 123, 419, 301, 424, 424, 398]          # files per VCTK test speaker (SURVEY section 4)
+    SEED = 20220328
+
+    @classmethod
+    def layout(cls):
+        """Lengths (samples @ 48 kHz, U(1.5 s, 9 s)) and speaker ids of the 2,937 utterances - the same on every rank."""
+        n = sum(cls.SPEAKER_COUNTS)
+        lens = (np.random.default_rng(cls.SEED).uniform(1.5, 9.0, n) * SR).astype(np.int64)
+        spk = np.repeat(np.arange(len(cls.SPEAKER_COUNTS)), cls.SPEAKER_COUNTS)
+        return lens, spk
+
+    def __init__(self, a, dev, rank):
+        from ssr_eval_amd import backend as B
+        self.B, self.a, self.dev, self.rank = B, a, dev, rank
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        lens, spk = self.layout()
+        self.n_total = len(lens)
+        self.mine = np.arange(rank, self.n_total, self.world)          # ssr_eval_amd.dist.shard_indices: round-robin
+        ml = lens[self.mine]
+        off = np.concatenate(([0], np.cumsum(ml)[:-1])) if len(ml) else np.zeros(0, np.int64)
+        tot = int(ml.sum())
+        self.fake = bool(getattr(a, "cpu_skeleton", False))            # launcher / collective self-test on CPU (gloo): no kernels
+        if self.fake:
+            tot = 0
+        self.est = torch.empty(tot, dtype=torch.float32, device=dev)
+        self.tgt = torch.empty(tot, dtype=torch.float32, device=dev)
+        g = torch.Generator(device=dev)
+        for i, o, n in zip(self.mine if not self.fake else [], off, ml):   # one seed per utterance: the set does not depend on N
+            g.manual_seed(self.SEED * 7 + int(i))
+            t = self.tgt[o:o + n]
+            torch.randn(int(n), generator=g, device=dev, out=t)
+            t.mul_(0.1)
+            e = self.est[o:o + n]
+            torch.randn(int(n), generator=g, device=dev, out=e)
+            e.mul_(0.01).add_(t)
+        mk = lambda buf: B.Ragged(buf, torch.from_numpy(off.astype(np.int64)).to(dev), torch.from_numpy(ml.astype(np.int32)).to(dev), ml)
+        if not self.fake:
+            self.plan = B.get_plan(N_FFT, HOP, a.precision, dev)
+            self.batch = B.PairBatch(self.plan, mk(self.est), mk(self.tgt))
+        else:   # four "metrics" that are pure functions of the GLOBAL utterance index: any sharding must reproduce one aggregate
+            gi = torch.from_numpy(self.mine.astype(np.float64)).to(dev)
+            self.fake_out = torch.stack([gi, 0.5 * gi, gi * gi * 1e-3, torch.cos(gi)], dim=1)
+        self.lens_local = ml
+        self.n_spk = len(self.SPEAKER_COUNTS)
+        self.spk_local = torch.from_numpy(spk[self.mine]).to(dev)
+        self.cnt_local = torch.bincount(self.spk_local, minlength=self.n_spk).to(torch.float64)
+        self.buf = torch.zeros((self.n_spk, 5), dtype=torch.float64, device=dev)      # [speakers, 4 metrics + count] (eval.py:200-216)
+        self.cap = -(-self.n_total // self.world)
+        self.pack = torch.full((self.cap, 5), float("nan"), dtype=torch.float64, device=dev)   # (global index, 4 metrics), padded
+        self.pack[:, 0] = -1.0
+        self.pack[:len(self.mine), 0] = torch.from_numpy(self.mine.astype(np.float64)).to(dev)
+        self.gathered = torch.empty((self.world * self.cap, 5), dtype=torch.float64, device=dev)
+        self.units_per_step = self.n_total                              # strong scaling: the whole set per step, whatever N
+
+    def step(self):
+        import torch.distributed as dist
+        out = self.fake_out if self.fake else self.batch.run(self.B.M_ALL)     # [n_local, 4]
+        self.buf.zero_()
+        self.buf[:, :4].index_add_(0, self.spk_local, out)
+        self.buf[:, 4] = self.cnt_local
+        self.pack[:len(self.mine), 1:] = out
+        if self.world > 1:
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)              # RCCL over xGMI: 320 B
+            dist.all_gather_into_tensor(self.gathered, self.pack)        # per-utterance rows for the per-file JSON block
+        return self.buf
+
+    def job_means(self, agg):
+        """mean over speakers of the per-speaker means (ssr_eval/eval.py:200-216), from the all-reduced buffer."""
+        a = np.asarray(agg).reshape(self.n_spk, 5)
+        ok = a[:, 4] > 0
+        return (a[ok, :4] / a[ok, 4:5]).mean(axis=0).tolist()
+
+    def config(self, world):
+        a = self.a
+        return {"workload": "cfg-4: the VCTK-shaped test set - %d ragged synthetic (est, target) pairs, 1.5-9 s @ 48 kHz, speakers with %s files - "
+                            "sharded round-robin over the ranks, resident in HBM; LSD + log-SISpec + SISpec + SSIM at STFT 2048/512, transform "
+                            "precision %s; every step ends with the float64 all-reduce of the [8 speakers, 4 sums + count] buffer and the "
+                            "padded all-gather of the per-utterance rows" % (sum(self.SPEAKER_COUNTS), self.SPEAKER_COUNTS, a.precision),
+                "utterances_total": sum(self.SPEAKER_COUNTS), "n_fft": N_FFT, "hop": HOP,
+                "parallelism": "strong scaling: %d utterances sharded x%d (round-robin), all-reduce 320 B + all-gather %d B per rank and step"
+                               % (sum(self.SPEAKER_COUNTS), world, -(-sum(self.SPEAKER_COUNTS) // world) * 40)}
+
+    def report(self, a):
+        import torch.distributed as dist
+        B = self.B
+        if self.fake:
+            g = self.gathered.cpu().numpy() if self.world > 1 else self.pack.cpu().numpy()
+            return None, {"allgather_rows_received": int((g[:, 0] >= 0).sum()), "shard_utterances": int(len(self.mine))}
+        ms_all = event_time_ms(lambda: self.batch.run(B.M_ALL), 3)
+        ms_stft = event_time_ms(lambda: self.batch.run(B.M_ALL, stages=1), 3)
+        alg = int((2 * self.lens_local * 4 + 32).sum())                  # SURVEY 8(d): each pair's own n
+        roof = hbm_roofline("ssr_stft_pair(k_stft_wave, four metrics, ragged)", alg, ms_stft, None,
+                            "rank 0's shard (%d of %d utterances); algorithmic bytes 2*n*4+32 per pair with each pair's own n"
+                            % (len(self.mine), self.n_total))
+        extra = {"shard_utterances": int(len(self.mine)), "shard_samples": int(self.lens_local.sum()),
+                 "stage_ms_rank0": {"pair_metrics": round(ms_all, 4), "stft+lsd+sispec": round(ms_stft, 4)},
+                 "allreduce_payload_bytes": int(self.buf.numel() * 8), "allgather_payload_bytes_per_rank": int(self.pack.numel() * 8)}
+        if self.world > 1:                                               # every rank calls report() for this workload
+            extra["allreduce_latency_us"] = round(1e3 * event_time_ms(lambda: dist.all_reduce(self.buf), 20), 2)
+            extra["allgather_latency_us"] = round(1e3 * event_time_ms(lambda: dist.all_gather_into_tensor(self.gathered, self.pack), 20), 2)
+            g = self.gathered.cpu().numpy()
+            extra["allgather_rows_received"] = int((g[:, 0] >= 0).sum())
+        return roof, extra
+
+    def cpu_inputs(self, n):
+        o = np.concatenate(([0], np.cumsum(self.lens_local)))
+        return [(self.est[o[i]:o[i + 1]].cpu().numpy(), self.tgt[o[i]:o[i + 1]].cpu().numpy()) for i in range(min(n, len(self.mine)))]
+
+    @staticmethod
+    def cpu_unit(item):
+        from oracle import metrics as om
+        r = om.evaluation(item[0], item[1], n_fft=N_FFT, hop=HOP)
+        return r["lsd"], r["ssim"], r["log_sispec"], r["sispec"]
+
+    cpu_desc = "ragged pairs of the same workload (rank 0's first utterances; STFT 2048/512 + 4 metrics through the oracle)"
+
+    def parity(self, out_vals, n, first):
+        got = self.batch.run(self.B.M_ALL)[first:first + n].cpu().numpy()
+        return max(max(abs(got[i, 0] - v[0]) / abs(v[0]), abs(got[i, 3] - v[1]) / abs(v[1])) for i, v in enumerate(out_vals[:n]))
 
 
 class Skeleton:
@@ -341,7 +491,7 @@ class Skeleton:
         return None, {}
 
 
-WORKLOADS = {"cfg2": Cfg2, "cfg3": Cfg3, "cfg5": Cfg5}
+WORKLOADS = {"cfg2": Cfg2, "cfg3": Cfg3, "cfg4": Cfg4, "cfg5": Cfg5}
 
 # ----------------------------------------------------------------------------------------------------------
 # CPU baseline (SURVEY 8(d) protocol): >= 64 units where a unit is short, first 4 discarded as warm-up, median of 3
@@ -470,7 +620,9 @@ def side_figures(a, dev):
         return {"workload": "AudioMetrics(48000) sizes: n_fft 2229 (radix-3 x Bluestein-743, M = 2048, three autonomous waves per frame pair) / hop 480, %d pairs of 4 s @ 48 kHz, "
                             "LSD + SSIM" % nb,
                 "pairs_per_s": round(nb / (ms * 1e-3), 1),
-                "roofline": hbm_roofline("ssr_stft_pair(k_stft_rn_wave<3>)", (2 * N_SAMPLES * 4 + 32) * nb, ms_stft)}
+                "roofline": hbm_roofline("ssr_stft_pair(k_stft_rn_wave<3>)", (2 * N_SAMPLES * 4 + 32) * nb, ms_stft,
+                                         "k_stft_rn_wave<double, false, 3" if nb == 1024 and a.precision == "f64" else None),
+                "note": "side figure: average of 3 launches in one short run"}
 
     def rates():
         """Every AudioMetrics(rate) size of the reference (ssr_eval/metrics.py:16-19), 4 s signals at that rate, four metrics."""
@@ -487,7 +639,8 @@ def side_figures(a, dev):
             out[str(rate)] = {"n_fft": n_fft, "hop": hop, "pairs_per_s": round(nb / (ms * 1e-3), 1)}
             del b2, est, tgt
             torch.cuda.empty_cache()
-        return {"workload": "%d pairs of 4 s per rate, LSD + log-SISpec + SISpec + SSIM" % nb, "rates": out}
+        return {"workload": "%d pairs of 4 s per rate, LSD + log-SISpec + SISpec + SSIM" % nb, "rates": out,
+                "note": "side figures: average of 3 launches per rate in one short run"}
 
     def other(cfg, steps):
         def run():
@@ -501,8 +654,17 @@ def side_figures(a, dev):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             roof, extra = wl.report(a)
+            parity = None
+            if getattr(wl, "parity", None) is not None and not a.no_cpu_baseline:
+                # a handful of this config's own units through the oracle (no CPU rate is reported for a side figure)
+                global _CPU_ITEMS, _CPU_FN
+                _CPU_FN, _CPU_ITEMS = wl.cpu_unit, wl.cpu_inputs(3)
+                parity = float(wl.parity(_cpu_run(list(range(len(_CPU_ITEMS))))[1], len(_CPU_ITEMS), 0))
             return {"metric": wl.metric, "value": round(wl.units_per_step * steps / dt, 1), "unit": wl.unit, "steps": steps,
-                    "ms_per_step": round(dt / steps * 1e3, 3), "config": wl.config(1), "roofline": roof, "extra": extra}
+                    "ms_per_step": round(dt / steps * 1e3, 3), "config": wl.config(1), "roofline": roof, "extra": extra,
+                    "parity_vs_oracle_max_rel_err": parity,
+                    "note": "side figure: ONE short run (%d steps after 1 warm-up) outside the headline's timed region; "
+                            "`python bench.py --config %s` is the measurement" % (steps, cfg)}
         return run
 
     def e2e():
@@ -538,6 +700,7 @@ def side_figures(a, dev):
     guarded("api_true_2229_480", api_true)
     guarded("audio_metrics_rates", rates)
     guarded("cfg3", other("cfg3", 2))
+    guarded("cfg4", other("cfg4", 2))
     guarded("cfg5", other("cfg5", 2))
     guarded("evaluate_end_to_end", e2e)
     return ex
@@ -568,37 +731,57 @@ def run(a):
     else:
         joined = 1
 
-    wl = (Skeleton if a.cpu_skeleton else WORKLOADS[a.config])(a, dev, rank)
+    wl = (Skeleton if (a.cpu_skeleton and a.config != "cfg4") else WORKLOADS[a.config])(a, dev, rank)
     wl_cls = type(wl)
+    strong = getattr(wl_cls, "scaling", "weak") == "strong"
 
-    def step():
-        agg = wl.step()
+    def timed(w, steps, warmup):
+        """`warmup` untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; MAX over ranks."""
+        def step():
+            agg = w.step()
+            if world > 1 and not getattr(w, "own_collectives", False):
+                dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+            return agg
+        for _ in range(warmup):
+            step()
+        sync()
         if world > 1:
-            dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        return agg
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            agg = step()
+        sync()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, agg.cpu().numpy()
 
-    for _ in range(a.warmup):
-        step()
-    sync()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        agg = step()
-    sync()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    value = wl.units_per_step * joined * a.steps / elapsed
-    agg = agg.cpu().numpy()
-    means = (agg[:-1] / agg[-1]).tolist()
+    elapsed, agg = timed(wl, a.steps, a.warmup)
+    # weak scaling: every rank owns units_per_step units; strong scaling: units_per_step is the whole job's
+    value = wl.units_per_step * (1 if strong else joined) * a.steps / elapsed
+    means = wl.job_means(agg) if hasattr(wl, "job_means") else (agg[:-1] / agg[-1]).tolist()
     payload = int(agg.nbytes)
 
+    # the fixed-size sharded test set next to a weak-scaling headline at N > 1 (every rank takes part; rank 0 reports)
+    cfg4_side = None
+    if world > 1 and a.config == "cfg2" and not a.no_side and not a.cpu_skeleton:
+        w4 = Cfg4(a, dev, rank)
+        dt4, agg4 = timed(w4, 3, 1)
+        roof4, extra4 = w4.report(a)
+        cfg4_side = {"metric": Cfg4.metric, "value": round(w4.units_per_step * 3 / dt4, 1), "unit": Cfg4.unit, "scaling": "strong",
+                     "n_gpus": joined, "steps": 3, "ms_per_step": round(dt4 / 3 * 1e3, 3), "config": w4.config(joined),
+                     "roofline": roof4, "extra": dict(extra4, job_means=w4.job_means(agg4)),
+                     "note": "side figure: one short run (3 steps after 1 warm-up), outside the timed region of the headline"}
+        del w4
+        torch.cuda.empty_cache()
+
     if rank != 0:
+        if getattr(wl_cls, "own_collectives", False) and world > 1:
+            wl.report(a)                                                # its report times the collectives: every rank takes part
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -607,11 +790,13 @@ def run(a):
     roofline, extra = wl.report(a)
     extra["job_means"] = means
     extra["allreduce_payload_bytes_per_step"] = payload if world > 1 else 0
+    if cfg4_side is not None:
+        extra["cfg4_strong_scaling"] = cfg4_side
     cpu = None
     if not a.no_cpu_baseline and world == 1 and not a.cpu_skeleton:      # contract: the CPU baseline is timed on rank 0 at N = 1 only
         cpu, vals = cpu_baseline(wl)
-        if wl.parity is not None:
-            extra["parity_vs_oracle_max_rel_err"] = float(wl.parity(vals, min(4, len(vals)), 4))   # vals[i] is pair 4 + i
+        if getattr(wl, "parity", None) is not None:
+            extra["parity_vs_oracle_max_rel_err"] = float(wl.parity(vals, min(4, len(vals)), 4))   # vals[i] is item 4 + i
     if world == 1 and a.config == "cfg2" and not a.no_side and not a.cpu_skeleton:
         del wl
         torch.cuda.empty_cache()
@@ -619,7 +804,7 @@ def run(a):
 
     line = {"metric": wl_cls.metric, "value": round(value, 2), "unit": wl_cls.unit, "n_gpus": joined,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": _config_of(wl_cls, a, joined),
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
     print(json.dumps(line), flush=True)

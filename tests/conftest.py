@@ -42,3 +42,39 @@ def golden_manifest():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "manifest.json")) as f:
         return json.load(f)
+
+
+# ---- SISpec parity bookkeeping: which branch of assert_sispec_parity every GPU assert took -------------
+SISPEC_LOG = []      # dicts: what, config, branch ("strict" | "band"), band_rel, err_vs_ref32_rel, err_vs_exact_rel
+
+
+def sispec_summary():
+    by = {}
+    for r in SISPEC_LOG:
+        c = by.setdefault(r["config"], {"asserts": 0, "strict_1e-5_vs_reference": 0, "inside_reference_band": 0,
+                                        "max_band_rel": 0.0, "max_err_vs_reference_rel": 0.0, "max_err_vs_float64_rel": 0.0})
+        c["asserts"] += 1
+        c["strict_1e-5_vs_reference" if r["branch"] == "strict" else "inside_reference_band"] += 1
+        c["max_band_rel"] = max(c["max_band_rel"], r["band_rel"])
+        c["max_err_vs_reference_rel"] = max(c["max_err_vs_reference_rel"], r["err_vs_ref32_rel"])
+        c["max_err_vs_float64_rel"] = max(c["max_err_vs_float64_rel"], r["err_vs_exact_rel"])
+    return by
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if not SISPEC_LOG:
+        return
+    import json
+    by = sispec_summary()
+    terminalreporter.write_sep("-", "SISpec parity: branch taken per config (strict = 1e-5 against the reference's float32 value)")
+    for cfg, c in sorted(by.items()):
+        terminalreporter.write_line("%-28s asserts %4d | strict %4d | band %4d | widest band %.2e | worst vs reference %.2e | worst vs float64 %.2e"
+                                    % (cfg, c["asserts"], c["strict_1e-5_vs_reference"], c["inside_reference_band"], c["max_band_rel"],
+                                       c["max_err_vs_reference_rel"], c["max_err_vs_float64_rel"]))
+    try:                                 # travels back from the GPU box with gpurun_out/
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "sispec_parity_summary.json"), "w") as f:
+            json.dump({"per_config": by, "band_cases": [r for r in SISPEC_LOG if r["branch"] == "band"]}, f, indent=1)
+    except OSError:
+        pass

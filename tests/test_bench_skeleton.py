@@ -53,3 +53,29 @@ def test_torchrun_launch_two_ranks_gloo():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["extra"]["job_means"] == [1.5]
+
+
+def test_cfg4_strong_scaling_shards_and_collectives_gloo():
+    """bench.py --config cfg4 (the 2,937-utterance sharded test set): with N = 1, 2 and 3 ranks (gloo, kernels replaced by
+    functions of the global utterance index) the all-reduced [speakers, sums + count] buffer yields the SAME mean of speaker
+    means, the all-gather delivers every utterance's row, and the line says strong scaling with value = 2,937 x steps / time."""
+    import numpy as np
+    means = {}
+    for n in (1, 2, 3):
+        r = _bench("--config", "cfg4", "--gpus", str(n), "--steps", "2", "--warmup", "1", "--_cpu-skeleton")
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == n and d["scaling"] == "strong" and d["unit"] == "pairs/s"
+        assert abs(d["value"] - 2937 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-3       # NOT multiplied by the rank count
+        assert d["extra"]["allgather_rows_received"] == 2937
+        assert d["extra"]["shard_utterances"] == len(range(0, 2937, n))
+        means[n] = np.array(d["extra"]["job_means"])
+    # reference value: mean over speakers of per-speaker means of the four index functions
+    counts = [424, 424, 123, 419, 301, 424, 424, 398]
+    gi = np.arange(2937, dtype=np.float64)
+    vals = np.stack([gi, 0.5 * gi, gi * gi * 1e-3, np.cos(gi)], axis=1)
+    want = np.mean([vals[s:s + c].mean(axis=0) for s, c in zip(np.cumsum([0] + counts[:-1]), counts)], axis=0)
+    for n in (1, 2, 3):
+        np.testing.assert_allclose(means[n], want, rtol=1e-12, atol=1e-12)

@@ -127,6 +127,67 @@ def test_cfg3_cutoff_sweep_full_metric_set():
         np.testing.assert_array_equal(y, est_h[2 * 7 + c])
 
 
+def test_cfg3_full_launch_1024_targets_spot_checks():
+    """cfg-3 at the bench's REAL launch geometry: 1024 targets of 4 s per ssr_fft_lowpass launch, every
+    cutoff of the sweep, oracle spot checks on (target, cutoff) items spread over the grid - the degraded signal against the
+    oracle's torchlibrosa restatement, the four metrics of the pair against the oracle on the same degraded signal."""
+    from ssr_eval_amd import backend as B
+    from oracle import lowpass as olp
+    N, n = 1024, 192000
+    g = torch.Generator(device="cuda").manual_seed(20220328)
+    tgt = (0.1 * torch.randn((N, n), generator=g, device="cuda", dtype=torch.float32)).contiguous()
+    tr = B.Ragged.from_uniform(tgt)
+    lp = B.LowpassBatch(B.get_plan(2048, 441, "f64"), tr, [CUT_BINS[0]] * N)
+    batch = B.PairBatch(B.get_plan(2048, 512, "f64"), lp.out_ragged(), tr)
+    spots = {0: (0, 513), 1: (1023,), 2: (255, 768), 3: (511,), 4: (1, 1022), 5: (640,), 6: (127, 1023)}     # cutoff index -> targets
+    pairs, rows = [], []
+    for c, cut in enumerate(CUT_BINS):
+        lp.cut = torch.full((N,), cut, dtype=torch.int32, device="cuda")
+        est = lp.run().view(N, n)
+        got = batch.run(B.M_ALL).cpu().numpy().copy()
+        assert np.isfinite(got).all()
+        for t in spots[c]:
+            e = est[t].cpu().numpy().copy()
+            ref = olp.lowpass(tgt[t].cpu().numpy(), CUTOFFS[c], 48000, 1, "stft_hard")
+            np.testing.assert_allclose(e, ref, atol=3e-7, err_msg="cfg3 target %d cutoff %d" % (t, CUTOFFS[c]))
+            pairs.append((e, tgt[t].cpu().numpy()))
+            rows.append(got[t])
+        # every target is an i.i.d. draw: the batch statistics are tight at every cutoff (a wrong chunk would stick out)
+        assert got[:, 0].std() / got[:, 0].mean() < 0.02 and got[:, 3].std() < 0.02
+    assert len(pairs) == 11
+    _check_rows(np.array(rows), _oracle_many(pairs), "cfg3-full-launch")
+
+
+def test_cfg5_full_launch_2048_utterances_bit_exact():
+    """cfg-5's chain at a launch that makes the persistent resampler ITERATE: 2048 utterances x 17 blocks
+    = 34,816 work items over ~768 persistent workgroups - 45 rounds with the cross-round register prefetch for 441/160 and
+    160/147 - against scipy.signal.resample_poly, bit for bit, after BOTH stages on utterances {0, mid, last}; then the
+    LSD of those utterances against the oracle."""
+    from ssr_eval_amd import backend as B
+    from oracle import metrics as om
+    N = 2048
+    g = torch.Generator(device="cuda").manual_seed(20220328)
+    x = (0.1 * torch.randn((N, 64000), generator=g, device="cuda", dtype=torch.float32)).contiguous()
+    tgt = (0.1 * torch.randn((N, 192000), generator=g, device="cuda", dtype=torch.float32)).contiguous()
+    s1 = B.ResampleBatch(B.Ragged.from_uniform(x), 44100, 16000)
+    s2 = B.ResampleBatch(s1.out_ragged(), 48000, 44100)
+    y1 = s1.run().view(N, 176400)
+    y2 = s2.run().view(N, 192000)
+    batch = B.PairBatch(B.get_plan(2048, 512, "f64"), s2.out_ragged(), B.Ragged.from_uniform(tgt))
+    lsd = batch.run(B.M_LSD).cpu().numpy()[:, 0]
+    for i in (0, 1, N // 2, N - 2, N - 1):
+        r1 = signal.resample_poly(x[i].cpu().numpy(), 441, 160)
+        np.testing.assert_array_equal(y1[i].cpu().numpy(), r1, err_msg="stage 1, utterance %d" % i)
+        r2 = signal.resample_poly(r1, 160, 147)
+        np.testing.assert_array_equal(y2[i].cpu().numpy(), r2, err_msg="stage 2, utterance %d" % i)
+        want = float(om.lsd(om.wav_to_spectrogram(r2, 2048, 512), om.wav_to_spectrogram(tgt[i].cpu().numpy(), 2048, 512)))
+        assert abs(lsd[i] - want) <= 1e-5 * want, (i, lsd[i], want)
+    # the rest of the launch: every utterance is an i.i.d. draw, so one wrong block anywhere would show in the energies
+    e1, e2 = (y1.double() ** 2).mean(dim=1), (y2.double() ** 2).mean(dim=1)
+    assert float(e1.std() / e1.mean()) < 0.02 and float(e2.std() / e2.mean()) < 0.02
+    assert np.isfinite(lsd).all() and lsd.std() / lsd.mean() < 0.01
+
+
 def test_cfg3_reference_vectors(golden_r2):
     """The sweep in small, against outputs of the imported reference (tests/golden/make_golden_r2.py)."""
     from ssr_eval_amd import SSR_Eval_Helper, BasicTestee, AudioMetrics
@@ -149,8 +210,8 @@ def test_cfg3_reference_vectors(golden_r2):
             got, want = _vec(am.evaluation(ref_y, x, "")), golden_r2[key][j]
             np.testing.assert_allclose(got[[0, 3]], want[[0, 3]], rtol=1e-5)
             _, exact = om.evaluation_with_exact(ref_y, x, n_fft=nf, hop=hp)
-            assert_sispec_parity(got[1], want[1], exact["log_sispec"], "%s log_sispec" % k)
-            assert_sispec_parity(got[2], want[2], exact["sispec"], "%s sispec" % k)
+            assert_sispec_parity(got[1], want[1], exact["log_sispec"], "cfg3-reference-vectors %s log_sispec" % k)
+            assert_sispec_parity(got[2], want[2], exact["sispec"], "cfg3-reference-vectors %s sispec" % k)
 
 
 # ---- multi-channel tensors on the metric API --------------------------------------------------------------------------------
@@ -267,9 +328,118 @@ print(json.dumps({"red": red.tolist(), "t": t.cpu().tolist(), "tab": tab.tolist(
     assert d["tab"] == np.arange(12.0).reshape(4, 3).tolist()
 
 
+_TWO_RANK_EVAL = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+rank = int(sys.argv[1]); world = int(sys.argv[2]); root = sys.argv[3]; port = sys.argv[4]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+import torch
+torch.cuda.set_device(0)                                  # both ranks share cuda:0; the exchange runs over gloo
+from ssr_eval_amd import SSR_Eval_Helper, BasicTestee
+from ssr_eval_amd import dist as D
+if world > 1:
+    D.init_from_env(backend="gloo")
+h = SSR_Eval_Helper(BasicTestee(), input_sr=44100, output_sr=44100, evaluation_sr=48000, test_data_root=root,
+                    setting_fft={"cutoff_freq": [4000, 12000]}, setting_lowpass_filtering={"filter": ["cheby"], "cutoff_freq": [6000], "filter_order": [6]})
+res = h.evaluate(save_json=False, batch_files=5)
+print("RESULT" + json.dumps({"res": res, "allreduce_avg": h.last_allreduce_average.tolist()}))
+if world > 1:
+    import torch.distributed as dist
+    dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_evaluate_sharded_two_processes_equals_single_process(tmp_path):
+    """The REAL SSR_Eval_Helper.evaluate() - file walk, round-robin shard, decode, degradations, kernels, all-gather of the
+    per-utterance rows, float64 sums + counts all-reduce - under TWO processes that share cuda:0 and exchange over gloo,
+    against the single-process run on the same wav tree: every per-file number, every per-speaker mean and the averaged
+    block (both ranks bit-identical to each other; against one process to 1e-12: the batches differ) (VERDICT r2 next #3; ssr_eval/eval.py:180-216)."""
+    from ssr_eval_amd.io import write_wav
+    rng = np.random.default_rng(12)
+    root = tmp_path / "vctk"
+    for s, c in (("p360", 4), ("p361", 3), ("s5", 2)):
+        (root / s).mkdir(parents=True)
+        for i in range(c):
+            n = int(rng.integers(int(0.6 * 44100), int(1.4 * 44100)))
+            write_wav(str(root / s / ("u%02d.wav" % i)), 0.1 * rng.standard_normal(n), 44100)
+    code = _TWO_RANK_EVAL % ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+
+    def launch(rank, world, port):
+        return subprocess.Popen([sys.executable, "-c", code, str(rank), str(world), str(root), str(port)], stdout=subprocess.PIPE,
+                                stderr=subprocess.PIPE, text=True, env=env, cwd=str(tmp_path))
+
+    def result(p):
+        out, err = p.communicate(timeout=900)
+        assert p.returncode == 0, err[-3000:]
+        return json.loads([l for l in out.splitlines() if l.startswith("RESULT")][-1][6:])
+    single = result(launch(0, 1, 0))
+    port = 34500 + os.getpid() % 1000
+    procs = [launch(r, 2, port) for r in range(2)]
+    both = [result(p) for p in procs]
+    assert len(single["res"]["p360"]) == 4 and set(single["res"]["averaged"]) == {"proc_ch_12000_6_44100", "proc_fft_8000_44100", "proc_fft_24000_44100"}
+    # every rank returns the SAME assembled result, bit for bit (the exchange transports float64 rows unchanged) ...
+    assert both[0]["res"] == both[1]["res"]
+
+    def flat(d, pre=""):
+        for k, v in d.items():
+            if isinstance(v, dict):
+                yield from flat(v, pre + k + "/")
+            else:
+                yield pre + k, v
+    a, b = dict(flat(single["res"])), dict(flat(both[0]["res"]))
+    assert list(a) == list(b)                                  # same schema, same key order
+    # ... and it is the single-process result: identical where the reference holds float32 values (lsd / sispec of float32
+    # pairs), within 1e-12 elsewhere - a batch of other files chunks the float64 partial sums differently (last-bit effects)
+    worst = max(abs(a[k] - b[k]) / max(abs(a[k]), 1e-300) for k in a)
+    assert worst <= 1e-12, worst
+    assert sum(a[k] == b[k] for k in a) >= len(a) // 2
+    np.testing.assert_allclose(both[0]["allreduce_avg"], single["allreduce_avg"], rtol=1e-12)
+
+
+def test_cabi_allreduce_sums_two_rank_communicator():
+    """ssr_allreduce_sums over a TWO-rank RCCL communicator (one process per device) where the box has two devices."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one HIP device on this box: the two-rank RCCL communicator needs two (covered by the gloo tests on CPU)")
+    code = r"""
+import os, sys, ctypes as C
+sys.path.insert(0, %r)
+rank = int(sys.argv[1]); path = sys.argv[2]
+import torch
+torch.cuda.set_device(rank)
+from ssr_eval_amd import _lib
+lib = _lib.load()
+uid = C.create_string_buffer(128)
+if rank == 0:
+    _lib.check(lib.ssr_comm_unique_id(uid)); open(path + ".tmp", "wb").write(uid.raw); os.rename(path + ".tmp", path)
+else:
+    import time
+    while not os.path.exists(path): time.sleep(0.05)
+    uid = C.create_string_buffer(open(path, "rb").read(), 128)
+comm = C.c_void_p()
+_lib.check(lib.ssr_comm_init_rank(uid, 2, rank, C.byref(comm)))
+t = torch.arange(10, dtype=torch.float64, device="cuda") * (rank + 1)
+_lib.check(lib.ssr_allreduce_sums(C.c_void_p(t.data_ptr()), 10, comm, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+torch.cuda.synchronize()
+assert t.cpu().tolist() == [3.0 * i for i in range(10)], t
+_lib.check(lib.ssr_comm_destroy(comm))
+print("OK")
+""" % ROOT
+    import tempfile
+    path = os.path.join(tempfile.mkdtemp(), "uid")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(2)]
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0 and "OK" in out, err[-3000:]
+
+
 def test_bench_cli_configs_smoke():
     """bench.py --config cfg3 / cfg5 at a small batch: one JSON line with the contract's fields."""
-    for cfg, extra in (("cfg3", ["--pairs", "32"]), ("cfg5", ["--utterances", "64"])):
+    for cfg, extra in (("cfg3", ["--pairs", "32"]), ("cfg5", ["--utterances", "64"]), ("cfg4", [])):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--steps", "2", "--warmup", "1",
                             "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
@@ -277,6 +447,7 @@ def test_bench_cli_configs_smoke():
         assert len(lines) == 1
         d = json.loads(lines[0])
         assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["frac"] > 0 and d["config"]["workload"].startswith(cfg[:3] + "-" + cfg[3])
+        assert d["scaling"] == ("strong" if cfg == "cfg4" else "weak")
 
 
 # ---- N2 ingest: windowed-sinc (resampy kaiser_best) resampling and the batched file loader ---------------------------------------

@@ -1,5 +1,5 @@
 """Developer experiment: engine clock and socket power while one stage of the pair pipeline runs back to back (sysfs, sampled
-from a thread), against the idle readings.  STAGE = stft (default) | ssim | full."""
+from a thread), against the idle readings.  STAGE = stft (default: LSD + magnitudes) | lsd (no magnitude stores) | ssim | full."""
 import glob, os, sys, threading, time, json
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,7 +40,7 @@ def main():
     tgt = (0.1 * torch.randn((n, bench.N_SAMPLES), generator=g, device=dev)).contiguous()
     est = (tgt + 0.01 * torch.randn((n, bench.N_SAMPLES), generator=g, device=dev)).contiguous()
     b = B.PairBatch(B.get_plan(2048, 512, "f64", dev), B.Ragged.from_uniform(est), B.Ragged.from_uniform(tgt))
-    mask, st = {"stft": (B.M_LSD | B.M_SSIM, 1), "ssim": (B.M_SSIM, 2), "full": (B.M_LSD | B.M_SSIM, 7)}[os.environ.get("STAGE", "stft")]
+    mask, st = {"stft": (B.M_LSD | B.M_SSIM, 1), "lsd": (B.M_LSD, 1), "ssim": (B.M_SSIM, 2), "full": (B.M_LSD | B.M_SSIM, 7)}[os.environ.get("STAGE", "stft")]
     b.run(mask, stages=st); torch.cuda.synchronize()
     print(json.dumps({"idle": sample()}))
     seen, stop = [], threading.Event()

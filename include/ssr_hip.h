@@ -195,13 +195,25 @@ int ssr_resample_poly_f64(const double* in, const int64_t* in_off, const int32_t
  * the `sox -r` target resampling of eval.py:133-134).  The caller supplies, as DEVICE arrays, the interpolation filter
  * (interp_win, already scaled by the ratio when downsampling, and interp_delta = its forward differences), resampy's
  * `precision` as num_table = 2^precision, index_step = int(scale * num_table), scale = min(1, ratio), and the time register of
- * every output index (t / ratio, accumulated sequentially as resampy does).  out_len[i] = int(in_len[i] * ratio).  float64
- * weights, float32 running sum rounded after every tap, no fused multiply-add: bit-identical to the NumPy restatement in
- * oracle/resampy.py.  (resampy itself is absent from the reference tree and the image: parity with the package is unpinned.) */
+ * every output index (t / ratio, accumulated sequentially as resampy does; time_register_len entries, at least max_out_len -
+ * checked).  out_len[i] = int(in_len[i] * ratio), ratio = sr_new / sr_orig.  phase_period: a of the reduced fraction
+ * sr_new / sr_orig = a / b when the rates are integers (the filter phase repeats every a outputs: a wave then works on one
+ * phase across 64 consecutive periods and its table reads coalesce), or 0 / 1 when unknown - a work-mapping hint only, the
+ * result does not depend on it.  float64 weights, float32 running sum rounded after every tap, no fused multiply-add:
+ * bit-identical to the NumPy restatement in oracle/resampy.py.  (resampy itself is absent from the reference tree and the
+ * image: parity with the package is unpinned.)  n_items * ceil(max_out_len / block) must stay below 2^31 (checked). */
 int ssr_resample_sinc(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
                       const int32_t* out_len, int n_items, int max_out_len, const double* time_register,
-                      const double* interp_win, const double* interp_delta, int n_win, int num_table, int index_step,
-                      double scale, float* out, void* stream);
+                      int64_t time_register_len, const double* interp_win, const double* interp_delta, int n_win,
+                      int num_table, int index_step, double scale, double ratio, int phase_period, float* out, void* stream);
+
+/* N2 (decode side).  16-bit PCM frames -> float32 mono, the values librosa.load(file, sr=None) returns for a PCM_16 file
+ * (ssr_eval/eval.py:242, metrics.py:21-24: soundfile's float32 read = sample / 32768, then the channel mean): the host decoder
+ * hands over the raw interleaved int16 frames (half the bytes across PCIe, no float pass on the host).
+ * pcm_off[i]: element offset of item i in `pcm`; item i holds n_frames[i] * n_channels[i] samples (1 <= n_channels <= 8);
+ * out_off[i]: element offset of its n_frames[i] float32 outputs. */
+int ssr_pcm16_to_float(const int16_t* pcm, const int64_t* pcm_off, const int32_t* n_frames, const int32_t* n_channels,
+                       int n_items, int max_frames, float* out, const int64_t* out_off, void* stream);
 
 /* N4.  Position of the maximum of the full cross-correlation of two equal-length signals,
  *   z[k] = sum_l a[l] * b[l - k + n - 1],  k = 0 .. 2n-2   (scipy.signal.correlate(a, b, "full")),

@@ -46,7 +46,9 @@ SIGNATURES = {
                                C.POINTER(_i), C.POINTER(_i)]),
     "ssr_resample_poly": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "ssr_resample_poly_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
-    "ssr_resample_sinc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, C.c_double, _vp, _vp]),
+    "ssr_resample_sinc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _vp, _vp, _i, _i, _i, C.c_double, C.c_double, _i,
+                                _vp, _vp]),
+    "ssr_pcm16_to_float": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "ssr_xcorr_workspace_bytes": (_sz, [_i, _i]),
     "ssr_xcorr_argmax": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "ssr_sosfiltfilt_workspace_bytes": (_sz, [_i64, _i, _i]),

@@ -505,6 +505,10 @@ class SincPlan:
             raise NotImplementedError("resampling filter %r (supported: %s)" % (name, sorted(_SINC_FILTERS)))
         nz, prec, beta, roll = _SINC_FILTERS[name]
         self.ratio = float(sr_new) / float(sr_orig)
+        # filter phases repeat every `a` outputs when sr_new / sr_orig = a / b in lowest terms (a work-mapping hint)
+        self.phase_period = 0
+        if float(sr_new).is_integer() and float(sr_orig).is_integer():
+            self.phase_period = int(sr_new) // math.gcd(int(sr_new), int(sr_orig))
         self.num_table = 2 ** prec
         n = self.num_table * nz
         win = kaiser(2 * n + 1, beta)[n:] * (roll * np.sinc(roll * np.linspace(0, nz, num=n + 1, endpoint=True)))
@@ -560,9 +564,77 @@ def resample_sinc(wavs, sr_orig, sr_new, res_type="kaiser_best", device=None, fi
             out_len_d = torch.from_numpy(out_len.astype(np.int32)).to(dev)
             tr = sp.time_register(int(out_len.max()))
             _lib.check(_lib.load().ssr_resample_sinc(_vp(r.data), _vp(r.off), _vp(r.len), _vp(out_off_d), _vp(out_len_d), r.n,
-                                                     int(out_len.max()), _vp(tr), _vp(sp.win), _vp(sp.delta), sp.n_win,
-                                                     sp.num_table, sp.index_step, float(sp.scale), _vp(out), _stream()))
+                                                     int(out_len.max()), _vp(tr), int(tr.numel()), _vp(sp.win), _vp(sp.delta),
+                                                     sp.n_win, sp.num_table, sp.index_step, float(sp.scale), float(sp.ratio),
+                                                     int(sp.phase_period), _vp(out), _stream()))
         return [out[out_off[i]:out_off[i] + want[i]] for i in range(r.n)]
+
+
+class _Staging:
+    """Two page-locked int16 arenas per device, used alternately: a batch's PCM is packed into one of them and crosses PCIe in
+    ONE asynchronous copy while the host packs the next batch into the other.  An arena is reused only after the copy that
+    last read it has completed (event)."""
+    _by_dev = {}
+
+    def __init__(self):
+        self.buf = [None, None]
+        self.ev = [None, None]
+        self.k = 0
+
+    @classmethod
+    def get(cls, dev):
+        return cls._by_dev.setdefault(str(dev), cls())
+
+    def arena(self, n):
+        self.k ^= 1
+        k = self.k
+        if self.ev[k] is not None:
+            self.ev[k].synchronize()
+        if self.buf[k] is None or self.buf[k].numel() < n:
+            self.buf[k] = torch.empty(max(n, 1 << 22), dtype=torch.int16, pin_memory=True)
+        return k, self.buf[k]
+
+    def sent(self, k):
+        self.ev[k] = torch.cuda.Event()
+        self.ev[k].record()
+
+
+def upload_decoded(raw, device=None):
+    """Decoded files (io.RawAudio) -> float32 mono device tensors, one per file.  16-bit PCM crosses the bus as int16 - half the
+    bytes, no float pass on the host - in one pinned asynchronous copy per batch and is converted / mixed to mono on the GPU
+    (ssr_pcm16_to_float); anything else is uploaded as the float32 mono array it already is."""
+    dev = torch.device(device) if device is not None else default_device()
+    out = [None] * len(raw)
+    with torch.cuda.device(dev):
+        pcm = [i for i, r in enumerate(raw) if r.pcm is not None and r.pcm.shape[0] > 0]
+        is_pcm = set(pcm)
+        for i, r in enumerate(raw):
+            if i not in is_pcm:
+                out[i] = torch.from_numpy(np.ascontiguousarray(r.to_float(), dtype=np.float32)).to(dev, non_blocking=True)
+        if pcm:
+            sizes = np.array([raw[i].pcm.shape[0] for i in pcm], dtype=np.int64)
+            frames = np.array([raw[i].n_frames for i in pcm], dtype=np.int64)
+            chans = np.array([raw[i].nch for i in pcm], dtype=np.int32)
+            total = int(sizes.sum())
+            st = _Staging.get(dev)
+            k, arena = st.arena(total)
+            host = arena.numpy()
+            in_off = np.concatenate(([0], np.cumsum(sizes)[:-1]))
+            for i, o in zip(pcm, in_off):
+                host[o:o + raw[i].pcm.shape[0]] = raw[i].pcm
+            d16 = torch.empty(total, dtype=torch.int16, device=dev)
+            d16.copy_(arena[:total], non_blocking=True)
+            st.sent(k)
+            out_off = np.concatenate(([0], np.cumsum(frames)[:-1]))
+            desc = torch.from_numpy(np.concatenate((in_off, out_off)).astype(np.int64)).to(dev, non_blocking=True)
+            desc32 = torch.from_numpy(np.concatenate((frames.astype(np.int32), chans))).to(dev, non_blocking=True)
+            n = len(pcm)
+            flat = torch.empty(int(frames.sum()), dtype=torch.float32, device=dev)
+            _lib.check(_lib.load().ssr_pcm16_to_float(_vp(d16), _vp(desc[:n]), _vp(desc32[:n]), _vp(desc32[n:]), n, int(frames.max()),
+                                                      _vp(flat), _vp(desc[n:]), _stream()))
+            for j, i in enumerate(pcm):
+                out[i] = flat[out_off[j]:out_off[j] + frames[j]]
+    return out
 
 
 def sosfiltfilt(sos, wavs, device=None):

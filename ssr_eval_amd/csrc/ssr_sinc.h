@@ -12,8 +12,21 @@
 // with float64 weights and products and the running sum y rounded to float32 after every tap (resampy accumulates
 // into the float32 output array).  No fused multiply-add: every product and sum is rounded separately, so the result is
 // bit-identical to the NumPy restatement (oracle/resampy.py) given the same tables.
+//
+// Work mapping (round 3; round 2 ran one thread per consecutive output with ~128 dependent table gathers from global memory
+// and every input sample fetched ~128 times through L1 / L2):
+//   * a workgroup owns a CONTIGUOUS run of outputs and stages the input window that run touches in LDS once (zero outside the
+//     signal; the taps beyond the signal's ends are skipped as in resampy, the zeros are never read);
+//   * for a rational rate pair sr_new / sr_orig = a / b the filter phase repeats every a outputs, so a wave takes ONE phase r
+//     and its 64 lanes take 64 CONSECUTIVE PERIODS (outputs a j + r): all lanes of a load read the same table entry (the
+//     accumulated time register drifts by < 1e-10, i.e. at most the neighbouring entry) - one cache line per load instead of 64 -
+//     and their input samples sit b apart in LDS (b odd for 44.1 <-> 48 kHz: conflict-free);
+//   * `period` = 1 (no rational structure given, or 64 periods of input do not fit the LDS window) falls back to consecutive
+//     outputs per lane: the table reads scatter again, the input still comes from LDS.
 #pragma once
 #include "ssr_block.h"
+
+constexpr int SSR_SINC_NT = 256;
 
 struct SsrSincParams {
   const float* in;
@@ -27,12 +40,16 @@ struct SsrSincParams {
   int nwin, num_table, index_step;
   double scale;             // min(1, ratio)
   float* out;
+  // block geometry (host: ssr_sinc_geometry)
+  int period;               // a (outputs per filter-phase period), or 1
+  int m;                    // a block = 64 m periods = 64 m period outputs
+  int max_room;             // most taps a wing can have: nwin / index_step (+1)
+  int lds_floats;           // floats of LDS the launch provides for the input window
 };
 
-SSR_DEV void ssr_sinc_output(const SsrSincParams& p, int item, int64_t t) {
-  const int n_in = p.in_len[item], n_out = p.out_len[item];
-  if (t >= n_out) return;
-  const float* x = p.in + p.in_off[item];
+// One output, input through `xs` (xs[s - lo] = x[s]; lo = 0 and xs = x: straight from global memory).
+SSR_DEV float ssr_sinc_one(const SsrSincParams& p, const SsrView<double>& vwin, const SsrView<double>& vdelta, const float* xs, int lo,
+                           int n_in, int64_t t) {
   const double tr = p.time_reg[t];
   const int n = (int)tr;
   double frac = ssr_fmul_rn(p.scale, ssr_fadd_rn(tr, -(double)n));
@@ -44,13 +61,71 @@ SSR_DEV void ssr_sinc_output(const SsrSincParams& p, int item, int64_t t) {
     const int room = (p.nwin - offset) / p.index_step;
     const int avail = wing == 0 ? n + 1 : n_in - n - 1;
     const int cnt = room < avail ? room : avail;
+    const int x0 = (wing == 0 ? n : n + 1) - lo, dx = wing == 0 ? -1 : 1;
     for (int i = 0; i < cnt; ++i) {
-      const int idx = offset + i * p.index_step;
-      const double weight = ssr_fadd_rn(p.win[idx], ssr_fmul_rn(eta, p.delta[idx]));
-      const double xv = (double)(wing == 0 ? x[n - i] : x[n + i + 1]);
+      const unsigned idx = (unsigned)(offset + i * p.index_step);
+      const double weight = ssr_fadd_rn(vwin.at(idx), ssr_fmul_rn(eta, vdelta.at(idx)));
+      const double xv = (double)xs[x0 + dx * i];
       y = (float)ssr_fadd_rn((double)y, ssr_fmul_rn(weight, xv));
     }
     frac = ssr_fadd_rn(p.scale, -frac);           // "invert P"
   }
-  p.out[p.out_off[item] + t] = y;
+  return y;
+}
+
+// grid = n_items * blocks_per_item workgroups of SSR_SINC_NT threads; dynamic LDS: lds_floats floats
+template <typename BLK>
+SSR_BODY void ssr_sinc_block_body(const SsrSincParams& p, BLK& blk, int item, int block, char* lds_base) {
+  constexpr int NT = SSR_SINC_NT, NWAVES = NT / 64;
+  float* xs = reinterpret_cast<float*>(lds_base);
+  const int n_in = p.in_len[item], n_out = p.out_len[item];
+  const int P = p.period, JB = 64 * p.m;
+  const int64_t t0 = (int64_t)block * JB * P;                   // the block's outputs: [t0, t1)
+  if (t0 >= n_out || n_in <= 0) return;
+  const int64_t t1 = (t0 + (int64_t)JB * P < n_out) ? t0 + (int64_t)JB * P : (int64_t)n_out;
+  const float* x = p.in + p.in_off[item];
+  const SsrView<double> vwin(p.win, p.nwin), vdelta(p.delta, p.nwin);
+  // input window of the block: every index a tap of one of its outputs can touch
+  const int lo = (int)p.time_reg[t0] - (p.max_room - 1);
+  const int hi = (int)p.time_reg[t1 - 1] + p.max_room;
+  const int W = hi - lo + 1;
+  const bool staged = W <= p.lds_floats;                        // (the host's geometry guarantees it; a safety net otherwise)
+  SSR_REGS(int, regs, blk);
+  SSR_PHASE(blk, regs, {
+    if (staged)
+      for (int i = tid; i < W; i += NT) {
+        const int s = lo + i;
+        xs[i] = (s >= 0 && s < n_in) ? x[s] : 0.0f;
+      }
+  });
+  SSR_PHASE(blk, regs, {
+    const int wave = ssr_wave_of(tid), lane = tid & 63;
+    for (int w = wave; w < P * p.m; w += NWAVES) {                // work item = (phase r, period group g): wave-uniform
+      const int r = w / p.m, g = w - r * p.m;
+      const int64_t t = t0 + (int64_t)(64 * g + lane) * P + r;
+      if (t < t1) p.out[p.out_off[item] + t] = staged ? ssr_sinc_one(p, vwin, vdelta, xs, lo, n_in, t) : ssr_sinc_one(p, vwin, vdelta, x, 0, n_in, t);
+    }
+  });
+}
+
+// Block geometry for a rate pair (host side; also used by the emulation harness).  period_hint: a of the reduced ratio
+// sr_new / sr_orig = a / b, or <= 1 when unknown.  lds_cap_floats: the largest input window to stage.
+struct SsrSincGeometry { int period, m, max_room, lds_floats, outputs_per_block; };
+SSR_HD SsrSincGeometry ssr_sinc_geometry(int period_hint, double ratio, int nwin, int index_step, int lds_cap_floats) {
+  SsrSincGeometry g;
+  g.max_room = nwin / index_step + 1;
+  const int halo = 2 * g.max_room + 4;
+  int P = period_hint > 1 ? period_hint : 1;
+  // input samples spanned by 64 periods
+  double span64 = 64.0 * (double)P / ratio;
+  if (P > 1 && span64 + halo > (double)lds_cap_floats) { P = 1; span64 = 64.0 / ratio; }
+  int m = (int)(((double)lds_cap_floats - halo) / span64);
+  const int m_target = (8192 + 64 * P - 1) / (64 * P);          // ~8 k outputs per block
+  if (m > m_target) m = m_target;
+  if (m < 1) m = 1;
+  g.period = P; g.m = m;
+  g.outputs_per_block = 64 * m * P;
+  double w = (double)g.outputs_per_block / ratio + halo + 2;
+  g.lds_floats = (int)w + 1;
+  return g;
 }

@@ -266,6 +266,28 @@ __global__ __launch_bounds__(256) void k_energy_sums(const float* a, const float
   if (threadIdx.x < 3) sums[(int64_t)blockIdx.x * 3 + threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
 }
 
+// N2 ingest: 16-bit PCM frames (interleaved channels, as a WAV / FLAC decoder hands them over) -> float32 mono, the values
+// librosa.load produces: sample / 32768 (soundfile's float32 read of PCM_16; a power of two, exact) and, for more than one
+// channel, the float32 channel mean (numpy.mean over <= 8 such values: their sum is exact in float32 whatever the order, the
+// division by the channel count rounds once).
+__global__ __launch_bounds__(256) void k_pcm16_to_float(const int16_t* in, const int64_t* in_off, const int32_t* n_frames,
+                                                        const int32_t* n_channels, int blocks_per_item, float* out,
+                                                        const int64_t* out_off) {
+  const int item = blockIdx.x / blocks_per_item;
+  const int nf = n_frames[item], nch = n_channels[item];
+  const int16_t* src = in + in_off[item];
+  float* dst = out + out_off[item];
+  for (int f = (blockIdx.x % blocks_per_item) * 256 + threadIdx.x; f < nf; f += blocks_per_item * 256) {
+    if (nch == 1) {
+      dst[f] = (float)src[f] * (1.0f / 32768.0f);
+    } else {
+      float acc = 0.0f;
+      for (int c = 0; c < nch; ++c) acc += (float)src[(int64_t)f * nch + c] * (1.0f / 32768.0f);
+      dst[f] = acc / (float)nch;
+    }
+  }
+}
+
 // Multi-channel SISpec (metrics.py:114-121 on [B, C, T, F] tensors with C > 1), stage 1: per image the sums on the
 // DIFFERENCE d = e - t (exact in float64): {Sdd, Stt, Sdt}; log_domain applies to_log (utils.py:43-44, float32) first.
 __global__ __launch_bounds__(256) void k_mc_diff_sums(const float* a, const float* b, int64_t per_item, int log_domain, double* sums) {
@@ -349,6 +371,19 @@ extern "C" int ssr_energy_sums(const float* a, const float* b, int n_items, int6
   if (n_items <= 0) return SSR_OK;
   if (per_item < 0) return ssr_fail(SSR_ERR_INVALID_ARG, "negative item size");
   hipLaunchKernelGGL(k_energy_sums, dim3((unsigned)n_items), dim3(256), 0, (hipStream_t)stream, a, b, per_item, sums);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+
+extern "C" int ssr_pcm16_to_float(const int16_t* pcm, const int64_t* pcm_off, const int32_t* n_frames, const int32_t* n_channels,
+                                  int n_items, int max_frames, float* out, const int64_t* out_off, void* stream) {
+  if (!pcm || !pcm_off || !n_frames || !n_channels || !out || !out_off) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n_items <= 0 || max_frames <= 0) return SSR_OK;
+  int bpi = ssr_ceil_div(max_frames, 256 * 8);                     // a thread converts ~8 frames
+  if (bpi > 1024) bpi = 1024;
+  if ((int64_t)n_items * bpi > 0x7fffffff) return ssr_fail(SSR_ERR_UNSUPPORTED, "batch too large for one launch");
+  hipLaunchKernelGGL(k_pcm16_to_float, dim3((unsigned)(n_items * bpi)), dim3(256), 0, (hipStream_t)stream, pcm, pcm_off, n_frames,
+                     n_channels, bpi, out, out_off);
   HIP_TRY(hipGetLastError());
   return SSR_OK;
 }

@@ -35,9 +35,10 @@ __global__ __launch_bounds__(256) void k_resample_direct(SsrResampleParamsT<S> p
   ssr_resample_direct_output<S>(p, item, (int64_t)(blockIdx.x % blocks_per_item) * 256 + threadIdx.x);
 }
 
-__global__ __launch_bounds__(256) void k_resample_sinc(SsrSincParams p, int blocks_per_item) {
-  const int item = blockIdx.x / blocks_per_item;
-  ssr_sinc_output(p, item, (int64_t)(blockIdx.x % blocks_per_item) * 256 + threadIdx.x);
+__global__ __launch_bounds__(SSR_SINC_NT) void k_resample_sinc(SsrSincParams p, int blocks_per_item) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  SsrBlk blk{(int)threadIdx.x};
+  ssr_sinc_block_body(p, blk, blockIdx.x / blocks_per_item, blockIdx.x % blocks_per_item, smem);
 }
 
 template <int G, typename X>
@@ -124,17 +125,27 @@ extern "C" int ssr_resample_poly_f64(const double* in, const int64_t* in_off, co
 // ----------------------------------------------------------------------------------------------------
 extern "C" int ssr_resample_sinc(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
                                  const int32_t* out_len, int n_items, int max_out_len, const double* time_register,
-                                 const double* interp_win, const double* interp_delta, int n_win, int num_table,
-                                 int index_step, double scale, float* out, void* stream) {
+                                 int64_t time_register_len, const double* interp_win, const double* interp_delta, int n_win,
+                                 int num_table, int index_step, double scale, double ratio, int phase_period, float* out,
+                                 void* stream) {
   if (!in || !in_off || !in_len || !out_off || !out_len || !time_register || !interp_win || !interp_delta || !out)
     return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
-  if (n_win < 1 || num_table < 1 || index_step < 1 || !(scale > 0.0) || scale > 1.0)
+  if (n_win < 1 || num_table < 1 || index_step < 1 || !(scale > 0.0) || scale > 1.0 || !(ratio > 0.0))
     return ssr_fail(SSR_ERR_INVALID_ARG, "bad interpolation filter description");
   if (n_items <= 0 || max_out_len <= 0) return SSR_OK;
+  if (time_register_len < (int64_t)max_out_len)
+    return ssr_fail(SSR_ERR_INVALID_ARG, "time_register holds fewer entries than max_out_len");
+  if ((int64_t)n_win * 8 >= ((int64_t)1 << 31)) return ssr_fail(SSR_ERR_UNSUPPORTED, "interpolation table of 2 GiB or more");
+  const SsrSincGeometry g = ssr_sinc_geometry(phase_period, ratio, n_win, index_step, 12288);   // <= 48 KB of input window
   SsrSincParams p{in, in_off, in_len, out_off, out_len, time_register, interp_win, interp_delta, n_win, num_table, index_step,
-                  scale, out};
-  const int bpi = ssr_ceil_div(max_out_len, 256);
-  hipLaunchKernelGGL(k_resample_sinc, dim3((unsigned)((int64_t)n_items * bpi)), dim3(256), 0, (hipStream_t)stream, p, bpi);
+                  scale, out, g.period, g.m, g.max_room, g.lds_floats};
+  const int bpi = ssr_ceil_div(max_out_len, g.outputs_per_block);
+  if ((int64_t)n_items * bpi > 0x7fffffff) return ssr_fail(SSR_ERR_UNSUPPORTED, "batch too large for one launch");
+  const size_t lds = (size_t)g.lds_floats * sizeof(float);
+  if (lds > 160 * 1024) return ssr_fail(SSR_ERR_UNSUPPORTED, "input window of one block exceeds the LDS (extreme down-sampling ratio)");
+  static thread_local SsrLdsSlot slot;
+  if (int rc = ssr_allow_lds((const void*)k_resample_sinc, lds, &slot)) return rc;
+  hipLaunchKernelGGL(k_resample_sinc, dim3((unsigned)((int64_t)n_items * bpi)), dim3(SSR_SINC_NT), lds, (hipStream_t)stream, p, bpi);
   HIP_TRY(hipGetLastError());
   return SSR_OK;
 }

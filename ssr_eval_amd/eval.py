@@ -245,12 +245,13 @@ class SSR_Eval_Helper:
             ret.update(self.lowpass_stft_hard(file, x, sr))
         return ret
 
-    def preprocess_arrays(self, xs, sr, files=None, resident=None):
+    def preprocess_arrays(self, xs, sr, files=None, resident=None, keep_on_device=False):
         """preprocess_array for a list of waveforms with every degradation batched over the list (one launch
         sequence per (filter, cutoff, order) instead of one per file).  Key order per item is the reference's
         (eval.py:243-269: butter, cheby, ellip, bessel, subsampling, mp3, fft).  `files`: the source paths, needed
         by the mp3 degradation only (sox encodes the file itself).  `resident`: the same waveforms as device tensors when the
-        caller has uploaded them already (used by the degradations that take float32 device input)."""
+        caller has uploaded them already (used by the degradations that take float32 device input).  keep_on_device: the
+        degraded signals stay device tensors (and `xs` may be device tensors): the resident evaluation path."""
         rets = [dict() for _ in xs]
         if not xs:
             return rets
@@ -270,21 +271,22 @@ class SSR_Eval_Helper:
                         if low_rate == sr:
                             low_rate -= 1
                         put("proc_%s_%s_%s_%s" % (tag, low_rate, order, sr),
-                            lowpass_batch(xs, low_rate // 2, sr, order=order, _type=ftype))
+                            lowpass_batch(xs, low_rate // 2, sr, order=order, _type=ftype, keep_on_device=keep_on_device))
         if self.setting_subsampling is not None:
             for low_rate in self.setting_subsampling["cutoff_freq"]:
                 if low_rate == sr:
                     low_rate -= 1
-                put("proc_subsampling_%s_%s" % (low_rate, sr), lowpass_batch(xs, low_rate // 2, sr, order=1, _type="subsampling"))
+                put("proc_subsampling_%s_%s" % (low_rate, sr),
+                    lowpass_batch(xs, low_rate // 2, sr, order=1, _type="subsampling", keep_on_device=keep_on_device))
         if self.setting_mp3_compression is not None:
             if files is None:
                 raise RuntimeError("mp3 degradation encodes the source files with sox: pass `files`")
             for ret, f, x in zip(rets, files, xs):
-                ret.update(self.mp3_encoding(f, x, sr))
+                ret.update(self.mp3_encoding(f, x.cpu().numpy() if isinstance(x, torch.Tensor) else x, sr))
         if self.setting_fft is not None:
             keys, ratios = self._fft_plan_keys(sr)
             src = xs if resident is None else resident
-            ys = stft_hard_lowpass_batch([x for x in src for _ in keys], ratios * len(xs), self._device)
+            ys = stft_hard_lowpass_batch([x for x in src for _ in keys], ratios * len(xs), self._device, keep_on_device=keep_on_device)
             for i, ret in enumerate(rets):
                 for j, k in enumerate(keys):
                     ret[k] = ys[i * len(keys) + j]
@@ -295,37 +297,51 @@ class SSR_Eval_Helper:
         return self.preprocess_array(load_audio(file, sr), sr, file)
 
     # ---- evaluation -----------------------------------------------------------------------------------
-    def _infer_and_collect(self, processed_inputs):
+    def _testee_takes_device_tensors(self):
+        """The resident path hands `infer` device tensors and takes device tensors back - no D2H / H2D round trip per degraded
+        input.  It is used when the testee is the base class's identity `infer` (which does not look at its input) or
+        declares `accepts_device_tensors = True`; every other testee gets and returns ndarrays, as in the reference."""
+        return bool(getattr(self.testee, "accepts_device_tensors", False)) or type(self.testee).infer is BasicTestee.infer
+
+    def _infer_and_collect(self, processed_inputs, device_mode=False):
         """Run the plugin on every degraded input; -> (keys, processed waveforms at output_sr, extra metrics)."""
         keys, outs, extras = [], [], []
         for k, v in processed_inputs.items():
             ret = self.testee.infer(v)                              # PLUGIN BOUNDARY (eval.py:138-143)
             processed, add = ret if isinstance(ret, tuple) else (ret, {})
             if isinstance(processed, torch.Tensor):
-                processed = processed.detach().cpu().numpy()
+                processed = processed.detach()
+                if not (device_mode and processed.is_cuda):
+                    processed = processed.cpu().numpy()
             keys.append(k)
-            outs.append(np.asarray(processed))
+            outs.append(processed if isinstance(processed, torch.Tensor) else np.asarray(processed))
             extras.append(add)
         return keys, outs, extras
 
-    def evaluate_arrays(self, items, files=None, resident_inputs=None):
+    def evaluate_arrays(self, items, files=None, resident_inputs=None, device_mode=False):
         """items: list of (target waveform @ evaluation_sr, input waveform @ input_sr).
         -> list of {key: {metric: float}} (one dict per item), everything batched on the GPU.
-        resident_inputs: the input waveforms as device tensors, if already uploaded."""
+        resident_inputs: the input waveforms as device tensors, if already uploaded.  device_mode: the inputs ARE device
+        tensors and stay so through degradation, `infer` and resampling (_testee_takes_device_tensors)."""
         all_keys, all_proc, all_tgt, all_extra, owner = [], [], [], [], []
-        degraded = self.preprocess_arrays([np.asarray(x) for _, x in items], self.model_input_sr, files, resident_inputs)
+        xs = [x for _, x in items] if device_mode else [np.asarray(x) for _, x in items]
+        degraded = self.preprocess_arrays(xs, self.model_input_sr, files, resident_inputs, keep_on_device=device_mode)
         for i, (target, x) in enumerate(items):
-            keys, outs, extras = self._infer_and_collect(degraded[i])
+            keys, outs, extras = self._infer_and_collect(degraded[i], device_mode)
             for k, o, e in zip(keys, outs, extras):
                 # a float64 output (IIR-degraded input through a pass-through testee) stays float64, as in the
                 # reference: librosa.resample and AudioMetrics.evaluation keep the dtype they are given
-                all_keys.append(k); all_proc.append(o if o.dtype == np.float64 else o.astype(np.float32))
+                if isinstance(o, torch.Tensor):
+                    o = o if o.dtype in (torch.float32, torch.float64) else o.float()
+                else:
+                    o = o if o.dtype == np.float64 else o.astype(np.float32)
+                all_keys.append(k); all_proc.append(o)
                 all_tgt.append(target if isinstance(target, torch.Tensor) else np.asarray(target, np.float32))
                 all_extra.append(e); owner.append(i)
         if self.model_output_sr != self.evaluationset_sr and all_proc:
             # eval.py:144-150; float64 and float32 outputs are resampled in their own dtype
             for want64 in (False, True):
-                idx = [i for i, o in enumerate(all_proc) if (o.dtype == np.float64) == want64]
+                idx = [i for i, o in enumerate(all_proc) if B._is_f64(o) == want64]
                 if idx:
                     ys = B.resample_poly([all_proc[i] for i in idx], self.evaluationset_sr, self.model_output_sr, self._device)
                     for i, y in zip(idx, ys):
@@ -344,20 +360,31 @@ class SSR_Eval_Helper:
 
     def evaluate_files(self, files, decoded=None):
         """eval.py:128-156 for a LIST of files in one batched pass (decode on the host, everything else on the GPU).
-        decoded: the files' io.decode_batch result if the caller already has it."""
-        from .io import decode_batch, to_rate, write_wav
-        # decode once on host threads, one ragged resampling launch per (file rate -> rate) group (ssr_eval_amd.io, N2)
+        decoded: the files' io.decode_async(raw=True) / decode_batch result if the caller already has it.
+        The decoded files cross the bus once (16-bit PCM as int16, converted on the GPU: backend.upload_decoded); the
+        evaluation-rate targets (the reference shells out to `sox -r`, eval.py:133-134) and the model-rate inputs
+        (librosa.load(file, sr=input_sr), eval.py:242) are resampled from that one upload and stay in HBM."""
+        from .io import RawAudio, decode_async, to_rate_resident, write_wav
         if decoded is None:
-            decoded = decode_batch(files)
-        # the decoded waveforms cross the bus once: target resampling and the float32 degradations read the same upload
-        on_dev = B.Ragged.from_list([x for x, _ in decoded], self._device).split() if decoded else []
-        # the reference shells out to `sox -r` here; resampled targets stay in HBM for the metric stage
-        targets = to_rate(decoded, self.evaluationset_sr, keep_on_device=True, resident=on_dev)
-        inputs = to_rate(decoded, self.model_input_sr, resident=on_dev)         # librosa.load(file, sr=input_sr), eval.py:242
-        same_rate = all(file_sr == int(self.model_input_sr) for _, file_sr in decoded)
-        # (the reference loads the file twice: target and input never share a buffer, whatever a testee does to its input)
-        items = [(t, x.copy() if x is t else x) for t, x in zip(targets, inputs)]
-        res = self.evaluate_arrays(items, files, on_dev if same_rate else None)
+            decoded = decode_async(files, raw=True)()
+        decoded = [d if isinstance(d, RawAudio) else RawAudio(None, np.ascontiguousarray(d[0], np.float32), 1, int(d[1])) for d in decoded]
+        on_dev = B.upload_decoded(decoded, self._device)
+        srs = [d.sr for d in decoded]
+        targets = to_rate_resident(on_dev, srs, self.evaluationset_sr)
+        same_rate = all(sr == int(self.model_input_sr) for sr in srs)
+        if self._testee_takes_device_tensors():
+            inputs = to_rate_resident(on_dev, srs, self.model_input_sr)
+            # (the reference loads the file twice: target and input never share a buffer, whatever a testee does to its input)
+            items = [(t, x.clone() if x is t else x) for t, x in zip(targets, inputs)]
+            res = self.evaluate_arrays(items, files, inputs if same_rate else None, device_mode=True)
+        else:
+            inputs = [d.to_float() if d.sr == int(self.model_input_sr) else None for d in decoded]
+            need = [i for i, x in enumerate(inputs) if x is None]
+            if need:
+                ys = to_rate_resident([on_dev[i] for i in need], [srs[i] for i in need], self.model_input_sr)
+                for i, y in zip(need, ys):
+                    inputs[i] = y.cpu().numpy()
+            res = self.evaluate_arrays(list(zip(targets, inputs)), files, on_dev if same_rate else None)
         if self.save_processed_result:
             for (i, k), y in self._last_processed.items():
                 write_wav(files[i] + k + "_processed_" + self.test_name + ".wav", y, self.evaluationset_sr)
@@ -395,10 +422,10 @@ class SSR_Eval_Helper:
         local = []
         step = max(1, int(batch_files))                            # ragged batches of files per launch sequence
         batches = [paths[b:b + step] for b in range(0, len(paths), step)]
-        ahead = decode_async(batches[0]) if batches else None      # host decode of batch k+1 runs under the GPU work of batch k
+        ahead = decode_async(batches[0], raw=True) if batches else None    # host decode of batch k+1 runs under the GPU work of batch k
         for k, batch in enumerate(batches):
             decoded = ahead()
-            ahead = decode_async(batches[k + 1]) if k + 1 < len(batches) else None
+            ahead = decode_async(batches[k + 1], raw=True) if k + 1 < len(batches) else None
             local += self.evaluate_files(batch, decoded)
         return self._assemble(work, speakers, mine, local, save_json, datetime.now())
 

@@ -55,6 +55,45 @@ def read_audio(path):
     return _mono(x, nch), int(sr)
 
 
+class RawAudio:
+    """A decoded file as the decoder hands it over: `pcm` = interleaved int16 frames [n * nch] of a PCM_16 file (the float32
+    conversion and the mono mix then run on the GPU, backend.upload_decoded), or `x` = float32 mono [n] for anything else."""
+    __slots__ = ("pcm", "x", "nch", "sr")
+
+    def __init__(self, pcm, x, nch, sr):
+        self.pcm, self.x, self.nch, self.sr = pcm, x, nch, sr
+
+    @property
+    def n_frames(self):
+        return self.pcm.shape[0] // self.nch if self.pcm is not None else self.x.shape[0]
+
+    def to_float(self):
+        """float32 mono on the host: exactly what read_audio returns."""
+        if self.x is None:
+            x = self.pcm.astype(np.float32)
+            x *= np.float32(1.0 / 32768.0)
+            self.x = _mono(x, self.nch)
+        return self.x
+
+
+def read_audio_raw(path):
+    """-> RawAudio: the int16 frames of a 16-bit PCM file untouched (up to 8 channels), float32 mono otherwise."""
+    if _sf is not None:
+        info = _sf.info(path)
+        if info.subtype == "PCM_16" and info.channels <= 8:
+            pcm, sr = _sf.read(path, dtype="int16", always_2d=True)
+            return RawAudio(np.ascontiguousarray(pcm).reshape(-1), None, int(info.channels), int(sr))
+        x, sr = read_audio(path)
+        return RawAudio(None, x, 1, sr)
+    if path.lower().endswith(".wav"):
+        with wave.open(path, "rb") as f:
+            sr, nch, sw, n = f.getframerate(), f.getnchannels(), f.getsampwidth(), f.getnframes()
+            if sw == 2 and nch <= 8:
+                return RawAudio(np.frombuffer(f.readframes(n), "<i2"), None, int(nch), int(sr))
+    x, sr = read_audio(path)
+    return RawAudio(None, x, 1, sr)
+
+
 def write_wav(path, x, sr):
     """``soundfile.write(path, x, sr)`` of a mono signal (ssr_eval/eval.py:153-154).  For a ``.wav`` name soundfile's default
     subtype is PCM_16, so the reference's artefact files are 16-bit as well: libsndfile scales by 32768, rounds to nearest
@@ -96,10 +135,28 @@ def decode_batch(paths, threads=None):
     return list(_decode_pool(threads or min(16, os.cpu_count() or 1)).map(read_audio, paths))
 
 
-def decode_async(paths, threads=None):
-    """Start decoding `paths` on the pool; -> a function that waits for and returns the decode_batch result."""
-    futures = [_decode_pool(threads or min(16, os.cpu_count() or 1)).submit(read_audio, p) for p in paths]
+def decode_async(paths, threads=None, raw=False):
+    """Start decoding `paths` on the pool; -> a function that waits for and returns the decode_batch result
+    (raw: RawAudio items - 16-bit PCM stays int16 for the GPU to convert)."""
+    fn = read_audio_raw if raw else read_audio
+    futures = [_decode_pool(threads or min(16, os.cpu_count() or 1)).submit(fn, p) for p in paths]
     return lambda: [f.result() for f in futures]
+
+
+def to_rate_resident(on_dev, file_srs, sr, res_type="kaiser_best"):
+    """to_rate for waveforms that already live in HBM (device tensors) -> device tensors; an item already at `sr` is returned
+    as it is (the same tensor)."""
+    out = list(on_dev)
+    groups = {}
+    for i, file_sr in enumerate(file_srs):
+        if sr is not None and int(sr) != file_sr:
+            groups.setdefault(file_sr, []).append(i)
+    if groups:
+        from . import backend as B
+        for file_sr, idx in groups.items():
+            for i, y in zip(idx, B.resample_sinc([on_dev[i] for i in idx], file_sr, int(sr), res_type)):
+                out[i] = y
+    return out
 
 
 def to_rate(decoded, sr, res_type="kaiser_best", keep_on_device=False, resident=None):

@@ -30,18 +30,28 @@ def stft_hard_lowpass_v0(data, lowpass_ratio):
     return stft_hard_lowpass_batch([data], [lowpass_ratio])[0]
 
 
-def stft_hard_lowpass_batch(datas, ratios, device=None):
+def stft_hard_lowpass_batch(datas, ratios, device=None, keep_on_device=False):
+    """keep_on_device: the degraded signals stay device tensors (views of the launch's output) for a GPU consumer."""
     plan = B.get_plan(N_FFT, HOP, _precision, device)
     ys = B.fft_lowpass(plan, [d if isinstance(d, torch.Tensor) else np.asarray(d, np.float32) for d in datas],
                        [cut_bin(r) for r in ratios])
-    return [y.cpu().numpy() for y in ys]
+    return list(ys) if keep_on_device else [y.cpu().numpy() for y in ys]
 
 
 def align_length(x, y):
     """Zero-pad or cut y to len(x) (lowpass.py:31-51)."""
     if len(y) < len(x):
+        if isinstance(y, torch.Tensor):
+            return torch.nn.functional.pad(y, (0, len(x) - len(y)))
         return np.pad(y, (0, len(x) - len(y)), mode="constant")
     return y[:len(x)]
+
+
+def _f32_unless_f64(x):
+    """The dtype rule of the degradations: a float64 signal is processed on its float64 values, anything else as float32."""
+    if isinstance(x, torch.Tensor):
+        return x if x.dtype in (torch.float32, torch.float64) else x.float()
+    return x if x.dtype == np.float64 else x.astype(np.float32)
 
 
 def subsampling(data, lowpass_ratio, fs_ori=44100):
@@ -51,17 +61,17 @@ def subsampling(data, lowpass_ratio, fs_ori=44100):
     return _subsample_batch([x], fs_down, fs_ori)[0]
 
 
-def _subsample_batch(xs, fs_down, fs_ori=44100):
+def _subsample_batch(xs, fs_down, fs_ori=44100, keep_on_device=False):
     """float64 signals are resampled in float64, everything else in float32 (what SciPy does per dtype)."""
     outs = [None] * len(xs)
     for want64 in (False, True):
-        idx = [i for i, x in enumerate(xs) if (x.dtype == np.float64) == want64]
+        idx = [i for i, x in enumerate(xs) if B._is_f64(x) == want64]
         if not idx:
             continue
-        sel = [xs[i] if want64 else xs[i].astype(np.float32) for i in idx]
+        sel = [_f32_unless_f64(xs[i]) for i in idx]
         up = B.resample_poly(B.resample_poly(sel, fs_down, fs_ori), fs_ori, fs_down)
         for i, u in zip(idx, up):
-            outs[i] = align_length(xs[i], u.cpu().numpy())
+            outs[i] = align_length(xs[i], u if keep_on_device else u.cpu().numpy())
     return outs
 
 
@@ -85,17 +95,17 @@ def _design(highcut, fs, order, ftype, lowcut=None):
     return design[ftype]()
 
 
-def _iir_batch(xs, highcut, fs, order, ftype, lowcut=None):
+def _iir_batch(xs, highcut, fs, order, ftype, lowcut=None, keep_on_device=False):
     """lowpass.py:54-131 for a list of signals: one ssr_sosfiltfilt launch (GPU, float64, bit-exact with SciPy)."""
     sos = _design(highcut, fs, order, ftype, lowcut)
-    xs = [np.asarray(x) for x in xs]
+    xs = [x if isinstance(x, torch.Tensor) else np.asarray(x) for x in xs]
     outs = [None] * len(xs)
     for want64 in (False, True):                     # float64 signals are filtered on their float64 values
-        idx = [i for i, x in enumerate(xs) if (x.dtype == np.float64) == want64]
+        idx = [i for i, x in enumerate(xs) if B._is_f64(x) == want64]
         if idx:
-            ys = B.sosfiltfilt(sos, [xs[i] if want64 else xs[i].astype(np.float32) for i in idx])
+            ys = B.sosfiltfilt(sos, [_f32_unless_f64(xs[i]) for i in idx])
             for i, y in zip(idx, ys):
-                outs[i] = align_length(xs[i], y.cpu().numpy())
+                outs[i] = align_length(xs[i], y if keep_on_device else y.cpu().numpy())
     return outs
 
 
@@ -131,20 +141,21 @@ def lowpass(data, highcut, fs, order=5, _type="butter"):
     raise ValueError("Error: Unexpected filter type " + _type)
 
 
-def lowpass_batch(datas, highcut, fs, order=5, _type="butter"):
-    """lowpass() for a LIST of 1-D signals with one batched launch sequence per call (same dispatch semantics)."""
+def lowpass_batch(datas, highcut, fs, order=5, _type="butter", keep_on_device=False):
+    """lowpass() for a LIST of 1-D signals with one batched launch sequence per call (same dispatch semantics).
+    keep_on_device: results stay device tensors (inputs may be device tensors too) - the resident evaluation path."""
     order = limit(order, high=10, low=2)
     for d in datas:
         _check_1d(d)
     for name in ("butter", "cheby1", "ellip", "bessel"):
         if _type in name:
-            return _iir_batch(datas, int(highcut), fs, order, name)
+            return _iir_batch(datas, int(highcut), fs, order, name, keep_on_device=keep_on_device)
     if _type in "subsampling":
         ratio = highcut / int(fs / 2)
         fs_down = int(ratio * 44100)
-        return _subsample_batch([np.asarray(d) for d in datas], fs_down)
+        return _subsample_batch([d if isinstance(d, torch.Tensor) else np.asarray(d) for d in datas], fs_down, keep_on_device=keep_on_device)
     if _type in "stft_hard":
-        return stft_hard_lowpass_batch(datas, [highcut / int(fs / 2)] * len(datas))
+        return stft_hard_lowpass_batch(datas, [highcut / int(fs / 2)] * len(datas), keep_on_device=keep_on_device)
     raise ValueError("Error: Unexpected filter type " + _type)
 
 

@@ -400,11 +400,19 @@ extern "C" int emu_resample_f64(const double* in, const int64_t* in_off, const i
 // ---- windowed-sinc resampler (N2) ------------------------------------------------------------------------
 extern "C" int emu_resample_sinc(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
                                  const int32_t* out_len, int n_items, int max_out_len, const double* tr, const double* win,
-                                 const double* delta, int n_win, int num_table, int index_step, double scale, float* out) {
-  SsrSincParams p{in, in_off, in_len, out_off, out_len, tr, win, delta, n_win, num_table, index_step, scale, out};
+                                 const double* delta, int n_win, int num_table, int index_step, double scale, double ratio,
+                                 int phase_period, int lds_cap_floats, float* out) {
+  const SsrSincGeometry g = ssr_sinc_geometry(phase_period, ratio, n_win, index_step, lds_cap_floats);
+  SsrSincParams p{in, in_off, in_len, out_off, out_len, tr, win, delta, n_win, num_table, index_step, scale, out,
+                  g.period, g.m, g.max_room, g.lds_floats};
+  const int bpi = (max_out_len + g.outputs_per_block - 1) / g.outputs_per_block;
+  SsrBlk blk{SSR_SINC_NT};
   for (int item = 0; item < n_items; ++item)
-    for (int64_t t = 0; t < max_out_len; ++t) ssr_sinc_output(p, item, t);
-  return 0;
+    for (int b = 0; b < bpi; ++b) {
+      auto lds = poisoned((size_t)g.lds_floats * sizeof(float));
+      ssr_sinc_block_body(p, blk, item, b, lds.data());
+    }
+  return g.period * 1000000 + g.m;        // geometry actually used (the tests check both mappings are exercised)
 }
 
 // ---- zero-phase IIR (sequential statement of the wavefront kernel's arithmetic) -------------------------------

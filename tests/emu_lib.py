@@ -249,10 +249,14 @@ def xcorr_argmax(a_list, b_list):
     return out
 
 
-def resample_sinc(sigs, sr_orig, sr_new, name="kaiser_best"):
-    """ssr_sinc.h on the host: tables / time register from the oracle module's published-parameter restatement."""
+def resample_sinc(sigs, sr_orig, sr_new, name="kaiser_best", phase_period=None, lds_cap_floats=12288, geometry=None):
+    """ssr_sinc.h on the host: tables / time register from the oracle module's published-parameter restatement.
+    phase_period: None = what the product passes (a of sr_new / sr_orig = a / b); geometry: a list that receives (period, m)."""
+    import math
     from oracle import resampy as orsy
     ratio = float(sr_new) / sr_orig
+    if phase_period is None:
+        phase_period = int(sr_new) // math.gcd(int(sr_new), int(sr_orig))
     win, delta, num_table, step, scale = orsy.filter_tables(ratio, name)
     a, off, lens = ragged(sigs)
     out_len = np.array([int(int(n) * ratio) for n in lens], np.int32)
@@ -261,6 +265,9 @@ def resample_sinc(sigs, sr_orig, sr_new, name="kaiser_best"):
     out = np.full(int(out_len.sum()), np.nan, np.float32)
     rc = lib().emu_resample_sinc(_p(a, C.c_float), _p(off, C.c_int64), _p(lens, C.c_int32), _p(out_off, C.c_int64),
                                  _p(out_len, C.c_int32), len(lens), int(out_len.max()), _p(tr, C.c_double), _p(win, C.c_double),
-                                 _p(delta, C.c_double), len(win), num_table, step, C.c_double(scale), _p(out, C.c_float))
-    assert rc == 0
+                                 _p(delta, C.c_double), len(win), num_table, step, C.c_double(scale), C.c_double(ratio),
+                                 int(phase_period), int(lds_cap_floats), _p(out, C.c_float))
+    assert rc > 0
+    if geometry is not None:
+        geometry.append((rc // 1000000, rc % 1000000))
     return [out[out_off[i]:out_off[i] + out_len[i]] for i in range(len(lens))]

@@ -354,16 +354,25 @@ def test_wave_autonomous_engine_matches_oracle_and_block_engine(wave):
         np.testing.assert_allclose(gi, got, rtol=1e-12)
 
 
-@pytest.mark.parametrize("sr_orig,sr_new", [(44100, 48000), (48000, 44100), (48000, 16000), (16000, 44100), (22050, 48000)])
+@pytest.mark.parametrize("sr_orig,sr_new", [(44100, 48000), (48000, 44100), (48000, 16000), (16000, 44100), (22050, 48000), (44100, 16000)])
 def test_sinc_resampler_bit_exact_vs_restatement(sr_orig, sr_new):
     """ssr_sinc.h (N2: resampy kaiser_best arithmetic) against oracle.resampy: same tables, same running time register,
-    float64 weights, float32 sum rounded per tap -> the same bits; ragged lengths incl. signals shorter than the filter."""
+    float64 weights, float32 sum rounded per tap -> the same bits; ragged lengths incl. signals shorter than the filter and
+    one long enough for several blocks.  Both work mappings: a wave per filter phase across 64 periods (what the product
+    passes for integer rates), consecutive outputs per lane (period 1), and a tiny LDS window that forces more blocks."""
     from oracle import resampy as orsy
     rng = np.random.default_rng(sr_new)
-    sigs = [(0.2 * rng.standard_normal(n)).astype(np.float32) for n in (3000, 37, 1)]
-    out = E.resample_sinc(sigs, sr_orig, sr_new)
-    for x, y in zip(sigs, out):
-        np.testing.assert_array_equal(y, orsy.resample(x, sr_orig, sr_new))
+    sigs = [(0.2 * rng.standard_normal(n)).astype(np.float32) for n in (30000, 3000, 37, 1)]
+    want = [orsy.resample(x, sr_orig, sr_new) for x in sigs]
+    geo = []
+    for kw in ({}, {"phase_period": 1}, {"lds_cap_floats": 2048}):
+        out = E.resample_sinc(sigs, sr_orig, sr_new, geometry=geo, **kw)
+        for w, y in zip(want, out):
+            np.testing.assert_array_equal(y, w)
+    import math
+    a = sr_new // math.gcd(sr_new, sr_orig)
+    b = sr_orig // math.gcd(sr_new, sr_orig)
+    assert geo[0][0] == (a if 64 * b + 2 * (32769 // int(min(1.0, sr_new / sr_orig) * 512) + 1) + 4 <= 12288 else 1) and geo[1][0] == 1
 
 
 def test_sispec_stays_accurate_at_very_high_snr():

@@ -451,18 +451,84 @@ def test_bench_cli_configs_smoke():
 
 
 # ---- N2 ingest: windowed-sinc (resampy kaiser_best) resampling and the batched file loader ---------------------------------------
-@pytest.mark.parametrize("sr_orig,sr_new", [(44100, 48000), (48000, 44100), (48000, 16000), (16000, 44100)])
+@pytest.mark.parametrize("sr_orig,sr_new", [(44100, 48000), (48000, 44100), (48000, 16000), (16000, 44100), (44100, 16000), (22050, 48000)])
 def test_sinc_resampler_bit_exact_vs_restatement_gpu(sr_orig, sr_new):
     from ssr_eval_amd import backend as B
     from oracle import resampy as orsy
     rng = np.random.default_rng(sr_orig + sr_new)
-    sigs = [(0.2 * rng.standard_normal(n)).astype(np.float32) for n in (20000, 4321, 50, 1)]
+    sigs = [(0.2 * rng.standard_normal(n)).astype(np.float32) for n in (60000, 20000, 4321, 50, 1)]    # several blocks / one / a fraction
     got = B.resample_sinc(sigs, sr_orig, sr_new)
     for x, y in zip(sigs, got):
         want = orsy.librosa_resample_kaiser(x, sr_orig, sr_new)
         assert y.dtype == torch.float32 and tuple(y.shape) == want.shape          # ceil(n * ratio): fix_length applied
         np.testing.assert_array_equal(y.cpu().numpy(), want)                      # bit-identical to the NumPy restatement
     assert [tuple(y.shape) for y in B.resample_sinc(sigs, 48000, 48000)] == [x.shape for x in sigs]
+
+
+def test_pcm16_upload_is_the_host_decode(tmp_path):
+    """backend.upload_decoded: 16-bit PCM crosses the bus as int16 and is converted / mixed to mono by ssr_pcm16_to_float -
+    bit-identical to the host decode (read_audio = soundfile's float32 read + librosa's channel mean), mono, stereo, 3 channels."""
+    import wave
+    from ssr_eval_amd import backend as B
+    from ssr_eval_amd.io import read_audio, read_audio_raw
+    rng = np.random.default_rng(8)
+    paths = []
+    for k, (nch, n) in enumerate([(1, 30001), (2, 12345), (3, 777), (1, 1), (2, 50000)]):
+        p = str(tmp_path / ("f%d.wav" % k))
+        with wave.open(p, "wb") as f:
+            f.setnchannels(nch); f.setsampwidth(2); f.setframerate(44100)
+            f.writeframes(rng.integers(-32768, 32768, n * nch).astype("<i2").tobytes())
+        paths.append(p)
+    raw = [read_audio_raw(p) for p in paths]
+    assert all(r.pcm is not None for r in raw)
+    for _ in range(3):                                   # (both staging arenas, and the reuse of the first)
+        got = B.upload_decoded(raw)
+        for p, g in zip(paths, got):
+            x, sr = read_audio(p)
+            assert sr == 44100 and g.dtype == torch.float32
+            np.testing.assert_array_equal(g.cpu().numpy(), x)
+    np.testing.assert_array_equal(raw[1].to_float(), read_audio(paths[1])[0])
+
+
+def test_resident_path_equals_ndarray_testee_path(tmp_path):
+    """The identity testee's resident path (device tensors through degradation, infer, resampling, metrics) against a testee
+    that insists on ndarrays (the reference's contract: D2H before infer, H2D after) and one that opts in to device tensors:
+    the same numbers, bit for bit - with a float32 (FFT low-pass), a float64 (IIR) and a subsampling degradation."""
+    from ssr_eval_amd import SSR_Eval_Helper, BasicTestee
+    from ssr_eval_amd.io import write_wav
+    rng = np.random.default_rng(21)
+    root = tmp_path / "set"
+    for s, c in (("p100", 3), ("p101", 2)):
+        (root / s).mkdir(parents=True)
+        for i in range(c):
+            write_wav(str(root / s / ("u%d.wav" % i)), 0.1 * rng.standard_normal(int(rng.integers(30000, 70000))), 44100)
+    seen = {"nd": 0, "dev": 0}
+
+    class NdTestee(BasicTestee):
+        def infer(self, x):
+            assert isinstance(x, np.ndarray); seen["nd"] += 1
+            return x.copy()
+
+    class DevTestee(BasicTestee):
+        accepts_device_tensors = True
+
+        def infer(self, x):
+            assert isinstance(x, torch.Tensor) and x.is_cuda; seen["dev"] += 1
+            return x * 1.0, {"extra_metric": 1.5}
+
+    def run(testee):
+        h = SSR_Eval_Helper(testee, input_sr=44100, output_sr=44100, evaluation_sr=48000, test_data_root=str(root),
+                            setting_fft={"cutoff_freq": [4000]}, setting_subsampling={"cutoff_freq": [8000]},
+                            setting_lowpass_filtering={"filter": ["butter"], "cutoff_freq": [6000], "filter_order": [4]})
+        assert h._testee_takes_device_tensors() == (not isinstance(testee, NdTestee))
+        return h.evaluate(save_json=False)
+    base, nd, dv = run(BasicTestee()), run(NdTestee()), run(DevTestee())
+    assert seen["nd"] == 15 and seen["dev"] == 15                    # 5 files x 3 keys
+    assert nd == base
+    for spk in ("p100", "p101"):
+        for f, keys in dv[spk].items():
+            for k, v in keys.items():
+                assert v.pop("extra_metric") == 1.5 and v == base[spk][f][k]
 
 
 def test_load_audio_is_librosa_load_shaped(tmp_path):

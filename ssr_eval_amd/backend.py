@@ -599,10 +599,38 @@ class _Staging:
         self.ev[k].record()
 
 
+def _pcm_to_float(d16, in_off, frames, chans, dev):
+    """int16 device buffer + host descriptors -> (flat float32 mono device buffer, host out offsets)."""
+    n = len(frames)
+    out_off = np.concatenate(([0], np.cumsum(frames)[:-1]))
+    desc = torch.from_numpy(np.concatenate((in_off, out_off)).astype(np.int64)).to(dev, non_blocking=True)
+    desc32 = torch.from_numpy(np.concatenate((frames.astype(np.int32), chans.astype(np.int32)))).to(dev, non_blocking=True)
+    flat = torch.empty(int(frames.sum()), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().ssr_pcm16_to_float(_vp(d16), _vp(desc[:n]), _vp(desc32[:n]), _vp(desc32[n:]), n, int(frames.max()),
+                                              _vp(flat), _vp(desc[n:]), _stream()))
+    return flat, out_off
+
+
 def upload_decoded(raw, device=None):
-    """Decoded files (io.RawAudio) -> float32 mono device tensors, one per file.  16-bit PCM crosses the bus as int16 - half the
-    bytes, no float pass on the host - in one pinned asynchronous copy per batch and is converted / mixed to mono on the GPU
-    (ssr_pcm16_to_float); anything else is uploaded as the float32 mono array it already is."""
+    """Decoded files -> float32 mono device tensors, one per file.  `raw`: an io.PackedBatch (the files' PCM already sits in a
+    page-locked arena) or a list of io.RawAudio.  16-bit PCM crosses the bus as int16 - half the bytes, no float pass on the
+    host - in one pinned asynchronous copy per batch and is converted / mixed to mono on the GPU (ssr_pcm16_to_float);
+    anything else is uploaded as the float32 mono array it already is."""
+    from .io import PackedBatch
+    if isinstance(raw, PackedBatch):
+        dev = torch.device(raw.device)
+        out = [None] * len(raw.paths)
+        with torch.cuda.device(dev):
+            for i, r in zip(raw.other_idx, raw.others):
+                out[i] = upload_decoded([r], dev)[0]
+            if raw.total:
+                d16 = torch.empty(raw.total, dtype=torch.int16, device=dev)
+                d16.copy_(raw.arena[:raw.total], non_blocking=True)
+                raw.staging.sent(raw.k)
+                flat, out_off = _pcm_to_float(d16, raw.in_off, raw.frames, raw.chans, dev)
+                for j, i in enumerate(raw.pcm_idx):
+                    out[i] = flat[out_off[j]:out_off[j] + raw.frames[j]]
+        return out
     dev = torch.device(device) if device is not None else default_device()
     out = [None] * len(raw)
     with torch.cuda.device(dev):
@@ -625,13 +653,7 @@ def upload_decoded(raw, device=None):
             d16 = torch.empty(total, dtype=torch.int16, device=dev)
             d16.copy_(arena[:total], non_blocking=True)
             st.sent(k)
-            out_off = np.concatenate(([0], np.cumsum(frames)[:-1]))
-            desc = torch.from_numpy(np.concatenate((in_off, out_off)).astype(np.int64)).to(dev, non_blocking=True)
-            desc32 = torch.from_numpy(np.concatenate((frames.astype(np.int32), chans))).to(dev, non_blocking=True)
-            n = len(pcm)
-            flat = torch.empty(int(frames.sum()), dtype=torch.float32, device=dev)
-            _lib.check(_lib.load().ssr_pcm16_to_float(_vp(d16), _vp(desc[:n]), _vp(desc32[:n]), _vp(desc32[n:]), n, int(frames.max()),
-                                                      _vp(flat), _vp(desc[n:]), _stream()))
+            flat, out_off = _pcm_to_float(d16, in_off, frames, chans, dev)
             for j, i in enumerate(pcm):
                 out[i] = flat[out_off[j]:out_off[j] + frames[j]]
     return out

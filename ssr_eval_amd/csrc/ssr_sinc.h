@@ -20,9 +20,13 @@
 //   * for a rational rate pair sr_new / sr_orig = a / b the filter phase repeats every a outputs, so a wave takes ONE phase r
 //     and its 64 lanes take 64 CONSECUTIVE PERIODS (outputs a j + r): all lanes of a load read the same table entry (the
 //     accumulated time register drifts by < 1e-10, i.e. at most the neighbouring entry) - one cache line per load instead of 64 -
-//     and their input samples sit b apart in LDS (b odd for 44.1 <-> 48 kHz: conflict-free);
-//   * `period` = 1 (no rational structure given, or 64 periods of input do not fit the LDS window) falls back to consecutive
-//     outputs per lane: the table reads scatter again, the input still comes from LDS.
+//     and their input samples sit b apart in LDS.  b odd (44.1 -> 48 kHz: 147) is conflict-free; an even b (48 -> 44.1 kHz and
+//     16 -> 44.1 kHz: 160 = 5 * 32 puts all 64 lanes on ONE bank - measured 2.5x slower) gets the window stored with one pad
+//     word per 32 (PAD: stride 165);
+//   * when 64 periods of input do not fit the LDS window (44.1 -> 16 kHz: b = 441) a wave takes 2 or 4 phases x 32 or 16
+//     periods (`pw`: 2 or 4 table lines per load instead of 1);
+//   * `period` = 1 (no rational structure given, or even 16 periods do not fit) falls back to consecutive outputs per lane:
+//     the table reads scatter again, the input still comes from LDS.
 #pragma once
 #include "ssr_block.h"
 
@@ -42,12 +46,14 @@ struct SsrSincParams {
   float* out;
   // block geometry (host: ssr_sinc_geometry)
   int period;               // a (outputs per filter-phase period), or 1
-  int m;                    // a block = 64 m periods = 64 m period outputs
+  int pw;                   // phases per wave (1, 2, 4): 64 / pw lanes = consecutive periods of one phase
+  int m;                    // a block = (64 / pw) m periods = (64 / pw) m period outputs
   int max_room;             // most taps a wing can have: nwin / index_step (+1)
   int lds_floats;           // floats of LDS the launch provides for the input window
 };
 
-// One output, input through `xs` (xs[s - lo] = x[s]; lo = 0 and xs = x: straight from global memory).
+// One output, input through `xs` (xs[pad(s - lo)] = x[s]; lo = 0, no pad and xs = x: straight from global memory).
+template <bool PAD>
 SSR_DEV float ssr_sinc_one(const SsrSincParams& p, const SsrView<double>& vwin, const SsrView<double>& vdelta, const float* xs, int lo,
                            int n_in, int64_t t) {
   const double tr = p.time_reg[t];
@@ -65,7 +71,8 @@ SSR_DEV float ssr_sinc_one(const SsrSincParams& p, const SsrView<double>& vwin, 
     for (int i = 0; i < cnt; ++i) {
       const unsigned idx = (unsigned)(offset + i * p.index_step);
       const double weight = ssr_fadd_rn(vwin.at(idx), ssr_fmul_rn(eta, vdelta.at(idx)));
-      const double xv = (double)xs[x0 + dx * i];
+      const int xi = x0 + dx * i;
+      const double xv = (double)xs[PAD ? xi + (xi >> 5) : xi];
       y = (float)ssr_fadd_rn((double)y, ssr_fmul_rn(weight, xv));
     }
     frac = ssr_fadd_rn(p.scale, -frac);           // "invert P"
@@ -74,12 +81,12 @@ SSR_DEV float ssr_sinc_one(const SsrSincParams& p, const SsrView<double>& vwin, 
 }
 
 // grid = n_items * blocks_per_item workgroups of SSR_SINC_NT threads; dynamic LDS: lds_floats floats
-template <typename BLK>
+template <bool PAD, typename BLK>
 SSR_BODY void ssr_sinc_block_body(const SsrSincParams& p, BLK& blk, int item, int block, char* lds_base) {
   constexpr int NT = SSR_SINC_NT, NWAVES = NT / 64;
   float* xs = reinterpret_cast<float*>(lds_base);
   const int n_in = p.in_len[item], n_out = p.out_len[item];
-  const int P = p.period, JB = 64 * p.m;
+  const int P = p.period, LPP = 64 / p.pw, JB = LPP * p.m;      // lanes per phase; periods per block
   const int64_t t0 = (int64_t)block * JB * P;                   // the block's outputs: [t0, t1)
   if (t0 >= n_out || n_in <= 0) return;
   const int64_t t1 = (t0 + (int64_t)JB * P < n_out) ? t0 + (int64_t)JB * P : (int64_t)n_out;
@@ -89,43 +96,56 @@ SSR_BODY void ssr_sinc_block_body(const SsrSincParams& p, BLK& blk, int item, in
   const int lo = (int)p.time_reg[t0] - (p.max_room - 1);
   const int hi = (int)p.time_reg[t1 - 1] + p.max_room;
   const int W = hi - lo + 1;
-  const bool staged = W <= p.lds_floats;                        // (the host's geometry guarantees it; a safety net otherwise)
+  const bool staged = (PAD ? W + (W >> 5) + 1 : W) <= p.lds_floats;   // (the host's geometry guarantees it; a safety net otherwise)
   SSR_REGS(int, regs, blk);
   SSR_PHASE(blk, regs, {
     if (staged)
       for (int i = tid; i < W; i += NT) {
         const int s = lo + i;
-        xs[i] = (s >= 0 && s < n_in) ? x[s] : 0.0f;
+        xs[PAD ? i + (i >> 5) : i] = (s >= 0 && s < n_in) ? x[s] : 0.0f;
       }
   });
   SSR_PHASE(blk, regs, {
     const int wave = ssr_wave_of(tid), lane = tid & 63;
-    for (int w = wave; w < P * p.m; w += NWAVES) {                // work item = (phase r, period group g): wave-uniform
-      const int r = w / p.m, g = w - r * p.m;
-      const int64_t t = t0 + (int64_t)(64 * g + lane) * P + r;
-      if (t < t1) p.out[p.out_off[item] + t] = staged ? ssr_sinc_one(p, vwin, vdelta, xs, lo, n_in, t) : ssr_sinc_one(p, vwin, vdelta, x, 0, n_in, t);
+    const int sub = lane / LPP, jl = lane - sub * LPP;
+    const int n_rg = (P + p.pw - 1) / p.pw;                       // groups of pw phases
+    for (int w = wave; w < n_rg * p.m; w += NWAVES) {             // work item = (phase group rg, period group g): wave-uniform
+      const int rg = w / p.m, g = w - rg * p.m;
+      const int r = rg * p.pw + sub;
+      const int64_t t = t0 + (int64_t)(LPP * g + jl) * P + r;
+      if (r < P && t < t1)
+        p.out[p.out_off[item] + t] = staged ? ssr_sinc_one<PAD>(p, vwin, vdelta, xs, lo, n_in, t)
+                                            : ssr_sinc_one<false>(p, vwin, vdelta, x, 0, n_in, t);
     }
   });
 }
 
 // Block geometry for a rate pair (host side; also used by the emulation harness).  period_hint: a of the reduced ratio
 // sr_new / sr_orig = a / b, or <= 1 when unknown.  lds_cap_floats: the largest input window to stage.
-struct SsrSincGeometry { int period, m, max_room, lds_floats, outputs_per_block; };
+struct SsrSincGeometry { int period, pw, m, max_room, lds_floats, outputs_per_block, pad; };
 SSR_HD SsrSincGeometry ssr_sinc_geometry(int period_hint, double ratio, int nwin, int index_step, int lds_cap_floats) {
   SsrSincGeometry g;
   g.max_room = nwin / index_step + 1;
   const int halo = 2 * g.max_room + 4;
-  int P = period_hint > 1 ? period_hint : 1;
-  // input samples spanned by 64 periods
-  double span64 = 64.0 * (double)P / ratio;
-  if (P > 1 && span64 + halo > (double)lds_cap_floats) { P = 1; span64 = 64.0 / ratio; }
-  int m = (int)(((double)lds_cap_floats - halo) / span64);
-  const int m_target = (8192 + 64 * P - 1) / (64 * P);          // ~8 k outputs per block
+  int P = period_hint > 1 ? period_hint : 1, pw = 1;
+  const double b = (double)P / ratio;                            // input samples per period
+  const double cap = (double)lds_cap_floats * 32.0 / 33.0 - 2.0; // (room for the pad words)
+  if (P > 1) {
+    while (pw < 4 && (64 / pw) * b + halo > cap) pw *= 2;
+    if ((64 / pw) * b + halo > cap) { P = 1; pw = 1; }
+  }
+  const double span = (P > 1 ? (64 / pw) * b : 64.0 / ratio);     // input samples spanned by one period group of a wave
+  int m = (int)((cap - halo) / span);
+  const int per_m = (64 / pw) * P;
+  const int m_target = (8192 + per_m - 1) / per_m;              // ~8 k outputs per block
   if (m > m_target) m = m_target;
   if (m < 1) m = 1;
-  g.period = P; g.m = m;
-  g.outputs_per_block = 64 * m * P;
-  double w = (double)g.outputs_per_block / ratio + halo + 2;
-  g.lds_floats = (int)w + 1;
+  g.period = P; g.pw = pw; g.m = m;
+  g.outputs_per_block = per_m * m;
+  // pad the LDS window when the lanes' input stride is even (a multiple of 32 would put every lane on one bank)
+  const long bi = (long)(b + 0.5);
+  g.pad = (P > 1 && (bi % 2) == 0) ? 1 : 0;
+  const double w = (double)g.outputs_per_block / ratio + halo + 2;
+  g.lds_floats = (int)(g.pad ? w * 33.0 / 32.0 + 2 : w) + 1;
   return g;
 }

@@ -35,10 +35,11 @@ __global__ __launch_bounds__(256) void k_resample_direct(SsrResampleParamsT<S> p
   ssr_resample_direct_output<S>(p, item, (int64_t)(blockIdx.x % blocks_per_item) * 256 + threadIdx.x);
 }
 
+template <bool PAD>
 __global__ __launch_bounds__(SSR_SINC_NT) void k_resample_sinc(SsrSincParams p, int blocks_per_item) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SsrBlk blk{(int)threadIdx.x};
-  ssr_sinc_block_body(p, blk, blockIdx.x / blocks_per_item, blockIdx.x % blocks_per_item, smem);
+  ssr_sinc_block_body<PAD>(p, blk, blockIdx.x / blocks_per_item, blockIdx.x % blocks_per_item, smem);
 }
 
 template <int G, typename X>
@@ -138,14 +139,15 @@ extern "C" int ssr_resample_sinc(const float* in, const int64_t* in_off, const i
   if ((int64_t)n_win * 8 >= ((int64_t)1 << 31)) return ssr_fail(SSR_ERR_UNSUPPORTED, "interpolation table of 2 GiB or more");
   const SsrSincGeometry g = ssr_sinc_geometry(phase_period, ratio, n_win, index_step, 12288);   // <= 48 KB of input window
   SsrSincParams p{in, in_off, in_len, out_off, out_len, time_register, interp_win, interp_delta, n_win, num_table, index_step,
-                  scale, out, g.period, g.m, g.max_room, g.lds_floats};
+                  scale, out, g.period, g.pw, g.m, g.max_room, g.lds_floats};
   const int bpi = ssr_ceil_div(max_out_len, g.outputs_per_block);
   if ((int64_t)n_items * bpi > 0x7fffffff) return ssr_fail(SSR_ERR_UNSUPPORTED, "batch too large for one launch");
   const size_t lds = (size_t)g.lds_floats * sizeof(float);
   if (lds > 160 * 1024) return ssr_fail(SSR_ERR_UNSUPPORTED, "input window of one block exceeds the LDS (extreme down-sampling ratio)");
-  static thread_local SsrLdsSlot slot;
-  if (int rc = ssr_allow_lds((const void*)k_resample_sinc, lds, &slot)) return rc;
-  hipLaunchKernelGGL(k_resample_sinc, dim3((unsigned)((int64_t)n_items * bpi)), dim3(SSR_SINC_NT), lds, (hipStream_t)stream, p, bpi);
+  static thread_local SsrLdsSlot slot[2];
+  if (int rc = ssr_allow_lds(g.pad ? (const void*)k_resample_sinc<true> : (const void*)k_resample_sinc<false>, lds, &slot[g.pad])) return rc;
+  if (g.pad) hipLaunchKernelGGL(k_resample_sinc<true>, dim3((unsigned)((int64_t)n_items * bpi)), dim3(SSR_SINC_NT), lds, (hipStream_t)stream, p, bpi);
+  else hipLaunchKernelGGL(k_resample_sinc<false>, dim3((unsigned)((int64_t)n_items * bpi)), dim3(SSR_SINC_NT), lds, (hipStream_t)stream, p, bpi);
   HIP_TRY(hipGetLastError());
   return SSR_OK;
 }

@@ -364,12 +364,18 @@ class SSR_Eval_Helper:
         The decoded files cross the bus once (16-bit PCM as int16, converted on the GPU: backend.upload_decoded); the
         evaluation-rate targets (the reference shells out to `sox -r`, eval.py:133-134) and the model-rate inputs
         (librosa.load(file, sr=input_sr), eval.py:242) are resampled from that one upload and stay in HBM."""
-        from .io import RawAudio, decode_async, to_rate_resident, write_wav
+        from .io import PackedBatch, RawAudio, decode_packed_async, to_rate_resident, write_wav
         if decoded is None:
-            decoded = decode_async(files, raw=True)()
-        decoded = [d if isinstance(d, RawAudio) else RawAudio(None, np.ascontiguousarray(d[0], np.float32), 1, int(d[1])) for d in decoded]
+            decoded = decode_packed_async(files, self._device)()
+        if isinstance(decoded, PackedBatch):
+            srs = list(decoded.srs)
+            decoded_host = None
+        else:
+            decoded = [d if isinstance(d, RawAudio) else RawAudio(None, np.ascontiguousarray(d[0], np.float32), 1, int(d[1]))
+                       for d in decoded]
+            srs = [d.sr for d in decoded]
+            decoded_host = decoded
         on_dev = B.upload_decoded(decoded, self._device)
-        srs = [d.sr for d in decoded]
         targets = to_rate_resident(on_dev, srs, self.evaluationset_sr)
         same_rate = all(sr == int(self.model_input_sr) for sr in srs)
         if self._testee_takes_device_tensors():
@@ -378,7 +384,9 @@ class SSR_Eval_Helper:
             items = [(t, x.clone() if x is t else x) for t, x in zip(targets, inputs)]
             res = self.evaluate_arrays(items, files, inputs if same_rate else None, device_mode=True)
         else:
-            inputs = [d.to_float() if d.sr == int(self.model_input_sr) else None for d in decoded]
+            # an ndarray testee: the inputs go to the host (from the decoder's arrays where they exist, else from the upload)
+            inputs = [(decoded_host[i].to_float() if decoded_host is not None else on_dev[i].cpu().numpy())
+                      if srs[i] == int(self.model_input_sr) else None for i in range(len(srs))]
             need = [i for i, x in enumerate(inputs) if x is None]
             if need:
                 ys = to_rate_resident([on_dev[i] for i in need], [srs[i] for i in need], self.model_input_sr)
@@ -418,14 +426,15 @@ class SSR_Eval_Helper:
         rank, world = D.rank_world()
         mine = D.shard_indices(len(work), rank, world)
         paths = [os.path.join(self.test_data_root, *work[i]) for i in mine]
-        from .io import decode_async
+        from .io import decode_packed_async
         local = []
         step = max(1, int(batch_files))                            # ragged batches of files per launch sequence
         batches = [paths[b:b + step] for b in range(0, len(paths), step)]
-        ahead = decode_async(batches[0], raw=True) if batches else None    # host decode of batch k+1 runs under the GPU work of batch k
+        # the file reads of batch k+1 (straight into a page-locked arena) run under the GPU work of batch k
+        ahead = decode_packed_async(batches[0], self._device) if batches else None
         for k, batch in enumerate(batches):
             decoded = ahead()
-            ahead = decode_async(batches[k + 1], raw=True) if k + 1 < len(batches) else None
+            ahead = decode_packed_async(batches[k + 1], self._device) if k + 1 < len(batches) else None
             local += self.evaluate_files(batch, decoded)
         return self._assemble(work, speakers, mine, local, save_json, datetime.now())
 

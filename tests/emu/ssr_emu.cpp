@@ -404,15 +404,16 @@ extern "C" int emu_resample_sinc(const float* in, const int64_t* in_off, const i
                                  int phase_period, int lds_cap_floats, float* out) {
   const SsrSincGeometry g = ssr_sinc_geometry(phase_period, ratio, n_win, index_step, lds_cap_floats);
   SsrSincParams p{in, in_off, in_len, out_off, out_len, tr, win, delta, n_win, num_table, index_step, scale, out,
-                  g.period, g.m, g.max_room, g.lds_floats};
+                  g.period, g.pw, g.m, g.max_room, g.lds_floats};
   const int bpi = (max_out_len + g.outputs_per_block - 1) / g.outputs_per_block;
   SsrBlk blk{SSR_SINC_NT};
   for (int item = 0; item < n_items; ++item)
     for (int b = 0; b < bpi; ++b) {
       auto lds = poisoned((size_t)g.lds_floats * sizeof(float));
-      ssr_sinc_block_body(p, blk, item, b, lds.data());
+      if (g.pad) ssr_sinc_block_body<true>(p, blk, item, b, lds.data());
+      else ssr_sinc_block_body<false>(p, blk, item, b, lds.data());
     }
-  return g.period * 1000000 + g.m;        // geometry actually used (the tests check both mappings are exercised)
+  return g.period * 1000000 + g.pw * 10000 + g.pad * 1000 + (g.m < 1000 ? g.m : 999);   // geometry actually used
 }
 
 // ---- zero-phase IIR (sequential statement of the wavefront kernel's arithmetic) -------------------------------

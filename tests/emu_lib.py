@@ -268,6 +268,6 @@ def resample_sinc(sigs, sr_orig, sr_new, name="kaiser_best", phase_period=None, 
                                  _p(delta, C.c_double), len(win), num_table, step, C.c_double(scale), C.c_double(ratio),
                                  int(phase_period), int(lds_cap_floats), _p(out, C.c_float))
     assert rc > 0
-    if geometry is not None:
-        geometry.append((rc // 1000000, rc % 1000000))
+    if geometry is not None:          # (period, phases per wave, padded window, blocks' m)
+        geometry.append((rc // 1000000, rc % 1000000 // 10000, rc % 10000 // 1000, rc % 1000))
     return [out[out_off[i]:out_off[i] + out_len[i]] for i in range(len(lens))]

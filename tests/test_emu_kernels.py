@@ -372,7 +372,11 @@ def test_sinc_resampler_bit_exact_vs_restatement(sr_orig, sr_new):
     import math
     a = sr_new // math.gcd(sr_new, sr_orig)
     b = sr_orig // math.gcd(sr_new, sr_orig)
-    assert geo[0][0] == (a if 64 * b + 2 * (32769 // int(min(1.0, sr_new / sr_orig) * 512) + 1) + 4 <= 12288 else 1) and geo[1][0] == 1
+    # the mappings the rate pairs are meant to exercise: one phase per wave (odd b unpadded, even b padded), several phases
+    # per wave when 64 periods of input exceed the window (b = 441), consecutive outputs per lane for period 1
+    want_geo = {(44100, 48000): (160, 1, 0), (48000, 44100): (147, 1, 1), (48000, 16000): (1, 1, 0), (16000, 44100): (441, 1, 1),
+                (22050, 48000): (320, 1, 0), (44100, 16000): (160, 4, 0)}[(sr_orig, sr_new)]
+    assert geo[0][:3] == want_geo and geo[1][:3] == (1, 1, 0), (geo, a, b)
 
 
 def test_sispec_stays_accurate_at_very_high_snr():

@@ -488,6 +488,19 @@ def test_pcm16_upload_is_the_host_decode(tmp_path):
             assert sr == 44100 and g.dtype == torch.float32
             np.testing.assert_array_equal(g.cpu().numpy(), x)
     np.testing.assert_array_equal(raw[1].to_float(), read_audio(paths[1])[0])
+    # the packed route of evaluate(): decoder threads read the data chunks straight into the page-locked arena; a 24-bit
+    # file in the same batch rides along as a float32 item
+    from ssr_eval_amd.io import decode_packed_async
+    p24 = str(tmp_path / "f24.wav")
+    with wave.open(p24, "wb") as f:
+        f.setnchannels(1); f.setsampwidth(3); f.setframerate(48000)
+        f.writeframes(rng.integers(0, 256, 3 * 999, dtype=np.uint8).tobytes())
+    mixed = paths[:2] + [p24] + paths[2:]
+    for _ in range(3):
+        pb = decode_packed_async(mixed)()
+        assert pb.other_idx == [2] and pb.srs == [44100, 44100, 48000, 44100, 44100, 44100]
+        for p, g in zip(mixed, B.upload_decoded(pb)):
+            np.testing.assert_array_equal(g.cpu().numpy(), read_audio(p)[0])
 
 
 def test_resident_path_equals_ndarray_testee_path(tmp_path):

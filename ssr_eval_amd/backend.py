@@ -101,6 +101,24 @@ class Ragged:
     @staticmethod
     def from_list(arrays, device=None, dtype=torch.float32):
         dev = torch.device(device) if device is not None else default_device()
+        arrays = list(arrays)
+        # Views that already sit back to back in ONE device buffer (the output of an earlier launch: upload_decoded,
+        # resample_sinc, fft_lowpass, resample_poly ...) are taken as they are: no per-signal transfer call, no concatenation.
+        if len(arrays) > 1 and all(isinstance(a, torch.Tensor) and a.is_cuda and a.dtype == dtype and a.dim() == 1 and a.is_contiguous()
+                                   for a in arrays):
+            es, ok, base, end = arrays[0].element_size(), True, arrays[0].data_ptr(), arrays[0].data_ptr()
+            for a in arrays:
+                ok = ok and a.data_ptr() == end and a.device == arrays[0].device
+                end += a.numel() * es
+            if ok and arrays[0].device.index == (dev.index if dev.index is not None else torch.cuda.current_device()):
+                lens = np.array([a.shape[0] for a in arrays], dtype=np.int64)
+                total = int(lens.sum())
+                if 0 < total and lens.max() < 2 ** 31:
+                    a0 = arrays[0]
+                    data = torch.empty(0, dtype=dtype, device=a0.device).set_(a0.untyped_storage(), a0.storage_offset(), (total,), (1,))
+                    off = np.concatenate(([0], np.cumsum(lens)[:-1]))
+                    desc = torch.from_numpy(off.astype(np.int64)).to(a0.device, non_blocking=True)
+                    return Ragged(data, desc, torch.from_numpy(lens.astype(np.int32)).to(a0.device, non_blocking=True), lens)
         ts = []
         for a in arrays:
             t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))

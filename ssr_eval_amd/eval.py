@@ -402,7 +402,7 @@ class SSR_Eval_Helper:
         """eval.py:128-156 for one file."""
         return self.evaluate_files([file])[0]
 
-    def evaluate(self, limit_test_nums=-1, limit_test_speaker=-1, save_json=True, batch_files=32):
+    def evaluate(self, limit_test_nums=-1, limit_test_speaker=-1, save_json=True, batch_files=128):
         """eval.py:171-227: walk speakers/files, evaluate, aggregate as mean of speaker means, write JSON.
         Files are evaluated `batch_files` at a time (one ragged launch sequence per batch).  With
         torch.distributed initialised the (speaker, file) list is sharded round-robin over ranks and the

@@ -22,8 +22,11 @@ try:
     h = SSR_Eval_Helper(BasicTestee(), input_sr=44100, output_sr=44100, evaluation_sr=48000, test_data_root=root,
                         setting_fft={"cutoff_freq": [12000]})
     h.evaluate(limit_test_nums=2, limit_test_speaker=1, save_json=False)
-    for rep in range(5):
-        t0 = time.perf_counter(); h.evaluate(save_json=False); print("plain run: %.3f s, %d files" % (time.perf_counter() - t0, n_files), flush=True)
+    for bf in [int(v) for v in os.environ.get("BATCHES", "32").split(",")]:
+        ts = []
+        for rep in range(6):
+            t0 = time.perf_counter(); h.evaluate(save_json=False, batch_files=bf); ts.append(time.perf_counter() - t0)
+        print("batch_files %d: passes %s s, median %.4f s = %.0f files/s (%d files)" % (bf, [round(t, 3) for t in ts], float(np.median(ts)), n_files / float(np.median(ts)), n_files), flush=True)
     if os.environ.get("STAGES"):          # wall-clock per stage (wrappers around the stage functions; GPU work is synchronised)
         import torch, collections
         from ssr_eval_amd import io as IO, backend as B, eval as EV, metrics as M

@@ -38,6 +38,7 @@ struct ssr_plan {
   DevTables<double> f64w;
   double* window64 = nullptr;  // always present (OLA normalisation)
   double* wss_tab = nullptr;   // [hop] overlap-added squared window where every overlapping frame exists (hop <= n_fft)
+  double* wss_rcp_tab = nullptr;   // [hop] its reciprocal
   std::vector<void*> allocs;
 };
 

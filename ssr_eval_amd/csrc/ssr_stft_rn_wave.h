@@ -26,8 +26,6 @@ template <typename T, bool SUMS, int NQ> struct SsrRnWaveRegs {
   cx<T> tw2[12];
 };
 
-template <typename T> struct SsrWaveBuf { T* re; T* im; };
-
 template <typename T, int NW> struct SsrRnWaveLds {
   // scratch (doubles first), then NW split-exchange arrays; the parked sub-spectra alias the arrays
   static constexpr size_t bytes() { return sizeof(double) * (4 + 6 * 4 + 2) + sizeof(int) * 16 + sizeof(T) * NW * SSR_W_PN; }

@@ -146,6 +146,9 @@ template <typename T, bool SPLIT> struct SsrWaveLds {
   }
 };
 
+// a wave's exchange array(s) inside a workgroup of several autonomous waves (ssr_stft_rn_wave.h, ssr_lowpass_group.h)
+template <typename T> struct SsrWaveBuf { T* re; T* im; };
+
 // LDS of one k_stft_wave wave.  The six SISpec / log-SISpec running sums of a lane live behind the exchange array (6 x 64
 // float64 = 3 KB: 16,968 + 3,072 B still makes eight waves per CU) and are updated with ds_add_f64 - as registers they
 // were twelve more than the variant had (11 spilled to scratch: 0.9 GB of scratch traffic per launch).

@@ -164,6 +164,8 @@ extern "C" int ssr_plan_create(int n_fft, int hop, int precision, ssr_plan** out
         tab[m] = wss < 1e-11 ? 1e-11 : wss;
       }
       rc = upload(pl, tab, &pl->wss_tab);
+      for (double& v : tab) v = 1.0 / v;                      // the fused overlap-add multiplies (ssr_lowpass_group.h)
+      if (!rc) rc = upload(pl, tab, &pl->wss_rcp_tab);
     }
   }
   if (rc) { ssr_plan_destroy(pl); return rc; }

@@ -1,6 +1,6 @@
 // libssrhip.so translation unit: STFT-domain low-pass / inverse STFT (K6) kernels and entry points.
 #include "ssr_host.h"
-#include "ssr_lowpass_wave.h"
+#include "ssr_lowpass_group.h"
 
 #ifndef SSR_LOWPASS_WAVES_PER_EU
 #define SSR_LOWPASS_WAVES_PER_EU 3   /* 168 VGPRs, no spill: 3 workgroups per CU instead of 2 */
@@ -51,6 +51,15 @@ __global__ __launch_bounds__(64, 2) void k_lowpass_wave(SsrLowpassParams<T> p, i
   ssr_lowpass_wave_body<T, true, ANALYSIS, PAIRED>(p, blk, chunk, item, smem);
 }
 
+// Fused engine (ssr_lowpass_group.h): four waves = four frame pairs per round, overlap-add inside the kernel, no workspace;
+// 80.5 KB of LDS per workgroup: two per CU.
+template <bool ANALYSIS>
+__global__ __launch_bounds__(SSR_LG_NT, 2) void k_lowpass_group(SsrLowpassGroupParams gp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  SsrBlk blk{(int)threadIdx.x};
+  ssr_lowpass_group_body<ANALYSIS>(gp, blk, blockIdx.x % gp.n_chunks, blockIdx.x / gp.n_chunks, smem);
+}
+
 bool ssr_lowpass_uses_wave_engine(const ssr_plan* pl) {
 #ifdef SSR_DEV_KNOBS
   static const int off = getenv("SSR_NO_WAVE") ? atoi(getenv("SSR_NO_WAVE")) : 0;
@@ -70,6 +79,45 @@ bool ssr_lowpass_pairs_frames(const ssr_plan* pl) {
   int64_t t = 1 + (pl->n_fft / 2 + 1) / pl->hop;          // fewest frames of a signal that passes the reflect-pad check ...
   if (t % 2 == 0) ++t;                                     // ... the tightest case is the smallest odd count from there
   return (t + 1) / 2 * ssr_seg_stride(pl->n_fft, pl->hop) <= t * pl->n_fft;
+}
+
+bool ssr_lowpass_fuses_ola(const ssr_plan* pl) {
+#ifdef SSR_DEV_KNOBS
+  static const int off = getenv("SSR_NO_FUSED_OLA") ? atoi(getenv("SSR_NO_FUSED_OLA")) : 0;
+  if (off) return false;
+#endif
+  return ssr_lowpass_uses_wave_engine(pl) && pl->precision == SSR_F64 && pl->wss_rcp_tab != nullptr && ssr_lowpass_group_ok(pl->hop);
+}
+
+static int launch_lowpass_group(const ssr_plan* pl, const float* in, const int64_t* in_off, const int32_t* len, const int32_t* cut,
+                                const float* re, const float* im, const int64_t* frame_off, const int64_t* out_off, int n_items,
+                                int max_len, float* out, hipStream_t s) {
+  const DevTables<double>& d = ssr_tables_of<double>(pl);
+  SsrLowpassGroupParams gp{};
+  gp.lp.in = in; gp.lp.in_off = in_off; gp.lp.len = len; gp.lp.cut = cut; gp.lp.frame_off = frame_off;
+  gp.lp.n_fft = pl->n_fft; gp.lp.hop = pl->hop; gp.lp.window = d.window; gp.lp.tw = d.tw; gp.lp.spec_re = re; gp.lp.spec_im = im;
+  gp.out_off = out_off; gp.out = out; gp.window64 = pl->window64; gp.wss_tab = pl->wss_tab; gp.wss_rcp_tab = pl->wss_rcp_tab;
+  const int max_rounds = ssr_ceil_div((ssr_num_frames(pl, max_len) + 1) / 2, SSR_LG_WAVES);
+  // a chunk = a run of rounds of one item; a chunk that starts inside a signal re-runs one warm-up round, so chunks are kept long
+  // (>= 8 rounds) and a signal of a few seconds is ONE chunk; long signals are split so that the launch has >= ~1024 workgroups
+  int rpc = ssr_units_per_chunk_for(max_rounds, n_items, 1024);
+  if (rpc < 8) rpc = 8;
+  if (rpc > max_rounds) rpc = max_rounds;
+#ifdef SSR_DEV_KNOBS
+  static const int rpc_env = getenv("SSR_LG_RPC") ? atoi(getenv("SSR_LG_RPC")) : 0;
+  if (rpc_env > 0) rpc = rpc_env;
+#endif
+  gp.rounds_per_chunk = rpc;
+  gp.n_chunks = ssr_ceil_div(max_rounds, rpc);
+  if ((int64_t)n_items * gp.n_chunks > 0x7fffffff) return ssr_fail(SSR_ERR_UNSUPPORTED, "batch too large for one launch");
+  const size_t lds = ssr_lowpass_group_lds_bytes(pl->hop);
+  const bool analysis = re == nullptr;
+  static thread_local SsrLdsSlot slot[2];
+  if (int rc = ssr_allow_lds(analysis ? (const void*)k_lowpass_group<true> : (const void*)k_lowpass_group<false>, lds, &slot[analysis])) return rc;
+  if (analysis) hipLaunchKernelGGL(k_lowpass_group<true>, dim3((unsigned)(n_items * gp.n_chunks)), dim3(SSR_LG_NT), lds, s, gp);
+  else hipLaunchKernelGGL(k_lowpass_group<false>, dim3((unsigned)(n_items * gp.n_chunks)), dim3(SSR_LG_NT), lds, s, gp);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
 }
 
 template <typename T> int ssr_launch_lowpass(const ssr_plan* pl, SsrLowpassParams<T>& p, int grid, hipStream_t s) {
@@ -116,6 +164,8 @@ static int run_inverse(const ssr_plan* pl, const float* in, const int64_t* in_of
   if (max_len <= pl->n_fft / 2) return ssr_fail(SSR_ERR_INVALID_ARG, "reflect padding needs len > n_fft/2");
   if (max_len >= (1 << 29)) return ssr_fail(SSR_ERR_UNSUPPORTED, "signals of 2^29 samples or more (4 GiB buffer views)");
   if (!workspace || workspace_bytes < ssr_ola_workspace_bytes(pl, total_rows)) return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small");
+  if (ssr_lowpass_fuses_ola(pl))      // (the workspace stays part of the contract: other plans / precisions overlap-add through it)
+    return launch_lowpass_group(pl, in, in_off, len, cut, re, im, frame_off, out_off, n_items, max_len, out, s);
   const int max_pairs = (int)((ssr_num_frames(pl, max_len) + 1) / 2);
   const int ppc = ssr_units_per_chunk_for(max_pairs, n_items, ssr_lowpass_uses_wave_engine(pl) ? 4 * ssr_target_wgs() : 0);
   int n_chunks = ssr_ceil_div(max_pairs, ppc);

@@ -16,6 +16,7 @@
 #include "../../ssr_eval_amd/csrc/ssr_stft_r3.h"
 #include "../../ssr_eval_amd/csrc/ssr_stft_wave.h"
 #include "../../ssr_eval_amd/csrc/ssr_lowpass_wave.h"
+#include "../../ssr_eval_amd/csrc/ssr_lowpass_group.h"
 #include "../../ssr_eval_amd/csrc/ssr_stft_rn_wave.h"
 #include "../../ssr_eval_amd/csrc/ssr_tables.h"
 
@@ -342,6 +343,37 @@ extern "C" int emu_lowpass_wave(int precision, int hop, int split, int paired, i
                                       re_in, im_in, frames);
   return emu_lowpass_wave_t<float>(hop, split, paired, interleave, in, in_off, len, cut, frame_off, n_items, pairs_per_chunk, n_chunks, re_in,
                                    im_in, frames);
+}
+
+// fused low-pass / ISTFT with the overlap-add inside the kernel (ssr_lowpass_group.h): 512-thread "workgroups", float64 plans
+extern "C" int emu_lowpass_group(int hop, const float* in, const int64_t* in_off, const int32_t* len, const int32_t* cut,
+                                 const int64_t* frame_off, const int64_t* out_off, int n_items, int rounds_per_chunk, int n_chunks,
+                                 const float* re_in, const float* im_in, float* out) {
+  if (!ssr_lowpass_group_ok(hop)) return -4;
+  SsrTables<double> t;
+  if (!ssr_build_tables<double>(2048, t)) return -3;
+  std::vector<double> tab((size_t)hop);
+  for (int m = 0; m < hop; ++m) {
+    double wss = 0.0;
+    for (int mm = m + ((2048 - 1 - m) / hop) * hop; mm >= m; mm -= hop) wss += t.window[mm] * t.window[mm];
+    tab[m] = wss < 1e-11 ? 1e-11 : wss;
+  }
+  SsrLowpassGroupParams gp{};
+  gp.lp.in = in; gp.lp.in_off = in_off; gp.lp.len = len; gp.lp.cut = cut; gp.lp.frame_off = frame_off;
+  gp.lp.n_fft = 2048; gp.lp.hop = hop; gp.lp.window = t.window.data(); gp.lp.tw = t.tw.data();
+  gp.lp.spec_re = re_in; gp.lp.spec_im = im_in;
+  std::vector<double> rtab(tab);
+  for (double& v : rtab) v = 1.0 / v;
+  gp.out_off = out_off; gp.out = out; gp.window64 = t.window.data(); gp.wss_tab = tab.data(); gp.wss_rcp_tab = rtab.data();
+  gp.rounds_per_chunk = rounds_per_chunk; gp.n_chunks = n_chunks;
+  SsrBlk blk{SSR_LG_NT};
+  for (int item = 0; item < n_items; ++item)
+    for (int c = 0; c < n_chunks; ++c) {
+      auto lds = poisoned(ssr_lowpass_group_lds_bytes(hop));
+      if (re_in) ssr_lowpass_group_body<false>(gp, blk, c, item, lds.data());
+      else ssr_lowpass_group_body<true>(gp, blk, c, item, lds.data());
+    }
+  return 0;
 }
 
 extern "C" int emu_ola(int n_fft, int hop, int paired, const float* frames, const int64_t* frame_off, const int32_t* len,

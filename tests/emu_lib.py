@@ -177,6 +177,34 @@ def lowpass(sigs, cuts, n_fft=2048, hop=441, precision=1, pairs_per_chunk=4, wav
     return [out[off[i]:off[i] + lens[i]] for i in range(len(lens))]
 
 
+def lowpass_group(sigs, cuts, hop=441, rounds_per_chunk=1000):
+    """ssr_lowpass_group.h (fused overlap-add, float64 2048-point plans): -> list of float32 outputs."""
+    a, off, lens = ragged(sigs)
+    cuts = np.asarray(cuts, np.int32)
+    max_rounds = -(-((num_frames(int(lens.max()), 2048, hop) + 1) // 2) // 4)
+    n_chunks = -(-max_rounds // rounds_per_chunk)
+    out = np.full(int(lens.sum()), np.nan, np.float32)
+    rc = lib().emu_lowpass_group(hop, _p(a, C.c_float), _p(off, C.c_int64), _p(lens, C.c_int32), _p(cuts, C.c_int32), None,
+                                 _p(off, C.c_int64), len(lens), rounds_per_chunk, n_chunks, None, None, _p(out, C.c_float))
+    assert rc == 0, rc
+    return [out[off[i]:off[i] + lens[i]] for i in range(len(lens))]
+
+
+def istft_group(res, ims, lengths, hop=441, rounds_per_chunk=1000):
+    re, frame_off, T = spectro_desc(res)
+    im, _, _ = spectro_desc(ims)
+    lens = np.asarray(lengths, np.int32)
+    assert all(num_frames(int(n), 2048, hop) == t for n, t in zip(lens, T))
+    off = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int64)
+    max_rounds = -(-((int(T.max()) + 1) // 2) // 4)
+    n_chunks = -(-max_rounds // rounds_per_chunk)
+    out = np.full(int(lens.sum()), np.nan, np.float32)
+    rc = lib().emu_lowpass_group(hop, None, None, _p(lens, C.c_int32), None, _p(frame_off, C.c_int64), _p(off, C.c_int64), len(lens),
+                                 rounds_per_chunk, n_chunks, _p(re, C.c_float), _p(im, C.c_float), _p(out, C.c_float))
+    assert rc == 0, rc
+    return [out[off[i]:off[i] + lens[i]] for i in range(len(lens))]
+
+
 def istft(res, ims, lengths, n_fft=2048, hop=441, precision=1, pairs_per_chunk=4, wave=None, interleave=1):
     re, frame_off, T = spectro_desc(res)
     im, _, _ = spectro_desc(ims)

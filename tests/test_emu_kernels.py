@@ -113,6 +113,41 @@ def test_fft_lowpass_and_istft(golden):
     np.testing.assert_allclose(y, golden["fd_roundtrip"], atol=2e-8)
 
 
+@pytest.mark.parametrize("hop", [441, 512, 300, 256, 700, 900])
+def test_lowpass_group_fused_overlap_add(hop):
+    """ssr_lowpass_group.h: four frame pairs per round on four waves, the overlap-add INSIDE the kernel (the round's buffer
+    aliases the four exchange arrays; wave-colour-ordered ds_add_f64; tail carried between rounds; warm-up round at a chunk start)
+    against the oracle's ISTFT definition; ragged lengths - a signal barely longer than the reflect pad, one shorter than a
+    round, one of several rounds, one that is skipped (len <= n_fft / 2) - and the SAME BITS whatever the chunking."""
+    rng = np.random.default_rng(hop)
+    lens = (40000, 5 * hop + 1030, 1025, 8 * hop + 1100, 33 * hop + 1029, 700)
+    sigs = [(0.3 * rng.standard_normal(n)).astype(np.float32) for n in lens]
+    cuts = [300, 1025, 77, 512, 900, 100]
+    want = [olp.stft_hard_lowpass(x, (c + 0.5) / 1025, n_fft=2048, hop=hop) for x, c in zip(sigs[:-1], cuts)]
+    atol = 5e-8 if hop <= 512 else 2.5e-7
+    base = E.lowpass_group(sigs, cuts, hop=hop)
+    for w, v in zip(want, base):
+        assert np.isfinite(v).all()
+        np.testing.assert_allclose(v, w, atol=atol)
+    assert np.abs(base[-1]).max() == 0.0                                # the item that violates the precondition: zeros, no crash
+    for rpc in (1, 2, 3):                                               # chunk starts inside the signal: warm-up rounds
+        got = E.lowpass_group(sigs, cuts, hop=hop, rounds_per_chunk=rpc)
+        for b0, b1 in zip(base, got):
+            np.testing.assert_array_equal(b0, b1)
+    # against the paired-segment engine (rounds each frame pair to float32 first): the same signal to float32 resolution
+    if hop <= 512:
+        old = E.lowpass(sigs[:-1], cuts[:-1], hop=hop, pairs_per_chunk=4, wave="paired")
+        for a, b in zip(old, base):
+            np.testing.assert_allclose(a, b, atol=1e-7)
+    # ISTFT mode on given spectra
+    re, im = ostft.tl_stft(sigs[0][None], n_fft=2048, hop=hop)
+    ref = E.istft([re[0, 0]], [im[0, 0]], [len(sigs[0])], hop=hop)[0]
+    for rpc in (1000, 2):
+        got = E.istft_group([re[0, 0]], [im[0, 0]], [len(sigs[0])], hop=hop, rounds_per_chunk=rpc)[0]
+        np.testing.assert_allclose(got, ref, atol=atol)
+        np.testing.assert_allclose(got, sigs[0], atol=4 * atol)         # STFT -> ISTFT round trip
+
+
 @pytest.mark.parametrize("hop", [441, 512, 300, 64, 1000, 1024])
 def test_lowpass_wave_engine_frames_and_paired_segments(hop):
     """ssr_lowpass_wave.h: one wave per frame pair, (a) writing two frames for k_ola and (b) PAIRED - the pair added up

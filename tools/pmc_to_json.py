@@ -2,19 +2,20 @@
 tools/collect_profiles.sh ran on the GPU box)."""
 import collections, csv, glob, json, os, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = "gpurun_out/prof_%s" % tag
 os.makedirs("profiles", exist_ok=True)
 summary = {"source": "rocprofv3 --kernel-trace --stats -- python bench.py --config <cfg> --steps 5 --warmup 2 --no-cpu-baseline "
-                     "--no-side; PMC: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace passes of the default "
-                     "config (tools/collect_profiles.sh)", "kernels": {}}
+                     "(cfg2 with its side figures, the others --no-side); PMC: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+                     "--kernel-trace passes per config and for tools/exp_api_true.py / tools/exp_sinc.py (tools/collect_profiles_r03.sh)",
+           "kernels": {}}
 for stats in sorted(glob.glob(src + "/stats_*/*kernel_stats.csv")):
     cfg = os.path.basename(os.path.dirname(stats)).replace("stats_", "")
     rows = list(csv.DictReader(open(stats)))
     with open("profiles/%s_%s_kernel_stats.csv" % (tag, cfg), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
         w.writeheader()
-        for r in rows[:12]:
+        for r in rows[:(24 if cfg == 'cfg2' else 12)]:
             r = dict(r); r["Name"] = r["Name"][:120]; w.writerow(r)
     summary["kernels"][cfg] = {r["Name"][:70]: {"calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 1),
                                                  "pct": float(r["Percentage"])}
@@ -23,10 +24,11 @@ for stats in sorted(glob.glob(src + "/stats_*/*kernel_stats.csv")):
     if os.path.exists(bj) and os.path.getsize(bj):
         summary.setdefault("bench_line_under_rocprof", {})[cfg] = json.load(open(bj))
 KEYS = ("k_stft_wave<double, false", "k_stft_wave<double, true", "k_ssim", "k_stft<double, 11")
-MORE = {"cfg3": ("k_lowpass_wave", "k_ola_paired", "k_ola("), "cfg5": ("k_resample",)}     # kernels only these configs run
+MORE = {"cfg3": ("k_lowpass_wave", "k_ola_paired", "k_ola(", "k_lowpass_group"), "cfg5": ("k_resample<",),
+        "api": ("k_stft_rn_wave<double, false, 3", "k_stft_rn_wave<double, true, 3"), "sinc": ("k_resample_sinc",)}
 pm = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    for sub, keys in [("", KEYS)] + [("_" + cfg, ks) for cfg, ks in MORE.items()]:
+    for sub, keys in [("", KEYS), ("_cfg2", KEYS)] + [("_" + cfg, ks) for cfg, ks in MORE.items()]:
         f = glob.glob(src + "/pmc_%s%s/*counter_collection.csv" % (c, sub))
         if not f:
             continue
@@ -34,10 +36,20 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(f[0])):
             for k in keys:
                 if k in r["Kernel_Name"] and r["Counter_Name"] == c:
-                    agg[k].append(float(r["Counter_Value"]))
+                    agg[k].append((int(r.get("Dispatch_Id", 0) or 0), float(r["Counter_Value"])))
         for k, v in agg.items():
-            v = sorted(v)
-            pm.setdefault(k, {})[c] = v[len(v) // 2]
+            vals = [x for _, x in sorted(v)]
+            if k == "k_resample<":            # cfg-5 launches the two stages alternately: 441/160 first, then 160/147
+                for name, part in (("k_resample stage 1", vals[0::2]), ("k_resample stage 2", vals[1::2])):
+                    if part:
+                        part = sorted(part)
+                        pm.setdefault(name, {})[c] = part[len(part) // 2]
+                continue
+            if k == "k_resample_sinc":        # one launch per rate pair of tools/exp_sinc.py: report the first pair (44.1 -> 48 kHz)
+                pm.setdefault(k + " 44.1->48 kHz, 128 files", {})[c] = vals[0]
+                continue
+            vals = sorted(vals)
+            pm.setdefault(k, {})[c] = vals[len(vals) // 2]
 summary["pmc_kb_per_launch"] = pm
 # gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reads exactly 1/2 of a coalesced streaming read: x2.
 # WRITE_SIZE is taken as reported (it matches the 3.16 GB of magnitudes the STFT kernel is known to write).  Both in KiB.

@@ -53,7 +53,7 @@ struct SsrSincParams {
 };
 
 // One output, input through `xs` (xs[pad(s - lo)] = x[s]; lo = 0, no pad and xs = x: straight from global memory).
-template <bool PAD>
+template <bool PAD, bool STAGED>
 SSR_DEV float ssr_sinc_one(const SsrSincParams& p, const SsrView<double>& vwin, const SsrView<double>& vdelta, const float* xs, int lo,
                            int n_in, int64_t t) {
   const double tr = p.time_reg[t];
@@ -68,6 +68,24 @@ SSR_DEV float ssr_sinc_one(const SsrSincParams& p, const SsrView<double>& vwin, 
     const int avail = wing == 0 ? n + 1 : n_in - n - 1;
     const int cnt = room < avail ? room : avail;
     const int x0 = (wing == 0 ? n : n + 1) - lo, dx = wing == 0 ? -1 : 1;
+#ifndef SSR_HOST_EMU
+    // One phase per wave: the lanes' table offsets are equal (they can differ by one entry where the accumulated time register
+    // crosses a table boundary).  When they are, the table entries are wave-uniform: SCALAR loads (one request per wave and
+    // tap instead of two 64-lane gathers), and the loop runs to the uniform tap count `room` with no per-lane condition at
+    // all: a tap beyond the signal's end reads one of the zeros staged around it, and y + w * 0 is y (resampy skips that
+    // tap; only the sign of an exact zero could differ).
+    const int offset_u = __builtin_amdgcn_readfirstlane(offset);
+    if (STAGED && __builtin_amdgcn_ballot_w64(offset != offset_u) == 0ull) {
+      const int room_u = (p.nwin - offset_u) / p.index_step;
+      SSR_UNROLL4 for (int i = 0; i < room_u; ++i) {
+        const int idx = offset_u + i * p.index_step;
+        const double weight = ssr_fadd_rn(p.win[idx], ssr_fmul_rn(eta, p.delta[idx]));
+        const int xi = x0 + dx * i;
+        const double xv = (double)xs[PAD ? xi + (xi >> 5) : xi];
+        y = (float)ssr_fadd_rn((double)y, ssr_fmul_rn(weight, xv));
+      }
+    } else
+#endif
     for (int i = 0; i < cnt; ++i) {
       const unsigned idx = (unsigned)(offset + i * p.index_step);
       const double weight = ssr_fadd_rn(vwin.at(idx), ssr_fmul_rn(eta, vdelta.at(idx)));
@@ -114,8 +132,8 @@ SSR_BODY void ssr_sinc_block_body(const SsrSincParams& p, BLK& blk, int item, in
       const int r = rg * p.pw + sub;
       const int64_t t = t0 + (int64_t)(LPP * g + jl) * P + r;
       if (r < P && t < t1)
-        p.out[p.out_off[item] + t] = staged ? ssr_sinc_one<PAD>(p, vwin, vdelta, xs, lo, n_in, t)
-                                            : ssr_sinc_one<false>(p, vwin, vdelta, x, 0, n_in, t);
+        p.out[p.out_off[item] + t] = staged ? ssr_sinc_one<PAD, true>(p, vwin, vdelta, xs, lo, n_in, t)
+                                            : ssr_sinc_one<false, false>(p, vwin, vdelta, x, 0, n_in, t);
     }
   });
 }

@@ -224,8 +224,8 @@ class Cfg3:
         stages = {"fft_lowpass": (ms_lp, 2 * N_SAMPLES * 4 * n), "stft+lsd+sispec": (ms_stft, (2 * N_SAMPLES * 4 + 32) * n),
                   "ssim": (ms_ssim, (2 * N_SAMPLES * 4 + 32) * n)}
         dom = max(stages, key=lambda k: stages[k][0])
-        tkey = {"fft_lowpass": "k_lowpass_wave+k_ola_paired", "stft+lsd+sispec": "k_stft_wave<double, true", "ssim": "k_ssim"}[dom]
-        roof = hbm_roofline("ssr_pair_metrics:" + dom if dom != "fft_lowpass" else "ssr_fft_lowpass(k_lowpass_wave+k_ola_paired)",
+        tkey = {"fft_lowpass": "k_lowpass_group", "stft+lsd+sispec": "k_stft_wave<double, true", "ssim": "k_ssim"}[dom]
+        roof = hbm_roofline("ssr_pair_metrics:" + dom if dom != "fft_lowpass" else "ssr_fft_lowpass(k_lowpass_group: transforms + overlap-add in one kernel)",
                             stages[dom][1], stages[dom][0], tkey if a.pairs == 1024 and a.precision == "f64" else None,
                             "per cutoff and 1024 utterances; algorithmic bytes: low-pass 2*n*4 per (utterance, cutoff), pair metrics "
                             "2*n*4+32 per pair (SURVEY 8(d))")

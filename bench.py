@@ -183,7 +183,7 @@ class Cfg3:
         n = a.pairs
         self.tgt = (0.1 * torch.randn((n, N_SAMPLES), generator=g, device=dev, dtype=torch.float32)).contiguous()
         tr = B.Ragged.from_uniform(self.tgt)
-        self.lp_plan = B.get_plan(2048, 441, a.precision, dev)            # FDomainHelper() of ssr_eval/lowpass.py:167
+        self.lp_plan = B.get_plan(2048, 441, a.precision, dev, lowpass_engine=getattr(a, "lowpass_engine", "segments"))   # FDomainHelper() of ssr_eval/lowpass.py:167
         self.plan = B.get_plan(N_FFT, HOP, a.precision, dev)
         # the seven cutoffs run one after the other on the stream and share the low-pass output / workspace buffers; only
         # the cut-bin descriptor changes
@@ -224,12 +224,15 @@ class Cfg3:
         stages = {"fft_lowpass": (ms_lp, 2 * N_SAMPLES * 4 * n), "stft+lsd+sispec": (ms_stft, (2 * N_SAMPLES * 4 + 32) * n),
                   "ssim": (ms_ssim, (2 * N_SAMPLES * 4 + 32) * n)}
         dom = max(stages, key=lambda k: stages[k][0])
-        tkey = {"fft_lowpass": "k_lowpass_group", "stft+lsd+sispec": "k_stft_wave<double, true", "ssim": "k_ssim"}[dom]
-        roof = hbm_roofline("ssr_pair_metrics:" + dom if dom != "fft_lowpass" else "ssr_fft_lowpass(k_lowpass_group: transforms + overlap-add in one kernel)",
+        fused = getattr(a, "lowpass_engine", "segments") == "fused"
+        tkey = {"fft_lowpass": "k_lowpass_group" if fused else "k_lowpass_wave+k_ola_paired", "stft+lsd+sispec": "k_stft_wave<double, true", "ssim": "k_ssim"}[dom]
+        roof = hbm_roofline("ssr_pair_metrics:" + dom if dom != "fft_lowpass" else
+                            ("ssr_fft_lowpass(k_lowpass_group: transforms + overlap-add in one kernel)" if fused else "ssr_fft_lowpass(k_lowpass_wave+k_ola_paired)"),
                             stages[dom][1], stages[dom][0], tkey if a.pairs == 1024 and a.precision == "f64" else None,
                             "per cutoff and 1024 utterances; algorithmic bytes: low-pass 2*n*4 per (utterance, cutoff), pair metrics "
                             "2*n*4+32 per pair (SURVEY 8(d))")
-        extra = {"stage_ms_per_cutoff": {k: round(v[0], 4) for k, v in stages.items()},
+        extra = {"lowpass_engine": getattr(a, "lowpass_engine", "segments"),
+                 "stage_ms_per_cutoff": {k: round(v[0], 4) for k, v in stages.items()},
                  "fft_lowpass_utterances_per_s": round(n / (ms_lp * 1e-3), 1),
                  "fft_lowpass_algorithmic_GBs": round(stages["fft_lowpass"][1] / (ms_lp * 1e-3) / 1e9, 1)}
         return roof, extra
@@ -880,6 +883,8 @@ def parse(argv=None):
     ap.add_argument("--pairs", type=int, default=1024, help="cfg2/cfg3: pairs (targets) per GPU per step (BASELINE: 1024)")
     ap.add_argument("--utterances", type=int, default=12500, help="cfg5: utterances per GPU per step (100k over 8 GPUs)")
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--lowpass-engine", dest="lowpass_engine", default="segments", choices=["segments", "fused"],
+                    help="cfg3: overlap-add through the segment workspace (default, faster inside the pipeline) or fused in the transform kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the cfg3 / cfg5 / API-true / end-to-end side figures")
     ap.add_argument("--_cpu-skeleton", dest="cpu_skeleton", action="store_true", help=argparse.SUPPRESS)

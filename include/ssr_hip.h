@@ -64,6 +64,16 @@ int ssr_plan_create(int n_fft, int hop, int precision, ssr_plan** plan);
 int ssr_plan_destroy(ssr_plan* plan);
 int ssr_plan_query(const ssr_plan* plan, int* n_fft, int* hop, int* n_bins, int* fft_len, int* bluestein,
                    int* precision);
+/* Engine of ssr_fft_lowpass / ssr_istft for this plan (set it before the plan is shared between threads):
+ *   SSR_LOWPASS_SEGMENTS (default): the frame kernel writes frames / paired segments to the workspace, a second kernel overlap-adds;
+ *   SSR_LOWPASS_FUSED: transforms AND overlap-add in one kernel, no workspace traffic (HBM bytes = signal in + signal out).
+ *     Float64 2048-point plans with 228 <= hop <= 914 only (SSR_ERR_UNSUPPORTED otherwise).  Measured on MI355X: 3 % faster when
+ *     the call runs alone, 8 % slower inside a pipeline of other FP64-heavy kernels (it needs more cycles at a lower power
+ *     density) - hence not the default.  Both give the reference's result to float32 resolution; the
+ *     fused engine rounds to float32 once (sums in float64 from the unrounded frames). */
+#define SSR_LOWPASS_SEGMENTS 0
+#define SSR_LOWPASS_FUSED 1
+int ssr_plan_set_lowpass_engine(ssr_plan* plan, int engine);
 /* T = 1 + (n + 2*(n_fft/2) - n_fft) / hop  (librosa / torchlibrosa frame count; bit-exact integer) */
 int64_t ssr_num_frames(const ssr_plan* plan, int64_t n_samples);
 

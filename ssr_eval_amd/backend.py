@@ -60,6 +60,13 @@ class Plan:
     def frames(self, n):
         return num_frames(n, self.n_fft, self.hop)
 
+    def set_lowpass_engine(self, engine):
+        """"segments" (default: frame kernel + overlap-add kernel through the workspace) or "fused" (one kernel, no workspace
+        traffic; float64 2048-point plans with 228 <= hop <= 914).  See include/ssr_hip.h: ssr_plan_set_lowpass_engine."""
+        _lib.check(self.lib.ssr_plan_set_lowpass_engine(self.handle, {"segments": _lib.LOWPASS_SEGMENTS, "fused": _lib.LOWPASS_FUSED}[engine]))
+        self.lowpass_engine = engine
+        return self
+
     def __del__(self):
         try:
             if getattr(self, "handle", None) is not None and self.handle.value:
@@ -73,13 +80,17 @@ _plans = {}
 _plans_lock = threading.Lock()
 
 
-def get_plan(n_fft, hop, precision="f64", device=None):
+def get_plan(n_fft, hop, precision="f64", device=None, lowpass_engine="segments"):
+    """The cached plan of (n_fft, hop, precision, device, low-pass engine)."""
     dev = torch.device(device) if device is not None else default_device()
-    key = (int(n_fft), int(hop), _PREC[precision], dev.index if dev.index is not None else torch.cuda.current_device())
+    key = (int(n_fft), int(hop), _PREC[precision], dev.index if dev.index is not None else torch.cuda.current_device(), lowpass_engine)
     with _plans_lock:
         p = _plans.get(key)
         if p is None:
-            p = _plans[key] = Plan(n_fft, hop, precision, dev)
+            p = Plan(n_fft, hop, precision, dev)
+            if lowpass_engine != "segments":
+                p.set_lowpass_engine(lowpass_engine)
+            _plans[key] = p
         return p
 
 

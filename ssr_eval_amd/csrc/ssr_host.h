@@ -39,6 +39,7 @@ struct ssr_plan {
   double* window64 = nullptr;  // always present (OLA normalisation)
   double* wss_tab = nullptr;   // [hop] overlap-added squared window where every overlapping frame exists (hop <= n_fft)
   double* wss_rcp_tab = nullptr;   // [hop] its reciprocal
+  int lowpass_engine = 0;      // SSR_LOWPASS_SEGMENTS / SSR_LOWPASS_FUSED (ssr_plan_set_lowpass_engine)
   std::vector<void*> allocs;
 };
 

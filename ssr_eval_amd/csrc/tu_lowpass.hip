@@ -81,12 +81,18 @@ bool ssr_lowpass_pairs_frames(const ssr_plan* pl) {
   return (t + 1) / 2 * ssr_seg_stride(pl->n_fft, pl->hop) <= t * pl->n_fft;
 }
 
-bool ssr_lowpass_fuses_ola(const ssr_plan* pl) {
-#ifdef SSR_DEV_KNOBS
-  static const int off = getenv("SSR_NO_FUSED_OLA") ? atoi(getenv("SSR_NO_FUSED_OLA")) : 0;
-  if (off) return false;
-#endif
+static bool lowpass_group_eligible(const ssr_plan* pl) {
   return ssr_lowpass_uses_wave_engine(pl) && pl->precision == SSR_F64 && pl->wss_rcp_tab != nullptr && ssr_lowpass_group_ok(pl->hop);
+}
+bool ssr_lowpass_fuses_ola(const ssr_plan* pl) { return pl->lowpass_engine == SSR_LOWPASS_FUSED && lowpass_group_eligible(pl); }
+
+extern "C" int ssr_plan_set_lowpass_engine(ssr_plan* pl, int engine) {
+  if (!pl) return ssr_fail(SSR_ERR_INVALID_ARG, "null plan");
+  if (engine != SSR_LOWPASS_SEGMENTS && engine != SSR_LOWPASS_FUSED) return ssr_fail(SSR_ERR_INVALID_ARG, "unknown low-pass engine");
+  if (engine == SSR_LOWPASS_FUSED && !lowpass_group_eligible(pl))
+    return ssr_fail(SSR_ERR_UNSUPPORTED, "the fused low-pass engine needs a float64 2048-point plan with 228 <= hop <= 914");
+  pl->lowpass_engine = engine;
+  return SSR_OK;
 }
 
 static int launch_lowpass_group(const ssr_plan* pl, const float* in, const int64_t* in_off, const int32_t* len, const int32_t* cut,

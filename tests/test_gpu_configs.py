@@ -188,6 +188,44 @@ def test_cfg5_full_launch_2048_utterances_bit_exact():
     assert np.isfinite(lsd).all() and lsd.std() / lsd.mean() < 0.01
 
 
+@pytest.mark.parametrize("hop", [441, 512])
+def test_lowpass_engines_fused_and_segments(hop, golden):
+    """ssr_plan_set_lowpass_engine: the fused engine (k_lowpass_group: overlap-add inside the transform kernel) against the default
+    one (paired segments + k_ola_paired) and the oracle, on a ragged batch - a signal of several rounds, one shorter than a round,
+    one barely longer than the reflect pad - in low-pass and in ISTFT mode; its bits do not depend on the batch it runs in; and
+    it refuses plans it does not cover."""
+    from ssr_eval_amd import backend as B
+    from ssr_eval_amd._lib import SsrHipError
+    from oracle import lowpass as olp, stft as ostft
+    rng = np.random.default_rng(hop)
+    sigs = [(0.3 * rng.standard_normal(n)).astype(np.float32) for n in (150000, 5 * hop + 1030, 1025, 40000)]
+    cuts = [300, 1025, 77, 512]
+    seg, fus = B.Plan(2048, hop, "f64"), B.Plan(2048, hop, "f64").set_lowpass_engine("fused")
+    ys = [y.cpu().numpy() for y in B.fft_lowpass(seg, sigs, cuts)]
+    yf = [y.cpu().numpy() for y in B.fft_lowpass(fus, sigs, cuts)]
+    for x, c, a, b in zip(sigs, cuts, ys, yf):
+        want = olp.stft_hard_lowpass(x, (c + 0.5) / 1025, n_fft=2048, hop=hop)
+        np.testing.assert_allclose(a, want, atol=5e-8)
+        np.testing.assert_allclose(b, want, atol=5e-8)
+        np.testing.assert_allclose(a, b, atol=1e-7)
+    alone = B.fft_lowpass(fus, [sigs[0]], [cuts[0]])[0].cpu().numpy()          # another batch geometry: the same bits
+    np.testing.assert_array_equal(alone, yf[0])
+    re, im = B.stft(seg, [sigs[3]], kind="complex")
+    for plan in (seg, fus):
+        back = B.istft(plan, re, im, [len(sigs[3])])[0].cpu().numpy()
+        np.testing.assert_allclose(back, sigs[3], atol=2e-6)
+    # the golden low-pass vectors of the imported reference through the fused engine as well (FDomainHelper's 2048 / 441)
+    if hop == 441:
+        x = golden["lp_x"]
+        for hc, fs in [(4000, 44100), (12000, 44100), (6000, 48000)]:
+            y = B.fft_lowpass(fus, [x], [olp.cut_bin(hc, fs)])[0].cpu().numpy()
+            np.testing.assert_allclose(y, golden["lp_y_%d_%d" % (hc, fs)], atol=3e-8)
+    with pytest.raises(SsrHipError):
+        B.Plan(2048, 100, "f64").set_lowpass_engine("fused")
+    with pytest.raises(SsrHipError):
+        B.Plan(2048, 441, "f32").set_lowpass_engine("fused")
+
+
 def test_cfg3_reference_vectors(golden_r2):
     """The sweep in small, against outputs of the imported reference (tests/golden/make_golden_r2.py)."""
     from ssr_eval_amd import SSR_Eval_Helper, BasicTestee, AudioMetrics

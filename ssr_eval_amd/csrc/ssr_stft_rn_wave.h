@@ -14,21 +14,24 @@
 #pragma once
 #include "ssr_stft_r3.h"
 #include "ssr_stft_wave.h"
+#include "ssr_fft24.h"
 
 // NQ: rows of 64 sub-sequence samples / sub-spectrum bins a wave handles, in fours: 3 for q <= 768 (every AudioMetrics
 // size: 743, 557), 4 for q <= 1024.  Twelve rows instead of sixteen is eight fewer prefetch registers and eight fewer
 // conditions per phase (the sixteen-row variants spill 18-40 VGPRs).
-template <typename T, bool SUMS, int NQ> struct SsrRnWaveRegs {
-  cx<T> v[SSR_W_P];
-  T tx[SSR_W_P];
+// P: points per lane of the chirp-z transforms: 32 (M = 2048, ssr_stft_wave.h) or 24 (M = 1536, ssr_fft24.h; q <= 768)
+template <typename T, bool SUMS, int NQ, int P = 32> struct SsrRnWaveRegs {
+  cx<T> v[P];
+  T tx[P];
   float pa[4 * NQ], pb[4 * NQ];   // the next unit's decimated samples m = lane + 64 i, requested a unit ahead
-  cx<T> tw1[7];
-  cx<T> tw2[12];
+  cx<T> tw1[P == 32 ? 7 : 9];
+  cx<T> tw2[P == 32 ? 12 : 9];
 };
+template <int P> SSR_HD constexpr int ssr_rn_wave_pn() { return P == 32 ? SSR_W_PN : SSR_W24_PN; }
 
-template <typename T, int NW> struct SsrRnWaveLds {
+template <typename T, int NW, int P = 32> struct SsrRnWaveLds {
   // scratch (doubles first), then NW split-exchange arrays; the parked sub-spectra alias the arrays
-  static constexpr size_t bytes() { return sizeof(double) * (4 + 6 * 4 + 2) + sizeof(int) * 16 + sizeof(T) * NW * SSR_W_PN; }
+  static constexpr size_t bytes() { return sizeof(double) * (4 + 6 * 4 + 2) + sizeof(int) * 16 + sizeof(T) * NW * ssr_rn_wave_pn<P>(); }
   double* sc1; double* wacc; double* res; int* nz; T* x;
   SSR_MEMBER explicit SsrRnWaveLds(char* base) {
     sc1 = reinterpret_cast<double*>(base);          // [3] per-wave LSD sums of the current unit (+1 pad)
@@ -41,9 +44,9 @@ template <typename T, int NW> struct SsrRnWaveLds {
 
 // LDS of one workgroup: scratch + exchange arrays, and for the variants with SISpec / log-SISpec running sums one float64
 // accumulator per sum and lane ([6][64 NW], updated with ds_add_f64; see ssr_stft_wave_lds_bytes)
-template <typename T, int NW> constexpr size_t ssr_stft_rn_wave_sums_offset() { return (SsrRnWaveLds<T, NW>::bytes() + 7) & ~(size_t)7; }
-template <typename T, int NW, bool SUMS> constexpr size_t ssr_stft_rn_wave_lds_bytes() {
-  return SUMS ? ssr_stft_rn_wave_sums_offset<T, NW>() + 6 * 64 * NW * sizeof(double) : SsrRnWaveLds<T, NW>::bytes();
+template <typename T, int NW, int P = 32> constexpr size_t ssr_stft_rn_wave_sums_offset() { return (SsrRnWaveLds<T, NW, P>::bytes() + 7) & ~(size_t)7; }
+template <typename T, int NW, bool SUMS, int P = 32> constexpr size_t ssr_stft_rn_wave_lds_bytes() {
+  return SUMS ? ssr_stft_rn_wave_sums_offset<T, NW, P>() + 6 * 64 * NW * sizeof(double) : SsrRnWaveLds<T, NW, P>::bytes();
 }
 
 // decimated samples of unit u (frame u of both signals), sub-sequence r: sample NW m + r of the frame, m = lane + 64 i
@@ -75,13 +78,16 @@ template <typename T, int NW> SSR_DEV cx<T> ssr_rn_combine(const T* yre, const T
 }
 
 // grid = n_items * n_chunks workgroups of 64 NW threads; PAIR mode, float32 signals, M = 2048, q = n_fft / NW <= 256 NQ.
-template <typename T, bool SUMS, int NW, int NQ, typename BLK>
+template <typename T, bool SUMS, int NW, int NQ, int P = 32, typename BLK>
 SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
   constexpr bool SPLIT = true;
-  constexpr int NT = 64 * NW, NI = 4 * NQ;                           // rows i = b + 4 qq, b < 4, qq < NQ
+  constexpr int NT = 64 * NW, NI = 4 * NQ;                           // input rows i < NI can be non-zero (q <= 64 NI)
+  constexpr int PB = P / 8, M = 64 * P, PN = ssr_rn_wave_pn<P>();   // butterflies per lane and pass; transform length; array length
+  constexpr int NQO = (P == 32) ? NQ : 4;                            // output rows b + PB qq, qq < NQO, cover k < q
   static_assert(NQ == 3 || NQ == 4, "q <= 768 or q <= 1024");
-  using Regs = SsrRnWaveRegs<T, SUMS, NQ>;
-  SsrRnWaveLds<T, NW> L(lds_base);
+  static_assert(P == 32 || (P == 24 && NQ == 3), "M = 1536 holds the chirp-z of q <= 768 only");
+  using Regs = SsrRnWaveRegs<T, SUMS, NQ, P>;
+  SsrRnWaveLds<T, NW, P> L(lds_base);
   const int n_fft = p.n_fft, hop = p.hop, F = n_fft / 2 + 1, q = n_fft / NW;
   T* yre = L.x;                       // parked sub-spectra [NW q] re, [NW q] im: alias the exchange arrays (2113 >= 2 q)
   T* yim = L.x + NW * q;
@@ -94,9 +100,9 @@ SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
   const int mask = SUMS ? p.metric_mask : (p.metric_mask & SSR_M_LSD);
   const bool want_lsd = mask & SSR_M_LSD;
   const SsrView<float> va(p.a + p.a_off[item], n), vb(p.b + p.b_off[item], n);
-  const SsrView<cx<T>> vbf(p.bfilt, SSR_W_N), vch(p.chirp, n_fft), vt(p.tw, SSR_W_N + SSR_W_TWP);
+  const SsrView<cx<T>> vbf(p.bfilt, M), vch(p.chirp, n_fft), vt(p.tw, M + (P == 32 ? SSR_W_TWP : SSR_W24_TWP));
 
-  double* lsum = reinterpret_cast<double*>(lds_base + ssr_stft_rn_wave_sums_offset<T, NW>());   // [6][NT], SUMS only
+  double* lsum = reinterpret_cast<double*>(lds_base + ssr_stft_rn_wave_sums_offset<T, NW, P>());   // [6][NT], SUMS only
   SSR_REGS(Regs, regs, blk);
   SSR_PHASE(blk, regs, {
     for (int i = tid; i < 6 * 4; i += NT) L.wacc[i] = 0.0;
@@ -108,7 +114,7 @@ SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
   BLK blk0 = blk;
   for (int u = u0; u < u1; ++u) {
     blk = blk0; ssr_launder(blk);
-#define SSR_R3_L (SsrWaveBuf<T>{L.x + ssr_wave_of(tid) * SSR_W_PN, L.x + ssr_wave_of(tid) * SSR_W_PN})
+#define SSR_R3_L (SsrWaveBuf<T>{L.x + ssr_wave_of(tid) * PN, L.x + ssr_wave_of(tid) * PN})
     // ---- wave r: decimated frame * (window * chirp) -> registers (only m < q is non-zero: NI of the 32 points), first pass
     SSR_WPHASE(blk, regs, {
       const int lane = tid & 63, r = ssr_wave_of(tid);
@@ -116,7 +122,7 @@ SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
       // padded points without a lane mask per row (their sample registers hold a repeat of the frame's sample m = q - 1)
       const SsrView<cx<T>> vwr(p.wchirp + (int64_t)r * q, q);
       unsigned ora = 0u, orb = 0u;
-      SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) {
+      SSR_UNROLL for (int i = 0; i < P; ++i) {
         if (i < NI) {
           R.v[i] = cmul(cx<T>{(T)R.pa[i], (T)R.pb[i]}, vwr.at_or_zero(SSR_UIDX(lane + 64 * i)));
           // silent-frame vote: every register holds a sample of this frame (the repeats included); frame sample 0 carries
@@ -132,7 +138,7 @@ SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
       // of the epilogue that reads them would need no double buffering, but the epilogue of unit u runs before these of u + 1)
       SSR_WAVE_ANY_STORE(lane, ora != 0u, L.nz + ((u - u0) & 1) * 3 + r);
       SSR_WAVE_ANY_STORE(lane, orb != 0u, L.nz + 8 + ((u - u0) & 1) * 3 + r);
-      ssr_dft32<T, NI>(R.v);
+      if constexpr (P == 32) ssr_dft32<T, NI>(R.v); else ssr_dft24<T, NI>(R.v);
       if (want_lsd && u > u0 && tid == 0) {
         double s = 0.0;
         for (int w = 0; w < NW; ++w) s += L.sc1[w];
@@ -140,26 +146,26 @@ SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
       }
     });
 #define VT vt
-    SSR_W_FFT_TAIL(blk, blk0, regs, SSR_R3_L, );
-    // spectrum * filter; the inverse transform's input register i takes swap(.) of k = lane + 64 i, i = b + 4 qq
+    if constexpr (P == 32) { SSR_W_FFT_TAIL(blk, blk0, regs, SSR_R3_L, ); } else { SSR_W24_FFT_TAIL(blk, blk0, regs, SSR_R3_L, ); }
+    // spectrum * filter; the inverse transform's input register i takes swap(.) of k = lane + 64 i, i = b + PB qq
     SSR_WPHASE(blk, regs, {
       const int lane = tid & 63;
-      cx<T> z[SSR_W_P];
-      SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int qq = 0; qq < 8; ++qq) {
-        const cx<T> y = cmul(R.v[8 * b + qq], vbf.at(SSR_UIDX(lane + 64 * b + 256 * qq)));
-        z[b + 4 * qq] = {y.y, y.x};
+      cx<T> z[P];
+      SSR_UNROLL for (int b = 0; b < PB; ++b) SSR_UNROLL for (int qq = 0; qq < 8; ++qq) {
+        const cx<T> y = cmul(R.v[8 * b + qq], vbf.at(SSR_UIDX(lane + 64 * (b + PB * qq))));
+        z[b + PB * qq] = {y.y, y.x};
       }
-      SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) R.v[i] = z[i];
-      ssr_dft32(R.v);
+      SSR_UNROLL for (int i = 0; i < P; ++i) R.v[i] = z[i];
+      if constexpr (P == 32) ssr_dft32(R.v); else ssr_dft24(R.v);
     });
-    SSR_W_FFT_TAIL(blk, blk0, regs, SSR_R3_L, );
+    if constexpr (P == 32) { SSR_W_FFT_TAIL(blk, blk0, regs, SSR_R3_L, ); } else { SSR_W24_FFT_TAIL(blk, blk0, regs, SSR_R3_L, ); }
 #undef VT
     // registers hold swap(IFFT * M): true real part = .y, imaginary = .x, at k = lane + 64 (b + 4 qq); k < q is wanted:
     // post-multiply (chirp * W_n^{r k} / 2) in place
     SSR_WPHASE(blk, regs, {
       const int lane = tid & 63, r = ssr_wave_of(tid);
-      SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int qq = 0; qq < NQ; ++qq) {
-        const int k = lane + 64 * (b + 4 * qq);
+      SSR_UNROLL for (int b = 0; b < PB; ++b) SSR_UNROLL for (int qq = 0; qq < NQO; ++qq) {
+        const int k = lane + 64 * (b + PB * qq);
         const cx<T> c = vch.at(SSR_UIDX(k < q ? k : q - 1), (int64_t)r * q);
         R.v[8 * b + qq] = cmul(cx<T>{R.v[8 * b + qq].y, R.v[8 * b + qq].x}, c);
       }
@@ -168,8 +174,8 @@ SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
     SSR_PHASE(blk, regs, {});
     SSR_PHASE(blk, regs, {
       const int lane = tid & 63, r = ssr_wave_of(tid);
-      SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int qq = 0; qq < NQ; ++qq) {
-        const int k = lane + 64 * (b + 4 * qq);
+      SSR_UNROLL for (int b = 0; b < PB; ++b) SSR_UNROLL for (int qq = 0; qq < NQO; ++qq) {
+        const int k = lane + 64 * (b + PB * qq);
         if (k < q) { yre[r * q + k] = R.v[8 * b + qq].x; yim[r * q + k] = R.v[8 * b + qq].y; }
       }
     });
@@ -186,7 +192,22 @@ SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
       bool a_nz = false, b_nz = false;
       for (int w = 0; w < NW; ++w) { a_nz = a_nz || L.nz[par + w] != 0; b_nz = b_nz || L.nz[8 + par + w] != 0; }
       const bool store = p.out_kind == SSR_OUT_MAG;
-      for (int K = tid; K < F; K += NT) {
+      int K = tid;
+      // both frames hold signal and the mask is the variant's full set (the common case, block-uniform): two bins of the
+      // lane at a time, their float32 arithmetic as packed instructions (ssr_pair_bins2_fast - the same values, added to the
+      // sums in the same order as the bin-by-bin loop below)
+      constexpr int FULL = SUMS ? (SSR_M_LSD | SSR_M_LOG_SISPEC | SSR_M_SISPEC) : SSR_M_LSD;
+      if (a_nz && b_nz && (mask & 7) == FULL) {
+        for (; K + NT < F; K += 2 * NT) {
+          const int K1 = K + NT;
+          const cx<T> zk0 = ssr_rn_combine<T, NW>(yre, yim, q, K), zn0 = ssr_rn_combine<T, NW>(yre, yim, q, (K == 0) ? 0 : n_fft - K);
+          const cx<T> zk1 = ssr_rn_combine<T, NW>(yre, yim, q, K1), zn1 = ssr_rn_combine<T, NW>(yre, yim, q, n_fft - K1);
+          f2 e, t;
+          ssr_pair_bins2_fast<T, SUMS>(acc, zk0, zn0, zk1, zn1, e, t);
+          if (store) { ra0[K] = e.x; rb0[K] = t.x; ra0[K1] = e.y; rb0[K1] = t.y; }
+        }
+      }
+      for (; K < F; K += NT) {
         const int Kn = (K == 0) ? 0 : n_fft - K;
         const cx<T> zk = ssr_rn_combine<T, NW>(yre, yim, q, K);
         const cx<T> zn = ssr_rn_combine<T, NW>(yre, yim, q, Kn);

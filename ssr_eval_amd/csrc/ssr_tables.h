@@ -19,9 +19,9 @@ inline int ssr_ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 //  * radix-3 x Bluestein when n_fft = 3 q and plain Bluestein would need M = 8192 while the three length-q
 //    sub-transforms fit M = 2048 (n_fft = 2229 = 3 * 743, i.e. AudioMetrics(48000)): 6 x FFT-2048 in a 35 KB LDS
 //    buffer (2 workgroups per CU) instead of 2 x FFT-8192 in 139 KB (1 workgroup per CU).
-struct SsrEngine { bool ok; bool bluestein; int logn; int radix; int q; };
+struct SsrEngine { bool ok; bool bluestein; int logn; int radix; int q; int m; };   // m: transform length when it is not 2^logn (1536), else 0
 inline SsrEngine ssr_pick_engine(int n_fft) {
-  SsrEngine e{false, false, 0, 1, 0};
+  SsrEngine e{false, false, 0, 1, 0, 0};
   if (n_fft < 2) return e;
   e.q = n_fft;
   if (ssr_is_pow2(n_fft) && n_fft >= 256 && n_fft <= 4096) { e.ok = true; e.logn = ssr_ilog2(n_fft); return e; }
@@ -47,15 +47,23 @@ inline SsrEngine ssr_pick_engine(int n_fft) {
 //    the block engine's (chirp of length q = n_fft / 2, filter spectrum of 2048 points) and are built separately.
 inline SsrEngine ssr_pick_wave_engine(int n_fft) {
   const SsrEngine e = ssr_pick_engine(n_fft);
-  SsrEngine none{false, false, 0, 1, 0};
+  SsrEngine none{false, false, 0, 1, 0, 0};
   if (!e.ok || !e.bluestein) return none;
-  if (e.radix == 3) return (e.logn == 11 && e.q <= 768) ? e : none;
-  if (e.logn == 11) return e;                                              // R = 1, q = n_fft
-  if (e.logn == 12 && n_fft % 2 == 0 && n_fft / 2 <= 1024) return SsrEngine{true, true, 11, 2, n_fft / 2};
-  return none;
+  SsrEngine w = none;
+  if (e.radix == 3) w = (e.logn == 11 && e.q <= 768) ? e : none;
+  else if (e.logn == 11) w = e;                                            // R = 1, q = n_fft
+  else if (e.logn == 12 && n_fft % 2 == 0 && n_fft / 2 <= 1024) w = SsrEngine{true, true, 11, 2, n_fft / 2, 0};
+#ifndef SSR_NO_M1536
+  // The chirp-z of a sub-sequence of q <= 768 samples only needs M >= 2 q - 1 = 1535: M = 1536 = 24 x 64 (24 points per lane, an
+  // in-register radix-24 first pass; ssr_fft24.h) does a quarter less arithmetic than M = 2048.  Every AudioMetrics(rate) size
+  // qualifies (q = 743 or 557).
+  if (w.ok && w.q <= 768) w.m = 1536;
+#endif
+  return w;
 }
 
 constexpr int SSR_WAVE_N = 2048, SSR_WAVE_TWP = 7 * 32 + 12 * 64;   // wave engines: transform length, lane-ordered twiddle copies
+constexpr int SSR_WAVE24_N = 1536, SSR_WAVE24_TWP = 2 * 9 * 64;     // the 24-points-per-lane variant (ssr_fft24.h)
 
 template <typename T> struct SsrTables {
   SsrEngine eng;
@@ -87,6 +95,23 @@ inline void ssr_host_fft_ld(std::vector<long double>& re, std::vector<long doubl
   }
 }
 
+// plain O(n^2) DFT in long double for lengths that are not a power of two (1536: once per plan)
+inline void ssr_host_dft_ld(std::vector<long double>& re, std::vector<long double>& im) {
+  const int n = (int)re.size();
+  std::vector<long double> c(n), s(n), orr(n), oi(n);
+  for (int i = 0; i < n; ++i) { const long double a = -2.0L * SSR_PI_L * i / n; c[i] = cosl(a); s[i] = sinl(a); }
+  for (int k = 0; k < n; ++k) {
+    long double ar = 0.0L, ai = 0.0L;
+    for (int m = 0; m < n; ++m) {
+      const int j = (int)(((int64_t)k * m) % n);
+      ar += re[m] * c[j] - im[m] * s[j];
+      ai += re[m] * s[j] + im[m] * c[j];
+    }
+    orr[k] = ar; oi[k] = ai;
+  }
+  re = orr; im = oi;
+}
+
 template <typename T> bool ssr_build_tables_for(int n_fft, SsrEngine eng, SsrTables<T>& t);
 template <typename T> bool ssr_build_tables(int n_fft, SsrTables<T>& t) { return ssr_build_tables_for<T>(n_fft, ssr_pick_engine(n_fft), t); }
 
@@ -94,7 +119,7 @@ template <typename T> bool ssr_build_tables_for(int n_fft, SsrEngine eng, SsrTab
   t.eng = eng;
   t.n_fft = n_fft;
   if (!t.eng.ok) return false;
-  const int N = 1 << t.eng.logn;
+  const int N = t.eng.m ? t.eng.m : (1 << t.eng.logn);
   t.window.resize(n_fft);
   std::vector<long double> w(n_fft);
   for (int m = 0; m < n_fft; ++m) {
@@ -107,6 +132,19 @@ template <typename T> bool ssr_build_tables_for(int n_fft, SsrEngine eng, SsrTab
   for (int i = 0; i < N; ++i) {
     const long double ang = -2.0L * SSR_PI_L * i / N;
     t.tw[i] = {(T)cosl(ang), (T)sinl(ang)};
+  }
+  if (N == SSR_WAVE24_N) {
+    // 24 points per lane (ssr_fft24.h): butterfly b < 3 of lane l is j = l + 64 b = 24 t_low + q; lane-ordered copies
+    //   [N + 64 (3 b + k) + l]        = tw[8 q 2^k mod N]        (pass 1: W_192^(q 2^k)),
+    //   [N + 576 + 64 (3 b + k) + l]  = tw[j 2^k]                (pass 2: w^j, w^2j, w^4j)
+    t.tw.resize(N + SSR_WAVE24_TWP);
+    for (int b = 0; b < 3; ++b)
+      for (int k = 0; k < 3; ++k)
+        for (int l = 0; l < 64; ++l) {
+          const int j = l + 64 * b, q = j % 24;
+          t.tw[N + 64 * (3 * b + k) + l] = t.tw[(8 * q << k) % N];
+          t.tw[N + 576 + 64 * (3 * b + k) + l] = t.tw[(j << k) % N];
+        }
   }
   if (N == SSR_WAVE_N) {
     // Lane-ordered copies of the twiddles the wave engines read (ssr_stft_wave.h: SSR_W_LOAD_TW1 / TW2), behind the table:
@@ -146,7 +184,7 @@ template <typename T> bool ssr_build_tables_for(int n_fft, SsrEngine eng, SsrTab
       br[m] = cr[m]; bi[m] = -ci[m];
       if (m) { br[N - m] = cr[m]; bi[N - m] = -ci[m]; }
     }
-    ssr_host_fft_ld(br, bi);
+    if (ssr_is_pow2(N)) ssr_host_fft_ld(br, bi); else ssr_host_dft_ld(br, bi);
     t.bfilt.resize(N);
     for (int i = 0; i < N; ++i) t.bfilt[i] = {(T)(br[i] / N), (T)(bi[i] / N)};
   }

@@ -103,7 +103,8 @@ template <typename T> static int build_dev_tables(ssr_plan* pl, DevTables<T>& d,
   SsrTables<T> t;
   if (!ssr_build_tables<T>(pl->n_fft, t)) return ssr_fail(SSR_ERR_UNSUPPORTED, "unsupported n_fft");
   int rc;
-  if (pl->weng.ok && pl->weng.radix != pl->eng.radix) {        // the wave engine splits differently: its own chirps and filter
+  const bool own_wave_tables = pl->weng.ok && (pl->weng.radix != pl->eng.radix || pl->weng.m != 0);
+  if (own_wave_tables) {                                       // the wave engine splits (or sizes its transforms) differently: its own tables
     SsrTables<T> w;
     if (!ssr_build_tables_for<T>(pl->n_fft, pl->weng, w)) return ssr_fail(SSR_ERR_UNSUPPORTED, "unsupported n_fft");
     if ((rc = upload(pl, w.tw, &dw.tw))) return rc;
@@ -117,7 +118,7 @@ template <typename T> static int build_dev_tables(ssr_plan* pl, DevTables<T>& d,
   if ((rc = upload(pl, t.wchirp, &d.wchirp))) return rc;
   if ((rc = upload(pl, t.bfilt, &d.bfilt))) return rc;
   if ((rc = upload(pl, t.chirp, &d.chirp))) return rc;
-  if (pl->weng.ok && pl->weng.radix == pl->eng.radix) dw = d;
+  if (pl->weng.ok && !own_wave_tables) dw = d;
   return SSR_OK;
 }
 

@@ -155,22 +155,24 @@ extern "C" int emu_stft_wave(int precision, int hop, int out_kind, int mask, int
 
 // radix-R x Bluestein pair engine on R autonomous waves (ssr_stft_rn_wave.h): n_fft = R q, M = 2048, R = 1 / 2 / 3 as
 // ssr_pick_wave_engine decides
-template <typename T, int NW, int NQ>
+template <typename T, int NW, int NQ, int P>
 static void emu_rn_wave_run(const SsrStftParams<T>& p, int n_items, int n_chunks, bool sums) {
   SsrBlk blk{64 * NW};
   for (int item = 0; item < n_items; ++item)
     for (int c = 0; c < n_chunks; ++c) {
-      auto lds = poisoned(ssr_stft_rn_wave_lds_bytes<T, NW, true>());
-      if (sums) ssr_stft_rn_wave_body<T, true, NW, NQ>(p, blk, c, item, lds.data());
-      else ssr_stft_rn_wave_body<T, false, NW, NQ>(p, blk, c, item, lds.data());
+      auto lds = poisoned(ssr_stft_rn_wave_lds_bytes<T, NW, true, P>());
+      if (sums) ssr_stft_rn_wave_body<T, true, NW, NQ, P>(p, blk, c, item, lds.data());
+      else ssr_stft_rn_wave_body<T, false, NW, NQ, P>(p, blk, c, item, lds.data());
     }
 }
+// m1536: 1 = what the product picks (M = 1536 for q <= 768), 0 = force the 2048-point transforms
 template <typename T>
-static int emu_stft_r3_wave_t(int n_fft, int hop, int out_kind, int mask, const float* a, const float* b, const int64_t* a_off,
+static int emu_stft_r3_wave_t(int n_fft, int hop, int out_kind, int mask, int m1536, const float* a, const float* b, const int64_t* a_off,
                               const int64_t* b_off, const int32_t* len, const int64_t* frame_off, int n_items,
                               int units_per_chunk, int n_chunks, float* out_a, float* out_b, double* part) {
-  const SsrEngine we = ssr_pick_wave_engine(n_fft);
+  SsrEngine we = ssr_pick_wave_engine(n_fft);
   if (!we.ok) return -4;
+  if (!m1536) we.m = 0;
   SsrTables<T> t;
   if (!ssr_build_tables_for<T>(n_fft, we, t)) return -3;
   SsrStftParams<T> p{};
@@ -183,18 +185,24 @@ static int emu_stft_r3_wave_t(int n_fft, int hop, int out_kind, int mask, const 
   p.out_a = out_a; p.out_b = out_b; p.part = part;
   const bool sums = mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC);
   const bool wide = we.q > 768;
-  if (we.radix == 1) { if (wide) emu_rn_wave_run<T, 1, 4>(p, n_items, n_chunks, sums); else emu_rn_wave_run<T, 1, 3>(p, n_items, n_chunks, sums); }
-  else if (we.radix == 2) { if (wide) emu_rn_wave_run<T, 2, 4>(p, n_items, n_chunks, sums); else emu_rn_wave_run<T, 2, 3>(p, n_items, n_chunks, sums); }
-  else emu_rn_wave_run<T, 3, 3>(p, n_items, n_chunks, sums);
-  return 0;
+  if (we.m == SSR_W24_N) {
+    if (we.radix == 1) emu_rn_wave_run<T, 1, 3, 24>(p, n_items, n_chunks, sums);
+    else if (we.radix == 2) emu_rn_wave_run<T, 2, 3, 24>(p, n_items, n_chunks, sums);
+    else emu_rn_wave_run<T, 3, 3, 24>(p, n_items, n_chunks, sums);
+    return 24;
+  }
+  if (we.radix == 1) { if (wide) emu_rn_wave_run<T, 1, 4, 32>(p, n_items, n_chunks, sums); else emu_rn_wave_run<T, 1, 3, 32>(p, n_items, n_chunks, sums); }
+  else if (we.radix == 2) { if (wide) emu_rn_wave_run<T, 2, 4, 32>(p, n_items, n_chunks, sums); else emu_rn_wave_run<T, 2, 3, 32>(p, n_items, n_chunks, sums); }
+  else emu_rn_wave_run<T, 3, 3, 32>(p, n_items, n_chunks, sums);
+  return 32;
 }
-extern "C" int emu_stft_r3_wave(int precision, int n_fft, int hop, int out_kind, int mask, const float* a, const float* b,
+extern "C" int emu_stft_r3_wave(int precision, int n_fft, int hop, int out_kind, int mask, int m1536, const float* a, const float* b,
                                 const int64_t* a_off, const int64_t* b_off, const int32_t* len, const int64_t* frame_off,
                                 int n_items, int units_per_chunk, int n_chunks, float* out_a, float* out_b, double* part) {
   if (precision == 1)
-    return emu_stft_r3_wave_t<double>(n_fft, hop, out_kind, mask, a, b, a_off, b_off, len, frame_off, n_items, units_per_chunk,
+    return emu_stft_r3_wave_t<double>(n_fft, hop, out_kind, mask, m1536, a, b, a_off, b_off, len, frame_off, n_items, units_per_chunk,
                                       n_chunks, out_a, out_b, part);
-  return emu_stft_r3_wave_t<float>(n_fft, hop, out_kind, mask, a, b, a_off, b_off, len, frame_off, n_items, units_per_chunk,
+  return emu_stft_r3_wave_t<float>(n_fft, hop, out_kind, mask, m1536, a, b, a_off, b_off, len, frame_off, n_items, units_per_chunk,
                                    n_chunks, out_a, out_b, part);
 }
 

@@ -470,20 +470,23 @@ def test_radix_n_wave_engine_matches_oracle_and_block_engine(n_fft, hop):
     tg = [(0.1 * rng.standard_normal(n)).astype(np.float32) for n in lens]
     es = [(t + 0.02 * rng.standard_normal(len(t))).astype(np.float32) for t in tg]
     es[3][1000:5500] = 0.0
-    mags_e, mags_t, _ = E.stft(es, tg, n_fft, hop, 1, 0, 1, 15, 3, wave="r3")
-    for x, m in zip(es + tg, mags_e + mags_t):
-        ref = ostft.stft_mag_TF(x, n_fft, hop)
-        assert np.abs(m - ref).max() <= 2e-7 * ref.max()
-        assert ((m == 0) == (ref == 0)).all()
-    assert (mags_e[3] == 0).all(axis=1).any()
-    got = E.pair_metrics(es, tg, n_fft, hop, 1, wave="r3", units_per_chunk=3)
-    blk = E.pair_metrics(es, tg, n_fft, hop, 1, units_per_chunk=3)
-    for e, t, g, b in zip(es, tg, got, blk):
-        w = om.evaluation(e, t, n_fft=n_fft, hop=hop)
-        np.testing.assert_allclose(g, [w[k] for k in ("lsd", "log_sispec", "sispec", "ssim")], rtol=1e-5)
-        np.testing.assert_allclose(g, b, rtol=1e-7)
-    lsd_only = E.pair_metrics(es, tg, n_fft, hop, 1, mask=E.M_LSD | E.M_SSIM, wave="r3", units_per_chunk=5)
-    np.testing.assert_allclose(lsd_only[:, [0, 3]], got[:, [0, 3]], rtol=1e-12)
+    # "r3": the product's choice - 1536-point transforms (24 points per lane, ssr_fft24.h) where q <= 768, i.e. every
+    # AudioMetrics size; "r3_2048": the 2048-point transforms forced (what sizes with q > 768 run)
+    for wave in ("r3", "r3_2048"):
+        mags_e, mags_t, _ = E.stft(es, tg, n_fft, hop, 1, 0, 1, 15, 3, wave=wave)
+        for x, m in zip(es + tg, mags_e + mags_t):
+            ref = ostft.stft_mag_TF(x, n_fft, hop)
+            assert np.abs(m - ref).max() <= 2e-7 * ref.max()
+            assert ((m == 0) == (ref == 0)).all()
+        assert (mags_e[3] == 0).all(axis=1).any()
+        got = E.pair_metrics(es, tg, n_fft, hop, 1, wave=wave, units_per_chunk=3)
+        blk = E.pair_metrics(es, tg, n_fft, hop, 1, units_per_chunk=3)
+        for e, t, g, b in zip(es, tg, got, blk):
+            w = om.evaluation(e, t, n_fft=n_fft, hop=hop)
+            np.testing.assert_allclose(g, [w[k] for k in ("lsd", "log_sispec", "sispec", "ssim")], rtol=1e-5)
+            np.testing.assert_allclose(g, b, rtol=1e-7)
+        lsd_only = E.pair_metrics(es, tg, n_fft, hop, 1, mask=E.M_LSD | E.M_SSIM, wave=wave, units_per_chunk=5)
+        np.testing.assert_allclose(lsd_only[:, [0, 3]], got[:, [0, 3]], rtol=1e-12)
     if n_fft in (1486, 743):                                   # the float32-transform instantiation: magnitudes to float32 accuracy
         m32, _, _ = E.stft(es[:1], tg[:1], n_fft, hop, 0, 0, 1, 15, 3, wave="r3")
         ref = ostft.stft_mag_TF(es[0], n_fft, hop)

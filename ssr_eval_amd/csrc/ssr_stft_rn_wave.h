@@ -192,22 +192,9 @@ SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
       bool a_nz = false, b_nz = false;
       for (int w = 0; w < NW; ++w) { a_nz = a_nz || L.nz[par + w] != 0; b_nz = b_nz || L.nz[8 + par + w] != 0; }
       const bool store = p.out_kind == SSR_OUT_MAG;
-      int K = tid;
-      // both frames hold signal and the mask is the variant's full set (the common case, block-uniform): two bins of the
-      // lane at a time, their float32 arithmetic as packed instructions (ssr_pair_bins2_fast - the same values, added to the
-      // sums in the same order as the bin-by-bin loop below)
-      constexpr int FULL = SUMS ? (SSR_M_LSD | SSR_M_LOG_SISPEC | SSR_M_SISPEC) : SSR_M_LSD;
-      if (a_nz && b_nz && (mask & 7) == FULL) {
-        for (; K + NT < F; K += 2 * NT) {
-          const int K1 = K + NT;
-          const cx<T> zk0 = ssr_rn_combine<T, NW>(yre, yim, q, K), zn0 = ssr_rn_combine<T, NW>(yre, yim, q, (K == 0) ? 0 : n_fft - K);
-          const cx<T> zk1 = ssr_rn_combine<T, NW>(yre, yim, q, K1), zn1 = ssr_rn_combine<T, NW>(yre, yim, q, n_fft - K1);
-          f2 e, t;
-          ssr_pair_bins2_fast<T, SUMS>(acc, zk0, zn0, zk1, zn1, e, t);
-          if (store) { ra0[K] = e.x; rb0[K] = t.x; ra0[K1] = e.y; rb0[K1] = t.y; }
-        }
-      }
-      for (; K < F; K += NT) {
+      // (two bins at a time with packed float32 arithmetic, as in ssr_stft_wave.h's epilogue, measured SLOWER here: 13.07 against
+      // 12.74 ms per 1024 pairs - four radix-3 combines in flight instead of two; profiles/r03_notes.md)
+      for (int K = tid; K < F; K += NT) {
         const int Kn = (K == 0) ? 0 : n_fft - K;
         const cx<T> zk = ssr_rn_combine<T, NW>(yre, yim, q, K);
         const cx<T> zn = ssr_rn_combine<T, NW>(yre, yim, q, Kn);

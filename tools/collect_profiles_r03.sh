@@ -23,6 +23,8 @@ if [ "${PMC:-0}" = "1" ]; then
       rm -rf $OUT/pmc_${P}_$C
       timeout 400 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pmc_${P}_$C -o p -- python $R/bench.py --config $C --steps 2 --warmup 1 --no-cpu-baseline --no-side > $OUT/pmc_${P}_$C.log 2>&1; echo "$P $C rc=$?"
     done
+    rm -rf $OUT/pmc_${P}_cfg3fused
+    timeout 400 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pmc_${P}_cfg3fused -o p -- python $R/bench.py --config cfg3 --lowpass-engine fused --steps 2 --warmup 1 --no-cpu-baseline --no-side > $OUT/pmc_${P}_cfg3fused.log 2>&1; echo "$P cfg3 fused rc=$?"
     rm -rf $OUT/pmc_${P}_api $OUT/pmc_${P}_sinc
     (cd $R && timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pmc_${P}_api -o p -- python tools/exp_api_true.py) > $OUT/pmc_${P}_api.log 2>&1; echo "$P api rc=$?"
     (cd $R && FILES=128 timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pmc_${P}_sinc -o p -- python tools/exp_sinc.py) > $OUT/pmc_${P}_sinc.log 2>&1; echo "$P sinc rc=$?"

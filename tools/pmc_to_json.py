@@ -24,7 +24,7 @@ for stats in sorted(glob.glob(src + "/stats_*/*kernel_stats.csv")):
     if os.path.exists(bj) and os.path.getsize(bj):
         summary.setdefault("bench_line_under_rocprof", {})[cfg] = json.load(open(bj))
 KEYS = ("k_stft_wave<double, false", "k_stft_wave<double, true", "k_ssim", "k_stft<double, 11")
-MORE = {"cfg3": ("k_lowpass_wave", "k_ola_paired", "k_ola(", "k_lowpass_group"), "cfg5": ("k_resample<",),
+MORE = {"cfg3": ("k_lowpass_wave", "k_ola_paired", "k_ola("), "cfg3fused": ("k_lowpass_group",), "cfg5": ("k_resample<",),
         "api": ("k_stft_rn_wave<double, false, 3", "k_stft_rn_wave<double, true, 3"), "sinc": ("k_resample_sinc",)}
 pm = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -186,8 +186,13 @@ SSR_BODY void ssr_resample_persistent_body(const SsrResampleParamsT<S>& p, BLK& 
       // negative one included, as an unsigned offset - is out of the view's range and loads 0, which IS the signal's zero
       // extension; slots beyond the window load something that is never written to LDS.  (44 lane masks kept in scalar
       // registers across the multiply-adds - for the select after the load - were 98 spilled SGPRs.)
+      // (round 3: in groups of four behind ONE block-uniform scalar test each - the window of 441/160 needs 16 of the 44 slots,
+      // and the other 28 requests per thread fetched 5.7 GB per 12,500 utterances that nobody read: PMC 8.9 GB for 3.2 GB of input)
       const int q_lo_n = (int)nb.q_lo + tid;
-      SSR_UNROLL for (int u = 0; u < PF; ++u) R.nx[u] = vn.at_or_zero((unsigned)(q_lo_n + u * NT));
+      SSR_UNROLL for (int u0 = 0; u0 < PF; u0 += 4)
+        if (u0 * NT < nb.win) {
+          SSR_UNROLL for (int u = u0; u < u0 + 4 && u < PF; ++u) R.nx[u] = vn.at_or_zero((unsigned)(q_lo_n + u * NT));
+        }
       if (b.live) ssr_resample_compute<S>(p, tid, item, b, xw, h, h_len);
     });
     SSR_PHASE(blk, regs, {

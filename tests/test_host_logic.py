@@ -153,6 +153,29 @@ def test_cabi_argument_validation_needs_no_gpu():
     assert lib.ssr_comm_destroy(None) == 0
 
 
+def test_cabi_round3_entry_points_validate_before_the_device():
+    """ssr_resample_sinc (time register length, table description), ssr_pcm16_to_float, ssr_sispec_multichannel and
+    ssr_plan_set_lowpass_engine reject bad arguments on the host (fake non-null pointers are never dereferenced)."""
+    from ssr_eval_amd import _lib
+    lib = _lib.load()
+    p = C.c_void_p(0x1000)
+    # null argument
+    assert lib.ssr_resample_sinc(None, p, p, p, p, 1, 100, p, 100, p, p, 8193, 512, 512, 1.0, 1.0, 1, p, None) == -1
+    # time register shorter than the longest output
+    assert lib.ssr_resample_sinc(p, p, p, p, p, 1, 100, p, 99, p, p, 8193, 512, 512, 1.0, 1.0, 1, p, None) == -1
+    assert b"time_register" in lib.ssr_last_error()
+    # nonsensical filter description (no table entries / zero step)
+    assert lib.ssr_resample_sinc(p, p, p, p, p, 1, 100, p, 100, p, p, 0, 512, 512, 1.0, 1.0, 1, p, None) == -1
+    assert lib.ssr_resample_sinc(p, p, p, p, p, 1, 100, p, 100, p, p, 8193, 512, 0, 1.0, 1.0, 1, p, None) == -1
+    assert lib.ssr_pcm16_to_float(None, p, p, p, 1, 10, p, p, None) == -1
+    assert lib.ssr_pcm16_to_float(p, p, p, p, 0, 10, p, p, None) == 0           # empty batch: nothing to do
+    assert lib.ssr_sispec_multichannel(None, p, 1, 2, 10, 0, p, p, 1024, None) == -1
+    assert lib.ssr_sispec_multichannel(p, p, 0, 2, 10, 0, p, p, 1024, None) == -1
+    assert lib.ssr_sispec_multichannel(p, p, 4, 2, 10, 0, p, p, 8, None) == -4  # workspace too small
+    assert b"workspace" in lib.ssr_last_error()
+    assert lib.ssr_plan_set_lowpass_engine(None, 0) == -1
+
+
 def test_wav_decode_mono_stereo_and_batch(tmp_path):
     """io.read_audio on 16-bit mono / stereo PCM and the pooled decode_batch; Ragged.from_list packing on the host device."""
     import torch

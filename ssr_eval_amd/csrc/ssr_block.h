@@ -37,6 +37,7 @@ static inline unsigned ssr_launder_index(unsigned i) { return i; }
     auto& R = (regs)[tid]; (void)R;                                \
     __VA_ARGS__;                                                   \
   }
+#define SSR_WPHASE SSR_PHASE
 // inside a phase: dst[tid / 64] = sum of `val` over the lanes of that wave (host: tids run in ascending order)
 #define SSR_WAVE_SUM_STORE(tid, NT_, val, dst)              \
   do {                                                      \
@@ -115,6 +116,21 @@ SSR_DEV unsigned ssr_launder_index(unsigned i) { asm volatile("" : "+v"(i)); ret
     __VA_ARGS__;                                                   \
   }                                                                \
   SSR_BARRIER();
+// Phase of a body whose hand-offs stay inside ONE wave (one-wave workgroups, or per-wave LDS arrays): a wave-scope ordering
+// point - it constrains the compiler and emits nothing (same-wave LDS traffic is ordered by the hardware), where SSR_PHASE's
+// workgroup fence costs an s_waitcnt lgkmcnt(0) per boundary.
+#define SSR_WAVE_SYNC()                                             \
+  do {                                                              \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          \
+    __builtin_amdgcn_wave_barrier();                                \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");          \
+  } while (0)
+#define SSR_WPHASE(blk, regs, ...)                                   \
+  {                                                                  \
+    const int tid = (blk).tid; auto& R = (regs); (void)R; (void)tid; \
+    __VA_ARGS__;                                                     \
+  }                                                                  \
+  SSR_WAVE_SYNC();
 // wave-level sum through cross-lane shuffles (no LDS round trip, no barrier); W = active lanes (<= 64)
 template <int W> SSR_DEV double ssr_wave_sum(double v) {
 #pragma unroll

@@ -45,12 +45,15 @@ SSR_DEV int ssr_ssim_pitch(const SsrSsimParams& p) { return p.pitch ? p.pitch : 
 // Only four window sums are needed: S depends on vx and vy through vx + vy alone, so x^2 and y^2 are
 // accumulated together:  q0 = sum x, q1 = sum y, q2 = sum (x^2 + y^2), q3 = sum x*y.
 template <int CPT> struct SsrSsimRegs {
-  double cs[CPT + 1][4];  // running 7-row sums for the thread's (strided) input columns tid + NT*i
+  double cs[CPT + 1][4];  // running 7-row sums for the thread's input columns (strided: tid + NT*i; CONTIG: ssr_ssim_col)
   double s;               // sum of S over the thread's outputs
   float px[2][4][CPT + 1];   // row values in flight, two row steps deep: [step parity][entering x, y, leaving x, y][column slot]
+                             // (CONTIG requests the entering rows only: the leaving ones come from the two rings)
   float ring[SSR_SSIM_WIN][CPT + 1];   // CONTIG: the x pixels of the last seven rows, slot = row step mod 7 - the leaving x row is
-                                       // not fetched again.  (A second ring for y: 172 VGPRs -> two waves per SIMD, or five spilled
-                                       // registers at three; or 168 with the loads only one step ahead - all measured slower.)
+                                       // not fetched again.  The y pixels of those rows sit in an LDS ring (SsrSsimLds::yring):
+                                       // a second REGISTER ring is 172 VGPRs -> two waves per SIMD, or spills at three (round 2:
+                                       // all measured slower than fetching y's leaving row again).
+  double w[4][CPT];       // CONTIG: the window sums of the thread's outputs, formed one quantity at a time
 };
 
 // Column-sum index in LDS.  The horizontal pass reads with a lane stride of CPT doubles; for even CPT that is a
@@ -58,17 +61,44 @@ template <int CPT> struct SsrSsimRegs {
 // is inserted every CPT columns to make the lane stride CPT + 1 (odd).  Odd CPT needs nothing.
 template <int CPT> SSR_DEV int ssr_ssim_slot(int c) { return (CPT % 2 == 0) ? c + c / CPT : c; }
 
-template <int CPT> struct SsrSsimLds {
+// CONTIG (round 3): the four column sums go through ONE array, a quantity at a time (write q, read q, write q + 1 ... - the DS
+// operations of the single wave execute in order), which makes room for a seven-row ring of the y pixels (rows of RW floats:
+// the thread's own four columns as one 16-byte slot at 4 tid, the strip's extra columns at 256 + tid) at twelve waves per CU:
+// 7,392 + 2,648 + 704 B per wave against 11,296 B with four column arrays and no ring.
+template <int CPT, bool CONTIG = false> struct SsrSsimLds {
   static constexpr int PW = SSR_SSIM_NT * CPT + 8 + ((CPT % 2 == 0) ? (SSR_SSIM_NT * CPT + 8) / CPT + 1 : 0);
-  static constexpr size_t bytes() { return sizeof(double) * (4 * PW + SSR_SSIM_NT + 16 + 8); }
-  double* col; double* sc0; double* sc1; double* res;
+  static constexpr int NQ = CONTIG ? 1 : 4;
+  static constexpr int RW = SSR_SSIM_NT * CPT + 8;
+  static constexpr size_t ring_bytes() { return CONTIG ? sizeof(float) * SSR_SSIM_WIN * RW : 0; }
+  static constexpr size_t bytes() { return ring_bytes() + sizeof(double) * (NQ * PW + SSR_SSIM_NT + 16 + 8); }
+  float* yring; double* col; double* sc0; double* sc1; double* res;
   SSR_MEMBER explicit SsrSsimLds(char* base) {
-    col = reinterpret_cast<double*>(base);
-    sc0 = col + 4 * PW;
+    yring = reinterpret_cast<float*>(base);
+    col = reinterpret_cast<double*>(base + ring_bytes());
+    sc0 = col + NQ * PW;
     sc1 = sc0 + SSR_SSIM_NT;
     res = sc1 + 16;
   }
 };
+
+// 16-byte slot of an LDS row (p 16-byte aligned)
+SSR_DEV void ssr_ld4(const float* p, float* o) {
+#ifdef SSR_HOST_EMU
+  memcpy(o, p, 16);
+#else
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 v = *reinterpret_cast<const f4*>(p);
+  o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+#endif
+}
+SSR_DEV void ssr_st4(float* p, const float* v) {
+#ifdef SSR_HOST_EMU
+  memcpy(p, v, 16);
+#else
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  *reinterpret_cast<f4*>(p) = f4{v[0], v[1], v[2], v[3]};
+#endif
+}
 
 // One [T, F] float32 image of the batch as the row loads see it.  Device: a raw buffer resource (scalar base +
 // scalar row offset + 32-bit lane offset in ONE instruction - the compiler otherwise keeps twenty per-lane 64-bit
@@ -122,15 +152,14 @@ SSR_DEV void ssr_ssim_row_load(const SsrSsimParams& p, SsrSsimRegs<CPT>& R, int 
     // (a quad past the strip's last column - narrow last strip - is clamped to the last aligned quad: never used, see apply)
     const int last4 = (ncol_in - 1) & ~3;
     const unsigned c4 = (unsigned)((4 * tid < last4) ? 4 * tid : last4);
-    // (the leaving x row comes from the thread's seven-row register ring: R.px[SET][2] is not loaded)
-    float q[4][4];
-    x.at4(ea, c4, q[0]); y.at4(ea, c4, q[1]); y.at4(es, c4, q[3]);
+    // (the leaving rows come from the rings - x: registers, y: LDS; R.px[SET][2..3] are not loaded)
+    float q[2][4];
+    x.at4(ea, c4, q[0]); y.at4(ea, c4, q[1]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { R.px[SET][0][i] = q[0][i]; R.px[SET][1][i] = q[1][i]; R.px[SET][3][i] = q[3][i]; }
+    for (int i = 0; i < 4; ++i) { R.px[SET][0][i] = q[0][i]; R.px[SET][1][i] = q[1][i]; }
     int ce = SSR_SSIM_NT * CPT + tid;
     if (ce >= ncol_in) ce = ncol_in - 1;
     R.px[SET][0][4] = x.at(ea, (unsigned)ce); R.px[SET][1][4] = y.at(ea, (unsigned)ce);
-    R.px[SET][3][4] = y.at(es, (unsigned)ce);
     return;
   }
 #pragma unroll
@@ -152,14 +181,40 @@ SSR_DEV void ssr_ssim_row_apply(SsrSsimRegs<CPT>& R, int tid, bool sub, int ncol
   for (int i = 0; i < VC; ++i) {
     if (ssr_ssim_col<CPT, CONTIG>(tid, i) < ncol_in) {
       const double a = (double)R.px[SET][0][i], b = (double)R.px[SET][1][i];
-      const double c = sub ? (double)(CONTIG ? R.ring[SLOT][i] : R.px[SET][2][i]) : 0.0, d = sub ? (double)R.px[SET][3][i] : 0.0;
+      const double c = sub ? (double)R.px[SET][2][i] : 0.0, d = sub ? (double)R.px[SET][3][i] : 0.0;
       // every product goes into its running sum with one fused multiply-add (10 operations per column instead of 13)
       R.cs[i][0] = (R.cs[i][0] + a) - c;
       R.cs[i][1] = (R.cs[i][1] + b) - d;
       R.cs[i][2] = fma(-d, d, fma(-c, c, fma(b, b, fma(a, a, R.cs[i][2]))));
       R.cs[i][3] = fma(-c, d, fma(a, b, R.cs[i][3]));
     }
-    if constexpr (CONTIG) R.ring[SLOT][i] = R.px[SET][0][i];    // the x row just added leaves seven steps from now (same slot)
+  }
+}
+
+// CONTIG row step: the entering row (R.px[SET][0..1], requested two steps ago) joins the running column sums and the row seven
+// steps older leaves them - its x pixels from the register ring, its y pixels from the LDS ring (`yrow`: the ring row of slot
+// step mod 7) - and takes their places in both rings.  No condition on the ring traffic: a thread past the strip's last column
+// moves clamped, never-used values, and threads without an extra column share one spare slot.
+template <int SET, int SLOT>
+SSR_DEV void ssr_ssim_row_apply_contig(SsrSsimRegs<4>& R, float* yrow, int tid, bool sub, int ncol_in) {
+  constexpr int CPT = 4, VC = CPT + 1;
+  float* own = yrow + CPT * tid;
+  float* ext = yrow + SSR_SSIM_NT * CPT + (tid < 7 ? tid : 7);
+  float d[VC];
+  ssr_ld4(own, d);
+  d[CPT] = *ext;
+  ssr_st4(own, R.px[SET][1]);
+  *ext = R.px[SET][1][CPT];
+  (void)ncol_in;     // (columns past the strip's end: the loads were clamped to valid pixels, their sums are formed and never used)
+#pragma unroll
+  for (int i = 0; i < VC; ++i) {
+    const double a = (double)R.px[SET][0][i], b = (double)R.px[SET][1][i];
+    const double c = sub ? (double)R.ring[SLOT][i] : 0.0, dd = sub ? (double)d[i] : 0.0;
+    R.cs[i][0] = (R.cs[i][0] + a) - c;
+    R.cs[i][1] = (R.cs[i][1] + b) - dd;
+    R.cs[i][2] = fma(-dd, dd, fma(-c, c, fma(b, b, fma(a, a, R.cs[i][2]))));
+    R.cs[i][3] = fma(-c, dd, fma(a, b, R.cs[i][3]));
+    R.ring[SLOT][i] = R.px[SET][0][i];
   }
 }
 
@@ -193,9 +248,10 @@ SSR_DEV double ssr_ssim_value(double sx, double sy, double sq, double sxy) {
 // CPT+6 column sums per quantity once and slides the 7-wide window across them.
 template <int CPT, bool CONTIG, typename BLK>
 SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item, char* lds_base) {
-  constexpr int NT = SSR_SSIM_NT, PW = SsrSsimLds<CPT>::PW, VC = CPT + 1, W = SSR_SSIM_WIN;
+  constexpr int NT = SSR_SSIM_NT, PW = SsrSsimLds<CPT, CONTIG>::PW, VC = CPT + 1, W = SSR_SSIM_WIN;
   using Regs = SsrSsimRegs<CPT>;
-  SsrSsimLds<CPT> L(lds_base);
+  using Lds = SsrSsimLds<CPT, CONTIG>;
+  Lds L(lds_base);
   const int row_tile = tile / p.n_strips, strip = tile % p.n_strips;
   const int T = p.n_rows[item];
   const int out_rows = T - (W - 1);
@@ -226,12 +282,12 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
 #endif
 #define SSR_SSIM_STEP(s_, SET, SLOT)                                                                                         \
   SSR_PHASE(blk, regs, {                                                                                                    \
-    ssr_ssim_row_apply<CPT, CONTIG, SET, SLOT>(R, tid, (s_) >= W, ncol_in);                                                  \
+    ssr_ssim_row_apply<CPT, false, SET, SLOT>(R, tid, (s_) >= W, ncol_in);                                                   \
     if ((s_) + 2 < n_steps && !SSR_SABL(4))                                                                                 \
-      ssr_ssim_row_load<CPT, CONTIG, SET>(p, R, tid, x, y, r0 + (s_) + 2, ((s_) + 2 >= W) ? r0 + (s_) + 2 - W : -1, c_in0, ncol_in); \
+      ssr_ssim_row_load<CPT, false, SET>(p, R, tid, x, y, r0 + (s_) + 2, ((s_) + 2 >= W) ? r0 + (s_) + 2 - W : -1, c_in0, ncol_in); \
     if ((s_) >= W - 1 && !SSR_SABL(2)) {                                                                                    \
       for (int i = 0; i < VC; ++i) {                                                                                        \
-        const int c = ssr_ssim_col<CPT, CONTIG>(tid, i);                                                                    \
+        const int c = ssr_ssim_col<CPT, false>(tid, i);                                                                     \
         if (c < ncol_in)                                                                                                    \
           for (int q = 0; q < 4; ++q) L.col[q * PW + ssr_ssim_slot<CPT>(c)] = R.cs[i][q];                                    \
       }                                                                                                                     \
@@ -247,7 +303,7 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
           for (int d = 0; d < CPT + W - 1; ++d) {                                                                           \
             int c = j0 + d;                                                                                                 \
             if (c >= ncol_in) c = ncol_in - 1;      /* only feeds outputs that are masked below */                          \
-            if ((CONTIG && d < CPT) || SSR_SABL(2)) v[d] = R.cs[d % VC][q];   /* the thread's own columns: already in its registers */ \
+            if (SSR_SABL(2)) v[d] = R.cs[d % VC][q];                                                                        \
             else v[d] = L.col[q * PW + ssr_ssim_slot<CPT>(c)];                                                              \
           }                                                                                                                 \
           double sw = v[0];                                                                                                 \
@@ -270,13 +326,51 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
     ssr_ssim_row_load<CPT, CONTIG, 0>(p, R, tid, x, y, r0, -1, c_in0, ncol_in);
     if (n_steps > 1) ssr_ssim_row_load<CPT, CONTIG, 1>(p, R, tid, x, y, r0 + 1, -1, c_in0, ncol_in);
   });
-  if constexpr (CONTIG) {          // ring slot = step mod 7, prefetch set = step mod 2: fourteen steps per trip, all indices static
+  if constexpr (CONTIG) {
+    // One wave per workgroup and every hand-off inside it: wave-scope phases (no s_waitcnt lgkmcnt(0) at the boundaries).  The
+    // column sums cross the lanes one quantity at a time through the single L.col array.
+#define SSR_SSIM_STEP_C(s_, SET, SLOT)                                                                                       \
+    SSR_WPHASE(blk, regs, {                                                                                                  \
+      ssr_ssim_row_apply_contig<SET, SLOT>(R, L.yring + (SLOT) * Lds::RW, tid, (s_) >= W, ncol_in);                           \
+      if ((s_) + 2 < n_steps && !SSR_SABL(4))                                                                                \
+        ssr_ssim_row_load<CPT, true, SET>(p, R, tid, x, y, r0 + (s_) + 2, -1, c_in0, ncol_in);                               \
+    });                                                                                                                      \
+    if ((s_) >= W - 1) {                                                                                                     \
+      SSR_UNROLL for (int q = 0; q < 4; ++q) {                                                                               \
+        SSR_WPHASE(blk, regs, {             /* every lane publishes: columns past the strip's end carry finite, unused sums */ \
+          SSR_UNROLL for (int i = 0; i < CPT; ++i) L.col[ssr_ssim_slot<CPT>(CPT * tid + i)] = R.cs[i][q];                    \
+          L.col[ssr_ssim_slot<CPT>(NT * CPT + (tid < 7 ? tid : 7))] = R.cs[CPT][q];                                          \
+        });                                                                                                                  \
+        SSR_WPHASE(blk, regs, {                                                                                              \
+          double v[CPT + W - 1];                                                                                             \
+          SSR_UNROLL for (int d = 0; d < CPT + W - 1; ++d)                                                                   \
+            v[d] = (d < CPT) ? R.cs[d < CPT ? d : 0][q]    /* the thread's own columns: already in its registers */         \
+                             : L.col[ssr_ssim_slot<CPT>(CPT * tid + d)];                                                     \
+          double sw = v[0];                                                                                                  \
+          SSR_UNROLL for (int d = 1; d < W; ++d) sw += v[d];                                                                 \
+          R.w[q][0] = sw;                                                                                                    \
+          SSR_UNROLL for (int i = 1; i < CPT; ++i) {                                                                         \
+            sw += v[i + W - 1] - v[i - 1];                                                                                   \
+            R.w[q][i] = sw;                                                                                                  \
+          }                                                                                                                  \
+        });                                                                                                                  \
+      }                                                                                                                      \
+      SSR_WPHASE(blk, regs, {                                                                                                \
+        const int j0 = tid * CPT;                                                                                            \
+        SSR_UNROLL for (int i = 0; i < CPT; ++i) {                                                                           \
+          const double sv = ssr_ssim_value(R.w[0][i], R.w[1][i], R.w[2][i], R.w[3][i]);                                      \
+          R.s += (j0 + i < ncol_out) ? sv : 0.0;                                                                             \
+        }                                                                                                                    \
+      });                                                                                                                    \
+    }
+    // ring slot = step mod 7, prefetch set = step mod 2: fourteen steps per trip, all indices static
     for (int s0 = 0; s0 < n_steps; s0 += 14) {
-#define SSR_SSIM_STEP_K(k) if (s0 + (k) < n_steps) { SSR_SSIM_STEP(s0 + (k), (k) % 2, (k) % 7) }
+#define SSR_SSIM_STEP_K(k) if (s0 + (k) < n_steps) { SSR_SSIM_STEP_C(s0 + (k), (k) % 2, (k) % 7) }
       SSR_SSIM_STEP_K(0) SSR_SSIM_STEP_K(1) SSR_SSIM_STEP_K(2) SSR_SSIM_STEP_K(3) SSR_SSIM_STEP_K(4) SSR_SSIM_STEP_K(5) SSR_SSIM_STEP_K(6)
       SSR_SSIM_STEP_K(7) SSR_SSIM_STEP_K(8) SSR_SSIM_STEP_K(9) SSR_SSIM_STEP_K(10) SSR_SSIM_STEP_K(11) SSR_SSIM_STEP_K(12) SSR_SSIM_STEP_K(13)
 #undef SSR_SSIM_STEP_K
     }
+#undef SSR_SSIM_STEP_C
   } else {
     for (int s0 = 0; s0 < n_steps; s0 += 2) {
       SSR_SSIM_STEP(s0, 0, 0)

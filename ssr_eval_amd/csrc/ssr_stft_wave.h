@@ -21,23 +21,7 @@
 #pragma once
 #include "ssr_stft.h"
 
-#ifdef SSR_HOST_EMU
-#define SSR_WPHASE SSR_PHASE
-#else
-// wave-scope ordering point: constrains the compiler, emits nothing (same-wave LDS traffic is ordered by the hardware)
-#define SSR_WAVE_SYNC()                                             \
-  do {                                                              \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          \
-    __builtin_amdgcn_wave_barrier();                                \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");          \
-  } while (0)
-#define SSR_WPHASE(blk, regs, ...)                                   \
-  {                                                                  \
-    const int tid = (blk).tid; auto& R = (regs); (void)R; (void)tid; \
-    __VA_ARGS__;                                                     \
-  }                                                                  \
-  SSR_WAVE_SYNC();
-#endif
+// (SSR_WPHASE / SSR_WAVE_SYNC: ssr_block.h)
 
 // Developer build (-DSSR_PHASE_CLOCKS): shader-clock stamps at the phase boundaries of k_stft_wave's frame loop, summed per
 // launch (tu_stft.inc prints them).  SSR_CLK(i) is empty everywhere else.

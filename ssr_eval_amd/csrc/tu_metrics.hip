@@ -92,7 +92,7 @@ template <int CPT, bool CONTIG = false> static int launch_ssim_inst(const SsrSsi
 #else
   const size_t extra = 0;
 #endif
-  const size_t lds = SsrSsimLds<CPT>::bytes() + extra;
+  const size_t lds = SsrSsimLds<CPT, CONTIG>::bytes() + extra;
   static thread_local SsrLdsSlot slot;
   if (int rc = ssr_allow_lds((const void*)k_ssim<CPT, CONTIG>, lds, &slot)) return rc;
   hipLaunchKernelGGL((k_ssim<CPT, CONTIG>), dim3(grid), dim3(SSR_SSIM_NT), lds, s, p);

@@ -223,7 +223,7 @@ static void run_ssim(const SsrSsimParams& p, int n_items) {
   SsrBlk blk{SSR_SSIM_NT};
   for (int item = 0; item < n_items; ++item)
     for (int t = 0; t < p.n_row_tiles * p.n_strips; ++t) {
-      auto lds = poisoned(SsrSsimLds<CPT>::bytes());
+      auto lds = poisoned(SsrSsimLds<CPT, CONTIG>::bytes());
       ssr_ssim_body<CPT, CONTIG>(p, blk, t, item, lds.data());
     }
 }

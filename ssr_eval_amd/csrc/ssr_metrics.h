@@ -53,7 +53,8 @@ template <int CPT> struct SsrSsimRegs {
                                        // not fetched again.  The y pixels of those rows sit in an LDS ring (SsrSsimLds::yring):
                                        // a second REGISTER ring is 172 VGPRs -> two waves per SIMD, or spills at three (round 2:
                                        // all measured slower than fetching y's leaving row again).
-  double w[4][CPT];       // CONTIG: the window sums of the thread's outputs, formed one quantity at a time
+  double pxy[CPT], pb[CPT];   // CONTIG: the SSIM expression of the thread's outputs while the window sums arrive one quantity at a
+                              // time (pxy: sx, then sx sy; pb: sx^2 + sy^2, then b1 b2 - ssr_ssim_stage1..3)
 };
 
 // Column-sum index in LDS.  The horizontal pass reads with a lane stride of CPT doubles; for even CPT that is a
@@ -194,9 +195,10 @@ SSR_DEV void ssr_ssim_row_apply(SsrSsimRegs<CPT>& R, int tid, bool sub, int ncol
 // CONTIG row step: the entering row (R.px[SET][0..1], requested two steps ago) joins the running column sums and the row seven
 // steps older leaves them - its x pixels from the register ring, its y pixels from the LDS ring (`yrow`: the ring row of slot
 // step mod 7) - and takes their places in both rings.  No condition on the ring traffic: a thread past the strip's last column
-// moves clamped, never-used values, and threads without an extra column share one spare slot.
+// moves clamped, never-used values, and threads without an extra column share one spare slot.  No condition on "is there a leaving
+// row yet" either: both rings start as zeros, and subtracting a zero row changes no bit of the sums.
 template <int SET, int SLOT>
-SSR_DEV void ssr_ssim_row_apply_contig(SsrSsimRegs<4>& R, float* yrow, int tid, bool sub, int ncol_in) {
+SSR_DEV void ssr_ssim_row_apply_contig(SsrSsimRegs<4>& R, float* yrow, int tid) {
   constexpr int CPT = 4, VC = CPT + 1;
   float* own = yrow + CPT * tid;
   float* ext = yrow + SSR_SSIM_NT * CPT + (tid < 7 ? tid : 7);
@@ -205,11 +207,11 @@ SSR_DEV void ssr_ssim_row_apply_contig(SsrSsimRegs<4>& R, float* yrow, int tid, 
   d[CPT] = *ext;
   ssr_st4(own, R.px[SET][1]);
   *ext = R.px[SET][1][CPT];
-  (void)ncol_in;     // (columns past the strip's end: the loads were clamped to valid pixels, their sums are formed and never used)
+  // (columns past the strip's end: the loads were clamped to valid pixels, their sums are formed and never used)
 #pragma unroll
   for (int i = 0; i < VC; ++i) {
     const double a = (double)R.px[SET][0][i], b = (double)R.px[SET][1][i];
-    const double c = sub ? (double)R.ring[SLOT][i] : 0.0, dd = sub ? (double)d[i] : 0.0;
+    const double c = (double)R.ring[SLOT][i], dd = (double)d[i];
     R.cs[i][0] = (R.cs[i][0] + a) - c;
     R.cs[i][1] = (R.cs[i][1] + b) - dd;
     R.cs[i][2] = fma(-dd, dd, fma(-c, c, fma(b, b, fma(a, a, R.cs[i][2]))));
@@ -224,22 +226,34 @@ SSR_DEV void ssr_ssim_row_apply_contig(SsrSsimRegs<4>& R, float* yrow, int tid, 
 //   A2 = 2 cov (uxy - ux uy) + C2 -> 2 cov (n sxy - sx sy) + C2 n^2
 //   B1 = ux^2 + uy^2 + C1       -> sx^2 + sy^2 + C1 n^2
 //   B2 = cov (uxx - ux^2 + uyy - uy^2) + C2 -> cov (n sq - (sx^2 + sy^2)) + C2 n^2
-SSR_DEV double ssr_ssim_value(double sx, double sy, double sq, double sxy) {
-  const double n = 49.0, cov = 49.0 / 48.0;
-  const double C1n = (0.01 * 2.0) * (0.01 * 2.0) * n * n, C2n = (0.03 * 2.0) * (0.03 * 2.0) * n * n;
-  const double pxy = sx * sy, pp = sx * sx + sy * sy;
-  const double a1 = 2.0 * pxy + C1n;
-  const double a2 = (2.0 * cov) * (n * sxy - pxy) + C2n;
-  const double b1 = pp + C1n;
-  const double b2 = cov * (n * sq - pp) + C2n;
+// (in three stages, so that a caller which forms the window sums one quantity at a time can fold each into the expression as soon
+// as it exists: two live values per output instead of four)
+struct SsrSsimK {
+  static constexpr double n = 49.0, cov = 49.0 / 48.0;
+  static constexpr double C1n = (0.01 * 2.0) * (0.01 * 2.0) * n * n, C2n = (0.03 * 2.0) * (0.03 * 2.0) * n * n;
+};
+SSR_DEV void ssr_ssim_stage1(double sx, double sy, double& pxy, double& pp) { pxy = sx * sy; pp = sx * sx + sy * sy; }
+SSR_DEV double ssr_ssim_stage2(double pp, double sq) {                        // b1 * b2
+  const double b1 = pp + SsrSsimK::C1n;
+  const double b2 = SsrSsimK::cov * (SsrSsimK::n * sq - pp) + SsrSsimK::C2n;
+  return b1 * b2;
+}
+SSR_DEV float ssr_ssim_stage3f(double pxy, double sxy, double b12) {
+  const double a1 = 2.0 * pxy + SsrSsimK::C1n;
+  const double a2 = (2.0 * SsrSsimK::cov) * (SsrSsimK::n * sxy - pxy) + SsrSsimK::C2n;
   // The ratio (a1 a2) / (b1 b2) is O(1) and carries no cancellation any more, so it is formed in float32 with the hardware
   // reciprocal (v_rcp_f32, 1 ulp): ~2e-7 per pixel, unbiased, against a 1e-5 bar on the MEAN of ~4e5 pixels (measured on the
   // test vectors: < 2e-7 on the mean).  All moment arithmetic above (where the cancellation lives) stays in float64.
 #ifndef SSR_HOST_EMU
-  return (double)((float)(a1 * a2) * __builtin_amdgcn_rcpf((float)(b1 * b2)));       // one reciprocal for both ratios
+  return (float)(a1 * a2) * __builtin_amdgcn_rcpf((float)b12);                        // one reciprocal for both ratios
 #else
-  return (double)((float)(a1 * a2) / (float)(b1 * b2));
+  return (float)(a1 * a2) / (float)b12;
 #endif
+}
+SSR_DEV double ssr_ssim_value(double sx, double sy, double sq, double sxy) {
+  double pxy, pp;
+  ssr_ssim_stage1(sx, sy, pxy, pp);
+  return (double)ssr_ssim_stage3f(pxy, sxy, ssr_ssim_stage2(pp, sq));
 }
 
 // grid = (n_row_tiles * n_strips, n_items); block = SSR_SSIM_NT.
@@ -323,6 +337,14 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
     for (int i = 0; i < VC; ++i)
       for (int q = 0; q < 4; ++q) R.cs[i][q] = 0.0;
     R.s = 0.0;
+    if constexpr (CONTIG) {                                     // both seven-row rings start as zero rows
+      const float z4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      for (int k = 0; k < W; ++k) {
+        for (int i = 0; i < VC; ++i) R.ring[k][i] = 0.0f;
+        ssr_st4(L.yring + k * Lds::RW + CPT * tid, z4);
+        L.yring[k * Lds::RW + NT * CPT + (tid & 7)] = 0.0f;
+      }
+    }
     ssr_ssim_row_load<CPT, CONTIG, 0>(p, R, tid, x, y, r0, -1, c_in0, ncol_in);
     if (n_steps > 1) ssr_ssim_row_load<CPT, CONTIG, 1>(p, R, tid, x, y, r0 + 1, -1, c_in0, ncol_in);
   });
@@ -331,7 +353,7 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
     // column sums cross the lanes one quantity at a time through the single L.col array.
 #define SSR_SSIM_STEP_C(s_, SET, SLOT)                                                                                       \
     SSR_WPHASE(blk, regs, {                                                                                                  \
-      ssr_ssim_row_apply_contig<SET, SLOT>(R, L.yring + (SLOT) * Lds::RW, tid, (s_) >= W, ncol_in);                           \
+      ssr_ssim_row_apply_contig<SET, SLOT>(R, L.yring + (SLOT) * Lds::RW, tid);                                              \
       if ((s_) + 2 < n_steps && !SSR_SABL(4))                                                                                \
         ssr_ssim_row_load<CPT, true, SET>(p, R, tid, x, y, r0 + (s_) + 2, -1, c_in0, ncol_in);                               \
     });                                                                                                                      \
@@ -348,20 +370,29 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
                              : L.col[ssr_ssim_slot<CPT>(CPT * tid + d)];                                                     \
           double sw = v[0];                                                                                                  \
           SSR_UNROLL for (int d = 1; d < W; ++d) sw += v[d];                                                                 \
-          R.w[q][0] = sw;                                                                                                    \
+          double wq[CPT];                                                                                                    \
+          wq[0] = sw;                                                                                                        \
           SSR_UNROLL for (int i = 1; i < CPT; ++i) {                                                                         \
             sw += v[i + W - 1] - v[i - 1];                                                                                   \
-            R.w[q][i] = sw;                                                                                                  \
+            wq[i] = sw;                                                                                                      \
           }                                                                                                                  \
+          /* fold the quantity into the SSIM expression at once (ssr_ssim_value's stages): two live values per output.       \
+             The thread's four float32 values of a row are added in float32 (values in [-1, 1]: 1e-7 per row, unbiased,    \
+             against the 1e-5 bar on the mean) and join the float64 sum once. */                                             \
+          const int j0 = tid * CPT;                                                                                          \
+          float row_s = 0.0f;                                                                                                \
+          SSR_UNROLL for (int i = 0; i < CPT; ++i) {                                                                         \
+            if (q == 0) R.pxy[i] = wq[i];                                                                                    \
+            if (q == 1) { const double sx = R.pxy[i]; ssr_ssim_stage1(sx, wq[i], R.pxy[i], R.pb[i]); }                       \
+            if (q == 2) R.pb[i] = ssr_ssim_stage2(R.pb[i], wq[i]);                                                           \
+            if (q == 3) {                                                                                                    \
+              const float sv = ssr_ssim_stage3f(R.pxy[i], wq[i], R.pb[i]);                                                   \
+              row_s += (j0 + i < ncol_out) ? sv : 0.0f;                                                                      \
+            }                                                                                                                \
+          }                                                                                                                  \
+          if (q == 3) R.s += (double)row_s;                                                                                  \
         });                                                                                                                  \
       }                                                                                                                      \
-      SSR_WPHASE(blk, regs, {                                                                                                \
-        const int j0 = tid * CPT;                                                                                            \
-        SSR_UNROLL for (int i = 0; i < CPT; ++i) {                                                                           \
-          const double sv = ssr_ssim_value(R.w[0][i], R.w[1][i], R.w[2][i], R.w[3][i]);                                      \
-          R.s += (j0 + i < ncol_out) ? sv : 0.0;                                                                             \
-        }                                                                                                                    \
-      });                                                                                                                    \
     }
     // ring slot = step mod 7, prefetch set = step mod 2: fourteen steps per trip, all indices static
     for (int s0 = 0; s0 < n_steps; s0 += 14) {

@@ -97,7 +97,9 @@ def test_ssim_contiguous_columns_variant(shape):
     out_c, out_s = E.finalize(None, sp_c, T, shape[1], 8), E.finalize(None, sp_s, T, shape[1], 8)
     for i in range(2):
         assert abs(out_c[i, 3] - ossim.structural_similarity(xs[i], ys[i])) < 2e-7
-        assert abs(out_c[i, 3] - out_s[i, 3]) < 1e-12                   # the same sums in a different order
+        # the same float64 moments; this variant adds a thread's four float32 SSIM values of a row in float32 before they join the
+        # float64 sum (<= 6e-8 worst case on the mean, ~1e-10 observed)
+        assert abs(out_c[i, 3] - out_s[i, 3]) < 5e-9
 
 
 def test_fft_lowpass_and_istft(golden):

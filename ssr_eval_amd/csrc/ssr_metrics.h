@@ -54,7 +54,7 @@ template <int CPT> struct SsrSsimRegs {
                                        // a second REGISTER ring is 172 VGPRs -> two waves per SIMD, or spills at three (round 2:
                                        // all measured slower than fetching y's leaving row again).
   double pxy[CPT], pb[CPT];   // CONTIG: the SSIM expression of the thread's outputs while the window sums arrive one quantity at a
-                              // time (pxy: sx, then sx sy; pb: sx^2 + sy^2, then b1 b2 - ssr_ssim_stage1..3)
+  float den[CPT];             // time (pxy: sx, then sx sy; pb: sx^2 + sy^2; den: b1 b2 - ssr_ssim_stage1..3)
 };
 
 // Column-sum index in LDS.  The horizontal pass reads with a lane stride of CPT doubles; for even CPT that is a
@@ -226,34 +226,39 @@ SSR_DEV void ssr_ssim_row_apply_contig(SsrSsimRegs<4>& R, float* yrow, int tid) 
 //   A2 = 2 cov (uxy - ux uy) + C2 -> 2 cov (n sxy - sx sy) + C2 n^2
 //   B1 = ux^2 + uy^2 + C1       -> sx^2 + sy^2 + C1 n^2
 //   B2 = cov (uxx - ux^2 + uyy - uy^2) + C2 -> cov (n sq - (sx^2 + sy^2)) + C2 n^2
-// (in three stages, so that a caller which forms the window sums one quantity at a time can fold each into the expression as soon
-// as it exists: two live values per output instead of four)
+// Evaluated in three stages, so that a caller which forms the window sums one quantity at a time can fold each into the expression
+// as soon as it exists (two live values per output instead of four).  float64 exactly where the cancellation lives - the products
+// sx sy, sx^2 + sy^2 and the two differences n sxy - sx sy, n sq - (sx^2 + sy^2) - and float32 for everything after it: the four
+// factors are sums of positive terms of O(1) relative accuracy 6e-8, the ratio is formed with the hardware reciprocal
+// (v_rcp_f32, 1 ulp).  ~3e-7 per pixel, unbiased, against a 1e-5 bar on the MEAN of ~4e5 pixels (measured on the test vectors:
+// < 2e-7 on the mean).  Round 3 moved the factors a1, a2, b1, b2 themselves to float32 (they were float64 up to the two
+// products a1 a2 and b1 b2): 5 float64 operations per output instead of 10 - the kernel's time follows its FP64 operation count.
 struct SsrSsimK {
-  static constexpr double n = 49.0, cov = 49.0 / 48.0;
-  static constexpr double C1n = (0.01 * 2.0) * (0.01 * 2.0) * n * n, C2n = (0.03 * 2.0) * (0.03 * 2.0) * n * n;
+  static constexpr double n = 49.0;
+  static constexpr float cov = (float)(49.0 / 48.0);
+  static constexpr float C1n = (float)((0.01 * 2.0) * (0.01 * 2.0) * 49.0 * 49.0), C2n = (float)((0.03 * 2.0) * (0.03 * 2.0) * 49.0 * 49.0);
 };
-SSR_DEV void ssr_ssim_stage1(double sx, double sy, double& pxy, double& pp) { pxy = sx * sy; pp = sx * sx + sy * sy; }
-SSR_DEV double ssr_ssim_stage2(double pp, double sq) {                        // b1 * b2
-  const double b1 = pp + SsrSsimK::C1n;
-  const double b2 = SsrSsimK::cov * (SsrSsimK::n * sq - pp) + SsrSsimK::C2n;
+SSR_DEV void ssr_ssim_stage1(double sx, double sy, double& pxy, double& pp) { pxy = sx * sy; pp = fma(sx, sx, sy * sy); }
+SSR_DEV float ssr_ssim_stage2f(double pp, double sq) {                       // b1 * b2
+  const double t2 = fma(SsrSsimK::n, sq, -pp);
+  const float b1 = (float)pp + SsrSsimK::C1n;
+  const float b2 = fmaf(SsrSsimK::cov, (float)t2, SsrSsimK::C2n);
   return b1 * b2;
 }
-SSR_DEV float ssr_ssim_stage3f(double pxy, double sxy, double b12) {
-  const double a1 = 2.0 * pxy + SsrSsimK::C1n;
-  const double a2 = (2.0 * SsrSsimK::cov) * (SsrSsimK::n * sxy - pxy) + SsrSsimK::C2n;
-  // The ratio (a1 a2) / (b1 b2) is O(1) and carries no cancellation any more, so it is formed in float32 with the hardware
-  // reciprocal (v_rcp_f32, 1 ulp): ~2e-7 per pixel, unbiased, against a 1e-5 bar on the MEAN of ~4e5 pixels (measured on the
-  // test vectors: < 2e-7 on the mean).  All moment arithmetic above (where the cancellation lives) stays in float64.
+SSR_DEV float ssr_ssim_stage3f(double pxy, double sxy, float b12) {
+  const double t1 = fma(SsrSsimK::n, sxy, -pxy);
+  const float a1 = fmaf(2.0f, (float)pxy, SsrSsimK::C1n);
+  const float a2 = fmaf(2.0f * SsrSsimK::cov, (float)t1, SsrSsimK::C2n);
 #ifndef SSR_HOST_EMU
-  return (float)(a1 * a2) * __builtin_amdgcn_rcpf((float)b12);                        // one reciprocal for both ratios
+  return (a1 * a2) * __builtin_amdgcn_rcpf(b12);                                      // one reciprocal for both ratios
 #else
-  return (float)(a1 * a2) / (float)b12;
+  return (a1 * a2) / b12;
 #endif
 }
 SSR_DEV double ssr_ssim_value(double sx, double sy, double sq, double sxy) {
   double pxy, pp;
   ssr_ssim_stage1(sx, sy, pxy, pp);
-  return (double)ssr_ssim_stage3f(pxy, sxy, ssr_ssim_stage2(pp, sq));
+  return (double)ssr_ssim_stage3f(pxy, sxy, ssr_ssim_stage2f(pp, sq));
 }
 
 // grid = (n_row_tiles * n_strips, n_items); block = SSR_SSIM_NT.
@@ -368,14 +373,11 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
           SSR_UNROLL for (int d = 0; d < CPT + W - 1; ++d)                                                                   \
             v[d] = (d < CPT) ? R.cs[d < CPT ? d : 0][q]    /* the thread's own columns: already in its registers */         \
                              : L.col[ssr_ssim_slot<CPT>(CPT * tid + d)];                                                     \
-          double sw = v[0];                                                                                                  \
-          SSR_UNROLL for (int d = 1; d < W; ++d) sw += v[d];                                                                 \
-          double wq[CPT];                                                                                                    \
-          wq[0] = sw;                                                                                                        \
-          SSR_UNROLL for (int i = 1; i < CPT; ++i) {                                                                         \
-            sw += v[i + W - 1] - v[i - 1];                                                                                   \
-            wq[i] = sw;                                                                                                      \
-          }                                                                                                                  \
+          /* four 7-wide windows over ten column sums: the shared core v3..v6, then v1 + v2 and v7 + v8 (11 additions) */   \
+          static_assert(CPT == 4 && W == 7, "window tree of the CONTIG variant");                                            \
+          const double core = (v[3] + v[4]) + (v[5] + v[6]);                                                                 \
+          const double wa = core + (v[1] + v[2]), wb = core + (v[7] + v[8]);                                                 \
+          const double wq[CPT] = {wa + v[0], wa + v[7], wb + v[2], wb + v[9]};                                               \
           /* fold the quantity into the SSIM expression at once (ssr_ssim_value's stages): two live values per output.       \
              The thread's four float32 values of a row are added in float32 (values in [-1, 1]: 1e-7 per row, unbiased,    \
              against the 1e-5 bar on the mean) and join the float64 sum once. */                                             \
@@ -384,9 +386,9 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
           SSR_UNROLL for (int i = 0; i < CPT; ++i) {                                                                         \
             if (q == 0) R.pxy[i] = wq[i];                                                                                    \
             if (q == 1) { const double sx = R.pxy[i]; ssr_ssim_stage1(sx, wq[i], R.pxy[i], R.pb[i]); }                       \
-            if (q == 2) R.pb[i] = ssr_ssim_stage2(R.pb[i], wq[i]);                                                           \
+            if (q == 2) R.den[i] = ssr_ssim_stage2f(R.pb[i], wq[i]);                                                         \
             if (q == 3) {                                                                                                    \
-              const float sv = ssr_ssim_stage3f(R.pxy[i], wq[i], R.pb[i]);                                                   \
+              const float sv = ssr_ssim_stage3f(R.pxy[i], wq[i], R.den[i]);                                                  \
               row_s += (j0 + i < ncol_out) ? sv : 0.0f;                                                                      \
             }                                                                                                                \
           }                                                                                                                  \

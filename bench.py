@@ -129,7 +129,8 @@ class Cfg2:
         return {"workload": "cfg-2: %d synthetic 48 kHz 4 s float32 (est, target) pairs per GPU resident in HBM, STFT n_fft=2048 "
                             "hop=512 (T=376, F=1025), LSD + SSIM, transform precision %s" % (a.pairs, a.precision),
                 "pairs_per_gpu": a.pairs, "samples_per_utterance": N_SAMPLES, "n_fft": N_FFT, "hop": HOP,
-                "parallelism": "utterance-sharded x%d, one float64 all-reduce (24 B) per step" % world}
+                "parallelism": "utterance-sharded x%d, one float64 all-reduce (24 B) per step%s"
+                               % (world, ", issued asynchronously: it overlaps the next step's kernels" if world > 1 else "")}
 
     def report(self, a):
         B, batch, mask = self.B, self.batch, self.mask
@@ -782,19 +783,35 @@ def run(a):
 
     def timed(w, steps, warmup):
         """`warmup` untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; MAX over ranks."""
+        # The step's one collective (a few dozen bytes of float64 sums) is issued asynchronously on RCCL's own stream against a
+        # private copy of the sums, so the kernels of step k + 1 run under the all-reduce of step k; a reduction is waited for two
+        # steps later, and every one of them before the closing synchronize - the timed region contains all K collectives.
+        overlap = world > 1 and not getattr(w, "own_collectives", False)
+        pending = []
+
         def step():
             agg = w.step()
-            if world > 1 and not getattr(w, "own_collectives", False):
-                dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+            if overlap:
+                red = agg.clone()
+                pending.append((dist.all_reduce(red, op=dist.ReduceOp.SUM, async_op=True), red))
+                if len(pending) > 2:
+                    pending.pop(0)[0].wait()
+                return red
             return agg
+
+        def drain():
+            while pending:
+                pending.pop(0)[0].wait()
         for _ in range(warmup):
             step()
+        drain()
         sync()
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             agg = step()
+        drain()
         sync()
         if world > 1:
             dist.barrier()

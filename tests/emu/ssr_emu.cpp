@@ -18,6 +18,7 @@
 #include "../../ssr_eval_amd/csrc/ssr_lowpass_wave.h"
 #include "../../ssr_eval_amd/csrc/ssr_lowpass_group.h"
 #include "../../ssr_eval_amd/csrc/ssr_stft_rn_wave.h"
+#include "../../ssr_eval_amd/csrc/ssr_stft_r3_rot.h"
 #include "../../ssr_eval_amd/csrc/ssr_tables.h"
 
 static std::vector<char> poisoned(size_t bytes) { return std::vector<char>(bytes + 64, (char)0xFF); }
@@ -165,7 +166,19 @@ static void emu_rn_wave_run(const SsrStftParams<T>& p, int n_items, int n_chunks
       else ssr_stft_rn_wave_body<T, false, NW, NQ, P>(p, blk, c, item, lds.data());
     }
 }
-// m1536: 1 = what the product picks (M = 1536 for q <= 768), 0 = force the 2048-point transforms
+// n_fft = 3 q, q <= 768: four waves rotating through the sub-sequence transforms (ssr_stft_r3_rot.h) - the product's kernel for 2229
+template <typename T>
+static void emu_r3_rot_run(const SsrStftParams<T>& p, int n_items, int n_chunks, bool sums) {
+  SsrBlk blk{64 * SSR_R3ROT_WAVES};
+  for (int item = 0; item < n_items; ++item)
+    for (int c = 0; c < n_chunks; ++c) {
+      auto lds = poisoned(SsrR3RotLds<T, 24>::bytes(p.n_fft / 3));
+      if (sums) ssr_stft_r3_rot_body<T, true, 3, 24>(p, blk, c, item, lds.data());
+      else ssr_stft_r3_rot_body<T, false, 3, 24>(p, blk, c, item, lds.data());
+    }
+}
+// m1536: 1 = what the product picks (M = 1536 for q <= 768; radix 3: the rotating four-wave kernel), 0 = force the 2048-point
+// transforms, 2 = M = 1536 on the three-wave workgroups (radix 3 only differs)
 template <typename T>
 static int emu_stft_r3_wave_t(int n_fft, int hop, int out_kind, int mask, int m1536, const float* a, const float* b, const int64_t* a_off,
                               const int64_t* b_off, const int32_t* len, const int64_t* frame_off, int n_items,
@@ -188,7 +201,8 @@ static int emu_stft_r3_wave_t(int n_fft, int hop, int out_kind, int mask, int m1
   if (we.m == SSR_W24_N) {
     if (we.radix == 1) emu_rn_wave_run<T, 1, 3, 24>(p, n_items, n_chunks, sums);
     else if (we.radix == 2) emu_rn_wave_run<T, 2, 3, 24>(p, n_items, n_chunks, sums);
-    else emu_rn_wave_run<T, 3, 3, 24>(p, n_items, n_chunks, sums);
+    else if (m1536 == 2) emu_rn_wave_run<T, 3, 3, 24>(p, n_items, n_chunks, sums);
+    else emu_r3_rot_run<T>(p, n_items, n_chunks, sums);
     return 24;
   }
   if (we.radix == 1) { if (wide) emu_rn_wave_run<T, 1, 4, 32>(p, n_items, n_chunks, sums); else emu_rn_wave_run<T, 1, 3, 32>(p, n_items, n_chunks, sums); }

@@ -474,7 +474,9 @@ def test_radix_n_wave_engine_matches_oracle_and_block_engine(n_fft, hop):
     es[3][1000:5500] = 0.0
     # "r3": the product's choice - 1536-point transforms (24 points per lane, ssr_fft24.h) where q <= 768, i.e. every
     # AudioMetrics size; "r3_2048": the 2048-point transforms forced (what sizes with q > 768 run)
-    for wave in ("r3", "r3_2048"):
+    # "r3_three" (n_fft = 3 q only): M = 1536 on three-wave workgroups - "r3" runs those sizes on the rotating four-wave kernel
+    # (ssr_stft_r3_rot.h: job j = (unit j / 3, sub-sequence j mod 3) on wave j mod 4; chunks of 3 and 5 units end mid-rotation)
+    for wave in ("r3", "r3_2048") + (("r3_three",) if n_fft % 3 == 0 and n_fft // 3 <= 768 else ()):
         mags_e, mags_t, _ = E.stft(es, tg, n_fft, hop, 1, 0, 1, 15, 3, wave=wave)
         for x, m in zip(es + tg, mags_e + mags_t):
             ref = ostft.stft_mag_TF(x, n_fft, hop)
@@ -489,6 +491,10 @@ def test_radix_n_wave_engine_matches_oracle_and_block_engine(n_fft, hop):
             np.testing.assert_allclose(g, b, rtol=1e-7)
         lsd_only = E.pair_metrics(es, tg, n_fft, hop, 1, mask=E.M_LSD | E.M_SSIM, wave=wave, units_per_chunk=5)
         np.testing.assert_allclose(lsd_only[:, [0, 3]], got[:, [0, 3]], rtol=1e-12)
+        if wave == "r3" and n_fft % 3 == 0:                     # every phase of the rotation at a chunk's end: 1, 2, 4, 7 units
+            for upc in (1, 2, 4, 7):
+                g2 = E.pair_metrics(es, tg, n_fft, hop, 1, wave=wave, units_per_chunk=upc)
+                np.testing.assert_allclose(g2, got, rtol=1e-12)
     if n_fft in (1486, 743):                                   # the float32-transform instantiation: magnitudes to float32 accuracy
         m32, _, _ = E.stft(es[:1], tg[:1], n_fft, hop, 0, 0, 1, 15, 3, wave="r3")
         ref = ostft.stft_mag_TF(es[0], n_fft, hop)

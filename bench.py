@@ -630,11 +630,11 @@ def side_figures(a, dev):
         mask = B.M_LSD | B.M_SSIM
         ms = event_time_ms(lambda: b2.run(mask), 3)
         ms_stft = event_time_ms(lambda: b2.run(mask, stages=1), 3)
-        return {"workload": "AudioMetrics(48000) sizes: n_fft 2229 (radix-3 x Bluestein-743, M = 2048, three autonomous waves per frame pair) / hop 480, %d pairs of 4 s @ 48 kHz, "
+        return {"workload": "AudioMetrics(48000) sizes: n_fft 2229 (radix-3 x Bluestein-743 over 1536-point transforms; four autonomous waves rotate through the sub-sequence transforms of consecutive frames) / hop 480, %d pairs of 4 s @ 48 kHz, "
                             "LSD + SSIM" % nb,
                 "pairs_per_s": round(nb / (ms * 1e-3), 1),
-                "roofline": hbm_roofline("ssr_stft_pair(k_stft_rn_wave<3>)", (2 * N_SAMPLES * 4 + 32) * nb, ms_stft,
-                                         "k_stft_rn_wave<double, false, 3" if nb == 1024 and a.precision == "f64" else None),
+                "roofline": hbm_roofline("ssr_stft_pair(k_stft_r3_rot)", (2 * N_SAMPLES * 4 + 32) * nb, ms_stft,
+                                         "k_stft_r3_rot<double, false" if nb == 1024 and a.precision == "f64" else None),
                 "note": "side figure: average of 3 launches in one short run"}
 
     def rates():

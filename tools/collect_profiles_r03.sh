@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): round-3 profile set.
 #  * rocprofv3 --kernel-trace --stats of the bench command of every config; cfg2 WITH its side figures, so the API-true kernel
-#    (k_stft_rn_wave), the ingest kernels (k_resample_sinc, k_pcm16_to_float) and the fused low-pass (k_lowpass_group) have rows;
+#    (k_stft_r3_rot), the ingest kernels (k_resample_sinc, k_pcm16_to_float) and the fused low-pass (k_lowpass_group) have rows;
 #  * PMC=1: the two TCC counter passes (FETCH_SIZE / WRITE_SIZE cannot share a pass on gfx950; counters are collected in their
 #    own runs, with --kernel-trace only) for cfg2 / cfg3 / cfg5 and for the API-true and ingest experiments.
 # Outputs under gpurun_out/prof_<tag>/; tools/pmc_to_json.py <tag> turns them into profiles/<tag>_*.

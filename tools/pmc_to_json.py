@@ -25,7 +25,7 @@ for stats in sorted(glob.glob(src + "/stats_*/*kernel_stats.csv")):
         summary.setdefault("bench_line_under_rocprof", {})[cfg] = json.load(open(bj))
 KEYS = ("k_stft_wave<double, false", "k_stft_wave<double, true", "k_ssim", "k_stft<double, 11")
 MORE = {"cfg3": ("k_lowpass_wave", "k_ola_paired", "k_ola("), "cfg3fused": ("k_lowpass_group",), "cfg5": ("k_resample<",),
-        "api": ("k_stft_rn_wave<double, false, 3", "k_stft_rn_wave<double, true, 3"), "sinc": ("k_resample_sinc",)}
+        "api": ("k_stft_r3_rot<double, false", "k_stft_r3_rot<double, true"), "sinc": ("k_resample_sinc",)}
 pm = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for sub, keys in [("", KEYS), ("_cfg2", KEYS)] + [("_" + cfg, ks) for cfg, ks in MORE.items()]:

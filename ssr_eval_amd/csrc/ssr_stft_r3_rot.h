@@ -16,6 +16,7 @@
 //     through the epilogue and parks it afterwards in one of two dedicated slots (the slot it needs may still be read by that
 //     epilogue), where it survives the next round's transforms.
 //   * Two barriers per round (three in the rounds that complete two units): 7 per four units, the three-wave engine has 12.
+//     (Both units of such a round in ONE phase - 6 barriers - measured no faster: 10.51-10.55 against 10.49-10.51 ms.)
 // LDS: 4 x 12.8 KB exchange arrays + 2 x 2 q values of dedicated slots + scratch = 75.4 KB per workgroup (q = 743), two per CU.
 // The SISpec / log-SISpec sums are register accumulators here (the 1536-point engine has the room; lane-private LDS
 // accumulators for 256 lanes would not fit next to the second workgroup).
@@ -45,7 +46,7 @@ template <typename T, bool SUMS, int NQ, int P> struct SsrR3RotRegs : SsrRnWaveR
 // X[K] (already carrying the factor 1/2) from three sub-spectra parked at y0 / y1 / y2 (re at [k], im at [q + k])
 template <typename T> SSR_DEV cx<T> ssr_r3_combine3(const T* y0p, const T* y1p, const T* y2p, int q, int K) {
   const T c = (T)-0.5, s = (T)0.86602540378443864676;   // W3 = exp(-2 pi i / 3) = c - i s
-  const int j = K / q, k = K - j * q;
+  const int j = (K >= q ? 1 : 0) + (K >= 2 * q ? 1 : 0), k = K - j * q;       // K < 3 q: no division
   const cx<T> y0 = {y0p[k], y0p[q + k]}, y1 = {y1p[k], y1p[q + k]}, y2 = {y2p[k], y2p[q + k]};
   if (j == 0) return {y0.x + y1.x + y2.x, y0.y + y1.y + y2.y};
   const cx<T> a = (j == 1) ? y1 : y2, b = (j == 1) ? y2 : y1;     // a * W3 + b * conj(W3)   (as ssr_r3_combine)

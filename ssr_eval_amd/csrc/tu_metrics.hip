@@ -29,7 +29,8 @@ __global__ __launch_bounds__(64) void k_finalize(SsrFinalizeParams p) {
 }
 
 struct SsimGeom { int rows_per_tile, n_row_tiles, n_strips, cpt; };
-static SsimGeom ssim_geom(int max_rows, int n_bins, int n_items) {
+// aligned_rows: the pair pipeline's images (rows padded to 16 bytes on 256-byte-aligned bases) - eligible for the CONTIG kernel
+static SsimGeom ssim_geom(int max_rows, int n_bins, int n_items, bool aligned_rows) {
   SsimGeom g;
   const int out_rows = max_rows - 6 > 1 ? max_rows - 6 : 1;
   int64_t r = ((int64_t)out_rows * n_items + ssr_target_wgs() - 1) / ssr_target_wgs();
@@ -39,6 +40,16 @@ static SsimGeom ssim_geom(int max_rows, int n_bins, int n_items) {
   g.rows_per_tile = (int)r;
   g.n_row_tiles = ssr_ceil_div(out_rows, g.rows_per_tile);
   g.cpt = ssr_ssim_pick_cpt(n_bins);
+  if (aligned_rows && g.cpt != 4) {
+    // The CONTIG kernel (four consecutive columns per lane, both seven-row rings, no branches) costs ~0.68 of the strided one per
+    // column slot (measured on 401 x 1115 images: five CONTIG strips 0.83 ms against three six-column strips 1.03 ms per 1024
+    // pairs), so it is taken whenever its strips x 5 slots x 0.68 undercut the strided choice's strips x (cpt + 1).
+    const int outs = n_bins - (SSR_SSIM_WIN - 1);
+    if (outs > 0) {
+      const int strips4 = ssr_ceil_div(outs, ssr_ssim_strip_out(4)), strips_c = ssr_ceil_div(outs, ssr_ssim_strip_out(g.cpt));
+      if (strips4 * 5 * 68 < strips_c * (g.cpt + 1) * 100) g.cpt = 4;
+    }
+  }
 #ifdef SSR_DEV_KNOBS
   static const int cpt_env = getenv("SSR_SSIM_CPT") ? atoi(getenv("SSR_SSIM_CPT")) : 0;
   if (cpt_env >= 1 && cpt_env <= SSR_SSIM_MAXCPT) g.cpt = cpt_env;
@@ -62,7 +73,7 @@ static PairWs pair_ws(const ssr_plan* pl, int n_items, int max_len, int64_t tota
   w.n_chunks = ssr_ceil_div(max_T, w.units_per_chunk);
   const int S = ssr_pair_interleave(pl, in64);                                 // whole interleaving groups (empty chunks write zeros)
   w.n_chunks = ssr_ceil_div(w.n_chunks, S) * S;
-  w.sg = ssim_geom(max_T, pl->n_bins, n_items);
+  w.sg = ssim_geom(max_T, pl->n_bins, n_items, true);
   size_t o = 0;
   w.off_est = o; o += want_mag ? ssr_align256((size_t)total_rows * mag_pitch(pl->n_bins) * sizeof(float)) : 0;
   w.off_tgt = o; o += want_mag ? ssr_align256((size_t)total_rows * mag_pitch(pl->n_bins) * sizeof(float)) : 0;
@@ -235,7 +246,7 @@ static SpecWs spec_ws(int n_items, int max_rows, int n_bins) {
   SpecWs w;
   w.rows_per_chunk = ssr_units_per_chunk_for(max_rows, n_items);
   w.n_chunks = ssr_ceil_div(max_rows, w.rows_per_chunk);
-  w.sg = ssim_geom(max_rows, n_bins, n_items);
+  w.sg = ssim_geom(max_rows, n_bins, n_items, false);
   size_t o = 0;
   w.off_part = o; o += ssr_align256((size_t)n_items * w.n_chunks * SSR_NPART * sizeof(double));
   w.off_ssim = o; o += ssr_align256((size_t)n_items * w.sg.n_row_tiles * w.sg.n_strips * sizeof(double));

@@ -329,6 +329,27 @@ class Cfg5:
         extra = {"stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
                  "stage_GBs_read_plus_write": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) for k, v in stages.items()},
                  "resample_only_output_samples_per_s": round(n * N_SAMPLES / ((ms1 + ms2) * 1e-3), 1)}
+        # side figure: the matrix-core mode of the resampler (ssr_resample_poly_mfma: fused multiply-adds, not SciPy's bits; the
+        # timed region above runs the bit-exact kernel).  Its outputs replace the exact ones for this measurement only.
+        try:
+            B = self.B
+            lsd_exact = self.batch.run(B.M_LSD)[:, 0].clone()
+            y_exact = self.s2.out.clone()
+            self.s1.exact = self.s2.exact = False
+            mm1 = event_time_ms(lambda: self.s1.run(), it)
+            mm2 = event_time_ms(lambda: self.s2.run(), it)
+            lsd_mfma = self.batch.run(B.M_LSD)[:, 0]
+            extra["matrix_core_mode"] = {
+                "stage_ms": {"resample_441_160": round(mm1, 4), "resample_160_147": round(mm2, 4)},
+                "samples_per_s_with_lsd_stage": round(n * N_SAMPLES / ((mm1 + mm2 + ms3) * 1e-3), 1),
+                "max_abs_sample_diff_vs_exact": float((self.s2.out - y_exact).abs().max()),
+                "max_rel_lsd_diff_vs_exact": float(((lsd_mfma - lsd_exact).abs() / lsd_exact.abs()).max()),
+                "note": "side figure: v_mfma_f32_32x32x2_f32 formulation (float32 fused multiply-adds in SciPy's order); not the "
+                        "mode `value` is measured in"}
+        finally:
+            self.s1.exact = self.s2.exact = True
+            self.s1.run()
+            self.s2.run()
         return roof, extra
 
     def cpu_inputs(self, n):

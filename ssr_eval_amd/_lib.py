@@ -14,6 +14,7 @@ SSR_F32, SSR_F64 = 0, 1
 M_LSD, M_LOG_SISPEC, M_SISPEC, M_SSIM, M_ALL = 1, 2, 4, 8, 15
 STFT_MAG, STFT_COMPLEX = 1, 2
 LOWPASS_SEGMENTS, LOWPASS_FUSED = 0, 1
+ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE = -1, -2, -3, -4      # include/ssr_hip.h
 
 _vp, _i, _i64, _sz, _u = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_uint
 
@@ -47,6 +48,7 @@ SIGNATURES = {
     "ssr_resample_plan": (_i, [_i64, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64), C.POINTER(_i),
                                C.POINTER(_i), C.POINTER(_i)]),
     "ssr_resample_poly": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "ssr_resample_poly_mfma": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "ssr_resample_poly_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "ssr_resample_sinc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _vp, _vp, _i, _i, _i, C.c_double, C.c_double, _i,
                                 _vp, _vp]),

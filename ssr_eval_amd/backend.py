@@ -474,9 +474,10 @@ class ResamplePlan:
 class ResampleBatch:
     """A ragged batch + cached output descriptors / buffer for repeated ssr_resample_poly calls (K7)."""
 
-    def __init__(self, ragged, up, down):
+    def __init__(self, ragged, up, down, exact=True):
         dev = ragged.device
         self.r, self.rp = ragged, ResamplePlan.get(up, down, dev)
+        self.exact = exact
         self.f64 = ragged.data.dtype == torch.float64
         if self.rp.identity:
             self.out_len = ragged.lens_host.copy()
@@ -493,23 +494,28 @@ class ResampleBatch:
             self.out.copy_(r.data)             # scipy returns x.copy() before designing any filter
         elif r.n and self.out_len.max() > 0:
             taps = rp.taps64 if self.f64 else rp.taps
-            fn = _lib.load().ssr_resample_poly_f64 if self.f64 else _lib.load().ssr_resample_poly
-            _lib.check(fn(_vp(r.data), _vp(r.off), _vp(r.len), _vp(self.out_off_d), _vp(self.out_len_d), r.n,
-                          int(self.out_len.max()), rp.up, rp.down, _vp(taps), int(taps.numel()), rp.n_pre_remove,
-                          _vp(self.out), _stream()))
+            lib = _lib.load()
+            args = (_vp(r.data), _vp(r.off), _vp(r.len), _vp(self.out_off_d), _vp(self.out_len_d), r.n,
+                    int(self.out_len.max()), rp.up, rp.down, _vp(taps), int(taps.numel()), rp.n_pre_remove, _vp(self.out), _stream())
+            # exact=False: the matrix-core kernel (float32 fused multiply-adds: within ~1 ulp per tap of SciPy's sums, not its
+            # bits) where the plan fits it; float64 signals and plans it does not hold run the bit-exact kernel
+            if self.f64 or self.exact or lib.ssr_resample_poly_mfma(*args) == _lib.ERR_UNSUPPORTED:
+                _lib.check((lib.ssr_resample_poly_f64 if self.f64 else lib.ssr_resample_poly)(*args))
         return self.out
 
     def out_ragged(self):
         return Ragged(self.out, self.out_off_d, self.out_len_d, self.out_len)
 
 
-def resample_poly(wavs, up, down, device=None):
+def resample_poly(wavs, up, down, device=None, exact=True):
     """Polyphase resampling (K7) of a list of waveforms; bit-identical to scipy.signal.resample_poly.  A batch
-    holding float64 signals is resampled in float64 (float64 taps and accumulation), everything else in float32."""
+    holding float64 signals is resampled in float64 (float64 taps and accumulation), everything else in float32.
+    exact=False: float32 signals go through the matrix-core kernel (ssr_resample_poly_mfma: the same sums with fused
+    multiply-adds, ~1 ulp per tap from SciPy's values, 1.2-1.5x the rate)."""
     dev = torch.device(device) if device is not None else default_device()
     with torch.cuda.device(dev):
         r = wavs if isinstance(wavs, Ragged) else Ragged.from_list_keep64(wavs, dev)
-        b = ResampleBatch(r, up, down)
+        b = ResampleBatch(r, up, down, exact=exact)
         out = b.run()
         return [out[b.out_off[i]:b.out_off[i] + b.out_len[i]] for i in range(r.n)]
 

@@ -4,6 +4,7 @@
 #include "ssr_iir.h"
 #include "ssr_xcorr.h"
 #include "ssr_resample.h"
+#include "ssr_resample_mfma.h"
 #include "ssr_sinc.h"
 
 __global__ __launch_bounds__(SSR_XC_NT) void k_xcorr(SsrXcorrParams p) {
@@ -121,6 +122,47 @@ extern "C" int ssr_resample_poly_f64(const double* in, const int64_t* in_off, co
                                      void* stream) {
   return resample_poly_t<double>(in, in_off, in_len, out_off, out_len, n_items, max_out_len, up, down, taps, n_taps,
                                  n_pre_remove, out, stream);
+}
+
+// matrix-core variant (ssr_resample_mfma.h): float32 fused multiply-add evaluation of the same sums - NOT SciPy's bits
+template <int MAXCH>
+__global__ __launch_bounds__(SSR_RMF_NT, 2) void k_resample_mfma(SsrResampleMfmaParams p, int total) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  SsrBlk blk{(int)threadIdx.x};
+  ssr_resample_mfma_body<MAXCH>(p, blk, (int)blockIdx.x, (int)gridDim.x, total, smem);
+}
+
+extern "C" int ssr_resample_poly_mfma(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
+                                      const int32_t* out_len, int n_items, int max_out_len, int up, int down,
+                                      const float* taps, int n_taps, int n_pre_remove, float* out, void* stream) {
+  if (!in || !in_off || !in_len || !out_off || !out_len || !taps || !out) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (up < 1 || down < 1 || n_taps < 1) return ssr_fail(SSR_ERR_INVALID_ARG, "bad resampling plan");
+  if (n_items <= 0 || max_out_len <= 0) return SSR_OK;
+  const SsrResampleMfmaGeom g = ssr_resample_mfma_geom(up, down, n_taps);
+  if (!g.ok)       // (tap table or block window beyond the LDS / the prefetch registers: the exact kernel serves every plan)
+    return ssr_fail(SSR_ERR_UNSUPPORTED, "this resampling plan does not fit the matrix-core kernel; use ssr_resample_poly");
+  SsrResampleMfmaParams p{};
+  p.rp = SsrResampleParams{in, in_off, in_len, out_off, out_len, up, down, taps, n_taps, n_pre_remove, 0, 1, out};
+  p.n_items_total = n_items;
+  p.max_out_len = max_out_len;
+  p.n_groups = ssr_ceil_div(n_items, SSR_RMF_T);
+  p.passes_per_group = ssr_ceil_div(max_out_len, 32 * g.NB);
+  const int64_t total = (int64_t)p.n_groups * p.passes_per_group;
+  if (total > 0x7fffffff) return ssr_fail(SSR_ERR_UNSUPPORTED, "batch too large for one launch");
+  const bool small = g.W <= 64 * 5;                       // window fits five 64-sample chunks per lane and utterance
+  static thread_local SsrLdsSlot slot[2];
+  if (int rc = ssr_allow_lds(small ? (const void*)k_resample_mfma<5> : (const void*)k_resample_mfma<SSR_RMF_MAXCH>, g.lds_bytes, &slot[small])) return rc;
+  int dev = 0, n_cu = 256;
+  HIP_TRY(hipGetDevice(&dev));
+  HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  int per_cu = (int)((160 * 1024) / (g.lds_bytes + 512));
+  per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+  int64_t wgs = (int64_t)n_cu * per_cu;
+  if (wgs > total) wgs = total;
+  if (small) hipLaunchKernelGGL(k_resample_mfma<5>, dim3((unsigned)wgs), dim3(SSR_RMF_NT), g.lds_bytes, (hipStream_t)stream, p, (int)total);
+  else hipLaunchKernelGGL(k_resample_mfma<SSR_RMF_MAXCH>, dim3((unsigned)wgs), dim3(SSR_RMF_NT), g.lds_bytes, (hipStream_t)stream, p, (int)total);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
 }
 
 // ----------------------------------------------------------------------------------------------------

@@ -12,6 +12,7 @@
 #include "../../ssr_eval_amd/csrc/ssr_iir.h"
 #include "../../ssr_eval_amd/csrc/ssr_xcorr.h"
 #include "../../ssr_eval_amd/csrc/ssr_resample.h"
+#include "../../ssr_eval_amd/csrc/ssr_resample_mfma.h"
 #include "../../ssr_eval_amd/csrc/ssr_sinc.h"
 #include "../../ssr_eval_amd/csrc/ssr_stft_r3.h"
 #include "../../ssr_eval_amd/csrc/ssr_stft_wave.h"
@@ -449,6 +450,28 @@ extern "C" int emu_resample_f64(const double* in, const int64_t* in_off, const i
                                 int n_taps, int n_pre_remove, int groups, int taps_in_lds, double* out) {
   return emu_resample_t<double>(in, in_off, in_len, out_off, out_len, n_items, max_out_len, up, down, taps, n_taps,
                                 n_pre_remove, groups, taps_in_lds, out);
+}
+
+// matrix-core variant (ssr_resample_mfma.h); returns NB * 1000 + K (the geometry used), -2 when the plan does not fit
+extern "C" int emu_resample_mfma(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
+                                 const int32_t* out_len, int n_items, int max_out_len, int up, int down, const float* taps,
+                                 int n_taps, int n_pre_remove, int n_wg, float* out) {
+  const SsrResampleMfmaGeom g = ssr_resample_mfma_geom(up, down, n_taps);
+  if (!g.ok) return -2;
+  SsrResampleMfmaParams p{};
+  p.rp = SsrResampleParams{in, in_off, in_len, out_off, out_len, up, down, taps, n_taps, n_pre_remove, 0, 1, out};
+  p.n_items_total = n_items;
+  p.max_out_len = max_out_len;
+  p.n_groups = (n_items + SSR_RMF_T - 1) / SSR_RMF_T;
+  p.passes_per_group = (max_out_len + 32 * g.NB - 1) / (32 * g.NB);
+  const int total = p.n_groups * p.passes_per_group;
+  SsrBlk blk{SSR_RMF_NT};
+  for (int w = 0; w < n_wg; ++w) {
+    auto lds = poisoned(g.lds_bytes);
+    if (g.W <= 64 * 5) ssr_resample_mfma_body<5>(p, blk, w, n_wg, total, lds.data());
+    else ssr_resample_mfma_body<SSR_RMF_MAXCH>(p, blk, w, n_wg, total, lds.data());
+  }
+  return g.NB * 1000 + g.K;
 }
 
 // ---- windowed-sinc resampler (N2) ------------------------------------------------------------------------

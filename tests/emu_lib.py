@@ -250,6 +250,25 @@ def resample(sigs, up, down, taps_full, n_pre_remove, groups=0, taps_in_lds=1, d
     return [out[out_off[i]:out_off[i] + out_len[i]] for i in range(len(lens))]
 
 
+def resample_mfma(sigs, up, down, taps_full, n_pre_remove, n_wg=3, geometry=None):
+    """ssr_resample_mfma.h on the host (the matrix core's fused-multiply-add chains restated per element)."""
+    lens = np.array([len(a) for a in sigs], np.int32)
+    off = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int64)
+    a = np.concatenate(sigs).astype(np.float32)
+    out_len = np.array([-(-int(n) * up // down) for n in lens], np.int32)
+    out_off = np.concatenate(([0], np.cumsum(out_len)[:-1])).astype(np.int64)
+    out = np.full(int(out_len.sum()), np.nan, np.float32)
+    taps = np.ascontiguousarray(taps_full, np.float32)
+    rc = lib().emu_resample_mfma(_p(a, C.c_float), _p(off, C.c_int64), _p(lens, C.c_int32), _p(out_off, C.c_int64),
+                                 _p(out_len, C.c_int32), len(lens), int(out_len.max()), up, down, _p(taps, C.c_float), len(taps),
+                                 n_pre_remove, n_wg, _p(out, C.c_float))
+    if rc < 0:
+        return None
+    if geometry is not None:
+        geometry.append((rc // 1000, rc % 1000))
+    return [out[out_off[i]:out_off[i] + out_len[i]] for i in range(len(lens))]
+
+
 def sosfiltfilt(sos, sigs, dtype=np.float32):
     from scipy.signal import sosfilt_zi
     a, off, lens = ragged(sigs)

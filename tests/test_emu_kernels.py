@@ -208,6 +208,35 @@ def test_resampler_bit_exact_vs_scipy(golden, up, down):
         np.testing.assert_array_equal(o, signal.resample_poly(s, up, down))
 
 
+@pytest.mark.parametrize("up,down", [(441, 160), (160, 147), (160, 441), (3, 2), (1, 2), (147, 160)])
+def test_resampler_matrix_core_variant_is_the_fma_evaluation_of_scipys_sums(golden, up, down):
+    """ssr_resample_mfma.h: the polyphase sums as a dense (32 outputs x window) x (window x 32 utterances) product.  The host
+    build restates the matrix core's arithmetic - D = fma(A[i][k], B[k][j], D) in ascending k - per element, so this checks the
+    index algebra (which tap meets which sample, for every block phase, ragged batches, more than 32 utterances, windows that
+    start before / end after the signal, up- and down-sampling plans) against SciPy: a wrong tap or sample would be off by the
+    size of a term, the fused multiply-adds are within 4e-7 x sum |h| x max |x|; the bit-exact kernel on the same input stays
+    SciPy's bits."""
+    x = golden["rs_x16k"]
+    rng = np.random.default_rng(up * 1000 + down)
+    sig = [x, x[:777], x[:5]] + [(0.1 * rng.standard_normal(int(n))).astype(np.float32) for n in rng.integers(40, 1500, 36)]
+    p = ors.poly_plan(len(x), up, down)
+    taps = p["h_full"][:p["n_pre_pad"] + len(p["h"])]
+    geo = []
+    out = E.resample_mfma(sig, up, down, taps, p["n_pre_remove"], geometry=geo)
+    assert out is not None and geo[0][0] >= 4 and geo[0][0] % 4 == 0
+    exact = E.resample(sig, up, down, taps, p["n_pre_remove"])
+    habs = float(np.abs(taps).reshape(-1).astype(np.float64).sum()) / up * 1.0      # ~ sum |h| of one phase
+    for s, o, e in zip(sig, out, exact):
+        ref = signal.resample_poly(s, up, down)
+        assert o.shape == ref.shape and np.isfinite(o).all()
+        np.testing.assert_array_equal(e, ref)
+        tol = 4e-7 * max(habs, 1.0) * float(np.abs(s).max())
+        assert np.abs(o.astype(np.float64) - ref.astype(np.float64)).max() <= tol
+    one = E.resample_mfma(sig, up, down, taps, p["n_pre_remove"], n_wg=1)        # one persistent workgroup walks every pass
+    for a, b in zip(out, one):
+        np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("up,down", [(7349, 7350), (7350, 7349), (11024, 11025), (160, 147)])
 def test_resampler_fallback_for_huge_rate_pairs_bit_exact_vs_scipy(up, down):
     """Rate pairs whose reduced `up` is too large for the phase-blocked kernel's LDS window (the subsampling degradation

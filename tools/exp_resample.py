@@ -13,4 +13,13 @@ x = (0.1 * torch.randn((n, 64000), device=dev)).contiguous()
 s1 = B.ResampleBatch(B.Ragged.from_uniform(x), 44100, 16000)
 s2 = B.ResampleBatch(s1.out_ragged(), 48000, 44100)
 it = int(os.environ.get("ITERS", "5"))
-print(json.dumps({"utt": n, "ms_441_160": round(bench.event_time_ms(s1.run, it), 4), "ms_160_147": round(bench.event_time_ms(s2.run, it), 4)}))
+res = {"utt": n, "ms_441_160": round(bench.event_time_ms(s1.run, it), 4), "ms_160_147": round(bench.event_time_ms(s2.run, it), 4)}
+if hasattr(B._lib.load(), "ssr_resample_poly_mfma") and not os.environ.get("NO_MFMA"):
+    e1, e2 = s1.run().clone(), s2.run().clone()
+    m1 = B.ResampleBatch(B.Ragged.from_uniform(x), 44100, 16000, exact=False)
+    m2 = B.ResampleBatch(s1.out_ragged(), 48000, 44100, exact=False)          # (same input as the exact second stage)
+    res["mfma_ms_441_160"] = round(bench.event_time_ms(m1.run, it), 4)
+    res["mfma_ms_160_147"] = round(bench.event_time_ms(m2.run, it), 4)
+    res["mfma_max_abs_diff"] = [float((m1.run() - e1).abs().max()), float((m2.run() - e2).abs().max())]
+    res["signal_max_abs"] = [float(e1.abs().max()), float(e2.abs().max())]
+print(json.dumps(res))

@@ -196,8 +196,9 @@ int ssr_resample_poly(const float* in, const int64_t* in_off, const int32_t* in_
 /* K7 on the matrix cores (round 3): the same sums as ssr_resample_poly, evaluated as a dense (outputs x input window) by
  * (input window x 32 utterances) product on v_mfma_f32_32x32x2_f32 - float32 FUSED multiply-adds in ascending input index, one
  * rounding per tap where SciPy's upfirdn rounds product and sum separately.  NOT bit-identical to scipy.signal.resample_poly:
- * within ~1 ulp per tap of it (LSD / SISpec / SSIM of a resampled signal agree to 4e-6; log-SISpec, the log of the resampler's own
- * stop-band round-off, to 2.5e-5); 1.2-1.5x the rate of the bit-exact kernel (measured: 441/160 1.45 against 2.23 ms, 160/147
+ * within ~1 ulp per tap of it.  Metrics of a resampled signal whose upper band is the resampler's own leakage move with those
+ * ulps: LSD by up to 1.2e-5 relative over 12,500 white-noise utterances (typically 1e-6), log-SISpec by 2.5e-5 - a caller that needs
+ * the 1e-5 bar against SciPy-resampled references uses ssr_resample_poly; 1.2-1.5x the rate of the bit-exact kernel (measured: 441/160 1.45 against 2.23 ms, 160/147
  * 1.93 against 2.27 ms per 4096 utterances of 4 s).  Same
  * arguments and sample indices.  SSR_ERR_UNSUPPORTED for plans whose tap table (> 96 KB) or 32-output window (> 446 samples)
  * do not fit - ssr_resample_poly serves every plan. */

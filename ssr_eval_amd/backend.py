@@ -499,8 +499,10 @@ class ResampleBatch:
                     int(self.out_len.max()), rp.up, rp.down, _vp(taps), int(taps.numel()), rp.n_pre_remove, _vp(self.out), _stream())
             # exact=False: the matrix-core kernel (float32 fused multiply-adds: within ~1 ulp per tap of SciPy's sums, not its
             # bits) where the plan fits it; float64 signals and plans it does not hold run the bit-exact kernel
-            if self.f64 or self.exact or lib.ssr_resample_poly_mfma(*args) == _lib.ERR_UNSUPPORTED:
-                _lib.check((lib.ssr_resample_poly_f64 if self.f64 else lib.ssr_resample_poly)(*args))
+            rc = _lib.ERR_UNSUPPORTED if (self.f64 or self.exact) else lib.ssr_resample_poly_mfma(*args)
+            if rc == _lib.ERR_UNSUPPORTED:
+                rc = (lib.ssr_resample_poly_f64 if self.f64 else lib.ssr_resample_poly)(*args)
+            _lib.check(rc)
         return self.out
 
     def out_ragged(self):

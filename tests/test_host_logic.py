@@ -174,6 +174,10 @@ def test_cabi_round3_entry_points_validate_before_the_device():
     assert lib.ssr_sispec_multichannel(p, p, 4, 2, 10, 0, p, p, 8, None) == -4  # workspace too small
     assert b"workspace" in lib.ssr_last_error()
     assert lib.ssr_plan_set_lowpass_engine(None, 0) == -1
+    # matrix-core resampler: null argument; a plan whose tap table does not fit the kernel is refused before any device call
+    assert lib.ssr_resample_poly_mfma(None, p, p, p, p, 1, 100, 441, 160, p, 8821, 50, p, None) == -1
+    assert lib.ssr_resample_poly_mfma(p, p, p, p, p, 1, 100, 7349, 7350, p, 147001, 10, p, None) == -2
+    assert b"ssr_resample_poly" in lib.ssr_last_error()
 
 
 def test_wav_decode_mono_stereo_and_batch(tmp_path):

@@ -38,6 +38,13 @@ def golden_r2():
 
 
 @pytest.fixture(scope="session")
+def golden_r3():
+    """Round-3 vectors (tests/golden/make_golden_r3.py: 32 kHz / long 48 kHz / 16 kHz evaluation pairs, the cfg-5 chain in small
+    through the reference's own resampling calls), produced by importing the reference."""
+    return np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors_r3.npz"))
+
+
+@pytest.fixture(scope="session")
 def golden_manifest():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "manifest.json")) as f:

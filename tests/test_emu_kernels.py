@@ -491,6 +491,16 @@ def test_frame_whose_only_nonzero_sample_has_window_weight_zero_is_silent(n_fft,
             assert ((mx[0] == 0) == (ref == 0)).all()
 
 
+@pytest.mark.parametrize("name", ["speech32k", "speech16k"])
+def test_wave_engines_match_round3_reference_vectors(golden_r3, name):
+    """The emulated wave engines (1486 / 320: two waves per frame pair; 743 / 160: one) against vectors the imported reference
+    produced (tests/golden/make_golden_r3.py)."""
+    n_fft, hop = [int(v) for v in golden_r3["ev3_%s_nfft_hop" % name]]
+    e, t = golden_r3["ev3_%s_est" % name], golden_r3["ev3_%s_tgt" % name]
+    got = E.pair_metrics([e], [t], n_fft, hop, 1, wave="r3", units_per_chunk=7)[0]
+    np.testing.assert_allclose(got, golden_r3["ev3_%s_out" % name], rtol=1e-5)
+
+
 @pytest.mark.parametrize("n_fft,hop", [(2229, 480), (2100, 500), (1486, 320), (1114, 240), (743, 160), (1000, 250), (2048 - 2, 500)])
 def test_radix_n_wave_engine_matches_oracle_and_block_engine(n_fft, hop):
     """ssr_stft_rn_wave.h (n_fft = R q over M = 2048 on R autonomous waves per workgroup, sub-spectra parked in the exchange

@@ -64,6 +64,36 @@ def test_evaluation_matches_reference_vectors(golden, name):
         assert abs(got[0] - 2 * abs(np.log10(0.5))) < 1e-5 and got[2] > 100.0
 
 
+@pytest.mark.parametrize("name", ["speech32k", "speech48k_long", "speech16k"])
+def test_evaluation_matches_round3_reference_vectors(golden_r3, name):
+    """Vectors produced by the imported reference for the engines round 3 added or changed: 1486/320 (two waves per frame pair,
+    1536-point transforms), 2229/480 over 211 frames (the rotating four-wave kernel through many rounds and several chunks),
+    743/160 (one wave, 1536-point transforms; SSIM on the CONTIG kernel by the round-3 geometry rule)."""
+    from ssr_eval_amd import AudioMetrics
+    am = AudioMetrics(int(golden_r3["ev3_%s_rate" % name]))
+    assert [am.n_fft, am.hop_length] == golden_r3["ev3_%s_nfft_hop" % name].tolist()
+    got = _vec(am.evaluation(golden_r3["ev3_%s_est" % name], golden_r3["ev3_%s_tgt" % name], ""))
+    np.testing.assert_allclose(got, golden_r3["ev3_%s_out" % name], rtol=1e-5)
+
+
+def test_cfg5_chain_in_small_matches_the_reference(golden_r3):
+    """BASELINE cfg-5 through the reference's own calls (librosa.resample(res_type="polyphase") 16 k -> 44.1 k -> 48 k, then
+    AudioMetrics at 2048 / 512): both resampling stages bit-identical, the four metrics to 1e-5."""
+    from ssr_eval_amd import backend as B, AudioMetrics
+    y44 = B.resample_poly([golden_r3["c5_x16"]], 44100, 16000)[0]
+    np.testing.assert_array_equal(y44.cpu().numpy(), golden_r3["c5_y44"])
+    y48 = B.resample_poly([y44], 48000, 44100)[0].cpu().numpy()
+    np.testing.assert_array_equal(y48, golden_r3["c5_y48"])
+    am = AudioMetrics(48000, n_fft=2048, hop_length=512)
+    got, want = _vec(am.evaluation(y48, golden_r3["c5_tgt"], "")), golden_r3["c5_out"]
+    np.testing.assert_allclose(got[[0, 3]], want[[0, 3]], rtol=1e-5)
+    # the estimate and the target are unrelated signals here (SISpec -1.4 dB): the reference's float32 sums carry their own noise
+    from oracle import metrics as om
+    _, exact = om.evaluation_with_exact(y48, golden_r3["c5_tgt"], n_fft=2048, hop=512)
+    assert_sispec_parity(got[1], want[1], exact["log_sispec"], "golden cfg5-chain log_sispec")
+    assert_sispec_parity(got[2], want[2], exact["sispec"], "golden cfg5-chain sispec")
+
+
 def test_bench_parameters_match_reference_vector(golden):
     from ssr_eval_amd import AudioMetrics
     am = AudioMetrics(48000, n_fft=2048, hop_length=512)

@@ -129,6 +129,24 @@ def test_resample_plan_and_restated_bit_exact():
         np.testing.assert_array_equal(ors.resample_poly_restated(x, up, down), signal.resample_poly(x, up, down))
 
 
+@pytest.mark.parametrize("name", ["speech32k", "speech48k_long", "speech16k"])
+def test_evaluation_matches_round3_reference_vectors(golden_r3, name):
+    """The oracle against the round-3 vectors of the imported reference (tests/golden/make_golden_r3.py)."""
+    res = om.evaluation(golden_r3["ev3_%s_est" % name], golden_r3["ev3_%s_tgt" % name], int(golden_r3["ev3_%s_rate" % name]))
+    got = np.array([res["lsd"], res["log_sispec"], res["sispec"], res["ssim"]])
+    np.testing.assert_allclose(got, golden_r3["ev3_%s_out" % name], rtol=1e-6)
+
+
+def test_cfg5_chain_matches_reference_vectors(golden_r3):
+    y44 = ors.librosa_resample_polyphase(golden_r3["c5_x16"], 16000, 44100)
+    np.testing.assert_array_equal(y44, golden_r3["c5_y44"])
+    y48 = ors.librosa_resample_polyphase(y44, 44100, 48000)
+    np.testing.assert_array_equal(y48, golden_r3["c5_y48"])
+    res = om.evaluation(y48, golden_r3["c5_tgt"], n_fft=2048, hop=512)
+    got = np.array([res["lsd"], res["log_sispec"], res["sispec"], res["ssim"]])
+    np.testing.assert_allclose(got, golden_r3["c5_out"], rtol=1e-6)
+
+
 def test_resample_matches_reference_vectors(golden):
     y1 = ors.librosa_resample_polyphase(golden["rs_x16k"], 16000, 44100)
     np.testing.assert_array_equal(y1, golden["rs_16k_to_44k"])

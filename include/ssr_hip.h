@@ -70,10 +70,26 @@ int ssr_plan_query(const ssr_plan* plan, int* n_fft, int* hop, int* n_bins, int*
  *     Float64 2048-point plans with 228 <= hop <= 914 only (SSR_ERR_UNSUPPORTED otherwise).  Measured on MI355X: 3 % faster when
  *     the call runs alone, 8 % slower inside a pipeline of other FP64-heavy kernels (it needs more cycles at a lower power
  *     density) - hence not the default.  Both give the reference's result to float32 resolution; the
- *     fused engine rounds to float32 once (sums in float64 from the unrounded frames). */
+ *     fused engine rounds to float32 once (sums in float64 from the unrounded frames).
+ *   SSR_LOWPASS_CONV: the REFERENCE'S ARITHMETIC CLASS.  torchlibrosa (ssr_eval/dsp.py:1,21-39) evaluates STFT / ISTFT as dense float32
+ *     DFT convolutions (nn.Conv1d with DFT x Hann weights computed in float64, stored float32); a hard-low-passed signal's stop band is
+ *     that transform's round-off floor, and LSD / log-SISpec of the degraded input take its logarithm: against the float64 FFT engines
+ *     above they differ by 2-7 % (LSD).  This engine runs the same dense products on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 =
+ *     a float32 fused-multiply-add chain), accumulating in chains of 128 terms added in float32 - the fixed member of the class that
+ *     oracle/tl_chain.c restates bit for bit - followed by F.fold's float32 overlap-add and window-sum division.  ssr_fft_lowpass,
+ *     ssr_istft and ssr_stft(SSR_STFT_COMPLEX) of such a plan all run it.  n_fft = 32 m.  Cost: 2 n_fft (2 cut) + 2 n_fft (4 cut)
+ *     flops per frame instead of two FFTs (10-30x the time of the default engine), and ssr_ola_workspace_bytes grows to
+ *     (4 n_fft + hop) floats per frame.  The Python mirror makes it the default of lowpass(_type="stft_hard") and FDomainHelper. */
 #define SSR_LOWPASS_SEGMENTS 0
 #define SSR_LOWPASS_FUSED 1
+#define SSR_LOWPASS_CONV 2
 int ssr_plan_set_lowpass_engine(ssr_plan* plan, int engine);
+/* The float32 weight tables of SSR_LOWPASS_CONV as the library builds them (torchlibrosa's DFTBase.dft_matrix / idft_matrix x
+ * periodic Hann: STFT.__init__, ISTFT.init_real_imag_conv), TRANSPOSED: fwd_*_t [n_fft][n_fft/2+1] (row = sample, column = bin),
+ * inv_*_t [n_fft][n_fft] (row = channel of the mirrored spectrum, column = output sample), w2 = hann^2 [n_fft].
+ * HOST pointers (the one exception to the device-pointer convention; any may be NULL): a host-only introspection call, needs no GPU;
+ * the parity tests feed these tables to oracle/tl_chain.c. */
+int ssr_tl_weights(int n_fft, float* fwd_re_t, float* fwd_im_t, float* inv_re_t, float* inv_im_t, float* w2);
 /* T = 1 + (n + 2*(n_fft/2) - n_fft) / hop  (librosa / torchlibrosa frame count; bit-exact integer) */
 int64_t ssr_num_frames(const ssr_plan* plan, int64_t n_samples);
 

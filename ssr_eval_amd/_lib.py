@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libssrhip.so")
 SSR_F32, SSR_F64 = 0, 1
 M_LSD, M_LOG_SISPEC, M_SISPEC, M_SSIM, M_ALL = 1, 2, 4, 8, 15
 STFT_MAG, STFT_COMPLEX = 1, 2
-LOWPASS_SEGMENTS, LOWPASS_FUSED = 0, 1
+LOWPASS_SEGMENTS, LOWPASS_FUSED, LOWPASS_CONV = 0, 1, 2
 ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE = -1, -2, -3, -4      # include/ssr_hip.h
 
 _vp, _i, _i64, _sz, _u = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_uint
@@ -26,6 +26,7 @@ SIGNATURES = {
     "ssr_plan_destroy": (_i, [_vp]),
     "ssr_plan_query": (_i, [_vp] + [C.POINTER(_i)] * 6),
     "ssr_plan_set_lowpass_engine": (_i, [_vp, _i]),
+    "ssr_tl_weights": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "ssr_num_frames": (_i64, [_vp, _i64]),
     "ssr_stft": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "ssr_magphase": (_i, [_vp, _vp, _i64, C.c_float, _vp, _vp, _vp, _vp]),

@@ -61,9 +61,14 @@ class Plan:
         return num_frames(n, self.n_fft, self.hop)
 
     def set_lowpass_engine(self, engine):
-        """"segments" (default: frame kernel + overlap-add kernel through the workspace) or "fused" (one kernel, no workspace
-        traffic; float64 2048-point plans with 228 <= hop <= 914).  See include/ssr_hip.h: ssr_plan_set_lowpass_engine."""
-        _lib.check(self.lib.ssr_plan_set_lowpass_engine(self.handle, {"segments": _lib.LOWPASS_SEGMENTS, "fused": _lib.LOWPASS_FUSED}[engine]))
+        """"segments" (frame kernel + overlap-add kernel through the workspace), "fused" (one kernel, no workspace traffic;
+        float64 2048-point plans with 228 <= hop <= 914) or "conv" (torchlibrosa's dense float32 DFT products on the matrix cores:
+        the reference's arithmetic class).  See include/ssr_hip.h: ssr_plan_set_lowpass_engine.  A plan handed out by
+        get_plan() is cached under its engine and refuses a change."""
+        if getattr(self, "_cached", False) and engine != getattr(self, "lowpass_engine", "segments"):
+            raise ValueError("this plan is shared through get_plan() under its engine; ask get_plan(..., lowpass_engine=%r)" % engine)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ssr_plan_set_lowpass_engine(self.handle, _ENGINES[engine]))
         self.lowpass_engine = engine
         return self
 
@@ -76,6 +81,7 @@ class Plan:
             pass
 
 
+_ENGINES = {"segments": _lib.LOWPASS_SEGMENTS, "fused": _lib.LOWPASS_FUSED, "conv": _lib.LOWPASS_CONV}
 _plans = {}
 _plans_lock = threading.Lock()
 
@@ -90,6 +96,8 @@ def get_plan(n_fft, hop, precision="f64", device=None, lowpass_engine="segments"
             p = Plan(n_fft, hop, precision, dev)
             if lowpass_engine != "segments":
                 p.set_lowpass_engine(lowpass_engine)
+            p.lowpass_engine = lowpass_engine
+            p._cached = True
             _plans[key] = p
         return p
 
@@ -117,10 +125,15 @@ class Ragged:
         # resample_sinc, fft_lowpass, resample_poly ...) are taken as they are: no per-signal transfer call, no concatenation.
         if len(arrays) > 1 and all(isinstance(a, torch.Tensor) and a.is_cuda and a.dtype == dtype and a.dim() == 1 and a.is_contiguous()
                                    for a in arrays):
-            es, ok, base, end = arrays[0].element_size(), True, arrays[0].data_ptr(), arrays[0].data_ptr()
+            # (address adjacency is NOT enough - two separate allocations are routinely back to back in the caching
+            # allocator, and set_() past the end of a0's storage silently reallocates it: every view must live in a0's storage
+            # and the whole run must fit inside it.)
+            a0 = arrays[0]
+            es, ok, end, st0 = a0.element_size(), True, a0.data_ptr(), a0.untyped_storage().data_ptr()
             for a in arrays:
-                ok = ok and a.data_ptr() == end and a.device == arrays[0].device
+                ok = ok and a.data_ptr() == end and a.device == a0.device and a.untyped_storage().data_ptr() == st0
                 end += a.numel() * es
+            ok = ok and end <= st0 + a0.untyped_storage().nbytes()
             if ok and arrays[0].device.index == (dev.index if dev.index is not None else torch.cuda.current_device()):
                 lens = np.array([a.shape[0] for a in arrays], dtype=np.int64)
                 total = int(lens.sum())

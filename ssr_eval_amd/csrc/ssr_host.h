@@ -39,7 +39,10 @@ struct ssr_plan {
   double* window64 = nullptr;  // always present (OLA normalisation)
   double* wss_tab = nullptr;   // [hop] overlap-added squared window where every overlapping frame exists (hop <= n_fft)
   double* wss_rcp_tab = nullptr;   // [hop] its reciprocal
-  int lowpass_engine = 0;      // SSR_LOWPASS_SEGMENTS / SSR_LOWPASS_FUSED (ssr_plan_set_lowpass_engine)
+  int lowpass_engine = 0;      // SSR_LOWPASS_SEGMENTS / SSR_LOWPASS_FUSED / SSR_LOWPASS_CONV (ssr_plan_set_lowpass_engine)
+  // SSR_LOWPASS_CONV: torchlibrosa's float32 Conv1d weights, transposed (tu_tlconv.hip; built when the engine is selected)
+  float *tl_wre_t = nullptr, *tl_wim_t = nullptr, *tl_ire_t = nullptr, *tl_iim_t = nullptr, *tl_w2 = nullptr;
+  int tl_ldw = 0;
   std::vector<void*> allocs;
 };
 
@@ -99,3 +102,11 @@ template <typename T> int ssr_launch_stft_r3_64(const ssr_plan*, SsrStftParams<T
 template <typename T> int ssr_launch_stft(const ssr_plan*, SsrStftParams<T>&, int grid, hipStream_t);
 // tu_lowpass.hip
 template <typename T> int ssr_launch_lowpass(const ssr_plan*, SsrLowpassParams<T>&, int grid, hipStream_t);
+// tu_tlconv.hip: the reference-arithmetic engine (dense float32 DFT products on the matrix cores)
+int ssr_tl_build(ssr_plan* pl);
+size_t ssr_tl_workspace_bytes(const ssr_plan* pl, int64_t total_rows);
+int ssr_tl_run_inverse(const ssr_plan* pl, const float* in, const int64_t* in_off, const int32_t* len, const int32_t* cut,
+                       const float* re, const float* im, const int64_t* frame_off, const int64_t* out_off, int n_items,
+                       int max_len, int64_t total_rows, float* out, void* workspace, size_t workspace_bytes, hipStream_t s);
+int ssr_tl_stft(const ssr_plan* pl, const float* wav, const int64_t* wav_off, const int32_t* wav_len, const int64_t* frame_off,
+                int n_items, int max_len, float* out_re, float* out_im, hipStream_t s);

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_magphase(const float* re, const float* 
                                                   float* cosv, float* sinv) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float r = re[i], q = im[i];
-    float p = r * r + q * q;          // torch: clamp(real**2 + imag**2, eps, inf) ** 0.5   (dsp.py:78)
+    float p = ssr_fadd_rn(ssr_fmul_rn(r, r), ssr_fmul_rn(q, q));   // torch: clamp(real**2 + imag**2, eps, inf) ** 0.5 (dsp.py:78): three roundings
     p = p < eps ? eps : p;
     const float m = sqrtf(p);
     mag[i] = m;
@@ -225,6 +225,8 @@ extern "C" int ssr_stft(const ssr_plan* pl, const float* wav, const int64_t* wav
   if (max_len < 1) return ssr_fail(SSR_ERR_INVALID_ARG, "empty signals");
   if (max_len >= (1 << 29)) return ssr_fail(SSR_ERR_UNSUPPORTED, "signals of 2^29 samples or more (4 GiB buffer views)");
   hipStream_t s = (hipStream_t)stream;
+  if (pl->lowpass_engine == SSR_LOWPASS_CONV && out_kind == SSR_STFT_COMPLEX)      // torchlibrosa's STFT.forward as it computes
+    return ssr_tl_stft(pl, wav, wav_off, wav_len, frame_off, n_items, max_len, out_a, out_b, s);
   return pl->precision == SSR_F64
              ? stft_single_t<double>(pl, wav, wav_off, wav_len, frame_off, n_items, max_len, out_kind, out_a, out_b, s)
              : stft_single_t<float>(pl, wav, wav_off, wav_len, frame_off, n_items, max_len, out_kind, out_a, out_b, s);

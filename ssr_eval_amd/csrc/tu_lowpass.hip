@@ -88,7 +88,12 @@ bool ssr_lowpass_fuses_ola(const ssr_plan* pl) { return pl->lowpass_engine == SS
 
 extern "C" int ssr_plan_set_lowpass_engine(ssr_plan* pl, int engine) {
   if (!pl) return ssr_fail(SSR_ERR_INVALID_ARG, "null plan");
-  if (engine != SSR_LOWPASS_SEGMENTS && engine != SSR_LOWPASS_FUSED) return ssr_fail(SSR_ERR_INVALID_ARG, "unknown low-pass engine");
+  if (engine != SSR_LOWPASS_SEGMENTS && engine != SSR_LOWPASS_FUSED && engine != SSR_LOWPASS_CONV)
+    return ssr_fail(SSR_ERR_INVALID_ARG, "unknown low-pass engine");
+  if (engine == SSR_LOWPASS_CONV) {
+    if (int rc_dev = ssr_check_plan_device(pl)) return rc_dev;
+    if (int rc = ssr_tl_build(pl)) return rc;
+  }
   if (engine == SSR_LOWPASS_FUSED && !lowpass_group_eligible(pl))
     return ssr_fail(SSR_ERR_UNSUPPORTED, "the fused low-pass engine needs a float64 2048-point plan with 228 <= hop <= 914");
   pl->lowpass_engine = engine;
@@ -160,6 +165,7 @@ template int ssr_launch_lowpass<double>(const ssr_plan*, SsrLowpassParams<double
 // ----------------------------------------------------------------------------------------------------
 extern "C" size_t ssr_ola_workspace_bytes(const ssr_plan* pl, int64_t total_rows) {
   if (!pl || total_rows <= 0) return 0;
+  if (pl->lowpass_engine == SSR_LOWPASS_CONV) return ssr_tl_workspace_bytes(pl, total_rows);
   return ssr_align256((size_t)total_rows * pl->n_fft * sizeof(float));
 }
 
@@ -170,6 +176,9 @@ static int run_inverse(const ssr_plan* pl, const float* in, const int64_t* in_of
   if (max_len <= pl->n_fft / 2) return ssr_fail(SSR_ERR_INVALID_ARG, "reflect padding needs len > n_fft/2");
   if (max_len >= (1 << 29)) return ssr_fail(SSR_ERR_UNSUPPORTED, "signals of 2^29 samples or more (4 GiB buffer views)");
   if (!workspace || workspace_bytes < ssr_ola_workspace_bytes(pl, total_rows)) return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small");
+  if (pl->lowpass_engine == SSR_LOWPASS_CONV)
+    return ssr_tl_run_inverse(pl, in, in_off, len, cut, re, im, frame_off, out_off, n_items, max_len, total_rows, out, workspace,
+                              workspace_bytes, s);
   if (ssr_lowpass_fuses_ola(pl))      // (the workspace stays part of the contract: other plans / precisions overlap-add through it)
     return launch_lowpass_group(pl, in, in_off, len, cut, re, im, frame_off, out_off, n_items, max_len, out, s);
   const int max_pairs = (int)((ssr_num_frames(pl, max_len) + 1) / 2);

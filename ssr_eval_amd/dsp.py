@@ -13,7 +13,7 @@ from . import backend as B
 
 class FDomainHelper(torch.nn.Module):
     def __init__(self, window_size=2048, hop_size=441, center=True, pad_mode="reflect", window="hann",
-                 freeze_parameters=True, subband=None, root=None, *, precision="f64", device=None):
+                 freeze_parameters=True, subband=None, root=None, *, precision="f64", device=None, engine="conv"):
         super().__init__()
         if not center or pad_mode != "reflect" or window != "hann":
             raise NotImplementedError("libssrhip implements the configuration the reference instantiates: "
@@ -22,9 +22,12 @@ class FDomainHelper(torch.nn.Module):
         div = 1 if subband is None else int(subband)          # dsp.py:40-59
         self.n_fft, self.hop = window_size // div, hop_size // div
         self.precision, self._device = precision, device
+        # "conv": torchlibrosa's own arithmetic (dense float32 DFT products; n_fft must be a multiple of 32) - the default, as in
+        # ssr_eval_amd.lowpass; "segments": float64 FFT (the exact transforms, faster)
+        self.engine = engine if self.n_fft % 32 == 0 else "segments"
 
     def _plan(self):
-        return B.get_plan(self.n_fft, self.hop, self.precision, self._device)
+        return B.get_plan(self.n_fft, self.hop, self.precision, self._device, lowpass_engine=self.engine)
 
     # ---- [B, n] helpers -------------------------------------------------------------------------------
     def _stft(self, x):

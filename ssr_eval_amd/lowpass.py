@@ -18,6 +18,12 @@ from . import backend as B
 
 N_FFT, HOP = 2048, 441          # FDomainHelper() defaults used by the reference's global f_helper (lowpass.py:167)
 _precision = "f64"
+# Engine of the STFT-domain low-pass (include/ssr_hip.h: ssr_plan_set_lowpass_engine).  "conv" = the reference's arithmetic class
+# (torchlibrosa's dense float32 DFT convolutions, on the fp32 matrix cores): the degraded input's stop band - the transform's
+# round-off floor - sits where the reference's does, so LSD / log-SISpec of the degraded input agree with the reference's to the
+# spread of the class itself instead of 2-7 % off.  "segments" / "fused" = float64 FFT engines: the exact
+# low-pass, 10-30x faster, for callers that want the ideal filter rather than the reference's numbers.
+DEFAULT_ENGINE = "conv"
 
 
 def cut_bin(lowpass_ratio, n_bins=N_FFT // 2 + 1):
@@ -25,14 +31,15 @@ def cut_bin(lowpass_ratio, n_bins=N_FFT // 2 + 1):
     return int(n_bins * lowpass_ratio)
 
 
-def stft_hard_lowpass_v0(data, lowpass_ratio):
+def stft_hard_lowpass_v0(data, lowpass_ratio, engine=None):
     """lowpass.py:17-28.  data: 1-D ndarray / tensor -> float32 ndarray of the same length."""
-    return stft_hard_lowpass_batch([data], [lowpass_ratio])[0]
+    return stft_hard_lowpass_batch([data], [lowpass_ratio], engine=engine)[0]
 
 
-def stft_hard_lowpass_batch(datas, ratios, device=None, keep_on_device=False):
-    """keep_on_device: the degraded signals stay device tensors (views of the launch's output) for a GPU consumer."""
-    plan = B.get_plan(N_FFT, HOP, _precision, device)
+def stft_hard_lowpass_batch(datas, ratios, device=None, keep_on_device=False, engine=None):
+    """keep_on_device: the degraded signals stay device tensors (views of the launch's output) for a GPU consumer.
+    engine: None = DEFAULT_ENGINE ("conv": the reference's arithmetic), or "segments" / "fused" (float64 FFT)."""
+    plan = B.get_plan(N_FFT, HOP, _precision, device, lowpass_engine=engine or DEFAULT_ENGINE)
     ys = B.fft_lowpass(plan, [d if isinstance(d, torch.Tensor) else np.asarray(d, np.float32) for d in datas],
                        [cut_bin(r) for r in ratios])
     return list(ys) if keep_on_device else [y.cpu().numpy() for y in ys]

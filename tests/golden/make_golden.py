@@ -5,6 +5,9 @@
 image (librosa, soundfile, scikit-image, torchlibrosa); name-only stub modules are injected into
 sys.modules and bound to the restatements in oracle/ (see oracle/__init__.py: parity at those three
 boundaries is unpinned; everything else executed below is the reference's own code).  SciPy is real.
+Round 4: the torchlibrosa stub is bound to the package's arithmetic AS PUBLISHED (oracle.stft.tl_stft_conv / tl_istft_conv:
+float32 F.conv1d with the float32 DFT x Hann weights, F.fold) - it used to be a float64-FFT idealisation, which made every
+lp_* / c3_* / *fftlp* vector circular at that boundary and 2-7 % off in LSD.
 
 Outputs are data only (inputs + the reference's outputs).  Run:  python tests/golden/make_golden.py
 """
@@ -61,7 +64,7 @@ def _install_stubs():
             self.n_fft, self.hop = n_fft, hop_length
 
         def forward(self, x):
-            re, im = ostft.tl_stft(x.detach().numpy(), self.n_fft, self.hop)
+            re, im = ostft.tl_stft_conv(x.detach().numpy(), self.n_fft, self.hop)
             return torch.tensor(re), torch.tensor(im)
 
     class ISTFT(torch.nn.Module):
@@ -71,8 +74,8 @@ def _install_stubs():
             self.n_fft, self.hop = n_fft, hop_length
 
         def forward(self, real, imag, length):
-            return torch.tensor(ostft.tl_istft(real.detach().numpy(), imag.detach().numpy(), length,
-                                               self.n_fft, self.hop))
+            return torch.tensor(ostft.tl_istft_conv(real.detach().numpy(), imag.detach().numpy(), length,
+                                                    self.n_fft, self.hop))
 
     def magphase(real, imag):
         mag = (real ** 2 + imag ** 2) ** 0.5
@@ -118,7 +121,9 @@ def noise_pair(seed, n):
 def main():
     out = {}
     manifest = {"numpy": np.__version__, "scipy": scipy.__version__, "torch": torch.__version__,
-                "reference": "haoheliu/ssr_eval v0.0.6 imported from /root/reference with stubs"}
+                "reference": "haoheliu/ssr_eval v0.0.6 imported from /root/reference with stubs",
+                "torchlibrosa_stub": "as published: float32 F.conv1d / F.fold on torch-CPU (oracle.stft.tl_*_conv), %d threads"
+                                     % torch.get_num_threads()}
 
     # ---- A1: integer tables (metrics.py:16-19)
     rates = [16000, 24000, 32000, 44100, 48000]

@@ -157,8 +157,12 @@ def test_resample_matches_reference_vectors(golden):
 def test_lowpass_matches_reference_vectors(golden):
     x = golden["lp_x"]
     for hc, fs in [(4000, 44100), (12000, 44100), (6000, 48000)]:
-        # float: numpy-vs-torch fp32 elementwise ops (pow 0.5, mag*cos) differ by <= 1 ulp
-        np.testing.assert_allclose(olp.lowpass(x, hc, fs, order=1, _type="stft_hard"), golden["lp_y_%d_%d" % (hc, fs)], atol=3e-8)
+        # the oracle's torchlibrosa restatement IS the published code (float32 F.conv1d / F.fold on torch-CPU), the vector is the
+        # imported reference driving that same code: identical up to what torch's conv kernel does with its summation order on this
+        # box / thread count (<= 1e-7 on the waveform, measured below) and numpy-vs-torch float32 elementwise ops (<= 1 ulp)
+        np.testing.assert_allclose(olp.lowpass(x, hc, fs, order=1, _type="stft_hard"), golden["lp_y_%d_%d" % (hc, fs)], atol=2e-7)
+        np.testing.assert_allclose(olp.lowpass(x, hc, fs, order=1, _type="stft_hard", arithmetic="chain"), golden["lp_y_%d_%d" % (hc, fs)], atol=2e-7)
+        np.testing.assert_allclose(olp.lowpass(x, hc, fs, order=1, _type="stft_hard", arithmetic="ideal"), golden["lp_y_%d_%d" % (hc, fs)], atol=2e-7)
     xs = golden["ss_x"]
     for hc in (2000, 4000, 12000):
         np.testing.assert_array_equal(np.asarray(olp.lowpass(xs, hc, 44100, 1, "subsampling"), np.float32), golden["ss_y_%d" % hc])
@@ -167,8 +171,130 @@ def test_lowpass_matches_reference_vectors(golden):
     np.testing.assert_array_equal(olp.align_length(np.arange(7.0), np.arange(4.0)), golden["al_pad"])
     np.testing.assert_array_equal(olp.align_length(np.arange(4.0), np.arange(7.0)), golden["al_cut"])
     mag, cos, sin = olp.spectrogram_phase(golden["fd_x"][None])
-    np.testing.assert_allclose(mag[0, 0], golden["fd_mag"], rtol=2e-7)
-    np.testing.assert_allclose(cos[0, 0], golden["fd_cos"], atol=2e-7)
+    np.testing.assert_allclose(mag[0, 0], golden["fd_mag"], rtol=2e-7, atol=2e-7 * golden["fd_mag"].max())
+    big = golden["fd_mag"] > 1e-2 * golden["fd_mag"].max()          # (cos of a bin at the float32 noise floor is that noise's phase)
+    np.testing.assert_allclose(cos[0, 0][big], golden["fd_cos"][big], atol=1e-4)
+
+
+def _tl_conv_lowpass(x, cut, threads=None, order=None):
+    """stft_hard_lowpass_v0 (lowpass.py:17-28) through the published torchlibrosa arithmetic; order: see oracle.stft.tl_istft_conv."""
+    old = torch.get_num_threads()
+    if threads:
+        torch.set_num_threads(threads)
+    try:
+        re, im = ostft.tl_stft_conv(x[None])
+        mag = np.clip(re ** 2 + im ** 2, np.float32(1e-8), np.inf) ** np.float32(0.5)
+        c, s_ = re / mag, im / mag
+        mag[..., cut:] = 0
+        return ostft.tl_istft_conv(mag * c, mag * s_, len(x), order=order)[0]
+    finally:
+        torch.set_num_threads(old)
+
+
+def test_tl_conv_restatement_against_exact_transforms():
+    """The published float32 conv arithmetic computes the same transforms as the exact (float64 FFT) ones, to float32 dot-product
+    round-off: STFT within 3e-6 of the largest bin, the low-passed waveform within 3e-7 of full scale; and the C restatement with
+    the fixed accumulation order (oracle/tl_chain.c, = the HIP conv engine) is one more member of that class."""
+    from oracle import tl_chain
+    rng = np.random.default_rng(4)
+    x = (0.1 * rng.standard_normal(12000)).astype(np.float32)
+    re_c, im_c = ostft.tl_stft_conv(x[None])
+    re_i, im_i = ostft.tl_stft_ideal(x[None])
+    re_k, im_k = tl_chain.stft(x)
+    top = np.abs(re_i).max()
+    assert np.abs(re_c - re_i).max() < 3e-6 * top and np.abs(im_c - im_i).max() < 3e-6 * top
+    assert np.abs(re_k - re_i[0, 0]).max() < 3e-6 * top and np.abs(im_k - im_i[0, 0]).max() < 3e-6 * top
+    y_c = _tl_conv_lowpass(x, 300)
+    y_i = olp.stft_hard_lowpass(x, 300.5 / 1025, arithmetic="ideal")
+    y_k = olp.stft_hard_lowpass(x, 300.5 / 1025, arithmetic="chain")
+    assert np.abs(y_c - y_i).max() < 3e-7 and np.abs(y_k - y_i).max() < 3e-7 and np.abs(y_k - y_c).max() < 3e-7
+    # round trip without a cut: the identity to float32 round-off in every member
+    assert np.abs(_tl_conv_lowpass(x, 1025) - x).max() < 5e-7
+    assert np.abs(tl_chain.stft_hard_lowpass(x, 1025) - x).max() < 5e-7
+
+
+def test_library_conv_tables_are_torchlibrosas():
+    """libssrhip's host-built weight tables (ssr_tl_weights: exact phase reduction, long double) against the numpy restatement of
+    torchlibrosa's own construction (np.power(omega, j k) in complex128): > 99 % of the 10.5 M entries bit-identical, the rest
+    1 float32 ulp apart (np.power's ~1e-10 phase error at large exponents crosses a rounding boundary now and then)."""
+    import ctypes as C
+    from ssr_eval_amd import _lib
+    n, F = 2048, 1025
+    a, b = np.empty((n, F), np.float32), np.empty((n, F), np.float32)
+    c, d = np.empty((n, n), np.float32), np.empty((n, n), np.float32)
+    w2 = np.empty(n, np.float32)
+    _lib.check(_lib.load().ssr_tl_weights(n, *[v.ctypes.data_as(C.c_void_p) for v in (a, b, c, d, w2)]))
+    fr, fi, ir, ii = ostft.tl_weights(n)
+    for got, want in ((a.T, fr), (b.T, fi), (c.T, ir), (d.T, ii)):
+        assert (got == want).mean() > 0.99
+        assert np.abs(got - want).max() <= np.spacing(np.float32(np.abs(want).max()))
+    np.testing.assert_array_equal(w2, (ostft.hann_periodic(n) ** 2).astype(np.float32))
+    assert _lib.load().ssr_tl_weights(2229, None, None, None, None, None) == _lib.ERR_UNSUPPORTED
+
+
+SENS_CUTS = [42, 85, 170, 256, 341, 512, 683]        # BASELINE cfg-3: cutoffs {1, 2, 4, 6, 8, 12, 16} kHz at fs 48 kHz
+
+
+def test_lowpass_arithmetic_class_sensitivity():
+    """how far LSD / log-SISpec of a hard-low-passed estimate move with the ARITHMETIC of the low-pass.
+
+    The estimate's stop band is the transform's round-off floor and LSD takes its logarithm.  Members of the reference's class
+    (float32 dense-DFT dot products: torch's conv1d at 8 threads / 1 thread, the fixed chains of 128 fused multiply-adds the HIP
+    conv engine runs, a plain sequential float32 sum in a PERMUTED bin order) against the float64-FFT idealisation that rounds once.
+    cfg-3's cut bins on a cfg-2 style target (1 s of 0.1 N(0,1) @ 48 kHz), metrics at (2048, 512), and the README Table-1 flow
+    (speech-like 44.1 kHz, cutoff 4 kHz, evaluation at 44.1 kHz: no resampler between low-pass and metric).
+    Asserted: the idealisation is OUTSIDE the class (LSD > 1.5 % high at every cut) - no test may pin a low-passed estimate's
+    LSD / log-SISpec to it; the class itself spans <= 4 % in LSD and <= 0.1 dB in log-SISpec; the HIP engine's member is within
+    1.5 % / 0.03 dB of torch's; SISpec and SSIM do not care (1e-5).  The table goes to profiles/r04_lowpass_class_sensitivity.json
+    when SSR_WRITE_PROFILES=1."""
+    import json
+    rng = np.random.default_rng(20220328)
+    x = (0.1 * rng.standard_normal(48000)).astype(np.float32)
+    rows = []
+
+    def metrics(y, tgt, n_fft=2048, hop=512):
+        m = om.evaluation(y, tgt, n_fft=n_fft, hop=hop)
+        return [m["lsd"], m["log_sispec"], m["sispec"], m["ssim"]]
+
+    def members(sig, cut):
+        out = {"conv_torch": _tl_conv_lowpass(sig, cut), "conv_torch_1thread": _tl_conv_lowpass(sig, cut, threads=1),
+               "chain128_hip": olp.stft_hard_lowpass(sig, (cut + 0.5) / 1025, arithmetic="chain"),
+               "ideal_f64_fft": olp.stft_hard_lowpass(sig, (cut + 0.5) / 1025, arithmetic="ideal")}
+        if cut in (85, 341):          # the slow member, on two cuts
+            out["sequential_permuted"] = _tl_conv_lowpass(sig, cut, order=np.random.default_rng(1).permutation(2048))
+        return out
+
+    for cut in SENS_CUTS:
+        ms = {k: metrics(v, x) for k, v in members(x, cut).items()}
+        rows.append({"flow": "cfg-3 noise 48 kHz, metrics 2048/512", "cut_bin": cut, "metrics[lsd,log_sispec,sispec,ssim]": ms})
+    sp = (0.08 * np.sin(2 * np.pi * 180 * np.arange(44100) / 44100 * (1 + 0.2 * np.arange(44100) / 44100))).astype(np.float32)
+    sp = sp + (0.02 * np.random.default_rng(9).standard_normal(44100) * np.linspace(1, 0.2, 44100)).astype(np.float32)
+    ms = {k: metrics(v, sp, 2048, 441) for k, v in members(sp, olp.cut_bin(4000, 44100)).items()}
+    rows.append({"flow": "README Table 1: 44.1 kHz, cutoff 4 kHz, evaluated at 44.1 kHz (2048/441)", "cut_bin": olp.cut_bin(4000, 44100),
+                 "metrics[lsd,log_sispec,sispec,ssim]": ms})
+    worst = {"ideal_lsd_rel": 1.0, "class_lsd_rel": 0.0, "class_logsi_abs": 0.0, "hip_lsd_rel": 0.0, "hip_logsi_abs": 0.0}
+    for r in rows:
+        ms = r["metrics[lsd,log_sispec,sispec,ssim]"]
+        ref = ms["conv_torch"]
+        worst["ideal_lsd_rel"] = min(worst["ideal_lsd_rel"], ms["ideal_f64_fft"][0] / ref[0] - 1)
+        for k, v in ms.items():
+            # SISpec (dB; 1e-5 relative + 5e-5 dB: the reference's own float32 energy sums are good to ~1e-5 relative = 4e-5 dB) and SSIM: any arithmetic
+            assert abs(v[2] - ref[2]) < 1e-5 * abs(ref[2]) + 5e-5 and abs(v[3] / ref[3] - 1) < 1e-5, (r["cut_bin"], k)
+            if k in ("conv_torch", "ideal_f64_fft"):
+                continue
+            worst["class_lsd_rel"] = max(worst["class_lsd_rel"], abs(v[0] / ref[0] - 1))
+            worst["class_logsi_abs"] = max(worst["class_logsi_abs"], abs(v[1] - ref[1]))
+            if k == "chain128_hip":
+                worst["hip_lsd_rel"] = max(worst["hip_lsd_rel"], abs(v[0] / ref[0] - 1))
+                worst["hip_logsi_abs"] = max(worst["hip_logsi_abs"], abs(v[1] - ref[1]))
+    assert worst["ideal_lsd_rel"] > 0.015, worst            # the idealisation: +1.5 ... +7 % LSD at EVERY cut
+    assert worst["class_lsd_rel"] < 0.04 and worst["class_logsi_abs"] < 0.1, worst
+    assert worst["hip_lsd_rel"] < 0.015 and worst["hip_logsi_abs"] < 0.03, worst
+    if os.environ.get("SSR_WRITE_PROFILES") == "1":
+        with open(os.path.join(ROOT, "profiles", "r04_lowpass_class_sensitivity.json"), "w") as f:
+            json.dump({"note": "LSD / log-SISpec / SISpec / SSIM of a hard-low-passed estimate per low-pass arithmetic; conv_torch = the "
+                               "published torchlibrosa code on torch-CPU (%d threads) = the reference's class" % torch.get_num_threads(),
+                       "worst": worst, "rows": rows}, f, indent=1)
 
 
 def test_lowpass_really_removes_the_band(golden):

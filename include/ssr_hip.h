@@ -254,6 +254,19 @@ int ssr_resample_sinc(const float* in, const int64_t* in_off, const int32_t* in_
 int ssr_pcm16_to_float(const int16_t* pcm, const int64_t* pcm_off, const int32_t* n_frames, const int32_t* n_channels,
                        int n_items, int max_frames, float* out, const int64_t* out_off, void* stream);
 
+/* N2.  FLAC ingest: the decode half of librosa.load(file) for the format the reference's data set ships in
+ * (ssr_eval/eval.py:158-169 lists ".wav" / ".flac"; eval.py:242, ssr_eval/metrics.py:21-24).  HOST entry points (paths and
+ * buffers are host memory; no GPU needed): the decoder threads of the Python mirror call them with the pinned staging arena as
+ * `out`, so 16-bit files cross PCIe as int16 exactly like PCM .wav files (ssr_pcm16_to_float then yields librosa's float32 values).
+ * Full format support (RFC 9639: CONSTANT / VERBATIM / FIXED / LPC subframes, Rice partitions incl. escapes, wasted bits, the three
+ * stereo decorrelations, 4-32 bits, CRC-8 / CRC-16 checked).  verify_md5 != 0: the MD5 of the decoded PCM is compared with the
+ * signature STREAMINFO carries (when the encoder stored one) - a bit-exact self-check; mismatch = SSR_ERR_INVALID_ARG.
+ * out: interleaved frames, capacity in SAMPLES (frames x channels); out == NULL only counts (and verifies); *frames_out = frames
+ * per channel.  ssr_flac_decode_pcm16 takes streams of <= 16 bits per sample (SSR_ERR_UNSUPPORTED otherwise); _i32 takes any. */
+int ssr_flac_info(const char* path, int* sample_rate, int* channels, int* bits, int64_t* total_samples, int* has_md5);
+int ssr_flac_decode_pcm16(const char* path, int16_t* out, int64_t capacity, int verify_md5, int64_t* frames_out);
+int ssr_flac_decode_i32(const char* path, int32_t* out, int64_t capacity, int verify_md5, int64_t* frames_out);
+
 /* N4.  Position of the maximum of the full cross-correlation of two equal-length signals,
  *   z[k] = sum_l a[l] * b[l - k + n - 1],  k = 0 .. 2n-2   (scipy.signal.correlate(a, b, "full")),
  * first maximum on ties (numpy.argmax): the alignment step of SSR_Eval_Helper.mp3_encoding

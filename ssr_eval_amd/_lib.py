@@ -54,6 +54,9 @@ SIGNATURES = {
     "ssr_resample_sinc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _vp, _vp, _i, _i, _i, C.c_double, C.c_double, _i,
                                 _vp, _vp]),
     "ssr_pcm16_to_float": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "ssr_flac_info": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64), C.POINTER(_i)]),
+    "ssr_flac_decode_pcm16": (_i, [C.c_char_p, _vp, _i64, _i, C.POINTER(_i64)]),
+    "ssr_flac_decode_i32": (_i, [C.c_char_p, _vp, _i64, _i, C.POINTER(_i64)]),
     "ssr_xcorr_workspace_bytes": (_sz, [_i, _i]),
     "ssr_xcorr_argmax": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "ssr_sosfiltfilt_workspace_bytes": (_sz, [_i64, _i, _i]),

@@ -625,28 +625,41 @@ class _Staging:
     ONE asynchronous copy while the host packs the next batch into the other.  An arena is reused only after the copy that
     last read it has completed (event)."""
     _by_dev = {}
+    _by_dev_lock = threading.Lock()
 
     def __init__(self):
         self.buf = [None, None]
         self.ev = [None, None]
         self.k = 0
+        self.lock = threading.Lock()
 
     @classmethod
-    def get(cls, dev):
-        return cls._by_dev.setdefault(str(dev), cls())
+    def get(cls, dev, role="packed"):
+        """One arena pair per (resolved device index, role).  role "packed": io.PackedBatch (the prefetching file path);
+        "list": upload_decoded() of a list of RawAudio - its own pair, so that a list upload in the middle of an in-flight
+        PackedBatch (its non-RIFF `others`) can never flip that batch's arenas."""
+        d = torch.device(dev)
+        idx = d.index if d.index is not None else torch.cuda.current_device()
+        with cls._by_dev_lock:
+            return cls._by_dev.setdefault((idx, role), cls())
 
     def arena(self, n):
-        self.k ^= 1
-        k = self.k
-        if self.ev[k] is not None:
-            self.ev[k].synchronize()
-        if self.buf[k] is None or self.buf[k].numel() < n:
-            self.buf[k] = torch.empty(max(n, 1 << 22), dtype=torch.int16, pin_memory=True)
-        return k, self.buf[k]
+        with self.lock:
+            self.k ^= 1
+            k = self.k
+            ev = self.ev[k]
+        if ev is not None:
+            ev.synchronize()
+        with self.lock:
+            if self.buf[k] is None or self.buf[k].numel() < n:
+                self.buf[k] = torch.empty(max(n, 1 << 22), dtype=torch.int16, pin_memory=True)
+            return k, self.buf[k]
 
     def sent(self, k):
-        self.ev[k] = torch.cuda.Event()
-        self.ev[k].record()
+        ev = torch.cuda.Event()
+        ev.record()
+        with self.lock:
+            self.ev[k] = ev
 
 
 def _pcm_to_float(d16, in_off, frames, chans, dev):
@@ -671,15 +684,15 @@ def upload_decoded(raw, device=None):
         dev = torch.device(raw.device)
         out = [None] * len(raw.paths)
         with torch.cuda.device(dev):
-            for i, r in zip(raw.other_idx, raw.others):
-                out[i] = upload_decoded([r], dev)[0]
-            if raw.total:
+            if raw.total:                      # the arena's copy (and its event) first: nothing else touches this batch's arena
                 d16 = torch.empty(raw.total, dtype=torch.int16, device=dev)
                 d16.copy_(raw.arena[:raw.total], non_blocking=True)
                 raw.staging.sent(raw.k)
                 flat, out_off = _pcm_to_float(d16, raw.in_off, raw.frames, raw.chans, dev)
                 for j, i in enumerate(raw.pcm_idx):
                     out[i] = flat[out_off[j]:out_off[j] + raw.frames[j]]
+            for i, r in zip(raw.other_idx, raw.others):           # (these go through the "list" arenas, a separate pair)
+                out[i] = upload_decoded([r], dev)[0]
         return out
     dev = torch.device(device) if device is not None else default_device()
     out = [None] * len(raw)
@@ -694,7 +707,7 @@ def upload_decoded(raw, device=None):
             frames = np.array([raw[i].n_frames for i in pcm], dtype=np.int64)
             chans = np.array([raw[i].nch for i in pcm], dtype=np.int32)
             total = int(sizes.sum())
-            st = _Staging.get(dev)
+            st = _Staging.get(dev, "list")
             k, arena = st.arena(total)
             host = arena.numpy()
             in_off = np.concatenate(([0], np.cumsum(sizes)[:-1]))

@@ -4,8 +4,10 @@ The reference decodes with librosa.load - soundfile decode, mono mix, then resam
 interpolation when the file's rate differs from the requested one (ssr_eval/eval.py:242, ssr_eval/metrics.py:21-24) - and
 shells out to ``sox -r`` for the evaluation-rate target (eval.py:133-134).  Here:
 
-* decode: ``soundfile`` when importable (WAV / FLAC / OGG), otherwise the standard-library ``wave`` module (PCM .wav) -
-  host work, fanned out over a thread pool by ``load_audio_batch``;
+* decode: FLAC - the format of the VCTK test set - through the native decoder behind the C ABI (``ssr_flac_*``, csrc/ssr_flac.h:
+  every file is checked against the MD5 of its PCM that STREAMINFO carries); PCM .wav through the arena reader / the
+  standard-library ``wave`` module; anything else through ``soundfile`` when that package is importable - host work, fanned out
+  over a thread pool by ``load_audio_batch``;
 * rate change: ``ssr_resample_sinc`` on the GPU - resampy's kaiser_best algorithm and filter (bit-identical to the NumPy
   restatement in oracle/resampy.py; resampy itself is not in the image, so parity with the package is unpinned), one
   ragged launch per (file rate -> requested rate) group.  It also stands in for sox's ``rate`` effect, whose filter is not
@@ -29,8 +31,46 @@ def _mono(x, nch):
     return x if nch == 1 else np.ascontiguousarray(x.reshape(-1, nch).mean(axis=1), dtype=np.float32)
 
 
+FLAC_VERIFY_MD5 = True      # compare every decoded file with the MD5 signature in its STREAMINFO (a mismatch raises)
+
+
+def _is_flac(path):
+    return path.lower().endswith(".flac")
+
+
+def flac_info(path):
+    """(sample_rate, channels, bits, frames per channel or 0 if unknown) of a FLAC file (ssr_flac_info: host code, no GPU)."""
+    import ctypes as C
+    from . import _lib
+    sr, nch, bits, has = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    total = C.c_int64()
+    _lib.check(_lib.load().ssr_flac_info(os.fsencode(path), C.byref(sr), C.byref(nch), C.byref(bits), C.byref(total), C.byref(has)))
+    return sr.value, nch.value, bits.value, total.value
+
+
+def read_flac_int(path):
+    """-> (interleaved integer frames [n * nch] - int16 for streams of <= 16 bits, int32 otherwise -, channels, rate, bits)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    sr, nch, bits, total = flac_info(path)
+    n = C.c_int64()
+    if total == 0:                                     # a streamed file without a sample count: count first
+        _lib.check(lib.ssr_flac_decode_i32(os.fsencode(path), None, 0, 0, C.byref(n)))
+        total = n.value
+    out = np.empty(total * nch, dtype=np.int16 if bits <= 16 else np.int32)
+    fn = lib.ssr_flac_decode_pcm16 if bits <= 16 else lib.ssr_flac_decode_i32
+    _lib.check(fn(os.fsencode(path), out.ctypes.data_as(C.c_void_p), out.size, 1 if FLAC_VERIFY_MD5 else 0, C.byref(n)))
+    return out[:n.value * nch], nch, sr, bits
+
+
 def read_audio(path):
     """-> (float32 mono [n], sample_rate)."""
+    if _is_flac(path):
+        v, nch, sr, bits = read_flac_int(path)
+        x = v.astype(np.float32)
+        x *= np.float32(1.0 / (1 << (bits - 1)))      # libsndfile's normalisation for float reads (a power of two: exact)
+        return _mono(x, nch), int(sr)
     if _sf is not None:
         x, sr = _sf.read(path, dtype="float32", always_2d=True)
         return _mono(np.ascontiguousarray(x, dtype=np.float32).reshape(-1), x.shape[1]), int(sr)
@@ -79,6 +119,13 @@ class RawAudio:
 
 def read_audio_raw(path):
     """-> RawAudio: the int16 frames of a 16-bit PCM file untouched (up to 8 channels), float32 mono otherwise."""
+    if _is_flac(path):
+        sr, nch, bits, _ = flac_info(path)
+        if bits == 16 and nch <= 8:
+            v, nch, sr, bits = read_flac_int(path)
+            return RawAudio(v, None, int(nch), int(sr))
+        x, sr = read_audio(path)
+        return RawAudio(None, x, 1, sr)
     if _sf is not None:
         info = _sf.info(path)
         if info.subtype == "PCM_16" and info.channels <= 8:
@@ -146,7 +193,15 @@ def decode_async(paths, threads=None, raw=False):
 
 def _wav_pcm16_layout(path):
     """(data offset, data bytes, channels, rate) of a 16-bit PCM RIFF / WAVE file - enough to read its frames straight into a
-    staging arena - or None for anything else (other sample formats, other containers: those go through read_audio_raw)."""
+    staging arena - or None for anything else (other sample formats, other containers: those go through read_audio_raw).
+    A 16-bit FLAC file with a known length answers ("flac", bytes of its decoded PCM, channels, rate): the decoder threads then
+    DECODE it straight into the arena (ssr_flac_decode_pcm16)."""
+    if _is_flac(path):
+        try:
+            sr, nch, bits, total = flac_info(path)
+        except Exception:
+            return None                                # (read_audio_raw will raise the real error)
+        return ("flac", 2 * total * nch, nch, sr) if bits == 16 and 1 <= nch <= 8 and total > 0 else None
     try:
         with open(path, "rb") as f:
             head = f.read(12)
@@ -207,6 +262,15 @@ class PackedBatch:
         def read_into(j):
             i = self.pcm_idx[j]
             o, n = int(self.in_off[j]), int(self.sizes[j])
+            if lay[i][0] == "flac":                    # decode into the arena (the C call releases the GIL)
+                import ctypes as C
+                from . import _lib
+                got = C.c_int64()
+                _lib.check(_lib.load().ssr_flac_decode_pcm16(os.fsencode(self.paths[i]), C.c_void_p(host[o:o + n].ctypes.data), n,
+                                                             1 if FLAC_VERIFY_MD5 else 0, C.byref(got)))
+                if got.value * int(lay[i][2]) != n:
+                    raise OSError("%s: decoded %d frames, STREAMINFO announces %d" % (self.paths[i], got.value, n // int(lay[i][2])))
+                return
             with open(self.paths[i], "rb") as f:
                 f.seek(lay[i][0])
                 got = f.readinto(memoryview(host[o:o + n]).cast("B"))

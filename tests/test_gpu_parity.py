@@ -845,3 +845,89 @@ def test_sispec_stays_accurate_at_very_high_snr():
         if amp >= 1e-4:
             assert abs(got[1] - exact_log) <= 1e-5 * abs(exact_log), (amp, got[1], exact_log)
     assert exact > 120.0
+
+
+def test_evaluate_flac_tree_equals_wav_tree_bit_for_bit(tmp_path, monkeypatch):
+    """N2 / VERDICT r3 item 4: SSR_Eval_Helper.evaluate() on a .flac tree - the format of the reference's data set
+    (ssr_eval/eval.py:158-169,242) - decoded by the native decoder (no soundfile), MD5 check on, against the same audio as 16-bit
+    PCM .wav files: every per-file metric, the aggregates and the uploaded waveforms identical bit for bit.  A third tree mixes .wav,
+    16-bit .flac (arena path) and a 24-bit .flac (float path) in ONE batch (the staging arenas used to get mixed up)."""
+    import shutil
+    import flac_fixture as FF
+    from ssr_eval_amd import SSR_Eval_Helper, BasicTestee
+    from ssr_eval_amd import backend as B, io as sio
+    assert sio.FLAC_VERIFY_MD5
+    rng = np.random.default_rng(77)
+    roots = {k: tmp_path / k / "vctk" for k in ("wav", "flac", "mixed")}
+    counts = {"p360": 3, "s5": 2}
+    pcm = {}
+    for spk, c in counts.items():
+        for r in roots.values():
+            (r / spk).mkdir(parents=True)
+        for i in range(c):
+            n = int(rng.integers(30000, 70000))
+            t = np.arange(n) / 44100.0
+            x = 0.2 * np.sin(2 * np.pi * (140 + 50 * i) * t) * np.sin(2 * np.pi * 2.5 * t) + 0.03 * rng.standard_normal(n)
+            q = np.clip(np.rint(x * 32768.0), -32768, 32767).astype(np.int64)
+            name = "%s_%03d_mic1" % (spk, i)
+            pcm[(spk, name)] = q
+            sio.write_wav(str(roots["wav"] / spk / (name + ".wav")), (q / 32768.0).astype(np.float32), 44100)
+            (roots["flac"] / spk / (name + ".flac")).write_bytes(FF.encode(q, 44100, 16, 4096 if i % 2 else 1152, seed=i))
+            if i % 2 == 0:
+                (roots["mixed"] / spk / (name + ".flac")).write_bytes(FF.encode(q, 44100, 16, 1152, seed=i))
+            else:
+                shutil.copy(str(roots["wav"] / spk / (name + ".wav")), str(roots["mixed"] / spk / (name + ".wav")))
+    # one 24-bit file whose samples are the 16-bit ones shifted up: the float path gives the same float32 values
+    q24 = pcm[("s5", "s5_000_mic1")] << 8
+    (roots["mixed"] / "s5" / "s5_000_mic1.flac").write_bytes(FF.encode(q24, 44100, 24, 2048, seed=5))
+    # the upload itself: arena (int16 over PCIe, GPU conversion) for .wav and .flac alike
+    names = sorted(pcm)
+    for kind in ("wav", "flac"):
+        paths = [str(roots[kind] / spk / (name + "." + kind)) for spk, name in names]
+        pb = sio.decode_packed_async(paths)()
+        assert len(pb.pcm_idx) == len(paths) and not pb.other_idx
+        up = B.upload_decoded(pb)
+        for (spk, name), u in zip(names, up):
+            np.testing.assert_array_equal(u.cpu().numpy(), (pcm[(spk, name)].astype(np.float32) * np.float32(1 / 32768.0)))
+    results = {}
+    for kind, root in roots.items():
+        monkeypatch.chdir(tmp_path / kind)
+        h = SSR_Eval_Helper(BasicTestee(), test_name="t", input_sr=44100, output_sr=44100, evaluation_sr=48000,
+                            test_data_root=str(root), setting_fft={"cutoff_freq": [4000, 12000]}, setting_lowpass_filtering={"filter": ["butter"], "filter_order": [4], "cutoff_freq": [6000]})
+        results[kind] = h.evaluate(limit_test_nums=-1, limit_test_speaker=-1)
+    strip = lambda res: {spk: {os.path.splitext(f)[0]: v for f, v in res[spk].items()} for spk in counts}
+    assert strip(results["flac"]) == strip(results["wav"])
+    assert strip(results["mixed"]) == strip(results["wav"])
+    for kind in ("flac", "mixed"):
+        assert results[kind]["averaged"] == results["wav"]["averaged"] and results[kind]["each_speaker"] == results["wav"]["each_speaker"]
+    # a corrupted file stops the evaluation loudly
+    bad = roots["flac"] / "p360" / "p360_000_mic1.flac"
+    data = bytearray(bad.read_bytes())
+    data[len(data) // 2] ^= 4
+    bad.write_bytes(bytes(data))
+    monkeypatch.chdir(tmp_path / "flac")
+    h = SSR_Eval_Helper(BasicTestee(), test_name="t", input_sr=44100, output_sr=44100, evaluation_sr=48000, test_data_root=str(roots["flac"]),
+                        setting_fft={"cutoff_freq": [4000]})
+    with pytest.raises(Exception):
+        h.evaluate(limit_test_nums=-1, limit_test_speaker=-1)
+
+
+def test_ragged_from_list_does_not_alias_separate_allocations():
+    """separately allocated CUDA tensors that happen to sit back to back in the caching allocator (sizes that are
+    multiples of 512 bytes) must NOT be taken as one buffer - Tensor.set_ past the first tensor's storage silently reallocates it."""
+    from ssr_eval_amd import backend as B
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for n in (48000, 4096, 128 * 77):
+        xs = [torch.randn(n, device="cuda", generator=g) for _ in range(4)]
+        keep = [x.clone() for x in xs]
+        r = B.Ragged.from_list(xs)
+        for i, k in enumerate(keep):
+            np.testing.assert_array_equal(r.data[int(r.lens_host[:i].sum()):int(r.lens_host[:i + 1].sum())].cpu().numpy(), k.cpu().numpy())
+            np.testing.assert_array_equal(xs[i].cpu().numpy(), k.cpu().numpy())
+        ys = B.resample_poly(xs, 160, 147)
+        want = signal.resample_poly(keep[2].cpu().numpy(), 160, 147)
+        np.testing.assert_array_equal(ys[2].cpu().numpy(), want)
+    # views of ONE buffer still take the zero-copy path
+    flat = torch.randn(3 * 1000, device="cuda", generator=g)
+    r = B.Ragged.from_list([flat[0:1000], flat[1000:2000], flat[2000:3000]])
+    assert r.data.data_ptr() == flat.data_ptr()

@@ -139,6 +139,22 @@ int ssr_pair_metrics_f64(const ssr_plan* plan, const double* est, const int64_t*
                          int64_t total_rows, unsigned metric_mask, double* out, void* workspace, size_t workspace_bytes,
                          void* stream);
 
+/* K1-K5 for ONE target and K estimates per item: SSR_Eval_Helper.evaluate_single scores every degradation key of a file against the
+ * same target (ssr_eval/eval.py:136-154).  est_off is key-major, [n_keys][n_items]: estimate k of item i starts at element
+ * est_off[k * n_items + i] of est; all K estimates and the target of item i share the truncated length len[i] (metrics.py:89-90);
+ * out: double [n_items][n_keys][4].  The target is transformed once (with estimate 0: that key is bit-identical to ssr_pair_metrics)
+ * and its magnitude image stored once; estimates 1 .. K-1 are transformed two per complex transform and reduced against the stored
+ * image - the same per-bin arithmetic on the same float32 magnitudes, so the metrics agree with K calls of ssr_pair_metrics to
+ * <= 1e-6 relative (not bit for bit: an estimate separated from another estimate instead of the target keeps ~1e-16 of its
+ * partner's spectrum, a last-bit flip of a float32 magnitude now and then; float64 partial sums are added in another order).
+ * K + 1 real transforms and K + 1 magnitude images per item instead of 2 K and 2 K.  Plans whose pair transform runs a block engine
+ * take K plain passes (bit-identical to ssr_pair_metrics). */
+size_t ssr_pair_metrics_multi_workspace_bytes(const ssr_plan* plan, int n_items, int n_keys, int max_len, int64_t total_rows,
+                                              unsigned metric_mask);
+int ssr_pair_metrics_multi(const ssr_plan* plan, const float* est, const int64_t* est_off, const float* tgt, const int64_t* tgt_off,
+                           const int32_t* len, const int64_t* frame_off, int n_items, int n_keys, int max_len, int64_t total_rows,
+                           unsigned metric_mask, double* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Same, restricted to a subset of its three launches (bit 0: STFT + fused LSD/SISpec epilogue, bit 1:
  * SSIM, bit 2: finalisation) so that bench.py can time the dominant kernel on its own stream with
  * HIP events.  stages = 7 is ssr_pair_metrics. */

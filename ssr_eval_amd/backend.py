@@ -253,6 +253,53 @@ class PairBatch:
         return self.out
 
 
+class MultiPairBatch:
+    """ONE target, K estimates per item (ssr_pair_metrics_multi): `est` holds n_keys * n items KEY-MAJOR (estimate k of item i
+    at index k * n + i), every estimate of item i as long as target i.  The target is transformed once and its magnitude image
+    stored once; estimates 1 .. K-1 are transformed two per complex transform.  out: [n, n_keys, 4] float64."""
+
+    def __init__(self, plan, est, tgt, n_keys):
+        n_keys = int(n_keys)
+        if n_keys < 1 or est.n != tgt.n * n_keys or not np.array_equal(est.lens_host, np.tile(tgt.lens_host, n_keys)):
+            raise ValueError("est must hold n_keys estimates per target, key-major, each as long as its target")
+        if est.data.dtype != torch.float32 or tgt.data.dtype != torch.float32:
+            raise ValueError("ssr_pair_metrics_multi takes float32 signals (float64 pairs go through PairBatch)")
+        _check_nonempty(tgt.lens_host)
+        self.plan, self.est, self.tgt, self.n_keys = plan, est, tgt, n_keys
+        self.rows = _Rows(plan, tgt.lens_host, tgt.device)
+        self.ws_bytes, self.ws, self._ws_mask = 0, None, 0
+        self.out = torch.empty((tgt.n, n_keys, 4), dtype=torch.float64, device=tgt.device)
+
+    def _workspace(self, mask):
+        if self.ws is None or (mask & ~self._ws_mask):
+            want = mask | self._ws_mask
+            p, t = self.plan, self.tgt
+            self.ws_bytes = int(p.lib.ssr_pair_metrics_multi_workspace_bytes(p.handle, t.n, self.n_keys, t.max_len, self.rows.total, want))
+            self.ws = None
+            self.ws = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=t.device)
+            self._ws_mask = want
+
+    def run(self, mask=M_ALL):
+        p, e, t = self.plan, self.est, self.tgt
+        if t.n == 0:
+            return self.out
+        self._workspace(mask)
+        if (mask & M_SSIM) and (self.rows.T.min() < 7 or p.n_bins < 7):
+            raise ValueError("win_size exceeds image extent")
+        _lib.check(p.lib.ssr_pair_metrics_multi(
+            p.handle, _vp(e.data), _vp(e.off), _vp(t.data), _vp(t.off), _vp(t.len), _vp(self.rows.off), t.n, self.n_keys, t.max_len,
+            self.rows.total, mask, _vp(self.out), _vp(self.ws), self.ws_bytes, _stream()))
+        return self.out
+
+
+def pair_metrics_multi(plan, est_lists, tgt_list, mask=M_ALL):
+    """est_lists: K lists (one per key) of n waveforms; tgt_list: n targets -> [n, K, 4] float64."""
+    with torch.cuda.device(plan.device):
+        flat = [e for key in est_lists for e in key]
+        b = MultiPairBatch(plan, Ragged.from_list(flat, plan.device), Ragged.from_list(tgt_list, plan.device), len(est_lists))
+        return b.run(mask).cpu().numpy()
+
+
 def pair_metrics(plan, est_list, tgt_list, mask=M_ALL):
     """[n, 4] float64 (lsd, log_sispec, sispec, ssim) for lists of equal-length (est, target) waveforms.
     float64 signals stay float64 (ssr_pair_metrics_est64 / ssr_pair_metrics_f64)."""
@@ -383,7 +430,7 @@ class LowpassBatch:
     item.  `run()` enqueues the launch sequence on the current stream and returns the flat output buffer (same layout as
     the input batch); `out_ragged()` views it as a Ragged batch for the metric stage."""
 
-    def __init__(self, plan, ragged, cut_bins):
+    def __init__(self, plan, ragged, cut_bins, out=None):
         _check_reflect(plan, ragged.lens_host)
         if ragged.data.dtype != torch.float32:
             raise ValueError("the STFT-domain low-pass takes float32 signals (torchlibrosa's convolution does too)")
@@ -394,7 +441,10 @@ class LowpassBatch:
             raise ValueError("one cut bin per item")
         self.ws_bytes = int(plan.lib.ssr_ola_workspace_bytes(plan.handle, self.rows.total))
         self.ws = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=ragged.device)
-        self.out = torch.empty_like(ragged.data)
+        # out: a caller-owned float32 buffer of the batch's size (e.g. one key's slice of a multi-key estimate buffer)
+        if out is not None and (out.dtype != torch.float32 or out.numel() != ragged.data.numel() or not out.is_contiguous()):
+            raise ValueError("out must be a contiguous float32 buffer of the batch's size")
+        self.out = out if out is not None else torch.empty_like(ragged.data)
 
     def run(self):
         p, r = self.plan, self.r

@@ -39,6 +39,10 @@ struct SsrSsimParams {
   int rows_per_tile, n_row_tiles, n_strips;
   double* part;              // [n_items, n_row_tiles * n_strips] sum of S over the tile
   int pitch;                 // floats between rows (0: F).  A multiple of 4 on a 16-byte-aligned base selects CONTIG.
+  // virtual items (ssr_pair_metrics_multi: K estimates per target): item v = k * vi_n + i reads estimate plane k (x + k * x_plane)
+  // against the ONE target image of item i; vi_n = 0: plain items
+  int vi_n;
+  int64_t x_plane;
 };
 SSR_DEV int ssr_ssim_pitch(const SsrSsimParams& p) { return p.pitch ? p.pitch : p.F; }
 
@@ -272,6 +276,9 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
   using Lds = SsrSsimLds<CPT, CONTIG>;
   Lds L(lds_base);
   const int row_tile = tile / p.n_strips, strip = tile % p.n_strips;
+  const int item_v = item;                           // index of the partial record
+  const float* xbase = p.x;
+  if (p.vi_n > 0) { xbase += (int64_t)(item / p.vi_n) * p.x_plane; item = item % p.vi_n; }
   const int T = p.n_rows[item];
   const int out_rows = T - (W - 1);
   const int r0 = row_tile * p.rows_per_tile;
@@ -279,9 +286,9 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
   const int c_in0 = strip * ssr_ssim_strip_out(CPT);
   const int ncol_in = (p.F - c_in0 < NT * CPT + (W - 1)) ? p.F - c_in0 : NT * CPT + (W - 1);
   const int ncol_out = ncol_in - (W - 1);
-  double* part = p.part + (int64_t)item * p.n_row_tiles * p.n_strips + tile;
+  double* part = p.part + (int64_t)item_v * p.n_row_tiles * p.n_strips + tile;
   const int pitch = ssr_ssim_pitch(p);
-  const SsrImage x(p.x + p.frame_off[item] * pitch, (int64_t)T * pitch);
+  const SsrImage x(xbase + p.frame_off[item] * pitch, (int64_t)T * pitch);
   const SsrImage y(p.y + p.frame_off[item] * pitch, (int64_t)T * pitch);
 
   SSR_REGS(Regs, regs, blk);
@@ -488,6 +495,9 @@ struct SsrFinalizeParams {
   const int32_t* n_rows;                   // T_i
   int F, metric_mask, n_items;
   double* out;                             // [n_items, 4]
+  // virtual items (ssr_pair_metrics_multi): record v = k * vi_n + i belongs to item i, key out_key0 + k of out_keys keys per item:
+  // out[(i * out_keys + out_key0 + k) * 4]; vi_n = 0: plain
+  int vi_n, out_keys, out_key0;
 };
 
 SSR_DEV double ssr_sispec_from_sums(double sdd, double stt, double sdt) {
@@ -506,9 +516,10 @@ SSR_DEV double ssr_sispec_from_sums(double sdd, double stt, double sdt) {
 
 SSR_DEV void ssr_finalize_item(const SsrFinalizeParams& p, int item) {
   const double nan_ = NAN;
-  double* o = p.out + (int64_t)item * 4;
+  const int real = p.vi_n > 0 ? item % p.vi_n : item;
+  double* o = p.vi_n > 0 ? p.out + ((int64_t)real * p.out_keys + p.out_key0 + item / p.vi_n) * 4 : p.out + (int64_t)item * 4;
+  const int T = p.n_rows[real];
   o[0] = o[1] = o[2] = o[3] = nan_;
-  const int T = p.n_rows[item];
   if (p.part) {
     double s[SSR_NPART];
     for (int q = 0; q < SSR_NPART; ++q) s[q] = 0.0;

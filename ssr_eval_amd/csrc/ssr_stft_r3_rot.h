@@ -185,7 +185,7 @@ SSR_BODY void ssr_stft_r3_rot_body(const SsrStftParams<T>& p, BLK& blk, int chun
           const cx<T> zn = ssr_r3_combine3<T>(yb[0], yb[1], yb[2], q, Kn);
           float ev, tv;
           ssr_pair_bin<T, 0, true>(mask, acc, zk, zn, a_nz, b_nz, ev, tv);
-          if (store) { ra0[K] = ev; rb0[K] = tv; }
+          if (store) { ra0[K] = ev; if (rb0 != nullptr) rb0[K] = tv; }
         }
         if (want_lsd) SSR_WAVE_SUM_STORE(tid, NT, acc[0], L.sc1 + 4 * e);
         if constexpr (SUMS)

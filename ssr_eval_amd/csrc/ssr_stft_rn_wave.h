@@ -200,7 +200,7 @@ SSR_BODY void ssr_stft_rn_wave_body(const SsrStftParams<T>& p, BLK& blk, int chu
         const cx<T> zn = ssr_rn_combine<T, NW>(yre, yim, q, Kn);
         float e, t;
         ssr_pair_bin<T, 0, true>(mask, acc, zk, zn, a_nz, b_nz, e, t);
-        if (store) { ra0[K] = e; rb0[K] = t; }
+        if (store) { ra0[K] = e; if (rb0 != nullptr) rb0[K] = t; }
       }
       if (want_lsd) SSR_WAVE_SUM_STORE(tid, NT, acc[0], L.sc1);
       if constexpr (SUMS)

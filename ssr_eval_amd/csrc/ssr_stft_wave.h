@@ -371,7 +371,8 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
       const bool store = MAG < 0 ? p.out_kind == SSR_OUT_MAG : MAG != 0;
       // the two magnitude rows as buffer views: scalar row base + one lane offset + an immediate per bin (a plain pointer
       // costs a 64-bit vector add per store)
-      const SsrRwView<float> wa(ra0, store ? F : 0), wb(rb0, store ? F : 0);
+      const SsrRwView<float> wa(ra0, store ? F : 0), wb(rb0, (store && rb0 != nullptr) ? F : 0);   // out_b == null: the target rows
+      // are not written (ssr_pair_metrics_multi: they exist already) - the stores fall to the buffer range check
       const int lane4 = 4 * tid;
       const int pr = ssr_wave_bases(tid).pr;
       constexpr int G = SUMS ? 2 : 4;                              // bins in flight (the variant with running sums is tighter)

@@ -241,6 +241,161 @@ extern "C" int ssr_pair_metrics_f64(const ssr_plan* pl, const double* est, const
 }
 
 // ----------------------------------------------------------------------------------------------------
+// ssr_pair_metrics_multi: ONE target, K estimates per item (SSR_Eval_Helper.evaluate_single, ssr_eval/eval.py:136-154: every
+// degradation key of a file is scored against the same target).  The target is transformed ONCE - with estimate 0, by the pair
+// kernel exactly as ssr_pair_metrics runs it (key 0 is bit-identical) - and its magnitude image written once; the other estimates
+// go through the same kernel TWO PER COMPLEX TRANSFORM (no target, no metric epilogue: magnitude rows only), their LSD / SISpec
+// terms come from k_specred_wave against the stored target image, and k_ssim reads that one image for every key:
+// K + 1 real transforms and K + 1 images instead of 2 K and 2 K.
+#include "ssr_specred_wave.h"
+__global__ __launch_bounds__(64) void k_specred_wave(SsrSpecWaveParams p) {
+  ssr_specred_wave_body(p, blockIdx.x % p.n_chunks, blockIdx.x / p.n_chunks);
+}
+
+struct MultiWs {
+  PairWs w;                       // chunking of the transform passes + SSIM geometry for n_items * n_keys virtual items
+  size_t plane, off_est, off_tgt, off_part_a, off_part_s, off_ssim, off_rows, total;
+  int spec_rows_per_chunk, spec_chunks, n_tiles;
+  bool fast;
+};
+static bool multi_fast_path(const ssr_plan* pl) { return ssr_stft_uses_wave_engine(pl, false) || ssr_stft_rn_wave_radix(pl) != 0; }
+static MultiWs multi_ws(const ssr_plan* pl, int n_items, int n_keys, int max_len, int64_t total_rows, unsigned mask) {
+  MultiWs m;
+  const bool want_ssim = mask & SSR_METRIC_SSIM;
+  m.fast = multi_fast_path(pl) && n_keys > 1;
+  const bool mag = want_ssim || m.fast;
+  m.w = pair_ws(pl, n_items, max_len, total_rows, false, mag);
+  const int max_T = (int)ssr_num_frames(pl, max_len);
+  m.w.sg = ssim_geom(max_T, pl->n_bins, m.fast ? n_items * n_keys : n_items, true);    // (the plain passes keep ssr_pair_metrics' tiles)
+  m.n_tiles = m.w.sg.n_row_tiles * m.w.sg.n_strips;
+  m.plane = mag ? ssr_align256((size_t)total_rows * mag_pitch(pl->n_bins) * sizeof(float)) : 0;
+  int64_t spc = ((int64_t)16384 + (int64_t)n_items * n_keys - 1) / ((int64_t)n_items * n_keys);      // ~16 k one-wave workgroups
+  if (spc > max_T / 8) spc = max_T / 8;
+  if (spc < 1) spc = 1;
+  m.spec_chunks = (int)spc;
+  m.spec_rows_per_chunk = ssr_ceil_div(max_T, m.spec_chunks);
+  m.spec_chunks = ssr_ceil_div(max_T, m.spec_rows_per_chunk);
+  size_t o = 0;
+  m.off_est = o; o += (size_t)n_keys * m.plane;
+  m.off_tgt = o; o += m.plane;
+  m.off_part_a = o; o += 2 * ssr_align256((size_t)n_items * m.w.n_chunks * SSR_NPART * sizeof(double));      // key 0 and an odd last key
+  m.off_part_s = o; o += ssr_align256((size_t)n_items * n_keys * m.spec_chunks * SSR_NPART * sizeof(double));
+  m.off_ssim = o; o += ssr_align256((size_t)n_items * n_keys * m.n_tiles * sizeof(double));
+  m.off_rows = o; o += ssr_align256((size_t)n_items * sizeof(int32_t));
+  m.total = o;
+  return m;
+}
+
+extern "C" size_t ssr_pair_metrics_multi_workspace_bytes(const ssr_plan* pl, int n_items, int n_keys, int max_len, int64_t total_rows,
+                                                         unsigned metric_mask) {
+  if (!pl || n_items <= 0 || n_keys <= 0) return 0;
+  return multi_ws(pl, n_items, n_keys, max_len, total_rows, metric_mask).total;
+}
+
+template <typename T>
+static int multi_stage_stft(const ssr_plan* pl, const float* a, const int64_t* a_off, const float* b, const int64_t* b_off, const int32_t* len,
+                            const int64_t* frame_off, int n_items, unsigned mask, bool mag, float* out_a, float* out_b, double* part,
+                            const PairWs& w, hipStream_t s) {
+  SsrStftParams<T> p{};
+  p.a = a; p.b = b; p.a_off = a_off; p.b_off = b_off; p.len = len; p.frame_off = frame_off;
+  p.mode = SSR_MODE_PAIR; p.out_kind = mag ? SSR_OUT_MAG : SSR_OUT_NONE; p.metric_mask = (int)mask;
+  p.n_fft = pl->n_fft; p.hop = pl->hop; p.n_bins = pl->n_bins;
+  p.units_per_chunk = w.units_per_chunk; p.n_chunks = w.n_chunks; p.interleave = ssr_pair_interleave(pl, false);
+  p.out_a = out_a; p.out_b = out_b; p.out_pitch = mag_pitch(pl->n_bins); p.part = part;
+  return ssr_launch_stft<T>(pl, p, n_items * w.n_chunks, s);
+}
+
+extern "C" int ssr_pair_metrics_multi(const ssr_plan* pl, const float* est, const int64_t* est_off, const float* tgt, const int64_t* tgt_off,
+                                      const int32_t* len, const int64_t* frame_off, int n_items, int n_keys, int max_len, int64_t total_rows,
+                                      unsigned mask, double* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!pl || !est || !est_off || !tgt || !tgt_off || !len || !frame_off || !out) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n_items <= 0 || n_keys <= 0) return SSR_OK;
+  if (int rc_dev = ssr_check_plan_device(pl)) return rc_dev;
+  if (max_len < 1) return ssr_fail(SSR_ERR_INVALID_ARG, "empty signals");
+  if (max_len >= (1 << 29)) return ssr_fail(SSR_ERR_UNSUPPORTED, "signals of 2^29 samples or more (4 GiB buffer views)");
+  if ((mask & ~SSR_METRIC_ALL) || mask == 0) return ssr_fail(SSR_ERR_INVALID_ARG, "bad metric mask");
+  if ((int64_t)n_items * n_keys > 0x3fffffff) return ssr_fail(SSR_ERR_UNSUPPORTED, "batch too large for one launch");
+  const int max_T = (int)ssr_num_frames(pl, max_len);
+  const bool want_ssim = mask & SSR_METRIC_SSIM;
+  if ((int64_t)max_T * pl->n_bins >= ((int64_t)1 << 30)) return ssr_fail(SSR_ERR_UNSUPPORTED, "spectrogram of 2^30 elements or more (4 GiB buffer views)");
+  if (want_ssim && (max_T < 7 || pl->n_bins < 7)) return ssr_fail(SSR_ERR_INVALID_ARG, "win_size exceeds image extent");
+  const MultiWs m = multi_ws(pl, n_items, n_keys, max_len, total_rows, mask);
+  if (!workspace || workspace_bytes < m.total) return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small");
+  char* ws = (char*)workspace;
+  hipStream_t s = (hipStream_t)stream;
+  int32_t* rows = (int32_t*)(ws + m.off_rows);
+  hipLaunchKernelGGL(k_rows_from_len, dim3(ssr_ceil_div(n_items, 256)), dim3(256), 0, s, len, n_items, pl->n_fft, pl->hop, rows);
+  HIP_TRY(hipGetLastError());
+  const bool mag = m.plane != 0;
+  const size_t part_a_bytes = ssr_align256((size_t)n_items * m.w.n_chunks * SSR_NPART * sizeof(double));
+  const int pitch = mag_pitch(pl->n_bins);
+  const unsigned red_mask = mask & (SSR_METRIC_LSD | SSR_METRIC_LOG_SISPEC | SSR_METRIC_SISPEC);
+  auto plane_of = [&](int k) { return mag ? (float*)(ws + m.off_est + (size_t)k * m.plane) : nullptr; };
+  float* tgt_plane = mag ? (float*)(ws + m.off_tgt) : nullptr;
+  double* ssim_part = (double*)(ws + m.off_ssim);
+  auto stft = [&](const float* a, const int64_t* a_off, const float* b, const int64_t* b_off, unsigned msk, float* oa, float* ob, double* part) {
+    return pl->precision == SSR_F64
+               ? multi_stage_stft<double>(pl, a, a_off, b, b_off, len, frame_off, n_items, msk, mag, oa, ob, part, m.w, s)
+               : multi_stage_stft<float>(pl, a, a_off, b, b_off, len, frame_off, n_items, msk, mag, oa, ob, part, m.w, s);
+  };
+  auto finalize = [&](const double* part, int n_chunks, const double* sp, int n_virtual, int key0) {
+    SsrFinalizeParams p{part, n_chunks, want_ssim ? sp : nullptr, m.n_tiles, rows, pl->n_bins, (int)mask, n_virtual, out, n_items, n_keys, key0};
+    hipLaunchKernelGGL(k_finalize, dim3(ssr_ceil_div(n_virtual, 64)), dim3(64), 0, s, p);
+    return hipGetLastError();
+  };
+  auto ssim = [&](int key0, int n_k) {      // keys key0 .. key0 + n_k - 1 against the one target image
+    SsrSsimParams p{plane_of(key0), tgt_plane, frame_off, rows, pl->n_bins, m.w.sg.rows_per_tile, m.w.sg.n_row_tiles, m.w.sg.n_strips,
+                    ssim_part + (size_t)key0 * n_items * m.n_tiles, pitch, n_items, (int64_t)(m.plane / sizeof(float))};
+    const int grid = n_items * n_k * m.n_tiles;
+    if (m.w.sg.cpt == 4) return launch_ssim_inst<4, true>(p, grid, s);
+    switch (m.w.sg.cpt) {
+      case 1: return launch_ssim_inst<1>(p, grid, s);
+      case 2: return launch_ssim_inst<2>(p, grid, s);
+      case 3: return launch_ssim_inst<3>(p, grid, s);
+      case 5: return launch_ssim_inst<5>(p, grid, s);
+      case 6: return launch_ssim_inst<6>(p, grid, s);
+    }
+    return ssr_fail(SSR_ERR_UNSUPPORTED, "bad SSIM geometry");
+  };
+  int rc;
+  if (!m.fast) {
+    // every key through the pair kernel against the target, as K calls of ssr_pair_metrics would (bit-identical to them): block
+    // engines (float64-signal plans have their own entry points), or a single key
+    for (int k = 0; k < n_keys; ++k) {
+      double* part = (double*)(ws + m.off_part_a);
+      if ((rc = stft(est, est_off + (size_t)k * n_items, tgt, tgt_off, mask, plane_of(k), tgt_plane, part))) return rc;
+      if (want_ssim && (rc = ssim(k, 1))) return rc;
+      HIP_TRY(finalize(part, m.w.n_chunks, ssim_part + (size_t)k * n_items * m.n_tiles, n_items, k));
+    }
+    return SSR_OK;
+  }
+  // key 0 with the target: metrics in the epilogue, both images written
+  double* part0 = (double*)(ws + m.off_part_a);
+  if ((rc = stft(est, est_off, tgt, tgt_off, mask, plane_of(0), tgt_plane, part0))) return rc;
+  // keys 1 .. in pairs: two estimates per complex transform, images only
+  int k = 1;
+  for (; k + 1 < n_keys; k += 2)
+    if ((rc = stft(est, est_off + (size_t)k * n_items, est, est_off + (size_t)(k + 1) * n_items, 0u, plane_of(k), plane_of(k + 1), nullptr))) return rc;
+  const int n_spec = k - 1;               // keys 1 .. k - 1 get their reductions from the images
+  double* part_last = (double*)(ws + m.off_part_a + part_a_bytes);
+  const bool odd_last = k < n_keys;
+  if (odd_last)                           // one estimate left: with the target again, whose rows are NOT rewritten (out_b = null)
+    if ((rc = stft(est, est_off + (size_t)k * n_items, tgt, tgt_off, mask, plane_of(k), nullptr, part_last))) return rc;
+  if (n_spec > 0 && red_mask) {
+    SsrSpecWaveParams q{plane_of(1), tgt_plane, frame_off, rows, pl->n_bins, pitch, (int)red_mask, m.spec_rows_per_chunk, m.spec_chunks, n_items,
+                        (int64_t)(m.plane / sizeof(float)), (double*)(ws + m.off_part_s)};
+    hipLaunchKernelGGL(k_specred_wave, dim3((unsigned)((int64_t)n_spec * n_items * m.spec_chunks)), dim3(64), 0, s, q);
+    HIP_TRY(hipGetLastError());
+  }
+  if (want_ssim && (rc = ssim(0, n_keys))) return rc;
+  HIP_TRY(finalize(part0, m.w.n_chunks, ssim_part, n_items, 0));
+  if (n_spec > 0)
+    HIP_TRY(finalize(red_mask ? (const double*)(ws + m.off_part_s) : nullptr, m.spec_chunks, ssim_part + (size_t)n_items * m.n_tiles, n_spec * n_items, 1));
+  if (odd_last) HIP_TRY(finalize(part_last, m.w.n_chunks, ssim_part + (size_t)k * n_items * m.n_tiles, n_items, k));
+  return SSR_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------
 struct SpecWs { size_t off_part, off_ssim, total; int rows_per_chunk, n_chunks; SsimGeom sg; };
 static SpecWs spec_ws(int n_items, int max_rows, int n_bins) {
   SpecWs w;

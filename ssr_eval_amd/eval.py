@@ -348,7 +348,17 @@ class SSR_Eval_Helper:
                         all_proc[i] = y                             # stays in HBM: the metric stage is the only consumer
         results = [dict() for _ in items]
         if all_proc:
-            vals = self.audio_metrics.evaluation_batch(all_proc, all_tgt, resident=True)
+            per_item = [owner.count(i) for i in range(len(items))]
+            K = per_item[0] if per_item else 0
+            if K > 1 and all(c == K for c in per_item):
+                # every file has the same K degradation keys (the normal case): one target, K estimates - the target is transformed
+                # once per file instead of once per key (ssr_pair_metrics_multi; evaluation_multi falls back by itself when the
+                # signals are float64 or their lengths differ between keys)
+                by_key = [[all_proc[i * K + k] for i in range(len(items))] for k in range(K)]
+                rows = self.audio_metrics.evaluation_multi(by_key, [all_tgt[i * K] for i in range(len(items))], resident=True)
+                vals = [rows[i][k] for i in range(len(items)) for k in range(K)]
+            else:
+                vals = self.audio_metrics.evaluation_batch(all_proc, all_tgt, resident=True)
             for i, k, v, e in zip(owner, all_keys, vals, all_extra):
                 v.update(e)
                 results[i][k] = v

@@ -85,6 +85,32 @@ class AudioMetrics:
                 out[i] = d
         return out
 
+    def evaluation_multi(self, ests_by_key, targets, mask=B.M_ALL, resident=False):
+        """K estimates per target (the degradation keys of a file, ssr_eval/eval.py:136-154): ests_by_key = K lists of n
+        waveforms, targets = n waveforms -> n lists of K dicts.  One ssr_pair_metrics_multi launch sequence: every target is
+        transformed once.  Needs float32 signals and, per item, one truncated length for all keys (metrics.py:89-90) - otherwise
+        (or for K = 1) the pairs go through evaluation_batch."""
+        K, n = len(ests_by_key), len(targets)
+        pairs = [[self._prepare_pair(ests_by_key[k][i], targets[i], resident) for i in range(n)] for k in range(K)]
+        same_len = all(len({pairs[k][i][0].shape[0] for k in range(K)}) == 1 for i in range(n))
+        f32 = not any(B._is_f64(pairs[k][i][0]) or B._is_f64(pairs[k][i][1]) for k in range(K) for i in range(n))
+        if K < 2 or n == 0 or not same_len or not f32:
+            flat = self.evaluation_batch([ests_by_key[k][i] for i in range(n) for k in range(K)],
+                                         [targets[i] for i in range(n) for _ in range(K)], mask, resident)
+            return [flat[i * K:(i + 1) * K] for i in range(n)]
+        vals = B.pair_metrics_multi(self._plan(), [[pairs[k][i][0] for i in range(n)] for k in range(K)], [pairs[0][i][1] for i in range(n)], mask)
+        out = []
+        for i in range(n):
+            row = []
+            for k in range(K):
+                d = {}
+                for name, v in zip(_KEYS, vals[i, k]):
+                    if not np.isnan(v) or (mask & (1 << _KEYS.index(name))):
+                        d[name] = float(v) if name == "ssim" else float(np.float32(v))
+                row.append(d)
+            out.append(row)
+        return out
+
     # ---- reductions on [B, C, T, F] tensors (est first)
     @staticmethod
     def _images(x):

@@ -782,3 +782,89 @@ def test_float32_precision_lowpass_and_istft(hop):
         for b, x in zip(back, xs):
             assert float((b.cpu() - torch.from_numpy(x)).abs().max()) <= (2e-7 if prec == "f64" else 6e-7)
     assert float((out["f64"] - out["f32"]).abs().max()) <= 3e-7
+
+
+# ---- ssr_pair_metrics_multi: one target, K estimates ------------------------------------------------------
+def _multi_inputs(seed, lens, K):
+    rng = np.random.default_rng(seed)
+    tgts = [(0.1 * rng.standard_normal(n)).astype(np.float32) for n in lens]
+    if len(tgts) > 1:
+        tgts[1][len(tgts[1]) // 3:len(tgts[1]) // 3 + 6000] = 0.0            # a silent stretch: zero-forced frames
+    ests = [[(t * (0.5 + 0.1 * k) + (0.01 + 0.01 * k) * rng.standard_normal(len(t))).astype(np.float32) for t in tgts] for k in range(K)]
+    if K > 2 and len(tgts) > 2:
+        ests[2][2][:] = 0.0                                                     # an all-zero estimate
+    return ests, tgts
+
+
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (2229, 480), (1486, 320), (743, 160), (1000, 250), (4096, 1024)])
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 7])
+def test_pair_metrics_multi_equals_k_calls_of_pair_metrics(n_fft, hop, K):
+    """ssr_pair_metrics_multi against K calls of ssr_pair_metrics on the same inputs, every engine family (2048: k_stft_wave; 2229:
+    rotating radix-3; 1486 / 743 / 1000: R waves; 4096: the block engine's plain-pass fallback), ragged items with a silent stretch
+    and an all-zero estimate.  Key 0, an odd last key (both transformed WITH the target) and every key of the fallback reproduce
+    ssr_pair_metrics' LSD / SISpec bit for bit; the estimates transformed two per complex transform agree to 1e-6
+    (include/ssr_hip.h says why not bit for bit)."""
+    from ssr_eval_amd import backend as B
+    plan = B.get_plan(n_fft, hop, "f64")
+    lens = (30000, 48000, 9000, 7 * hop + 100)                                # (the last one: seven frames, SSIM's minimum)
+    ests, tgts = _multi_inputs(n_fft + K, lens, K)
+    for mask in (B.M_ALL, B.M_LSD | B.M_SSIM, B.M_LSD, B.M_SISPEC | B.M_LOG_SISPEC):
+        got = B.pair_metrics_multi(plan, ests, tgts, mask)
+        assert got.shape == (len(lens), K, 4)
+        for k in range(K):
+            want = B.pair_metrics(plan, ests[k], tgts, mask)
+            g = got[:, k]
+            assert np.array_equal(np.isnan(g), np.isnan(want)), (k, mask)
+            ok = ~np.isnan(want)
+            if k == 0 or n_fft == 4096 or (k == K - 1 and K % 2 == 0):
+                np.testing.assert_array_equal(g[:, :3][ok[:, :3]], want[:, :3][ok[:, :3]])
+            # dB values: 1e-6 relative + 1e-6 dB; LSD / SSIM 1e-6 relative
+            np.testing.assert_allclose(g[ok], want[ok], rtol=1e-6, atol=1e-6, err_msg="key %d mask %d" % (k, mask))
+
+
+def test_cfg3_through_pair_metrics_multi_against_the_oracle():
+    """cfg-3's sweep through the new entry: 16 targets x 7 cutoffs of 4 s @ 48 kHz, the seven low-passed estimates of a target written
+    key-major into one buffer, ONE ssr_pair_metrics_multi launch sequence (8 real transforms per target instead of 14), every
+    (degraded, target) pair against the oracle on the same degraded signal at the bars of the pair tests."""
+    from ssr_eval_amd import backend as B
+    n_t, n, K = 16, 192000, 7
+    g = torch.Generator(device="cuda").manual_seed(20220328)
+    tgt = (0.1 * torch.randn((n_t, n), generator=g, device="cuda", dtype=torch.float32)).contiguous()
+    tr = B.Ragged.from_uniform(tgt)
+    est = torch.empty((K, n_t, n), dtype=torch.float32, device="cuda")
+    lplan = B.get_plan(2048, 441, "f64")
+    for k, cut in enumerate(CUT_BINS):
+        B.LowpassBatch(lplan, tr, [cut] * n_t, out=est[k].reshape(-1)).run()
+    mb = B.MultiPairBatch(B.get_plan(2048, 512, "f64"), B.Ragged.from_uniform(est.view(K * n_t, n)), tr, K)
+    got = mb.run(B.M_ALL).cpu().numpy()
+    assert np.isfinite(got).all()
+    est_h, tgt_h = est.cpu().numpy(), tgt.cpu().numpy()
+    n_check = n_t if (os.cpu_count() or 1) >= 16 else 3
+    pairs = [(est_h[k, t], tgt_h[t]) for t in range(n_check) for k in range(K)]
+    _check_rows(got[:n_check].reshape(-1, 4), _oracle_many(pairs), "cfg3-multi")
+    assert (np.diff(got[:, :, 0], axis=1) < 0).all()                       # LSD falls as the cutoff rises
+
+
+def test_evaluate_arrays_scores_every_key_through_the_multi_entry(monkeypatch):
+    """SSR_Eval_Helper.evaluate_arrays with four float32 degradation keys per file goes through ssr_pair_metrics_multi (one target
+    transform per file) and returns what the per-pair path returns."""
+    from ssr_eval_amd import SSR_Eval_Helper, BasicTestee, backend as B
+    calls = {"multi": 0}
+    orig = B.pair_metrics_multi
+
+    def spy(*a, **k):
+        calls["multi"] += 1
+        return orig(*a, **k)
+    monkeypatch.setattr(B, "pair_metrics_multi", spy)
+    h = SSR_Eval_Helper(BasicTestee(), input_sr=48000, output_sr=48000, evaluation_sr=48000, test_data_root=None,
+                        setting_fft={"cutoff_freq": [2000, 4000, 8000]}, setting_subsampling={"cutoff_freq": [6000]})
+    rng = np.random.default_rng(8)
+    items = [((0.1 * rng.standard_normal(n)).astype(np.float32),) * 2 for n in (20000, 31000, 26000)]
+    res = h.evaluate_arrays(items)
+    assert calls["multi"] == 1 and all(len(r) == 4 for r in res)
+    for (tgt, x), r in zip(items, res):
+        d = h.preprocess_array(x, 48000)
+        assert list(d.keys()) == list(r.keys())
+        for key, y in d.items():
+            want = h.audio_metrics.evaluation(np.asarray(y, np.float32), tgt, "")
+            np.testing.assert_allclose(_vec(r[key]), _vec(want), rtol=2e-6, atol=2e-6)

@@ -93,7 +93,8 @@ def hbm_roofline(kernel, alg_bytes, ms, traffic_key=None, note=None):
     traffic, src = pmc_traffic(traffic_key) if traffic_key else (None, None)
     r = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": src,
-         "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(ms, 4)}
+         "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(ms, 4),
+         "kernel_ms_source": "hip_events on the launch stream, 3-10 iterations on this box (the rocprofv3 average of the same command: profiles/)"}
     if note:
         r["note"] = note
     return r
@@ -190,54 +191,79 @@ class Cfg3:
         self.plan = B.get_plan(N_FFT, HOP, a.precision, dev)
         # the seven cutoffs run one after the other on the stream and share the low-pass output / workspace buffers; only
         # the cut-bin descriptor changes
-        self.lp = B.LowpassBatch(self.lp_plan, tr, [CUT_BINS[0]] * n)
-        self.cuts = [torch.full((n,), c, dtype=torch.int32, device=dev) for c in CUT_BINS]
-        self.batch = B.PairBatch(self.plan, self.lp.out_ragged(), tr)
-        self.units_per_step = n * len(CUT_BINS)
+        # ONE estimate buffer, key-major [7][n][samples]: cutoff k's low-pass writes plane k; the metric stage is ONE
+        # ssr_pair_metrics_multi launch sequence over the 7 keys (each target transformed and stored once: 8 real transforms and 8
+        # magnitude images per target instead of 14 and 14 - ssr_eval/eval.py:136-154 scores every key against the same target)
+        K = len(CUT_BINS)
+        self.est = torch.empty((K, n, N_SAMPLES), dtype=torch.float32, device=dev)
+        self.lps = [B.LowpassBatch(self.lp_plan, tr, [c] * n, out=self.est[k].reshape(-1)) for k, c in enumerate(CUT_BINS)]
+        for lp in self.lps[1:]:
+            lp.ws = self.lps[0].ws                      # the cutoffs run one after the other on the stream: one workspace
+        self.batch = B.MultiPairBatch(self.plan, B.Ragged.from_uniform(self.est.view(K * n, N_SAMPLES)), tr, K)
+        self.units_per_step = n * K
         self.cnt = torch.full((1,), float(self.units_per_step), dtype=torch.float64, device=dev)
-        self.acc = torch.zeros(4, dtype=torch.float64, device=dev)
         self.agg = torch.zeros(5, dtype=torch.float64, device=dev)
 
     def step(self):
-        lp = self.lp
-        self.acc.zero_()
-        for cut in self.cuts:
-            lp.cut = cut
-            lp.run()                                     # est <- fft_lowpass(target, cut)
-            self.acc += self.batch.run(self.B.M_ALL).sum(0)
-        torch.cat([self.acc, self.cnt], out=self.agg)
+        for lp in self.lps:
+            lp.run()                                     # est[k] <- fft_lowpass(target, cut k)
+        acc = self.batch.run(self.B.M_ALL).sum((0, 1))
+        torch.cat([acc, self.cnt], out=self.agg)
         return self.agg
 
     def config(self, world):
         a = self.a
         return {"workload": "cfg-3: %d synthetic 48 kHz 4 s float32 targets per GPU resident in HBM x 7 cutoffs "
-                            "(cut bins %s of FDomainHelper 2048/441 at fs 48 kHz): est = ssr_fft_lowpass(target, cut), then LSD + "
-                            "log-SISpec + SISpec + SSIM at STFT 2048/512, transform precision %s" % (a.pairs, CUT_BINS, a.precision),
+                            "(cut bins %s of FDomainHelper 2048/441 at fs 48 kHz): est[k] = ssr_fft_lowpass(target, cut k) (engine: %s), then "
+                            "LSD + log-SISpec + SISpec + SSIM of the 7 keys at STFT 2048/512 through ONE ssr_pair_metrics_multi call, "
+                            "transform precision %s" % (a.pairs, CUT_BINS, getattr(a, "lowpass_engine", "segments"), a.precision),
+                "lowpass_engine": getattr(a, "lowpass_engine", "segments"),
                 "targets_per_gpu": a.pairs, "cutoffs_hz": CUTOFFS_HZ, "cut_bins": CUT_BINS, "samples_per_utterance": N_SAMPLES,
                 "parallelism": "utterance-sharded x%d, one float64 all-reduce (40 B) per step" % world}
 
     def report(self, a):
-        B, lp, batch = self.B, self.lp, self.batch
-        it = 3
-        lp.cut = self.cuts[3]
-        ms_lp = event_time_ms(lambda: lp.run(), it)
-        ms_stft = event_time_ms(lambda: batch.run(B.M_ALL, stages=1), it)
-        ms_ssim = event_time_ms(lambda: batch.run(B.M_ALL, stages=2), it)
-        n = a.pairs
-        stages = {"fft_lowpass": (ms_lp, 2 * N_SAMPLES * 4 * n), "stft+lsd+sispec": (ms_stft, (2 * N_SAMPLES * 4 + 32) * n),
-                  "ssim": (ms_ssim, (2 * N_SAMPLES * 4 + 32) * n)}
+        B, batch = self.B, self.batch
+        it, K, n = 3, len(CUT_BINS), a.pairs
+        engine = getattr(a, "lowpass_engine", "segments")
+        ms_lp = event_time_ms(lambda: self.lps[3].run(), it)
+        ms_lp_all = event_time_ms(lambda: [lp.run() for lp in self.lps], it)
+        ms_multi = event_time_ms(lambda: batch.run(B.M_ALL), it)
+        per_key = B.PairBatch(self.plan, B.Ragged.from_uniform(self.est[3]), B.Ragged.from_uniform(self.tgt))
+        ms_pair = event_time_ms(lambda: per_key.run(B.M_ALL), it)       # what one key cost before ssr_pair_metrics_multi
+        stages = {"fft_lowpass": (ms_lp, 2 * N_SAMPLES * 4 * n), "pair_metrics_multi/7": (ms_multi / K, (2 * N_SAMPLES * 4 + 32) * n)}
         dom = max(stages, key=lambda k: stages[k][0])
-        fused = getattr(a, "lowpass_engine", "segments") == "fused"
-        tkey = {"fft_lowpass": "k_lowpass_group" if fused else "k_lowpass_wave+k_ola_paired", "stft+lsd+sispec": "k_stft_wave<double, true", "ssim": "k_ssim"}[dom]
-        roof = hbm_roofline("ssr_pair_metrics:" + dom if dom != "fft_lowpass" else
-                            ("ssr_fft_lowpass(k_lowpass_group: transforms + overlap-add in one kernel)" if fused else "ssr_fft_lowpass(k_lowpass_wave+k_ola_paired)"),
-                            stages[dom][1], stages[dom][0], tkey if a.pairs == 1024 and a.precision == "f64" else None,
+        tkey = {"segments": "k_lowpass_wave+k_ola_paired", "fused": "k_lowpass_group", "conv": "k_tl_gemm"}[engine]
+        lp_name = {"segments": "ssr_fft_lowpass(k_lowpass_wave+k_ola_paired)", "fused": "ssr_fft_lowpass(k_lowpass_group: transforms + overlap-add in one kernel)",
+                   "conv": "ssr_fft_lowpass(conv engine: k_tl_gemm forward + inverse, k_tl_fold)"}[engine]
+        roof = hbm_roofline(lp_name if dom == "fft_lowpass" else "ssr_pair_metrics_multi (7 keys, per key)", stages[dom][1], stages[dom][0],
+                            tkey if dom == "fft_lowpass" and a.pairs == 1024 and a.precision == "f64" else None,
                             "per cutoff and 1024 utterances; algorithmic bytes: low-pass 2*n*4 per (utterance, cutoff), pair metrics "
                             "2*n*4+32 per pair (SURVEY 8(d))")
-        extra = {"lowpass_engine": getattr(a, "lowpass_engine", "segments"),
-                 "stage_ms_per_cutoff": {k: round(v[0], 4) for k, v in stages.items()},
+        extra = {"lowpass_engine": engine,
+                 "stage_ms": {"fft_lowpass_one_cutoff(bin 256)": round(ms_lp, 4), "fft_lowpass_7_cutoffs": round(ms_lp_all, 4),
+                              "pair_metrics_multi_7_keys": round(ms_multi, 4), "pair_metrics_one_key(round 3 path)": round(ms_pair, 4)},
+                 "metric_stage_speedup_vs_7_pair_calls": round(K * ms_pair / ms_multi, 3),
                  "fft_lowpass_utterances_per_s": round(n / (ms_lp * 1e-3), 1),
                  "fft_lowpass_algorithmic_GBs": round(stages["fft_lowpass"][1] / (ms_lp * 1e-3) / 1e9, 1)}
+        if engine != "conv" and not getattr(a, "no_conv_side", False):
+            # the reference-arithmetic engine (the default of lowpass(_type="stft_hard")) on the same batch, next to the timed one
+            try:
+                cplan = B.get_plan(2048, 441, a.precision, self.dev, lowpass_engine="conv")
+                tr = B.Ragged.from_uniform(self.tgt)
+                ms = []
+                for k, c in enumerate(CUT_BINS):
+                    lp = B.LowpassBatch(cplan, tr, [c] * n, out=self.est[k].reshape(-1))
+                    ms.append(event_time_ms(lambda: lp.run(), 1))
+                    del lp
+                flops = sum(n * (1 + N_SAMPLES // 441) * (2.0 * 2048 * 2 * c + 2.0 * 2048 * 2 * (c + min(c - 1, 1023))) for c in CUT_BINS)
+                extra["conv_engine(reference arithmetic: dense float32 DFT on the matrix cores)"] = {
+                    "ms_per_cutoff": [round(v, 3) for v in ms], "ms_7_cutoffs": round(sum(ms), 3),
+                    "useful_TFLOPs": round(flops / (sum(ms) * 1e-3) / 1e12, 1), "fp32_mfma_peak_TFLOPs": 157.3,
+                    "cfg3_pairs_per_s_with_it": round(n * K / ((sum(ms) + ms_multi) * 1e-3), 1)}
+                for lp in self.lps:
+                    lp.run()                             # (restore the timed engine's estimates)
+            except Exception as e:                       # a side figure must not take the line down
+                extra["conv_engine_error"] = repr(e)
         return roof, extra
 
     def cpu_inputs(self, n):
@@ -260,6 +286,8 @@ class Cfg3:
         side, the degraded signal itself against the oracle's torchlibrosa restatement (max abs difference)."""
         from oracle import lowpass as olp, metrics as om
         B, worst, self.parity_lowpass_max_abs = self.B, 0.0, 0.0
+        dev_ideal, dev_conv = [0.0, 0.0], [0.0, 0.0]
+        cplan = B.get_plan(2048, 441, self.a.precision, self.dev, lowpass_engine="conv")
         for i in range(first, first + n):
             j, c = i % self.a.pairs, i % 7
             t = B.Ragged.from_uniform(self.tgt[j:j + 1])
@@ -269,8 +297,19 @@ class Cfg3:
             got = B.PairBatch(self.plan, lp.out_ragged(), t).run(B.M_ALL)[0].cpu().numpy()
             want = om.evaluation(est, tgt, n_fft=N_FFT, hop=HOP)
             worst = max(worst, abs(got[0] - want["lsd"]) / abs(want["lsd"]), abs(got[3] - want["ssim"]) / abs(want["ssim"]))
-            self.parity_lowpass_max_abs = max(self.parity_lowpass_max_abs,
-                                              float(np.abs(est - olp.lowpass(tgt, CUTOFFS_HZ[c], SR, 1, "stft_hard")).max()))
+            ref_est = olp.lowpass(tgt, CUTOFFS_HZ[c], SR, 1, "stft_hard")        # the published torchlibrosa arithmetic on torch-CPU
+            self.parity_lowpass_max_abs = max(self.parity_lowpass_max_abs, float(np.abs(est - ref_est).max()))
+            # the PIPELINE against the reference's arithmetic: this run's engine, and the conv engine
+            ref = om.evaluation(ref_est, tgt, n_fft=N_FFT, hop=HOP)
+            lpc = B.LowpassBatch(cplan, t, [CUT_BINS[c]])
+            lpc.run()
+            gc = B.PairBatch(self.plan, lpc.out_ragged(), t).run(B.M_ALL)[0].cpu().numpy()
+            for dst, g in ((dev_ideal, got), (dev_conv, gc)):
+                dst[0] = max(dst[0], abs(g[0] / ref["lsd"] - 1))
+                dst[1] = max(dst[1], abs(g[1] - ref["log_sispec"]))
+        self.pipeline_dev = {"timed_engine(%s)" % getattr(self.a, "lowpass_engine", "segments"): {"lsd_rel_max": dev_ideal[0], "log_sispec_abs_max_db": dev_ideal[1]},
+                             "conv_engine": {"lsd_rel_max": dev_conv[0], "log_sispec_abs_max_db": dev_conv[1]},
+                             "against": "published torchlibrosa low-pass (float32 conv1d, torch-CPU) -> oracle metrics, same targets"}
         return worst
 
 
@@ -884,6 +923,8 @@ def run(a):
             extra["parity_vs_oracle_max_rel_err"] = float(wl.parity(vals, min(4, len(vals)), 4))   # vals[i] is item 4 + i
             if hasattr(wl, "parity_lowpass_max_abs"):
                 extra["parity_lowpass_max_abs_err_vs_oracle"] = wl.parity_lowpass_max_abs
+            if hasattr(wl, "pipeline_dev"):
+                extra["pipeline_deviation_from_reference_arithmetic"] = wl.pipeline_dev
     if world == 1 and a.config == "cfg2" and not a.no_side and not a.cpu_skeleton:
         del wl
         torch.cuda.empty_cache()
@@ -923,7 +964,7 @@ def parse(argv=None):
     ap.add_argument("--pairs", type=int, default=1024, help="cfg2/cfg3: pairs (targets) per GPU per step (BASELINE: 1024)")
     ap.add_argument("--utterances", type=int, default=12500, help="cfg5: utterances per GPU per step (100k over 8 GPUs)")
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--lowpass-engine", dest="lowpass_engine", default="segments", choices=["segments", "fused"],
+    ap.add_argument("--lowpass-engine", dest="lowpass_engine", default="segments", choices=["segments", "fused", "conv"],
                     help="cfg3: overlap-add through the segment workspace (default, faster inside the pipeline) or fused in the transform kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the cfg3 / cfg5 / API-true / end-to-end side figures")

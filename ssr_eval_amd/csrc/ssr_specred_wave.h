@@ -22,44 +22,60 @@ struct SsrSpecWaveParams {
   double* part;                // [n_keys * vi_n, n_chunks, SSR_NPART]
 };
 
-__device__ __forceinline__ void ssr_specred_wave_body(const SsrSpecWaveParams& p, int chunk, int item_v) {
+// KG keys per wave: the target row is fetched once for KG estimates (the kernel is HBM-bound: 2 KG images -> KG + 1), and the
+// target-only float32 terms (t * t, log10(t + 1e-12)) are formed once per bin.
+template <int KG>
+__device__ __forceinline__ void ssr_specred_wave_body(const SsrSpecWaveParams& p, int chunk, int group_v) {
   const int lane = (int)threadIdx.x;
-  const int key = item_v / p.vi_n, item = item_v % p.vi_n;
+  const int key0 = (group_v / p.vi_n) * KG, item = group_v % p.vi_n;
   const int T = p.n_rows[item];
   const int t0 = chunk * p.rows_per_chunk;
   const int t1 = (t0 + p.rows_per_chunk < T) ? t0 + p.rows_per_chunk : T;
-  const float* x = p.x + (int64_t)key * p.x_plane + p.frame_off[item] * (int64_t)p.pitch;
+  const float* x = p.x + (int64_t)key0 * p.x_plane + p.frame_off[item] * (int64_t)p.pitch;
   const float* y = p.y + p.frame_off[item] * (int64_t)p.pitch;
-  double* part = p.part + ((int64_t)item_v * p.n_chunks + chunk) * SSR_NPART;
   const int mask = p.metric_mask;
   const bool want_lsd = mask & SSR_M_LSD;
-  double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  double lsd_sum = 0.0;
+  double acc[KG][7];
+  double lsd_sum[KG];
+#pragma unroll
+  for (int g = 0; g < KG; ++g) {
+    lsd_sum[g] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) acc[g][q] = 0.0;
+  }
   const int nq = (p.F + 3) / 4;                      // quads per row (the last one may be partial)
   for (int t = t0; t < t1; ++t) {
-    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)t * p.pitch);
     const float4* yr = reinterpret_cast<const float4*>(y + (int64_t)t * p.pitch);
-    acc[0] = 0.0;
+#pragma unroll
+    for (int g = 0; g < KG; ++g) acc[g][0] = 0.0;
     for (int q = lane; q < nq; q += 64) {
-      const float4 xv = xr[q], yv = yr[q];
+      const float4 yv = yr[q];
       const int k = 4 * q;
-      ssr_accumulate_metrics<true>(xv.x, yv.x, mask, acc);
-      if (k + 1 < p.F) ssr_accumulate_metrics<true>(xv.y, yv.y, mask, acc);
-      if (k + 2 < p.F) ssr_accumulate_metrics<true>(xv.z, yv.z, mask, acc);
-      if (k + 3 < p.F) ssr_accumulate_metrics<true>(xv.w, yv.w, mask, acc);
+#pragma unroll
+      for (int g = 0; g < KG; ++g) {
+        const float4 xv = reinterpret_cast<const float4*>(x + (int64_t)g * p.x_plane + (int64_t)t * p.pitch)[q];
+        ssr_accumulate_metrics<true>(xv.x, yv.x, mask, acc[g]);
+        if (k + 1 < p.F) ssr_accumulate_metrics<true>(xv.y, yv.y, mask, acc[g]);
+        if (k + 2 < p.F) ssr_accumulate_metrics<true>(xv.z, yv.z, mask, acc[g]);
+        if (k + 3 < p.F) ssr_accumulate_metrics<true>(xv.w, yv.w, mask, acc[g]);
+      }
     }
     if (want_lsd) {
-      const double s = ssr_wave_sum<64>(acc[0]);
-      lsd_sum += sqrt(s / (double)p.F);
+#pragma unroll
+      for (int g = 0; g < KG; ++g) lsd_sum[g] += sqrt(ssr_wave_sum<64>(acc[g][0]) / (double)p.F);
     }
   }
-  double tot[6];
 #pragma unroll
-  for (int q = 0; q < 6; ++q) tot[q] = ssr_wave_sum<64>(acc[1 + q]);
-  if (lane == 0) {
-    part[0] = lsd_sum;
+  for (int g = 0; g < KG; ++g) {
+    double tot[6];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) part[1 + q] = tot[q];
-    part[7] = 0.0;
+    for (int q = 0; q < 6; ++q) tot[q] = ssr_wave_sum<64>(acc[g][1 + q]);
+    if (lane == 0) {
+      double* part = p.part + (((int64_t)(key0 + g) * p.vi_n + item) * p.n_chunks + chunk) * SSR_NPART;
+      part[0] = lsd_sum[g];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) part[1 + q] = tot[q];
+      part[7] = 0.0;
+    }
   }
 }

@@ -248,14 +248,14 @@ extern "C" int ssr_pair_metrics_f64(const ssr_plan* pl, const double* est, const
 // terms come from k_specred_wave against the stored target image, and k_ssim reads that one image for every key:
 // K + 1 real transforms and K + 1 images instead of 2 K and 2 K.
 #include "ssr_specred_wave.h"
-__global__ __launch_bounds__(64) void k_specred_wave(SsrSpecWaveParams p) {
-  ssr_specred_wave_body(p, blockIdx.x % p.n_chunks, blockIdx.x / p.n_chunks);
+template <int KG> __global__ __launch_bounds__(64) void k_specred_wave(SsrSpecWaveParams p) {
+  ssr_specred_wave_body<KG>(p, blockIdx.x % p.n_chunks, blockIdx.x / p.n_chunks);
 }
 
 struct MultiWs {
   PairWs w;                       // chunking of the transform passes + SSIM geometry for n_items * n_keys virtual items
   size_t plane, off_est, off_tgt, off_part_a, off_part_s, off_ssim, off_rows, total;
-  int spec_rows_per_chunk, spec_chunks, n_tiles;
+  int spec_rows_per_chunk, spec_chunks, spec_kg, n_tiles;
   bool fast;
 };
 static bool multi_fast_path(const ssr_plan* pl) { return ssr_stft_uses_wave_engine(pl, false) || ssr_stft_rn_wave_radix(pl) != 0; }
@@ -269,7 +269,16 @@ static MultiWs multi_ws(const ssr_plan* pl, int n_items, int n_keys, int max_len
   m.w.sg = ssim_geom(max_T, pl->n_bins, m.fast ? n_items * n_keys : n_items, true);    // (the plain passes keep ssr_pair_metrics' tiles)
   m.n_tiles = m.w.sg.n_row_tiles * m.w.sg.n_strips;
   m.plane = mag ? ssr_align256((size_t)total_rows * mag_pitch(pl->n_bins) * sizeof(float)) : 0;
-  int64_t spc = ((int64_t)16384 + (int64_t)n_items * n_keys - 1) / ((int64_t)n_items * n_keys);      // ~16 k one-wave workgroups
+  const int n_spec = ((n_keys - 1) / 2) * 2;                                  // keys whose reductions come from the images (in pairs)
+  // keys of an item per wave (they share the target's rows).  Measured on cfg-3 (6 such keys, 1024 items): 1 key per wave 4.37 ms
+  // (20 GB of images at 4.6 TB/s: HBM-bound), 2 per wave 3.2-3.4 ms (90 VGPRs, five waves per SIMD), 3 per wave the same,
+  // 6 per wave 5.11 ms (173 VGPRs: latency-bound at two waves per SIMD)
+  m.spec_kg = 2;
+#ifdef SSR_DEV_KNOBS
+  if (getenv("SSR_SPEC_KG")) m.spec_kg = atoi(getenv("SSR_SPEC_KG"));
+#endif
+  const int64_t groups = (int64_t)n_items * (n_spec > 0 ? n_spec / m.spec_kg : 1);
+  int64_t spc = ((int64_t)16384 + groups - 1) / groups;                       // ~16 k one-wave workgroups
   if (spc > max_T / 8) spc = max_T / 8;
   if (spc < 1) spc = 1;
   m.spec_chunks = (int)spc;
@@ -384,7 +393,12 @@ extern "C" int ssr_pair_metrics_multi(const ssr_plan* pl, const float* est, cons
   if (n_spec > 0 && red_mask) {
     SsrSpecWaveParams q{plane_of(1), tgt_plane, frame_off, rows, pl->n_bins, pitch, (int)red_mask, m.spec_rows_per_chunk, m.spec_chunks, n_items,
                         (int64_t)(m.plane / sizeof(float)), (double*)(ws + m.off_part_s)};
-    hipLaunchKernelGGL(k_specred_wave, dim3((unsigned)((int64_t)n_spec * n_items * m.spec_chunks)), dim3(64), 0, s, q);
+    // KG keys of an item per wave share the target's rows (n_spec is even: the keys came in pairs)
+    const int kg = m.spec_kg;
+    const dim3 grid((unsigned)((int64_t)(n_spec / kg) * n_items * m.spec_chunks));
+    if (kg == 3) hipLaunchKernelGGL(k_specred_wave<3>, grid, dim3(64), 0, s, q);
+    else if (kg == 2) hipLaunchKernelGGL(k_specred_wave<2>, grid, dim3(64), 0, s, q);
+    else hipLaunchKernelGGL(k_specred_wave<1>, grid, dim3(64), 0, s, q);
     HIP_TRY(hipGetLastError());
   }
   if (want_ssim && (rc = ssim(0, n_keys))) return rc;

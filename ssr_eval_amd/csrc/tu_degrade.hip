@@ -5,6 +5,7 @@
 #include "ssr_xcorr.h"
 #include "ssr_resample.h"
 #include "ssr_resample_mfma.h"
+#include "ssr_resample_rc.h"
 #include "ssr_sinc.h"
 
 __global__ __launch_bounds__(SSR_XC_NT) void k_xcorr(SsrXcorrParams p) {
@@ -70,6 +71,50 @@ extern "C" int ssr_resample_plan(int64_t n_in, int up, int down, int* up_r, int*
   return SSR_OK;
 }
 
+// Residue-class kernel (ssr_resample_rc.h): float32, 21 taps per phase (every up-sampling plan of resample_poly), 33 <= up <= 1024.
+template <int HPP, int NTMAX> __global__ __launch_bounds__(NTMAX, 4) void k_resample_rc(SsrResampleRcParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ssr_resample_rc_body<HPP>(p, smem);
+}
+static bool resample_rc_eligible(int up, int down, int n_taps) {
+#ifdef SSR_DEV_KNOBS
+  static const int off = getenv("SSR_NO_RC") ? atoi(getenv("SSR_NO_RC")) : 0;
+  if (off) return false;
+#endif
+  if (up < 33 || up > 1024 || (n_taps + up - 1) / up != 21) return false;
+  return (size_t)4 * (ssr_rc_seg_len(up, down, 21) + 128) * sizeof(float) <= 64 * 1024;      // two stages x two window copies
+}
+static int resample_rc_launch(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off, const int32_t* out_len,
+                              int n_items, int max_out_len, int up, int down, const float* taps, int n_taps, int n_pre_remove, float* out,
+                              hipStream_t s) {
+  SsrResampleRcParams p{in, in_off, in_len, out_off, out_len, up, down, n_taps, n_pre_remove, taps, 1, 1, 0, out};
+  const int seg_len = ssr_rc_seg_len(up, down, 21);
+  // whole 64-sample deposits (a wave's LDS-DMA instruction) must stay inside a copy; + 32: copy B sits on the other half of the 64 banks
+  p.seg_floats = ((seg_len + 1 + 63) / 64) * 64 + 32;
+  const int seg = p.seg_floats;
+  const int steps = ssr_ceil_div(max_out_len, up), blocks = ssr_ceil_div(steps, SSR_RC_JB);
+  int n_chunks = ssr_ceil_div(4096, n_items);                   // >= ~4 k workgroups per launch, whole items where the batch is large
+  if (n_chunks > blocks) n_chunks = blocks;
+  if (n_chunks < 1) n_chunks = 1;
+  p.blocks_per_chunk = ssr_ceil_div(blocks, n_chunks);
+  p.n_chunks = ssr_ceil_div(blocks, p.blocks_per_chunk);
+  const int64_t grid = (int64_t)n_items * p.n_chunks;
+  if (grid > 0x7fffffff) return ssr_fail(SSR_ERR_UNSUPPORTED, "batch too large for one launch");
+  const size_t lds = (size_t)4 * seg * sizeof(float);           // two stages x two copies
+  const int nt = ssr_ceil_div(up, 64) * 64;
+  static thread_local SsrLdsSlot slot;
+  if (nt <= 512) {                                              // (the launch bound sets the register budget: 8 waves -> 256 VGPRs)
+    if (int rc = ssr_allow_lds((const void*)k_resample_rc<21, 512>, lds, &slot)) return rc;
+    hipLaunchKernelGGL((k_resample_rc<21, 512>), dim3((unsigned)grid), dim3(nt), lds, s, p);
+  } else {
+    static thread_local SsrLdsSlot slot2;
+    if (int rc = ssr_allow_lds((const void*)k_resample_rc<21, 1024>, lds, &slot2)) return rc;
+    hipLaunchKernelGGL((k_resample_rc<21, 1024>), dim3((unsigned)grid), dim3(nt), lds, s, p);
+  }
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+
 template <typename S>
 static int resample_poly_t(const S* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
                            const int32_t* out_len, int n_items, int max_out_len, int up, int down, const S* taps,
@@ -79,6 +124,11 @@ static int resample_poly_t(const S* in, const int64_t* in_off, const int32_t* in
   if (n_items <= 0 || max_out_len <= 0) return SSR_OK;
   SsrResampleParamsT<S> p{in, in_off, in_len, out_off, out_len, up, down, taps, n_taps, n_pre_remove,
                           ssr_resample_pick_groups(up, down, n_taps, sizeof(S)), 1, out};
+  if constexpr (sizeof(S) == 4) {
+    if (resample_rc_eligible(up, down, n_taps))
+      return resample_rc_launch((const float*)in, in_off, in_len, out_off, out_len, n_items, max_out_len, up, down, (const float*)taps, n_taps,
+                                n_pre_remove, (float*)out, (hipStream_t)stream);
+  }
   if (ssr_resample_lds_bytes(p) > 96 * 1024) p.taps_in_lds = 0;      // huge tap tables stay in HBM / L2
   const size_t lds = ssr_resample_lds_bytes(p);
   if (lds > 160 * 1024) {           // huge reduced `up`: the phase-blocked kernel's window does not fit LDS

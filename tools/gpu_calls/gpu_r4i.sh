@@ -1,0 +1,5 @@
+#!/bin/bash
+# round 4: the residue-class resampler: bit-exactness + timing
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -m gpu -q -x -k "resampl or cfg5 or subsampl" 2>&1 | tail -8
+for i in 1 2; do NO_MFMA=1 python tools/exp_resample.py 2>&1 | tail -1; done
+NO_MFMA=1 UTT=12500 ITERS=3 python tools/exp_resample.py 2>&1 | tail -1

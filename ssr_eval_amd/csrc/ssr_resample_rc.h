@@ -7,18 +7,19 @@
 //   * its HPP (= 21 for every up-sampling plan of resample_poly) taps are loop-invariant REGISTERS - no tap table in LDS, no tap
 //     reads, no tap index arithmetic in the loop (the round-2/3 kernel read one tap per 8 multiply-adds from a 37 KB table that
 //     capped the CU at three workgroups, with 3-way bank conflicts for 441/160);
-//   * the input of output j starts `down` samples after that of output j - 1: all LDS addresses of a block of JB outputs are one
-//     per-lane base plus compile-time-known strides;
-//   * the window is staged TWICE (the second copy shifted by one sample, on the other half of the banks), so that every lane reads
-//     its 21 consecutive samples as 11 ALIGNED 8-byte loads whatever the parity of its first index: ds_read_b64 moves twice the
-//     bytes per LDS cycle of ds_read_b32 - the old kernel's 1.125 four-byte reads per multiply-add were 41 % of the CU's LDS
-//     rate at three waves per SIMD; this one issues 0.52 eight-byte reads per multiply-add, the same cycles as the multiply-adds
-//     themselves take on the VALU;
-//   * consecutive lanes = consecutive outputs: stores are full 256-byte runs; consecutive lanes read input indices 0.36
-//     (441/160) or 0.92 (160/147) apart: broadcasts, no bank conflict;
-//   * a workgroup is ceil(up / 64) waves streaming over one item's outputs in blocks of JB steps; the next block's window goes
-//     global -> LDS by LDS-DMA while the current one is computed (no staging registers, no ds_write; two LDS stages of ~12 KB:
-//     four workgroups per CU), one barrier per block.
+//   * two successive outputs of a lane read inputs exactly `down` samples apart, and the window sits in LDS as PAIRS
+//     L[i] = (x[lo + i], x[lo + i + down]): ONE aligned ds_read_b64 at pair i hands the lane sample k of output j AND sample k of
+//     output j + 1 in a register pair - the operand of a packed multiply by (tap k, tap k) and a packed add into
+//     (acc j, acc j + 1): v_pk_mul_f32 + v_pk_add_f32, each half rounded on its own exactly like the scalar multiply and add
+//     (no fused multiply-add: SciPy's two roundings), at HALF the vector instructions - a wave64 float32 instruction occupies its
+//     SIMD for 4 cycles packed or not, and the scalar version of this kernel sat at 62 % VALU occupancy;
+//   * 0.5 eight-byte LDS reads per multiply-add, every read aligned whatever the lane's first index, 32 consecutive lanes on at
+//     most 31 consecutive pairs = 62 of the 64 banks: no conflict (ds_read_b64: 256 B/clk; the compiler's ds_read2_b64 merge is
+//     half that rate on 32 banks and is defeated by passing a chain's address through an empty asm statement every step);
+//   * consecutive lanes = consecutive outputs: stores are full 256-byte runs;
+//   * a workgroup is ceil(up / 64) waves streaming over one item's outputs in blocks of JB = 8 steps; the next block's window goes
+//     global -> LDS by LDS-DMA while the current one is computed (no staging registers, no ds_write; two LDS stages), one
+//     barrier per block, and the wait before it leaves the block's own stores in flight (counted vmcnt).
 // Device code only (the host emulation keeps exercising ssr_resample.h, which remains the kernel of every plan this one does not
 // take: taps per phase != 21, up < 33 or > 1024, float64 signals).
 #pragma once
@@ -27,7 +28,7 @@
 
 #include "ssr_resample.h"
 
-#define SSR_RC_JB 8            /* outputs per lane and block */
+#define SSR_RC_JB 8            /* outputs per lane and block (JB / 2 packed chains) */
 
 struct SsrResampleRcParams {
   const float* in;
@@ -38,18 +39,22 @@ struct SsrResampleRcParams {
   int up, down, n_taps, n_pre_remove;
   const float* taps;
   int blocks_per_chunk, n_chunks;     // a workgroup walks `blocks_per_chunk` blocks of JB steps of ONE item
-  int seg_floats;                     // floats per window copy (even, and = 32 mod 64: the two copies sit on opposite bank halves)
+  int stage_floats;                   // floats per LDS stage (2 per pair; a multiple of 64)
   float* out;
 };
 
-// window of a block of JB steps starting at step j0: inputs [lo, lo + len)
-__host__ __device__ inline int ssr_rc_seg_len(int up, int down, int hpp) {
-  return (SSR_RC_JB - 1) * down + (int)(((int64_t)(up - 1) * down + (up - 1)) / up) + hpp + 6;      // (+ the last chain's over-read)
+// pairs a block's window holds: pair i = (x[lo + i], x[lo + i + down]), i < n_pairs; the chains of steps 0, 2, .., JB - 2 start at
+// pair (q(r) - q(0)) + j down and read HPP pairs
+__host__ __device__ inline int ssr_rc_pairs(int up, int down, int hpp) {
+  return (SSR_RC_JB - 2) * down + (int)(((int64_t)(up - 1) * down + (up - 1)) / up) + hpp + 2;
 }
 
 template <int HPP>
 __device__ __forceinline__ void ssr_resample_rc_body(const SsrResampleRcParams& p, char* smem) {
-  constexpr int JB = SSR_RC_JB, NP = (HPP + 1) / 2;
+  constexpr int JB = SSR_RC_JB, NC = JB / 2;
+  typedef float ssr_v2f __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) float lds_float;              // 32-bit LDS addresses (a generic pointer costs a register pair)
+  typedef __attribute__((address_space(3))) ssr_v2f lds_float2;
   const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
   const int item = (int)blockIdx.x / p.n_chunks, chunk = (int)blockIdx.x % p.n_chunks;
   const int up = p.up, down = p.down;
@@ -61,11 +66,8 @@ __device__ __forceinline__ void ssr_resample_rc_body(const SsrResampleRcParams& 
   if (blk0 * JB >= steps) return;
   int blk1 = blk0 + p.blocks_per_chunk;
   if (blk1 * JB > steps) blk1 = (steps + JB - 1) / JB;
-  typedef __attribute__((address_space(3))) float lds_float;               // 32-bit LDS addresses (a generic pointer costs a register pair)
-  typedef float ssr_v2f __attribute__((ext_vector_type(2)));
-  typedef __attribute__((address_space(3))) ssr_v2f lds_float2;
   lds_float* lds = (lds_float*)smem;
-  const int SEG = p.seg_floats;                                         // stage s: copies at lds + s * 2 SEG and + s * 2 SEG + SEG
+  const int STAGE = p.stage_floats;
 
   // lane constants: phase, first input index, taps (k ascending = input ascending = tap index descending)
   const bool active = tid < up;
@@ -80,39 +82,25 @@ __device__ __forceinline__ void ssr_resample_rc_body(const SsrResampleRcParams& 
   }
   const SsrRwView<float> vy(y, n_out);
   const int qmin0 = (int)(((unsigned)p.n_pre_remove * (unsigned)down) / (unsigned)up);    // q of residue 0 at step 0
-  const int seg_len = ssr_rc_seg_len(up, down, HPP);
+  const int n_pairs = ssr_rc_pairs(up, down, HPP);
 
-  // Staging.  A block whose window lies inside the signal goes global -> LDS directly (LDS-DMA, 4 bytes per lane: a wave deposits
-  // 64 consecutive samples per instruction, once for copy A[i] = x[lo + i] and once, one float lower, for copy B[i] = x[lo + i + 1]):
-  // no staging registers, no ds_write, the transfer runs under the current block's multiply-adds.  The first / last blocks of an
-  // item, whose windows reach outside [0, n_in), take ordinary loads with the zero extension upfirdn applies.
+  // Staging.  A block whose window lies inside the signal goes global -> LDS directly (LDS-DMA, 4 bytes per lane: a wave deposits 32
+  // consecutive PAIRS per instruction - its even lanes fetch x[lo + i], its odd lanes x[lo + i + down]): no staging registers, no
+  // ds_write, the transfer runs under the current block's multiply-adds.  The first / last blocks of an item, whose windows reach
+  // outside [0, n_in), take ordinary loads with the zero extension upfirdn applies.
   auto stage = [&](int blk, int s) {
     const int lo = qmin0 + blk * JB * down - (HPP - 1);
-    lds_float* a = lds + s * 2 * SEG;
-    lds_float* b = a + SEG;
-    if (lo >= 0 && lo + seg_len + 1 + 64 <= n_in) {                       // block-uniform
+    lds_float* a = lds + s * STAGE;
+    if (lo >= 0 && lo + n_pairs + 64 + down <= n_in) {                    // block-uniform
       const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
-      for (int i0 = wave * 64; i0 < seg_len + 1; i0 += nw * 64) {         // wave-uniform trip count
-        const float* src = x + lo + i0 + lane;
-#ifndef SSR_RC_DEBUG_SLOWA
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(a + i0), 4, 0, 0);
-#else
-        a[i0 + lane] = src[0];
-#endif
-#ifndef SSR_RC_DEBUG_SLOWB
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 1),
-                                         (__attribute__((address_space(3))) void*)(b + i0), 4, 0, 0);
-#else
-        b[i0 + lane] = src[1];
-#endif
-      }
+      const float* src = x + lo + (lane >> 1) + ((lane & 1) ? down : 0);
+      for (int i0 = wave * 32; i0 < n_pairs; i0 += nw * 32)               // wave-uniform trip count
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i0),
+                                         (__attribute__((address_space(3))) void*)(a + 2 * i0), 4, 0, 0);
     } else {
-      for (int i = tid; i < seg_len + 1; i += nt) {
-        const int g = lo + i;
-        const float v = (g >= 0 && g < n_in) ? x[g] : 0.0f;
-        if (i < seg_len) a[i] = v;
-        if (i >= 1) b[i - 1] = v;
+      for (int i = tid; i < 2 * n_pairs; i += nt) {
+        const int g = lo + (i >> 1) + ((i & 1) ? down : 0);
+        a[i] = (g >= 0 && g < n_in) ? x[g] : 0.0f;
       }
     }
   };
@@ -124,54 +112,62 @@ __device__ __forceinline__ void ssr_resample_rc_body(const SsrResampleRcParams& 
     const int s = (blk - blk0) & 1;
     if (blk + 1 < blk1) stage(blk + 1, s ^ 1);
     {                                                                     // (lanes past `up` compute residue 0 again; their stores are dropped)
-      const lds_float* a = lds + s * 2 * SEG;
-      const int b0 = q0 - qmin0;                                          // index (in copy A) of the first input of the block's first output
-      // JB independent accumulation chains (k ascending within each: SciPy's order), one aligned sample PAIR per chain and step.
-      // The pairs are single ds_read_b64 on purpose (256 B/clk, banks mod 64: the two window copies never collide); the compiler
-      // would merge neighbouring pairs of a chain into ds_read2_b64 - half the rate, banks mod 32: 45 % of the LDS cycles were bank
-      // conflicts - so a chain's address goes through an empty asm statement every step (distinct, opaque bases cannot be merged).
-      // The order is pinned through the data: step i + 1's loads are issued before step i's multiply-adds.
-      float acc[JB];
-      unsigned ad[JB];                                                    // LDS byte address of the chain's first pair
+      const lds_float* a = lds + s * STAGE;
+      // NC packed chains: chain c = outputs of steps 2 c and 2 c + 1 of this block; its pair k sits at pair index
+      // (q0 - qmin0) + 2 c down + k.  The order is pinned through the data: step k + 1's loads are issued before step k's
+      // multiply-adds, and a chain's address goes through an empty asm statement every step (opaque bases cannot be merged into
+      // ds_read2_b64).
+      ssr_v2f acc[NC];
+      unsigned ad[NC];                                                    // LDS byte address of the chain's first pair
 #pragma unroll
-      for (int j = 0; j < JB; ++j) {
-        const int bj = b0 + j * down;
-        // even index: copy A; odd index: copy B, one slot lower (B[bj - 1] = A[bj])
-        ad[j] = (unsigned)(uintptr_t)(a + ((bj & 1) ? SEG + bj - 1 : bj));
-        acc[j] = 0.0f;
+      for (int c = 0; c < NC; ++c) {
+        ad[c] = (unsigned)(uintptr_t)(a + 2 * ((q0 - qmin0) + 2 * c * down));
+        acc[c] = (ssr_v2f){0.0f, 0.0f};
       }
-      float cur[JB][2], nxt[JB][2];
-      auto fetch = [&](float (*dst)[2], int i) {
+      ssr_v2f cur[NC], nxt[NC];
+      auto fetch = [&](ssr_v2f* dst, int k) {
 #pragma unroll
-        for (int j = 0; j < JB; ++j) {
-          asm volatile("" : "+v"(ad[j]));
-          const ssr_v2f v = *(const lds_float2*)(uintptr_t)(ad[j] + 8u * (unsigned)i);
-          dst[j][0] = v.x; dst[j][1] = v.y;
+        for (int c = 0; c < NC; ++c) {
+          asm volatile("" : "+v"(ad[c]));
+          dst[c] = *(const lds_float2*)(uintptr_t)(ad[c] + 8u * (unsigned)k);
         }
       };
       fetch(cur, 0);
+      static_assert(NC == 4, "the asm below");
 #pragma unroll
-      for (int i = 0; i < NP; ++i) {
-        if (i + 1 < NP) fetch(nxt, i + 1);
+      for (int k = 0; k < HPP; ++k) {
+        if (k + 1 < HPP) fetch(nxt, k + 1);
+        // Step k of the four chains: products first, sums second (a packed float32 instruction that reads the result of the one
+        // just before it costs wait states - the compiler's own schedule paired every product with its sum and padded each pair
+        // with two s_nop), the tap broadcast to both halves through op_sel (taps stay 11 register pairs instead of 21).
+        // v_pk_mul_f32 then v_pk_add_f32: every half is multiplied, rounded, added, rounded - SciPy's two roundings per tap.
+        ssr_v2f p0, p1, p2, p3;
+        const ssr_v2f tp = {tap[k & ~1], tap[(k | 1) < HPP ? (k | 1) : k]};
+        if (k & 1)
+          asm volatile("v_pk_mul_f32 %4, %8, %12 op_sel:[0,1]\n\tv_pk_mul_f32 %5, %9, %12 op_sel:[0,1]\n\t"
+                       "v_pk_mul_f32 %6, %10, %12 op_sel:[0,1]\n\tv_pk_mul_f32 %7, %11, %12 op_sel:[0,1]\n\t"
+                       "v_pk_add_f32 %0, %0, %4\n\tv_pk_add_f32 %1, %1, %5\n\tv_pk_add_f32 %2, %2, %6\n\tv_pk_add_f32 %3, %3, %7"
+                       : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3)
+                       : "v"(cur[0]), "v"(cur[1]), "v"(cur[2]), "v"(cur[3]), "v"(tp));
+        else
+          asm volatile("v_pk_mul_f32 %4, %8, %12 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %5, %9, %12 op_sel_hi:[1,0]\n\t"
+                       "v_pk_mul_f32 %6, %10, %12 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %7, %11, %12 op_sel_hi:[1,0]\n\t"
+                       "v_pk_add_f32 %0, %0, %4\n\tv_pk_add_f32 %1, %1, %5\n\tv_pk_add_f32 %2, %2, %6\n\tv_pk_add_f32 %3, %3, %7"
+                       : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3)
+                       : "v"(cur[0]), "v"(cur[1]), "v"(cur[2]), "v"(cur[3]), "v"(tp));
+        if (k + 1 < HPP) {
 #pragma unroll
-        for (int j = 0; j < JB; ++j) { ssr_touch(cur[j][0]); ssr_touch(cur[j][1]); }     // step i's values are consumed from here on ...
-#pragma unroll
-        for (int j = 0; j < JB; ++j) {
-          acc[j] = ssr_fadd_rn(acc[j], ssr_fmul_rn(cur[j][0], tap[2 * i]));
-          if (2 * i + 1 < HPP) acc[j] = ssr_fadd_rn(acc[j], ssr_fmul_rn(cur[j][1], tap[2 * i + 1]));
-        }
-#pragma unroll
-        for (int j = 0; j < JB; ++j) ssr_touch(acc[j]);                   // ... and its multiply-adds are complete here
-        if (i + 1 < NP) {
-#pragma unroll
-          for (int j = 0; j < JB; ++j) { cur[j][0] = nxt[j][0]; cur[j][1] = nxt[j][1]; }
+          for (int c = 0; c < NC; ++c) cur[c] = nxt[c];
         }
       }
       // JB stores per wave, ALWAYS issued (a buffer view drops what lies past the item's end or belongs to a lane past `up`): the
       // wait below counts on exactly JB vector-memory instructions being younger than the LDS-DMA of the next block
       const int m0 = r + blk * JB * up;
 #pragma unroll
-      for (int j = 0; j < JB; ++j) vy.st_raw(active ? 4 * (m0 + j * up) : -1, acc[j]);
+      for (int c = 0; c < NC; ++c) {
+        vy.st_raw(active ? 4 * (m0 + 2 * c * up) : -1, acc[c].x);
+        vy.st_raw(active ? 4 * (m0 + (2 * c + 1) * up) : -1, acc[c].y);
+      }
     }
     // the next block's LDS-DMA (issued before the multiply-adds) has landed - the stores just issued may still be in flight (vmcnt
     // retires in order) - and this wave's DS operations are complete, before anyone passes the barrier

@@ -82,16 +82,14 @@ static bool resample_rc_eligible(int up, int down, int n_taps) {
   if (off) return false;
 #endif
   if (up < 33 || up > 1024 || (n_taps + up - 1) / up != 21) return false;
-  return (size_t)4 * (ssr_rc_seg_len(up, down, 21) + 128) * sizeof(float) <= 64 * 1024;      // two stages x two window copies
+  return (size_t)4 * (ssr_rc_pairs(up, down, 21) + 32) * sizeof(float) <= 64 * 1024;      // two stages of (x[i], x[i + down]) pairs
 }
 static int resample_rc_launch(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off, const int32_t* out_len,
                               int n_items, int max_out_len, int up, int down, const float* taps, int n_taps, int n_pre_remove, float* out,
                               hipStream_t s) {
   SsrResampleRcParams p{in, in_off, in_len, out_off, out_len, up, down, n_taps, n_pre_remove, taps, 1, 1, 0, out};
-  const int seg_len = ssr_rc_seg_len(up, down, 21);
-  // whole 64-sample deposits (a wave's LDS-DMA instruction) must stay inside a copy; + 32: copy B sits on the other half of the 64 banks
-  p.seg_floats = ((seg_len + 1 + 63) / 64) * 64 + 32;
-  const int seg = p.seg_floats;
+  // whole 32-pair deposits (a wave's LDS-DMA instruction) must stay inside a stage
+  p.stage_floats = 2 * (((ssr_rc_pairs(up, down, 21) + 31) / 32) * 32);
   const int steps = ssr_ceil_div(max_out_len, up), blocks = ssr_ceil_div(steps, SSR_RC_JB);
   int n_chunks = ssr_ceil_div(4096, n_items);                   // >= ~4 k workgroups per launch, whole items where the batch is large
   if (n_chunks > blocks) n_chunks = blocks;
@@ -100,7 +98,7 @@ static int resample_rc_launch(const float* in, const int64_t* in_off, const int3
   p.n_chunks = ssr_ceil_div(blocks, p.blocks_per_chunk);
   const int64_t grid = (int64_t)n_items * p.n_chunks;
   if (grid > 0x7fffffff) return ssr_fail(SSR_ERR_UNSUPPORTED, "batch too large for one launch");
-  const size_t lds = (size_t)4 * seg * sizeof(float);           // two stages x two copies
+  const size_t lds = (size_t)2 * p.stage_floats * sizeof(float);      // two stages
   const int nt = ssr_ceil_div(up, 64) * 64;
   static thread_local SsrLdsSlot slot;
   if (nt <= 512) {                                              // (the launch bound sets the register budget: 8 waves -> 256 VGPRs)

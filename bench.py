@@ -436,7 +436,13 @@ class Cfg4:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         lens, spk = self.layout()
         self.n_total = len(lens)
-        self.mine = np.arange(rank, self.n_total, self.world)          # ssr_eval_amd.dist.shard_indices: round-robin
+        from ssr_eval_amd import dist as D
+        self.shard = getattr(a, "shard", "balanced")
+        # length-balanced dealing (longest first to the least-loaded rank) or static round-robin
+        self.mine = D.shard_indices_balanced(lens, rank, self.world) if self.shard == "balanced" else np.arange(rank, self.n_total, self.world)
+        loads = [int(lens[D.shard_indices_balanced(lens, r, self.world) if self.shard == "balanced" else np.arange(r, self.n_total, self.world)].sum())
+                 for r in range(self.world)]
+        self.shard_balance = max(loads) / (sum(loads) / len(loads))
         ml = lens[self.mine]
         off = np.concatenate(([0], np.cumsum(ml)[:-1])) if len(ml) else np.zeros(0, np.int64)
         tot = int(ml.sum())
@@ -466,11 +472,15 @@ class Cfg4:
         self.spk_local = torch.from_numpy(spk[self.mine]).to(dev)
         self.cnt_local = torch.bincount(self.spk_local, minlength=self.n_spk).to(torch.float64)
         self.buf = torch.zeros((self.n_spk, 5), dtype=torch.float64, device=dev)      # [speakers, 4 metrics + count] (eval.py:200-216)
-        self.cap = -(-self.n_total // self.world)
-        self.pack = torch.full((self.cap, 5), float("nan"), dtype=torch.float64, device=dev)   # (global index, 4 metrics), padded
-        self.pack[:, 0] = -1.0
+        sizes = [len(D.shard_indices_balanced(lens, r, self.world)) if self.shard == "balanced" else len(range(r, self.n_total, self.world))
+                 for r in range(self.world)]
+        self.cap = max(sizes)
+        # ONE collective per step: the rank's padded (global index, 4 metrics) rows and, behind them, its
+        # [speakers, 4 sums + count] block; every rank adds the gathered speaker blocks in rank order (bit-identical aggregate)
+        self.pack = torch.full((self.cap + self.n_spk, 5), float("nan"), dtype=torch.float64, device=dev)
+        self.pack[:self.cap, 0] = -1.0
         self.pack[:len(self.mine), 0] = torch.from_numpy(self.mine.astype(np.float64)).to(dev)
-        self.gathered = torch.empty((self.world * self.cap, 5), dtype=torch.float64, device=dev)
+        self.gathered = torch.empty((self.world, self.cap + self.n_spk, 5), dtype=torch.float64, device=dev)
         self.units_per_step = self.n_total                              # strong scaling: the whole set per step, whatever N
 
     def step(self):
@@ -480,9 +490,10 @@ class Cfg4:
         self.buf[:, :4].index_add_(0, self.spk_local, out)
         self.buf[:, 4] = self.cnt_local
         self.pack[:len(self.mine), 1:] = out
+        self.pack[self.cap:] = self.buf
         if self.world > 1:
-            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)              # RCCL over xGMI: 320 B
-            dist.all_gather_into_tensor(self.gathered, self.pack)        # per-utterance rows for the per-file JSON block
+            dist.all_gather_into_tensor(self.gathered.view(-1, 5), self.pack)      # RCCL over xGMI: the step's only collective
+            torch.sum(self.gathered[:, self.cap:], dim=0, out=self.buf)           # ranks added in rank order, on every rank alike
         return self.buf
 
     def job_means(self, agg):
@@ -494,19 +505,21 @@ class Cfg4:
     def config(self, world):
         a = self.a
         return {"workload": "cfg-4: the VCTK-shaped test set - %d ragged synthetic (est, target) pairs, 1.5-9 s @ 48 kHz, speakers with %s files - "
-                            "sharded round-robin over the ranks, resident in HBM; LSD + log-SISpec + SISpec + SSIM at STFT 2048/512, transform "
-                            "precision %s; every step ends with the float64 all-reduce of the [8 speakers, 4 sums + count] buffer and the "
-                            "padded all-gather of the per-utterance rows" % (sum(self.SPEAKER_COUNTS), self.SPEAKER_COUNTS, a.precision),
+                            "sharded over the ranks (length-balanced dealing), resident in HBM; LSD + log-SISpec + SISpec + SSIM at STFT 2048/512, transform "
+                            "precision %s; every step ends with ONE all-gather: the per-utterance rows and, behind them, the rank's "
+                            "[8 speakers, 4 sums + count] block, added in rank order on every rank" % (sum(self.SPEAKER_COUNTS), self.SPEAKER_COUNTS, a.precision),
                 "utterances_total": sum(self.SPEAKER_COUNTS), "n_fft": N_FFT, "hop": HOP,
-                "parallelism": "strong scaling: %d utterances sharded x%d (round-robin), all-reduce 320 B + all-gather %d B per rank and step"
-                               % (sum(self.SPEAKER_COUNTS), world, -(-sum(self.SPEAKER_COUNTS) // world) * 40)}
+                "parallelism": "strong scaling: %d utterances sharded x%d (%s dealing), ONE all-gather of %d B per rank and step"
+                               % (sum(self.SPEAKER_COUNTS), world, getattr(a, "shard", "balanced"),
+                                  (-(-sum(self.SPEAKER_COUNTS) // world) + 8 + len(self.SPEAKER_COUNTS)) * 40)}
 
     def report(self, a):
         import torch.distributed as dist
         B = self.B
         if self.fake:
-            g = self.gathered.cpu().numpy() if self.world > 1 else self.pack.cpu().numpy()
-            return None, {"allgather_rows_received": int((g[:, 0] >= 0).sum()), "shard_utterances": int(len(self.mine))}
+            g = self.gathered[:, :self.cap].reshape(-1, 5).cpu().numpy() if self.world > 1 else self.pack[:self.cap].cpu().numpy()
+            return None, {"allgather_rows_received": int((g[:, 0] >= 0).sum()), "shard_utterances": int(len(self.mine)),
+                          "shard_balance_max_over_mean": round(self.shard_balance, 5)}
         ms_all = event_time_ms(lambda: self.batch.run(B.M_ALL), 3)
         ms_stft = event_time_ms(lambda: self.batch.run(B.M_ALL, stages=1), 3)
         alg = int((2 * self.lens_local * 4 + 32).sum())                  # each pair's own n
@@ -515,11 +528,11 @@ class Cfg4:
                             % (len(self.mine), self.n_total))
         extra = {"shard_utterances": int(len(self.mine)), "shard_samples": int(self.lens_local.sum()),
                  "stage_ms_rank0": {"pair_metrics": round(ms_all, 4), "stft+lsd+sispec": round(ms_stft, 4)},
-                 "allreduce_payload_bytes": int(self.buf.numel() * 8), "allgather_payload_bytes_per_rank": int(self.pack.numel() * 8)}
+                 "shard": self.shard, "shard_balance_max_over_mean": round(self.shard_balance, 5),
+                 "allgather_payload_bytes_per_rank": int(self.pack.numel() * 8), "collectives_per_step": 1 if self.world > 1 else 0}
         if self.world > 1:                                               # every rank calls report() for this workload
-            extra["allreduce_latency_us"] = round(1e3 * event_time_ms(lambda: dist.all_reduce(self.buf), 20), 2)
-            extra["allgather_latency_us"] = round(1e3 * event_time_ms(lambda: dist.all_gather_into_tensor(self.gathered, self.pack), 20), 2)
-            g = self.gathered.cpu().numpy()
+            extra["allgather_latency_us"] = round(1e3 * event_time_ms(lambda: dist.all_gather_into_tensor(self.gathered.view(-1, 5), self.pack), 20), 2)
+            g = self.gathered[:, :self.cap].reshape(-1, 5).cpu().numpy()
             extra["allgather_rows_received"] = int((g[:, 0] >= 0).sum())
         return roof, extra
 
@@ -966,6 +979,7 @@ def parse(argv=None):
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
     ap.add_argument("--lowpass-engine", dest="lowpass_engine", default="segments", choices=["segments", "fused", "conv"],
                     help="cfg3: overlap-add through the segment workspace (default, faster inside the pipeline) or fused in the transform kernel")
+    ap.add_argument("--shard", default="balanced", choices=["balanced", "round-robin"], help="cfg4: how the fixed set is dealt to the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the cfg3 / cfg5 / API-true / end-to-end side figures")
     ap.add_argument("--_cpu-skeleton", dest="cpu_skeleton", action="store_true", help=argparse.SUPPRESS)

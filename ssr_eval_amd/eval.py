@@ -468,7 +468,9 @@ class SSR_Eval_Helper:
         rows = np.empty((len(local), len(keys) * len(mets)), dtype=np.float64)
         for i, r in enumerate(local):
             rows[i] = [r[k][m] for k in keys for m in mets]
-        table = D.allgather_rows(rows, mine, len(work))             # [n_files, n_keys * n_metrics]
+        # ONE collective: the per-file rows and, behind them, the per-speaker sums + counts (added in rank order on every rank)
+        spk_id = {s: i for i, s in enumerate(speakers)}
+        table, buf = D.gather_rows_and_speaker_sums(rows, mine, len(work), [spk_id[work[i][0]] for i in mine], len(speakers))
         final_result = {s: {} for s in speakers}
         for (spk, f), row in zip(work, table):
             final_result[spk][f] = {k: {m: float(row[i * len(mets) + j]) for j, m in enumerate(mets)}
@@ -476,9 +478,7 @@ class SSR_Eval_Helper:
         # aggregation (eval.py:200-216): per speaker mean over files, then mean over speakers
         result_cache = {s: {k: dict_mean([v[k] for v in final_result[s].values()]) for k in keys} for s in speakers}
         averaged = {k: dict_mean([result_cache[s][k] for s in speakers]) for k in keys}
-        # the same aggregate through the float64 sums+counts all-reduce; kept for cross-checking
-        spk_id = {s: i for i, s in enumerate(speakers)}
-        buf = D.allreduce_sums(D.speaker_sums(rows, [spk_id[work[i][0]] for i in mine], len(speakers)))
+        # the same aggregate from the float64 sums + counts that rode along; kept for cross-checking
         self.last_allreduce_average = D.mean_of_speaker_means(buf)[1] if len(keys) else None
         final_result["each_speaker"] = result_cache
         final_result["averaged"] = averaged

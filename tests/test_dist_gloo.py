@@ -114,3 +114,44 @@ def test_allgather_rows_width_mismatch_raises_on_every_rank(tmp_path):
     port = 33500 + os.getpid() % 2000
     mp.spawn(_worker_width_mismatch, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert open(tmp_path / "w0").read() == "ValueError,ValueError" and open(tmp_path / "w1").read() == "ValueError,ValueError"
+
+
+def _worker_one_collective(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from ssr_eval_amd import dist as D
+    D.init_from_env(backend="gloo")
+    rng = np.random.default_rng(5)
+    n, K, S = 37, 6, 4
+    rows = rng.standard_normal((n, K)) * 10.0 ** rng.integers(-3, 4, (n, 1))
+    spk = rng.integers(0, S, n)
+    lens = rng.integers(1000, 90000, n)
+    mine = D.shard_indices_balanced(lens)                       # uneven counts per rank: the padded capacity is agreed on
+    import torch.distributed as dist
+    calls = {"n": 0}
+    orig = dist.all_gather
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    dist.all_gather = counting
+    table, buf = D.gather_rows_and_speaker_sums(rows[mine], mine, n, spk[mine], S)
+    dist.all_gather = orig
+    ok = calls["n"] == 1 and np.array_equal(table, rows)
+    want = np.zeros((S, K + 1))
+    for r in range(world):                                       # the documented order: rank blocks added in rank order
+        want += D.speaker_sums(rows[D.shard_indices_balanced(lens, r, world)], spk[D.shard_indices_balanced(lens, r, world)], S)
+    ok = ok and np.array_equal(buf, want)
+    np.save(os.path.join(out_dir, "buf%d.npy" % rank), buf)
+    open(os.path.join(out_dir, "ok%d" % rank), "w").write("1" if ok else "0")
+    dist.destroy_process_group()
+
+
+def test_rows_and_speaker_sums_in_one_collective_world3(tmp_path):
+    """the per-file rows and the per-speaker sums + counts cross in ONE all-gather; every rank adds the speaker
+    blocks in rank order, so the aggregate buffer is BIT-identical on every rank (length-balanced, uneven shards)."""
+    port = 29500 + (os.getpid() + 911) % 2000
+    mp.spawn(_worker_one_collective, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    assert all(open(tmp_path / ("ok%d" % r)).read() == "1" for r in range(3))
+    b = [np.load(tmp_path / ("buf%d.npy" % r)) for r in range(3)]
+    assert b[0].tobytes() == b[1].tobytes() == b[2].tobytes()

@@ -57,9 +57,10 @@ int ssr_version(void);
 /* STFT plan: centred, reflect-padded, periodic-Hann, win_length = n_fft.
  * Replaces the parameter choice of AudioMetrics.__init__ (ssr_eval/metrics.py:16-19: rate -> n_fft, hop),
  * FDomainHelper.__init__ (ssr_eval/dsp.py:7-59: 2048 / 441) and librosa.stft defaults (eval.py:29: 2048 / 512).
- * Any 2 <= n_fft <= 4096 is accepted: powers of two in [256, 4096] run a direct FFT; n_fft = 3q whose plain
- * chirp-z length would be 8192 (2229 = 3 * 743) runs a radix-3 step over three Bluestein transforms of
- * length 2048; everything else (1486, 1114, 743 ...) runs Bluestein over a power of two >= 2 n_fft - 1. */
+ * Any 2 <= n_fft <= 4096 is accepted: powers of two in [256, 4096] run a direct FFT; n_fft = R q with R in {1, 2, 3} and
+ * q <= 768 - every AudioMetrics(rate) size: 2229 = 3 * 743, 1486 = 2 * 743, 1114 = 2 * 557, 743 - runs one radix-R step over R
+ * chirp-z (Bluestein) transforms of length 1536 on float32 pairs (q up to 1024: length 2048); everything else, float64 signals
+ * and single-signal mode run Bluestein over a power of two >= 2 n_fft - 1 (radix 3 over three 2048-point ones for 2229). */
 int ssr_plan_create(int n_fft, int hop, int precision, ssr_plan** plan);
 int ssr_plan_destroy(ssr_plan* plan);
 int ssr_plan_query(const ssr_plan* plan, int* n_fft, int* hop, int* n_bins, int* fft_len, int* bluestein,

@@ -247,6 +247,35 @@ def test_cfg5_full_launch_2048_utterances_bit_exact():
     assert np.isfinite(lsd).all() and lsd.std() / lsd.mean() < 0.01
 
 
+def test_cfg5_bench_launch_12500_utterances_oracle_spot_checks():
+    """cfg-5 at the bench's REAL launch: 12,500 utterances of 64,000 samples through both resampling
+    stages (the residue-class kernel: one workgroup per utterance and stage, 50 / 150 blocks each) and the LSD against a 48 kHz
+    target - the first, a middle and the last utterance bit-identical to scipy.signal.resample_poly after BOTH stages, their LSD at
+    1e-5 against the oracle, and every utterance's energy in line (an i.i.d. draw: one wrong block anywhere would stick out)."""
+    from ssr_eval_amd import backend as B
+    from oracle import metrics as om
+    N = 12500
+    g = torch.Generator(device="cuda").manual_seed(20220329)
+    x = (0.1 * torch.randn((N, 64000), generator=g, device="cuda", dtype=torch.float32)).contiguous()
+    s1 = B.ResampleBatch(B.Ragged.from_uniform(x), 44100, 16000)
+    s2 = B.ResampleBatch(s1.out_ragged(), 48000, 44100)
+    y1 = s1.run().view(N, 176400)
+    y2 = s2.run().view(N, 192000)
+    spots = (0, 1, N // 2, N - 2, N - 1)
+    tgt = (0.1 * torch.randn((len(spots), 192000), generator=g, device="cuda", dtype=torch.float32)).contiguous()
+    lsd = B.PairBatch(B.get_plan(2048, 512, "f64"), B.Ragged.from_uniform(y2[list(spots)].contiguous()), B.Ragged.from_uniform(tgt)).run(B.M_LSD).cpu().numpy()[:, 0]
+    for j, i in enumerate(spots):
+        r1 = signal.resample_poly(x[i].cpu().numpy(), 441, 160)
+        np.testing.assert_array_equal(y1[i].cpu().numpy(), r1, err_msg="stage 1, utterance %d" % i)
+        r2 = signal.resample_poly(r1, 160, 147)
+        np.testing.assert_array_equal(y2[i].cpu().numpy(), r2, err_msg="stage 2, utterance %d" % i)
+        want = float(om.lsd(om.wav_to_spectrogram(r2, 2048, 512), om.wav_to_spectrogram(tgt[j].cpu().numpy(), 2048, 512)))
+        assert abs(lsd[j] - want) <= 1e-5 * want, (i, lsd[j], want)
+    e1, e2 = (y1.double() ** 2).mean(dim=1), (y2.double() ** 2).mean(dim=1)
+    assert float(e1.std() / e1.mean()) < 0.02 and float(e2.std() / e2.mean()) < 0.02
+    assert float((e1 / e1.mean() - 1).abs().max()) < 0.1 and float((e2 / e2.mean() - 1).abs().max()) < 0.1
+
+
 @pytest.mark.parametrize("hop", [441, 512])
 def test_lowpass_engines_fused_and_segments(hop, golden):
     """ssr_plan_set_lowpass_engine: the fused engine (k_lowpass_group: overlap-add inside the transform kernel) against the default

@@ -9,6 +9,8 @@ summary = {"source": "rocprofv3 --kernel-trace --stats -- python bench.py --conf
                      "(cfg2 with its side figures, the others --no-side); PMC: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
                      "--kernel-trace passes per config and for tools/exp_api_true.py / tools/exp_sinc.py (tools/collect_profiles_r03.sh)",
            "kernels": {}}
+if tag >= "r04":
+    summary["source"] = summary["source"].replace("collect_profiles_r03.sh", "collect_profiles_r04.sh") + "; cfg3conv = bench.py --config cfg3 --lowpass-engine conv"
 for stats in sorted(glob.glob(src + "/stats_*/*kernel_stats.csv")):
     cfg = os.path.basename(os.path.dirname(stats)).replace("stats_", "")
     rows = list(csv.DictReader(open(stats)))
@@ -24,7 +26,8 @@ for stats in sorted(glob.glob(src + "/stats_*/*kernel_stats.csv")):
     if os.path.exists(bj) and os.path.getsize(bj):
         summary.setdefault("bench_line_under_rocprof", {})[cfg] = json.load(open(bj))
 KEYS = ("k_stft_wave<double, false", "k_stft_wave<double, true", "k_ssim", "k_stft<double, 11")
-MORE = {"cfg3": ("k_lowpass_wave", "k_ola_paired", "k_ola("), "cfg3fused": ("k_lowpass_group",), "cfg5": ("k_resample<",),
+MORE = {"cfg3": ("k_lowpass_wave", "k_ola_paired", "k_ola(", "k_specred_wave"), "cfg3fused": ("k_lowpass_group",), "cfg5": ("k_resample<", "k_resample_rc"),
+        "cfg3conv": ("k_tl_gemm<0>", "k_tl_gemm<2>", "k_tl_fold", "k_tl_pad"),
         "api": ("k_stft_r3_rot<double, false", "k_stft_r3_rot<double, true"), "sinc": ("k_resample_sinc",)}
 pm = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -39,8 +42,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                     agg[k].append((int(r.get("Dispatch_Id", 0) or 0), float(r["Counter_Value"])))
         for k, v in agg.items():
             vals = [x for _, x in sorted(v)]
-            if k == "k_resample<":            # cfg-5 launches the two stages alternately: 441/160 first, then 160/147
-                for name, part in (("k_resample stage 1", vals[0::2]), ("k_resample stage 2", vals[1::2])):
+            if k in ("k_resample<", "k_resample_rc"):   # cfg-5 launches the two stages alternately: 441/160 first, then 160/147
+                for name, part in ((k.rstrip("<") + " stage 1", vals[0::2]), (k.rstrip("<") + " stage 2", vals[1::2])):
                     if part:
                         part = sorted(part)
                         pm.setdefault(name, {})[c] = part[len(part) // 2]

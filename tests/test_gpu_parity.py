@@ -931,3 +931,56 @@ def test_ragged_from_list_does_not_alias_separate_allocations():
     flat = torch.randn(3 * 1000, device="cuda", generator=g)
     r = B.Ragged.from_list([flat[0:1000], flat[1000:2000], flat[2000:3000]])
     assert r.data.data_ptr() == flat.data_ptr()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_residue_class_resampler_random_rate_pairs_bit_exact(seed):
+    """k_resample_rc (round 4) on rate pairs nobody tuned it for: random coprime up > down with 33 <= up <= 1024 (21 taps per phase:
+    the kernel's domain; odd and even `down`, 1 to 16 waves per workgroup, both launch-bound variants), ragged batches with signals
+    shorter than one block and longer than many, few and many items (one and several chunks per item) - bit-identical to
+    scipy.signal.resample_poly, as are the neighbours the old kernel keeps (up < 33, down > up)."""
+    from math import gcd
+    from ssr_eval_amd import backend as B
+    rng = np.random.default_rng(1000 + seed)
+    pairs = [(147, 80), (320, 147), (33, 32), (1024, 1023), (640, 441)]
+    while len(pairs) < 12:
+        up = int(rng.integers(33, 1025))
+        down = int(rng.integers(1, up))
+        if gcd(up, down) == 1:
+            pairs.append((up, down))
+    pairs += [(32, 31), (3, 2), (80, 147)]                      # outside the domain: the persistent kernel
+    for up, down in pairs:
+        lens = [int(rng.integers(5, 400)), int(rng.integers(2000, 9000)), int(rng.integers(20000, 60000) * down // up) + 50, 1]
+        sigs = [(0.3 * rng.standard_normal(n)).astype(np.float32) for n in lens]
+        for batch in (sigs, sigs[1:2] * 5):
+            ys = B.resample_poly(batch, up, down)
+            for x, y in zip(batch, ys):
+                np.testing.assert_array_equal(y.cpu().numpy(), signal.resample_poly(x, up, down), err_msg="%d/%d n=%d" % (up, down, len(x)))
+
+
+@pytest.mark.parametrize("n_fft,hop", [(1024, 220), (512, 110), (2048, 512), (256, 64)])
+def test_conv_engine_other_transform_sizes_bit_exact_against_tl_chain(n_fft, hop):
+    """The conv (reference-arithmetic) low-pass engine away from FDomainHelper's 2048 / 441: its sub-band variants
+    (FDomainHelper(subband=2 / 4): 1024 / 220, 512 / 110, ssr_eval/dsp.py:40-59), librosa's 2048 / 512 and a small plan - low-pass
+    at several cuts, ISTFT of given spectra and the complex STFT, all bit for bit against oracle/tl_chain.c fed the library's tables."""
+    from ssr_eval_amd import backend as B
+    from oracle import tl_chain
+    wts = lib_tl_weights(n_fft)
+    plan = B.get_plan(n_fft, hop, "f64", lowpass_engine="conv")
+    rng = np.random.default_rng(n_fft)
+    F = n_fft // 2 + 1
+    lens = [n_fft // 2 + 1, 3 * n_fft + 17, 9000, 20011]
+    cuts = [F, 1, F // 3, F - 1]
+    sigs = [(0.2 * rng.standard_normal(n)).astype(np.float32) for n in lens]
+    ys = B.fft_lowpass(plan, sigs, cuts)
+    for x, c, y in zip(sigs, cuts, ys):
+        np.testing.assert_array_equal(y.cpu().numpy(), tl_chain.stft_hard_lowpass(x, c, n_fft, hop, weights=wts), err_msg="n=%d cut=%d" % (len(x), c))
+    re, im = B.stft(plan, sigs[1:3], kind="complex", torch_style_pad=True)
+    for x, r, i in zip(sigs[1:3], re, im):
+        wr, wi = tl_chain.stft(x, n_fft, hop, weights=wts)
+        np.testing.assert_array_equal(r.cpu().numpy(), wr)
+        np.testing.assert_array_equal(i.cpu().numpy(), wi)
+        back = B.istft(plan, [r], [i], [len(x)])[0].cpu().numpy()
+        np.testing.assert_array_equal(back, tl_chain.istft(wr, wi, len(x), n_fft, hop, weights=wts))
+        assert np.abs(back - x).max() < 2e-6
+    assert np.abs(B.fft_lowpass(plan, sigs[2:3], [0])[0].cpu().numpy()).max() == 0.0       # cut 0: silence

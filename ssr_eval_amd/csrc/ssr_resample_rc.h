@@ -17,7 +17,8 @@
 //     most 31 consecutive pairs = 62 of the 64 banks: no conflict (ds_read_b64: 256 B/clk; the compiler's ds_read2_b64 merge is
 //     half that rate on 32 banks and is defeated by passing a chain's address through an empty asm statement every step);
 //   * consecutive lanes = consecutive outputs: stores are full 256-byte runs;
-//   * a workgroup is ceil(up / 64) waves streaming over one item's outputs in blocks of JB = 8 steps; the next block's window goes
+//   * a workgroup is G lane groups of `up` residues (G up lanes in whole waves: 441 -> 1 x 441 of 448 lanes, 160 -> 2 x 160 = 320)
+//     streaming over one item's outputs in blocks of G x 8 steps; the next block's window goes
 //     global -> LDS by LDS-DMA while the current one is computed (no staging registers, no ds_write; two LDS stages), one
 //     barrier per block, and the wait before it leaves the block's own stores in flight (counted vmcnt).
 // Device code only (the host emulation keeps exercising ssr_resample.h, which remains the kernel of every plan this one does not
@@ -40,13 +41,14 @@ struct SsrResampleRcParams {
   const float* taps;
   int blocks_per_chunk, n_chunks;     // a workgroup walks `blocks_per_chunk` blocks of JB steps of ONE item
   int stage_floats;                   // floats per LDS stage (2 per pair; a multiple of 64)
+  int groups;                         // G: lane groups of `up` residues per workgroup; a block is G * JB steps, group g its steps g JB ..
   float* out;
 };
 
-// pairs a block's window holds: pair i = (x[lo + i], x[lo + i + down]), i < n_pairs; the chains of steps 0, 2, .., JB - 2 start at
+// pairs a block's window holds: pair i = (x[lo + i], x[lo + i + down]), i < n_pairs; the chains of steps 0, 2, .., G JB - 2 start at
 // pair (q(r) - q(0)) + j down and read HPP pairs
-__host__ __device__ inline int ssr_rc_pairs(int up, int down, int hpp) {
-  return (SSR_RC_JB - 2) * down + (int)(((int64_t)(up - 1) * down + (up - 1)) / up) + hpp + 2;
+__host__ __device__ inline int ssr_rc_pairs(int up, int down, int hpp, int groups) {
+  return (groups * SSR_RC_JB - 2) * down + (int)(((int64_t)(up - 1) * down + (up - 1)) / up) + hpp + 2;
 }
 
 template <int HPP>
@@ -62,16 +64,20 @@ __device__ __forceinline__ void ssr_resample_rc_body(const SsrResampleRcParams& 
   const float* x = p.in + p.in_off[item];
   float* y = p.out + p.out_off[item];
   const int steps = (n_out + up - 1) / up;                              // outputs r + j up, j < steps
+  const int G = p.groups, SB = G * JB;                                  // steps per block
   const int blk0 = chunk * p.blocks_per_chunk;
-  if (blk0 * JB >= steps) return;
+  if (blk0 * SB >= steps) return;
   int blk1 = blk0 + p.blocks_per_chunk;
-  if (blk1 * JB > steps) blk1 = (steps + JB - 1) / JB;
+  if (blk1 * SB > steps) blk1 = (steps + SB - 1) / SB;
   lds_float* lds = (lds_float*)smem;
   const int STAGE = p.stage_floats;
 
   // lane constants: phase, first input index, taps (k ascending = input ascending = tap index descending)
-  const bool active = tid < up;
-  const int r = active ? tid : 0;
+  // lane -> (group g, residue r): `up` = 160 fills 2 x 160 = 320 lanes = five whole waves (three waves per group of one would
+  // leave 17 % of the lanes idle); lanes past G up compute group 0 / residue 0 again and their stores are dropped
+  const bool active = tid < G * up;
+  const int g = active ? tid / up : 0;
+  const int r = active ? tid - g * up : 0;
   const unsigned t0 = (unsigned)(r + p.n_pre_remove) * (unsigned)down;
   const int q0 = (int)(t0 / (unsigned)up), ph = (int)(t0 - (unsigned)q0 * (unsigned)up);
   float tap[HPP];
@@ -82,14 +88,14 @@ __device__ __forceinline__ void ssr_resample_rc_body(const SsrResampleRcParams& 
   }
   const SsrRwView<float> vy(y, n_out);
   const int qmin0 = (int)(((unsigned)p.n_pre_remove * (unsigned)down) / (unsigned)up);    // q of residue 0 at step 0
-  const int n_pairs = ssr_rc_pairs(up, down, HPP);
+  const int n_pairs = ssr_rc_pairs(up, down, HPP, G);
 
   // Staging.  A block whose window lies inside the signal goes global -> LDS directly (LDS-DMA, 4 bytes per lane: a wave deposits 32
   // consecutive PAIRS per instruction - its even lanes fetch x[lo + i], its odd lanes x[lo + i + down]): no staging registers, no
   // ds_write, the transfer runs under the current block's multiply-adds.  The first / last blocks of an item, whose windows reach
   // outside [0, n_in), take ordinary loads with the zero extension upfirdn applies.
   auto stage = [&](int blk, int s) {
-    const int lo = qmin0 + blk * JB * down - (HPP - 1);
+    const int lo = qmin0 + blk * SB * down - (HPP - 1);
     lds_float* a = lds + s * STAGE;
     if (lo >= 0 && lo + n_pairs + 64 + down <= n_in) {                    // block-uniform
       const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
@@ -113,15 +119,15 @@ __device__ __forceinline__ void ssr_resample_rc_body(const SsrResampleRcParams& 
     if (blk + 1 < blk1) stage(blk + 1, s ^ 1);
     {                                                                     // (lanes past `up` compute residue 0 again; their stores are dropped)
       const lds_float* a = lds + s * STAGE;
-      // NC packed chains: chain c = outputs of steps 2 c and 2 c + 1 of this block; its pair k sits at pair index
-      // (q0 - qmin0) + 2 c down + k.  The order is pinned through the data: step k + 1's loads are issued before step k's
+      // NC packed chains: chain c = outputs of steps g JB + 2 c and g JB + 2 c + 1 of this block; its pair k sits at pair index
+      // (q0 - qmin0) + (g JB + 2 c) down + k.  The order is pinned through the data: step k + 1's loads are issued before step k's
       // multiply-adds, and a chain's address goes through an empty asm statement every step (opaque bases cannot be merged into
       // ds_read2_b64).
       ssr_v2f acc[NC];
       unsigned ad[NC];                                                    // LDS byte address of the chain's first pair
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        ad[c] = (unsigned)(uintptr_t)(a + 2 * ((q0 - qmin0) + 2 * c * down));
+        ad[c] = (unsigned)(uintptr_t)(a + 2 * ((q0 - qmin0) + (g * JB + 2 * c) * down));
         acc[c] = (ssr_v2f){0.0f, 0.0f};
       }
       ssr_v2f cur[NC], nxt[NC];
@@ -162,7 +168,7 @@ __device__ __forceinline__ void ssr_resample_rc_body(const SsrResampleRcParams& 
       }
       // JB stores per wave, ALWAYS issued (a buffer view drops what lies past the item's end or belongs to a lane past `up`): the
       // wait below counts on exactly JB vector-memory instructions being younger than the LDS-DMA of the next block
-      const int m0 = r + blk * JB * up;
+      const int m0 = r + (blk * SB + g * JB) * up;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         vy.st_raw(active ? 4 * (m0 + 2 * c * up) : -1, acc[c].x);

@@ -76,21 +76,36 @@ template <int HPP, int NTMAX> __global__ __launch_bounds__(NTMAX, 4) void k_resa
   extern __shared__ __attribute__((aligned(16))) char smem[];
   ssr_resample_rc_body<HPP>(p, smem);
 }
+// lane groups per workgroup.  Measured (round 4, 160/147: 2 x 160 = 320 lanes, five full waves, against one group on three waves at
+// 83 %): 1.74 against 1.71 ms per 4096 utterances - the kernel waits (barrier, LDS-DMA), it does not lack lanes, and a larger
+// workgroup waits longer - so several groups are taken only where one group leaves more than a quarter of its lanes idle (up < 48
+// or so: 33 residues on a 64-lane wave).
+static int ssr_rc_groups(int up) {
+  int best = 1;
+  double best_eff = (double)up / (ssr_ceil_div(up, 64) * 64);
+  if (best_eff >= 0.75) return 1;
+  for (int g = 2; g * up <= 512 && g <= 8; ++g) {
+    const double eff = (double)(g * up) / (ssr_ceil_div(g * up, 64) * 64);
+    if (eff > best_eff + 0.02) { best_eff = eff; best = g; }
+  }
+  return best;
+}
 static bool resample_rc_eligible(int up, int down, int n_taps) {
 #ifdef SSR_DEV_KNOBS
   static const int off = getenv("SSR_NO_RC") ? atoi(getenv("SSR_NO_RC")) : 0;
   if (off) return false;
 #endif
   if (up < 33 || up > 1024 || (n_taps + up - 1) / up != 21) return false;
-  return (size_t)4 * (ssr_rc_pairs(up, down, 21) + 32) * sizeof(float) <= 64 * 1024;      // two stages of (x[i], x[i + down]) pairs
+  return (size_t)4 * (ssr_rc_pairs(up, down, 21, ssr_rc_groups(up)) + 32) * sizeof(float) <= 64 * 1024;      // two stages of (x[i], x[i + down]) pairs
 }
 static int resample_rc_launch(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off, const int32_t* out_len,
                               int n_items, int max_out_len, int up, int down, const float* taps, int n_taps, int n_pre_remove, float* out,
                               hipStream_t s) {
-  SsrResampleRcParams p{in, in_off, in_len, out_off, out_len, up, down, n_taps, n_pre_remove, taps, 1, 1, 0, out};
+  SsrResampleRcParams p{in, in_off, in_len, out_off, out_len, up, down, n_taps, n_pre_remove, taps, 1, 1, 0, 1, out};
+  p.groups = ssr_rc_groups(up);
   // whole 32-pair deposits (a wave's LDS-DMA instruction) must stay inside a stage
-  p.stage_floats = 2 * (((ssr_rc_pairs(up, down, 21) + 31) / 32) * 32);
-  const int steps = ssr_ceil_div(max_out_len, up), blocks = ssr_ceil_div(steps, SSR_RC_JB);
+  p.stage_floats = 2 * (((ssr_rc_pairs(up, down, 21, p.groups) + 31) / 32) * 32);
+  const int steps = ssr_ceil_div(max_out_len, up), blocks = ssr_ceil_div(steps, SSR_RC_JB * p.groups);
   int n_chunks = ssr_ceil_div(4096, n_items);                   // >= ~4 k workgroups per launch, whole items where the batch is large
   if (n_chunks > blocks) n_chunks = blocks;
   if (n_chunks < 1) n_chunks = 1;
@@ -99,7 +114,7 @@ static int resample_rc_launch(const float* in, const int64_t* in_off, const int3
   const int64_t grid = (int64_t)n_items * p.n_chunks;
   if (grid > 0x7fffffff) return ssr_fail(SSR_ERR_UNSUPPORTED, "batch too large for one launch");
   const size_t lds = (size_t)2 * p.stage_floats * sizeof(float);      // two stages
-  const int nt = ssr_ceil_div(up, 64) * 64;
+  const int nt = ssr_ceil_div(p.groups * up, 64) * 64;
   static thread_local SsrLdsSlot slot;
   if (nt <= 512) {                                              // (the launch bound sets the register budget: 8 waves -> 256 VGPRs)
     if (int rc = ssr_allow_lds((const void*)k_resample_rc<21, 512>, lds, &slot)) return rc;

@@ -361,8 +361,8 @@ class Cfg5:
                   "stft+lsd": (ms3, (2 * N_SAMPLES * 4 + 32) * n)}
         # the fused resampling chain's algorithmic bytes are 4*(n_in + n_out_final) = 1,024,000 B / utterance
         chain_alg = 4 * (64000 + 192000) * n
-        roof = hbm_roofline("ssr_resample_poly x2 (k_resample, both stages)", chain_alg, ms1 + ms2,
-                            "k_resample stage 1+k_resample stage 2" if a.utterances == 12500 else None,
+        roof = hbm_roofline("ssr_resample_poly x2 (k_resample_rc, both stages)", chain_alg, ms1 + ms2,
+                            "k_resample_rc stage 1+k_resample_rc stage 2" if a.utterances == 12500 else None,
                             "the resampling chain is the HBM-side kernel of this config; per-stage read+write rates and the LSD "
                             "stage are under extra.stage_ms / extra.stage_GBs")
         extra = {"stage_ms": {k: round(v[0], 4) for k, v in stages.items()},

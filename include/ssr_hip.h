@@ -62,6 +62,22 @@ int ssr_version(void);
  * chirp-z (Bluestein) transforms of length 1536 on float32 pairs (q up to 1024: length 2048); everything else, float64 signals
  * and single-signal mode run Bluestein over a power of two >= 2 n_fft - 1 (radix 3 over three 2048-point ones for 2229). */
 int ssr_plan_create(int n_fft, int hop, int precision, ssr_plan** plan);
+/* FDomainHelper(window_size, hop_size, center, pad_mode, window) with anything but the defaults (ssr_eval/dsp.py:7-59 passes the
+ * five straight to torchlibrosa's STFT / ISTFT, win_length = n_fft).  window: HOST pointer to n_fft float64 values - what
+ * librosa.filters.get_window(name, n_fft, fftbins=True) returns for the caller's window name - or NULL for the periodic Hann;
+ * center: 0 = no padding, frames start at sample 0, T = 1 + (n - n_fft) / hop, ISTFT trims nothing at the front;
+ * pad_mode: torch's F.pad mode when center != 0 (SSR_PAD_REFLECT, SSR_PAD_CONSTANT = zeros).
+ * Such a plan has the SSR_LOWPASS_CONV engine only (n_fft = 32 m <= 4096; torchlibrosa's own construction - conv weights from any
+ * window - is the only one defined for it) and serves ssr_stft(SSR_STFT_COMPLEX), ssr_istft, ssr_fft_lowpass, ssr_num_frames,
+ * ssr_ola_workspace_bytes and ssr_plan_query; every other entry point returns SSR_ERR_UNSUPPORTED for it.
+ * Per item: center + reflect needs len > n_fft / 2, center + constant len >= 1, center = 0 len >= n_fft (an item that cannot be
+ * framed gets 0 rows and a zeroed output; the LONGEST item failing is SSR_ERR_INVALID_ARG).  With center = 0 the overlap-added signal
+ * is (T - 1) hop + n_fft samples long; torch's slice ends there, the C ABI's fixed-size output is zero-filled beyond it.
+ * Parity: bit-exact against oracle/tl_chain.c; the non-default branches of that oracle are restated from the published torchlibrosa
+ * module without a reference-generated vector (the reference only ever constructs FDomainHelper(), lowpass.py:18): "parity unpinned". */
+#define SSR_PAD_REFLECT 0
+#define SSR_PAD_CONSTANT 1
+int ssr_plan_create_ex(int n_fft, int hop, const double* window, int center, int pad_mode, ssr_plan** plan);
 int ssr_plan_destroy(ssr_plan* plan);
 int ssr_plan_query(const ssr_plan* plan, int* n_fft, int* hop, int* n_bins, int* fft_len, int* bluestein,
                    int* precision);
@@ -91,7 +107,10 @@ int ssr_plan_set_lowpass_engine(ssr_plan* plan, int engine);
  * HOST pointers (the one exception to the device-pointer convention; any may be NULL): a host-only introspection call, needs no GPU;
  * the parity tests feed these tables to oracle/tl_chain.c. */
 int ssr_tl_weights(int n_fft, float* fwd_re_t, float* fwd_im_t, float* inv_re_t, float* inv_im_t, float* w2);
-/* T = 1 + (n + 2*(n_fft/2) - n_fft) / hop  (librosa / torchlibrosa frame count; bit-exact integer) */
+/* The same for a caller-supplied window (HOST float64 [n_fft], NULL = periodic Hann): the tables of an ssr_plan_create_ex plan. */
+int ssr_tl_weights_ex(int n_fft, const double* window, float* fwd_re_t, float* fwd_im_t, float* inv_re_t, float* inv_im_t, float* w2);
+/* T = 1 + (n + 2 pad - n_fft) / hop, pad = n_fft / 2 (0 for a center = 0 plan; then T = 0 when n < n_fft)
+ * (librosa / torchlibrosa frame count; bit-exact integer) */
 int64_t ssr_num_frames(const ssr_plan* plan, int64_t n_samples);
 
 /* K1+K2.  Batched STFT of ragged float32 waveforms -> [total_rows, n_bins] float32.

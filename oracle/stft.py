@@ -31,6 +31,15 @@ def hann_periodic(n):
     return 0.5 - 0.5 * np.cos(2.0 * np.pi * k / n)
 
 
+def window_array(window, n):
+    """librosa.filters.get_window(window, n, fftbins=True) in float64 (torchlibrosa STFT.__init__ / ISTFT.__init__ with
+    win_length = n_fft, as dsp.py:21-58 builds them): "hann" is restated, every other name goes to scipy as librosa does."""
+    if window == "hann":
+        return hann_periodic(n)
+    import scipy.signal
+    return np.asarray(scipy.signal.get_window(window, n, fftbins=True), dtype=np.float64)
+
+
 def num_frames(n, n_fft, hop):
     """T for a centred STFT: 1 + (n + 2*(n_fft//2) - n_fft)//hop (SURVEY 8(a) A2)."""
     return 1 + (n + 2 * (n_fft // 2) - n_fft) // hop
@@ -153,7 +162,7 @@ def tl_istft_ideal(real, imag, length, n_fft=2048, hop=441):
 # torchlibrosa as published: float32 dense-DFT convolutions on torch-CPU
 # ------------------------------------------------------------------------------------------------------------------
 @functools.lru_cache(maxsize=8)
-def tl_weights(n_fft):
+def tl_weights(n_fft, window="hann"):
     """The four float32 weight matrices torchlibrosa builds (DFTBase.dft_matrix / idft_matrix, STFT.__init__,
     ISTFT.init_real_imag_conv): computed in float64 / complex128, stored float32.
 
@@ -166,43 +175,50 @@ def tl_weights(n_fft):
     omega = np.exp(-2 * np.pi * 1j / n)
     W = np.power(omega, x * y)                         # DFTBase.dft_matrix
     Wi = np.power(np.exp(2 * np.pi * 1j / n), x * y)   # DFTBase.idft_matrix
-    win = hann_periodic(n)
+    win = window_array(window, n)
     fw = W[:, :F] * win[:, None]
     iw = (Wi / n) * win[None, :]
     return (np.ascontiguousarray(np.real(fw).T).astype(np.float32), np.ascontiguousarray(np.imag(fw).T).astype(np.float32),
             np.ascontiguousarray(np.real(iw).T).astype(np.float32), np.ascontiguousarray(np.imag(iw).T).astype(np.float32))
 
 
-def tl_stft_conv(x, n_fft=2048, hop=441):
+def tl_stft_conv(x, n_fft=2048, hop=441, window="hann", center=True, pad_mode="reflect"):
     """torchlibrosa STFT.forward as published: x [B, n] float32 -> (real, imag) each [B, 1, T, F] float32.
-    F.pad(reflect) + two F.conv1d(stride=hop) with the float32 DFT x Hann weights."""
+    `if self.center: x = F.pad(x, (n_fft//2, n_fft//2), mode=self.pad_mode)` + two F.conv1d(stride=hop) with the float32
+    DFT x window weights.  (The non-default center / pad_mode / window branches are restated from the published module text;
+    the reference itself only ever builds FDomainHelper() with the defaults - lowpass.py:18 - so no golden vector covers them.)"""
     import torch
     import torch.nn.functional as Fn
     x = torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float32)))
-    if x.shape[-1] <= n_fft // 2:
+    if center and pad_mode == "reflect" and x.shape[-1] <= n_fft // 2:
         raise ValueError("reflect padding needs len(y) > n_fft//2 (got %d <= %d)" % (x.shape[-1], n_fft // 2))
-    fr, fi, _, _ = tl_weights(n_fft)
-    xp = Fn.pad(x[:, None, :], (n_fft // 2, n_fft // 2), mode="reflect")
+    fr, fi, _, _ = tl_weights(n_fft, window)
+    xp = x[:, None, :]
+    if center:
+        xp = Fn.pad(xp, (n_fft // 2, n_fft // 2), mode=pad_mode)
+    if xp.shape[-1] < n_fft:
+        raise ValueError("signal shorter than one frame")
     re = Fn.conv1d(xp, torch.from_numpy(fr)[:, None, :], stride=hop)      # [B, F, T]
     im = Fn.conv1d(xp, torch.from_numpy(fi)[:, None, :], stride=hop)
     return (re[:, None].transpose(2, 3).contiguous().numpy(), im[:, None].transpose(2, 3).contiguous().numpy())
 
 
-def tl_window_sum_f32(T, n_fft, hop):
-    """ISTFT._get_ifft_window: F.fold of the float32 hann**2 (float32 additions in frame order), clamped at 1e-11."""
+def tl_window_sum_f32(T, n_fft, hop, window="hann"):
+    """ISTFT._get_ifft_window: F.fold of the float32 window**2 (float32 additions in frame order), clamped at 1e-11."""
     import torch
     import torch.nn.functional as Fn
-    w2 = torch.from_numpy((hann_periodic(n_fft) ** 2).astype(np.float32))
+    w2 = torch.from_numpy((window_array(window, n_fft) ** 2).astype(np.float32))
     L = (T - 1) * hop + n_fft
     s = Fn.fold(w2[None, :, None].repeat(1, 1, T), output_size=(1, L), kernel_size=(1, n_fft), stride=(1, hop))
     return torch.clamp(s.squeeze(), 1e-11, np.inf)
 
 
-def tl_istft_conv(real, imag, length, n_fft=2048, hop=441, order=None):
+def tl_istft_conv(real, imag, length, n_fft=2048, hop=441, order=None, window="hann", center=True):
     """torchlibrosa ISTFT.forward as published: [B,1,T,F] x2 float32 -> [B, length] float32.
 
     Hermitian mirror (torch.cat + flip), s = conv_real(full_re) - conv_imag(full_im) (two 1x1 conv1d with the float32
-    IDFT x Hann weights), F.fold overlap-add, / clamp(folded hann**2, 1e-11), trim [n_fft//2 : n_fft//2 + length].
+    IDFT x window weights), F.fold overlap-add, / clamp(folded window**2, 1e-11), ISTFT._trim_edges: [start : start + length]
+    with start = n_fft//2 if center else 0 (a slice past the overlap-added signal just ends; the rest of `out` stays zero).
 
     order: None = torch's own conv1d.  A permutation of range(n_fft) = the SAME float32 products summed in that bin
     order (a sequential float32 accumulation per output sample): a different member of the same arithmetic class, used to
@@ -213,7 +229,7 @@ def tl_istft_conv(real, imag, length, n_fft=2048, hop=441, order=None):
     imag = torch.as_tensor(np.ascontiguousarray(np.asarray(imag, dtype=np.float32)))
     B, _, T, F = real.shape
     assert F == n_fft // 2 + 1
-    _, _, ir, ii = tl_weights(n_fft)
+    _, _, ir, ii = tl_weights(n_fft, window)
     re = real[:, 0].transpose(1, 2)                       # [B, F, T]
     im = imag[:, 0].transpose(1, 2)
     full_re = torch.cat((re, torch.flip(re[:, 1:-1, :], dims=[1])), dim=1)
@@ -224,8 +240,9 @@ def tl_istft_conv(real, imag, length, n_fft=2048, hop=441, order=None):
         s = torch.from_numpy(_seq_f32_matmul(ir, full_re.numpy(), order) - _seq_f32_matmul(ii, full_im.numpy(), order))
     L = (T - 1) * hop + n_fft
     y = Fn.fold(s, output_size=(1, L), kernel_size=(1, n_fft), stride=(1, hop))[:, 0, 0, :]
-    y = y / tl_window_sum_f32(T, n_fft, hop)[None, :]
-    y = y[:, n_fft // 2:n_fft // 2 + length]
+    y = y / tl_window_sum_f32(T, n_fft, hop, window)[None, :]
+    start = n_fft // 2 if center else 0
+    y = y[:, start:start + length]
     out = np.zeros((B, length), dtype=np.float32)
     out[:, :y.shape[1]] = y.numpy()
     return out

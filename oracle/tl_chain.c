@@ -70,9 +70,10 @@ void tl_chain_magphase_cut(float* re, float* im, int64_t rows, int nb, int cut, 
 
 /* Inverse transform + fold + window-sum division + trim.  re / im: [T][nb] (bins >= nbz are taken as zero);
  * ire_t / iim_t: [n_fft][n_fft] TRANSPOSED inverse weights (row = bin k of the FULL spectrum, column = output sample);
- * w2: hann^2 float32 [n_fft]; out: [length]. */
+ * w2: window^2 float32 [n_fft]; out: [length]; start: first kept sample of the overlap-added signal (ISTFT._trim_edges: n_fft / 2
+ * when the forward transform was centred, 0 otherwise); samples past its end are written as 0. */
 void tl_chain_istft(const float* re, const float* im, int T, int nb, int nbz, int n_fft, int hop, const float* ire_t,
-                    const float* iim_t, const float* w2, int kb, int length, float* out) {
+                    const float* iim_t, const float* w2, int kb, int length, int start, float* out) {
   const int half = n_fft / 2;
   if (nbz > nb) nbz = nb;
   int mmax = nbz - 1 < half - 1 ? nbz - 1 : half - 1;       /* mirrored bins 1 .. mmax */
@@ -103,7 +104,8 @@ void tl_chain_istft(const float* re, const float* im, int T, int nb, int nbz, in
     for (int m = 0; m < n_fft; ++m) s[(size_t)t * n_fft + m] = sr[m] - si[m];
   }
   for (int p = 0; p < length; ++p) {
-    const int q = p + half;
+    const int q = p + start;
+    if (q >= (T - 1) * hop + n_fft) { out[p] = 0.0f; continue; }
     int t_hi = q / hop;
     if (t_hi > T - 1) t_hi = T - 1;
     float y = 0.0f, ws = 0.0f;

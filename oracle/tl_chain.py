@@ -36,42 +36,51 @@ def _f(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
-def transposed_weights(n_fft, weights=None):
-    """(fwd_re_t [n_fft, F], fwd_im_t, inv_re_t [n_fft(bin), n_fft(sample)], inv_im_t, hann^2 float32)."""
-    fr, fi, ir, ii = weights if weights is not None else _stft.tl_weights(n_fft)
-    w2 = (_stft.hann_periodic(n_fft) ** 2).astype(np.float32)
+def transposed_weights(n_fft, weights=None, window="hann"):
+    """(fwd_re_t [n_fft, F], fwd_im_t, inv_re_t [n_fft(bin), n_fft(sample)], inv_im_t, window^2 float32)."""
+    fr, fi, ir, ii = weights if weights is not None else _stft.tl_weights(n_fft, window)
+    w2 = (_stft.window_array(window, n_fft) ** 2).astype(np.float32)
     return (np.ascontiguousarray(fr.T), np.ascontiguousarray(fi.T), np.ascontiguousarray(ir.T), np.ascontiguousarray(ii.T), w2)
 
 
-def stft(x, n_fft=2048, hop=441, kb=KB, weights=None, nb=None):
+def stft(x, n_fft=2048, hop=441, kb=KB, weights=None, nb=None, window="hann", center=True, pad_mode="reflect"):
     """x [n] float32 -> (re, im) [T, nb] float32 (nb = n_fft//2+1 by default)."""
     x = np.ascontiguousarray(x, dtype=np.float32)
-    frt, fit, _, _, _ = transposed_weights(n_fft, weights)
+    frt, fit, _, _, _ = transposed_weights(n_fft, weights, window)
     nb = n_fft // 2 + 1 if nb is None else nb
-    xp = np.ascontiguousarray(_stft.reflect_pad(x, n_fft // 2, torch_style=True))
-    T = 1 + len(x) // hop if n_fft % 2 == 0 else _stft.num_frames(len(x), n_fft, hop)
+    if not center:
+        xp = x
+    elif pad_mode == "reflect":
+        xp = np.ascontiguousarray(_stft.reflect_pad(x, n_fft // 2, torch_style=True))
+    elif pad_mode == "constant":
+        xp = np.ascontiguousarray(np.pad(x, n_fft // 2))
+    else:
+        raise ValueError(pad_mode)
+    if len(xp) < n_fft:
+        raise ValueError("signal shorter than one frame")
+    T = 1 + (len(xp) - n_fft) // hop
     re = np.empty((T, nb), np.float32)
     im = np.empty((T, nb), np.float32)
     lib().tl_chain_stft(_f(xp), T, n_fft, hop, _f(frt), _f(fit), C.c_int64(frt.shape[1]), nb, kb, _f(re), _f(im))
     return re, im
 
 
-def istft(re, im, length, n_fft=2048, hop=441, kb=KB, weights=None, nbz=None):
+def istft(re, im, length, n_fft=2048, hop=441, kb=KB, weights=None, nbz=None, window="hann", center=True):
     re = np.ascontiguousarray(re, dtype=np.float32)
     im = np.ascontiguousarray(im, dtype=np.float32)
     T, nb = re.shape
-    _, _, irt, iit, w2 = transposed_weights(n_fft, weights)
+    _, _, irt, iit, w2 = transposed_weights(n_fft, weights, window)
     out = np.empty(length, np.float32)
     lib().tl_chain_istft(_f(re), _f(im), T, nb, nb if nbz is None else nbz, n_fft, hop, _f(irt), _f(iit), _f(w2), kb, length,
-                         _f(out))
+                         n_fft // 2 if center else 0, _f(out))
     return out
 
 
-def stft_hard_lowpass(x, cut, n_fft=2048, hop=441, kb=KB, weights=None):
+def stft_hard_lowpass(x, cut, n_fft=2048, hop=441, kb=KB, weights=None, window="hann", center=True, pad_mode="reflect"):
     """ssr_eval/lowpass.py:17-28 with cut = the first zeroed bin."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     F = n_fft // 2 + 1
     cut = min(int(cut), F)
-    re, im = stft(x, n_fft, hop, kb, weights, nb=cut)
+    re, im = stft(x, n_fft, hop, kb, weights, nb=cut, window=window, center=center, pad_mode=pad_mode)
     lib().tl_chain_magphase_cut(_f(re), _f(im), C.c_int64(re.shape[0]), cut, cut, C.c_float(1e-8))
-    return istft(re, im, len(x), n_fft, hop, kb, weights)
+    return istft(re, im, len(x), n_fft, hop, kb, weights, window=window, center=center)

@@ -14,6 +14,7 @@ SSR_F32, SSR_F64 = 0, 1
 M_LSD, M_LOG_SISPEC, M_SISPEC, M_SSIM, M_ALL = 1, 2, 4, 8, 15
 STFT_MAG, STFT_COMPLEX = 1, 2
 LOWPASS_SEGMENTS, LOWPASS_FUSED, LOWPASS_CONV = 0, 1, 2
+PAD_REFLECT, PAD_CONSTANT = 0, 1
 ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE = -1, -2, -3, -4      # include/ssr_hip.h
 
 _vp, _i, _i64, _sz, _u = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_uint
@@ -23,10 +24,12 @@ SIGNATURES = {
     "ssr_last_error": (C.c_char_p, []),
     "ssr_version": (_i, []),
     "ssr_plan_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
+    "ssr_plan_create_ex": (_i, [_i, _i, _vp, _i, _i, C.POINTER(_vp)]),
     "ssr_plan_destroy": (_i, [_vp]),
     "ssr_plan_query": (_i, [_vp] + [C.POINTER(_i)] * 6),
     "ssr_plan_set_lowpass_engine": (_i, [_vp, _i]),
     "ssr_tl_weights": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
+    "ssr_tl_weights_ex": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssr_num_frames": (_i64, [_vp, _i64]),
     "ssr_stft": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "ssr_magphase": (_i, [_vp, _vp, _i64, C.c_float, _vp, _vp, _vp, _vp]),

@@ -60,6 +60,11 @@ class Plan:
     def frames(self, n):
         return num_frames(n, self.n_fft, self.hop)
 
+    def check_lengths(self, lens_host):
+        """torch-style reflect padding (torchlibrosa STFT / ISTFT: F.pad refuses a pad >= the signal length)."""
+        if len(lens_host) and int(np.min(lens_host)) <= self.n_fft // 2:
+            raise ValueError("reflect padding needs every signal longer than n_fft//2 = %d samples" % (self.n_fft // 2))
+
     def set_lowpass_engine(self, engine):
         """"segments" (frame kernel + overlap-add kernel through the workspace), "fused" (one kernel, no workspace traffic;
         float64 2048-point plans with 228 <= hop <= 914) or "conv" (torchlibrosa's dense float32 DFT products on the matrix cores:
@@ -81,9 +86,71 @@ class Plan:
             pass
 
 
+class PlanEx(Plan):
+    """ssr_plan_create_ex: FDomainHelper(center=, pad_mode=, window=) beyond the defaults (ssr_eval/dsp.py:7-59) - the conv engine
+    with torchlibrosa's weights built from `window` (float64 [n_fft], librosa.filters.get_window(name, n_fft, fftbins=True); None =
+    periodic Hann), no padding when center is False, zeros instead of the reflection for pad_mode "constant".  Serves stft(kind=
+    "complex"), istft and LowpassBatch / lowpass only."""
+
+    _PAD = {"reflect": _lib.PAD_REFLECT, "constant": _lib.PAD_CONSTANT}
+
+    def __init__(self, n_fft, hop, window=None, center=True, pad_mode="reflect", device=None):
+        require_gpu()
+        if pad_mode not in self._PAD:
+            raise NotImplementedError("pad_mode %r: torch's F.pad modes 'reflect' and 'constant' are implemented" % (pad_mode,))
+        self.lib = _lib.load()
+        self.device = torch.device(device) if device is not None else default_device()
+        self.n_fft, self.hop, self.n_bins = int(n_fft), int(hop), int(n_fft) // 2 + 1
+        self.precision = _PREC["f32"]
+        self.center, self.pad_mode = bool(center), pad_mode
+        w = None if window is None else np.ascontiguousarray(window, dtype=np.float64)
+        if w is not None and w.shape != (self.n_fft,):
+            raise ValueError("window must hold n_fft values")
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ssr_plan_create_ex(self.n_fft, self.hop, None if w is None else w.ctypes.data, int(self.center),
+                                                   self._PAD[pad_mode], C.byref(h)))
+        self.handle = h
+        self.fft_len, self.bluestein = 0, False
+        self.lowpass_engine = "conv"
+
+    def frames(self, n):
+        pad = self.n_fft // 2 if self.center else 0
+        return 0 if int(n) + 2 * pad < self.n_fft else 1 + (int(n) + 2 * pad - self.n_fft) // self.hop
+
+    def check_lengths(self, lens_host):
+        if not len(lens_host):
+            return
+        lo = int(np.min(lens_host))
+        if self.center and self.pad_mode == "reflect" and lo <= self.n_fft // 2:
+            raise ValueError("reflect padding needs every signal longer than n_fft//2 = %d samples" % (self.n_fft // 2))
+        if lo < 1 or (not self.center and lo < self.n_fft):
+            raise ValueError("every signal needs one whole frame (n_fft = %d samples without centring)" % self.n_fft)
+
+    def set_lowpass_engine(self, engine):
+        if engine != "conv":
+            raise ValueError("a PlanEx has the conv engine only")
+        return self
+
+
 _ENGINES = {"segments": _lib.LOWPASS_SEGMENTS, "fused": _lib.LOWPASS_FUSED, "conv": _lib.LOWPASS_CONV}
 _plans = {}
 _plans_lock = threading.Lock()
+
+
+_plans_ex = {}
+
+
+def get_plan_ex(n_fft, hop, window_name, window, center, pad_mode, device=None):
+    """The cached PlanEx of (n_fft, hop, window name, center, pad_mode, device); `window` = the float64 array of that name."""
+    dev = torch.device(device) if device is not None else default_device()
+    key = (int(n_fft), int(hop), window_name, bool(center), pad_mode, dev.index if dev.index is not None else torch.cuda.current_device())
+    with _plans_lock:
+        p = _plans_ex.get(key)
+        if p is None:
+            p = _plans_ex[key] = PlanEx(n_fft, hop, window, center, pad_mode, dev)
+            p._cached = True
+        return p
 
 
 def get_plan(n_fft, hop, precision="f64", device=None, lowpass_engine="segments"):
@@ -192,9 +259,7 @@ class _Rows:
 
 
 def _check_reflect(plan, lens_host):
-    """torch-style reflect padding (torchlibrosa STFT / ISTFT: F.pad refuses a pad >= the signal length)."""
-    if len(lens_host) and int(np.min(lens_host)) <= plan.n_fft // 2:
-        raise ValueError("reflect padding needs every signal longer than n_fft//2 = %d samples" % (plan.n_fft // 2))
+    plan.check_lengths(lens_host)
 
 
 def _check_nonempty(lens_host):

@@ -43,6 +43,10 @@ struct ssr_plan {
   // SSR_LOWPASS_CONV: torchlibrosa's float32 Conv1d weights, transposed (tu_tlconv.hip; built when the engine is selected)
   float *tl_wre_t = nullptr, *tl_wim_t = nullptr, *tl_ire_t = nullptr, *tl_iim_t = nullptr, *tl_w2 = nullptr;
   int tl_ldw = 0;
+  // ssr_plan_create_ex: a caller-supplied analysis / synthesis window, center = False, constant padding - conv engine only
+  std::vector<double> ex_window;     // empty: periodic Hann
+  int ex_center = 1, ex_pad_reflect = 1;
+  bool ex = false;                   // true: only ssr_stft(COMPLEX) / ssr_istft / ssr_fft_lowpass on the conv engine exist for this plan
   std::vector<void*> allocs;
 };
 
@@ -55,7 +59,7 @@ template <> inline const DevTables<double>& ssr_wave_tables_of<double>(const ssr
 
 // Every entry point that takes a plan runs on the plan's device: its tables live there.  (The Python mirror selects
 // the device before calling in; a C caller that forgot gets an error instead of an illegal address.)
-int ssr_check_plan_device(const ssr_plan* pl);
+int ssr_check_plan_device(const ssr_plan* pl, bool ex_ok = false);      // ex_ok: the entry point serves ssr_plan_create_ex plans
 
 // Opt a kernel into more than 48 KiB of dynamic LDS, once per (kernel, device, largest size so far) instead of once per
 // launch.  `slot` is a per-kernel static the caller owns (one per template instantiation): the largest size each device has
@@ -104,6 +108,14 @@ template <typename T> int ssr_launch_stft(const ssr_plan*, SsrStftParams<T>&, in
 template <typename T> int ssr_launch_lowpass(const ssr_plan*, SsrLowpassParams<T>&, int grid, hipStream_t);
 // tu_tlconv.hip: the reference-arithmetic engine (dense float32 DFT products on the matrix cores)
 int ssr_tl_build(ssr_plan* pl);
+inline int ssr_plan_pad(const ssr_plan* pl) { return pl->ex_center ? pl->n_fft / 2 : 0; }
+// the longest item must be transformable (lengths live on the device: a shorter item in a batch is skipped and its output zeroed)
+inline int ssr_check_max_len(const ssr_plan* pl, int max_len) {
+  const int pad = ssr_plan_pad(pl);
+  if (pad && pl->ex_pad_reflect && max_len <= pad) return ssr_fail(SSR_ERR_INVALID_ARG, "reflect padding needs len > n_fft/2");
+  if ((int64_t)max_len + 2 * pad < pl->n_fft || max_len < 1) return ssr_fail(SSR_ERR_INVALID_ARG, "signals shorter than one frame");
+  return SSR_OK;
+}
 size_t ssr_tl_workspace_bytes(const ssr_plan* pl, int64_t total_rows);
 int ssr_tl_run_inverse(const ssr_plan* pl, const float* in, const int64_t* in_off, const int32_t* len, const int32_t* cut,
                        const float* re, const float* im, const int64_t* frame_off, const int64_t* out_off, int n_items,

@@ -47,6 +47,8 @@ struct SsrTlParams {
   const int32_t* cut;          // first zeroed bin per item, or nullptr = no cut (n_bins)
   const int64_t* frame_off;    // first row of item i in every [total_rows, *] matrix
   int n_fft, hop, n_bins, n_items, m_tiles;   // m_tiles = ceil(max frames / 64)
+  int pad;                     // samples padded on each side: n_fft / 2 (center = True), 0 (center = False)
+  int pad_reflect;             // 1: F.pad(mode="reflect"), 0: "constant" (zeros)
   // forward
   const float* xpad;           // reflect-padded signals; item i starts at ssr_tl_pad_off(...)
   int64_t pad_stride;          // > 0: item i's padded signal starts at i * pad_stride; 0: at frame_off[i] * hop + i * n_fft
@@ -65,12 +67,17 @@ struct SsrTlParams {
 
 enum { SSR_TL_FWD_LOWPASS = 0, SSR_TL_FWD_STFT = 1, SSR_TL_INV = 2 };
 
-__device__ __forceinline__ int ssr_tl_frames_of(int len, int n_fft, int hop) { return 1 + (len + 2 * (n_fft / 2) - n_fft) / hop; }
+__device__ __forceinline__ int ssr_tl_frames_of(int len, int n_fft, int hop, int pad) { return 1 + (len + 2 * pad - n_fft) / hop; }
+// items the transform cannot frame are skipped (the fold kernel zeroes their output): torch's reflect padding refuses len <= pad,
+// and a frame needs n_fft samples
+__device__ __forceinline__ bool ssr_tl_item_ok(int len, int n_fft, int pad, int pad_reflect) {
+  return (!pad_reflect || pad == 0 || len > pad) && len + 2 * pad >= n_fft && len >= 1;
+}
 // non-zero channels of the mirrored full spectrum for a cut: bins [0, c) and the mirrors of bins 1 .. mmax
 __device__ __forceinline__ int ssr_tl_mmax(int c, int n_fft) { const int m = c - 1 < n_fft / 2 - 1 ? c - 1 : n_fft / 2 - 1; return m < 0 ? 0 : m; }
 
 __device__ __forceinline__ int64_t ssr_tl_pad_off(int64_t pad_stride, int64_t row0, int hop, int item, int n_fft) {
-  return pad_stride > 0 ? (int64_t)item * pad_stride : row0 * hop + (int64_t)item * n_fft;
+  return pad_stride > 0 ? (int64_t)item * pad_stride : row0 * hop + (int64_t)item * n_fft;      // (T hop + n_fft >= len + 2 pad for every item)
 }
 
 __device__ __forceinline__ void ssr_tl_glds16(const float* src, char* lds_wave_base) {
@@ -100,8 +107,8 @@ __device__ __forceinline__ void ssr_tl_gemm_body(const SsrTlParams& p, char* sme
   const int ntile = (int)blockIdx.x / per_n, rest = (int)blockIdx.x % per_n;
   const int item = rest / p.m_tiles, mtile = rest % p.m_tiles;
   const int len = p.len[item];
-  if (len <= p.n_fft / 2) return;                                 // (entry-point contract: skipped, output zeroed by the fold kernel)
-  const int T = ssr_tl_frames_of(len, p.n_fft, p.hop);
+  if (!ssr_tl_item_ok(len, p.n_fft, p.pad, p.pad_reflect)) return;   // (entry-point contract: skipped, output zeroed by the fold kernel)
+  const int T = ssr_tl_frames_of(len, p.n_fft, p.hop, p.pad);
   const int m0 = mtile * SSR_TL_BM;
   if (m0 >= T) return;
   int c = p.cut ? p.cut[item] : p.n_bins;
@@ -257,18 +264,24 @@ __device__ __forceinline__ void ssr_tl_gemm_body(const SsrTlParams& p, char* sme
     }
 }
 
-// Reflect padding as torch's F.pad(mode="reflect") (torchlibrosa STFT.forward): xpad[i] = x[reflect(i - n_fft/2)].
+// Padding as torchlibrosa's STFT.forward does it: F.pad(x, (n_fft/2, n_fft/2), mode = "reflect" | "constant") when center, none otherwise.
 struct SsrTlPadParams {
   const float* in; const int64_t* in_off; const int32_t* len; const int64_t* frame_off;
-  int n_fft, hop; float* xpad; int64_t pad_stride;
+  int n_fft, hop; float* xpad; int64_t pad_stride; int pad, pad_reflect;
 };
 __device__ __forceinline__ void ssr_tl_pad_body(const SsrTlPadParams& p, int item, int64_t i) {
-  const int len = p.len[item], half = p.n_fft / 2;
-  if (len <= half || i >= (int64_t)len + p.n_fft) return;
-  int64_t s = i - half;
-  if (s < 0) s = -s;
-  if (s >= len) s = 2 * ((int64_t)len - 1) - s;
-  p.xpad[ssr_tl_pad_off(p.pad_stride, p.frame_off[item], p.hop, item, p.n_fft) + i] = p.in[p.in_off[item] + s];
+  const int len = p.len[item];
+  if (!ssr_tl_item_ok(len, p.n_fft, p.pad, p.pad_reflect) || i >= (int64_t)len + 2 * p.pad) return;
+  int64_t s = i - p.pad;
+  float v;
+  if (s >= 0 && s < len) v = p.in[p.in_off[item] + s];
+  else if (!p.pad_reflect) v = 0.0f;                               // F.pad(mode="constant")
+  else {
+    if (s < 0) s = -s;
+    if (s >= len) s = 2 * ((int64_t)len - 1) - s;
+    v = p.in[p.in_off[item] + s];
+  }
+  p.xpad[ssr_tl_pad_off(p.pad_stride, p.frame_off[item], p.hop, item, p.n_fft) + i] = v;
 }
 
 // ISTFT given (re, im) [rows][n_bins]: build the compact mirrored rows (cut = n_bins: every channel).
@@ -290,19 +303,19 @@ __device__ __forceinline__ void ssr_tl_pack_body(const SsrTlPackParams& p, int64
 // F.fold + / clamp(folded hann^2, 1e-11) + trim (ISTFT._overlap_add_divide_window_sum, _trim_edges): one thread per output sample.
 struct SsrTlFoldParams {
   const float* frames; const int64_t* frame_off; const int32_t* len; const int64_t* out_off; int n_fft, hop;
-  const float* w2; float* out;
+  const float* w2; float* out; int pad, pad_reflect;
 };
 __device__ __forceinline__ void ssr_tl_fold_body(const SsrTlFoldParams& p, int item, int s) {
   const int len = p.len[item];
   if (s >= len) return;
   float* out = p.out + p.out_off[item];
-  const int half = p.n_fft / 2;
-  if (len <= half) { out[s] = 0.0f; return; }
-  const int T = ssr_tl_frames_of(len, p.n_fft, p.hop);
-  const int q = s + half;
+  if (!ssr_tl_item_ok(len, p.n_fft, p.pad, p.pad_reflect)) { out[s] = 0.0f; return; }
+  const int T = ssr_tl_frames_of(len, p.n_fft, p.hop, p.pad);
+  const int q = s + p.pad;                             // ISTFT._trim_edges: start = n_fft / 2 if center else 0
   int t = q / p.hop;
   t = t < T - 1 ? t : T - 1;
   const float* fr = p.frames + p.frame_off[item] * (int64_t)p.n_fft;
+  if (q >= (T - 1) * p.hop + p.n_fft) { out[s] = 0.0f; return; }     // past the overlap-added signal (the slice ends there; zero-filled)
   float y = 0.0f, ws = 0.0f;
   for (; t >= 0 && q - t * p.hop < p.n_fft; --t) {
     y = ssr_tl_add(y, fr[(int64_t)t * p.n_fft + (q - t * p.hop)]);

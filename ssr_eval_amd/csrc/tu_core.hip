@@ -12,7 +12,9 @@ int ssr_fail(int code, const std::string& msg) { g_err = msg; return code; }
 extern "C" const char* ssr_last_error(void) { return g_err.c_str(); }
 extern "C" int ssr_version(void) { return SSR_VERSION; }
 
-int ssr_check_plan_device(const ssr_plan* pl) {
+int ssr_check_plan_device(const ssr_plan* pl, bool ex_ok) {
+  if (pl->ex && !ex_ok)
+    return ssr_fail(SSR_ERR_UNSUPPORTED, "a plan from ssr_plan_create_ex serves ssr_stft(SSR_STFT_COMPLEX), ssr_istft and ssr_fft_lowpass only");
   int dev = -1;
   HIP_TRY(hipGetDevice(&dev));
   if (dev != pl->device)
@@ -174,6 +176,26 @@ extern "C" int ssr_plan_create(int n_fft, int hop, int precision, ssr_plan** out
   return SSR_OK;
 }
 
+// FDomainHelper(window_size, hop_size, center, pad_mode, window) with anything but the defaults (dsp.py:7-15): torchlibrosa builds
+// its Conv1d weights from ANY window and pads or not as asked, so the conv engine is the natural (and only) home of such a plan.
+extern "C" int ssr_plan_create_ex(int n_fft, int hop, const double* window, int center, int pad_mode, ssr_plan** out) {
+  if (!out) return ssr_fail(SSR_ERR_INVALID_ARG, "plan output pointer is null");
+  *out = nullptr;
+  if (n_fft < 2 || hop < 1) return ssr_fail(SSR_ERR_INVALID_ARG, "n_fft must be >= 2 and hop >= 1");
+  if (pad_mode != SSR_PAD_REFLECT && pad_mode != SSR_PAD_CONSTANT) return ssr_fail(SSR_ERR_INVALID_ARG, "pad_mode must be SSR_PAD_REFLECT or SSR_PAD_CONSTANT");
+  ssr_plan* pl = new ssr_plan();
+  pl->n_fft = n_fft; pl->hop = hop; pl->n_bins = n_fft / 2 + 1; pl->precision = SSR_F32;
+  pl->ex = true; pl->ex_center = center ? 1 : 0; pl->ex_pad_reflect = pad_mode == SSR_PAD_REFLECT ? 1 : 0;
+  if (window) pl->ex_window.assign(window, window + n_fft);
+  int rc = SSR_OK;
+  if (hipGetDevice(&pl->device) != hipSuccess) rc = ssr_fail(SSR_ERR_HIP, "hipGetDevice failed (no HIP device?)");
+  if (!rc) rc = ssr_tl_build(pl);
+  if (rc) { ssr_plan_destroy(pl); return rc; }
+  pl->lowpass_engine = SSR_LOWPASS_CONV;
+  *out = pl;
+  return SSR_OK;
+}
+
 extern "C" int ssr_plan_destroy(ssr_plan* pl) {
   if (!pl) return SSR_OK;
   for (void* p : pl->allocs) (void)hipFree(p);
@@ -195,7 +217,8 @@ extern "C" int ssr_plan_query(const ssr_plan* pl, int* n_fft, int* hop, int* n_b
 
 extern "C" int64_t ssr_num_frames(const ssr_plan* pl, int64_t n) {
   if (!pl) return -1;
-  return 1 + (n + 2 * (int64_t)(pl->n_fft / 2) - pl->n_fft) / pl->hop;
+  if (n + 2 * (int64_t)ssr_plan_pad(pl) < pl->n_fft) return 0;             // (center = False only: not one whole frame)
+  return 1 + (n + 2 * (int64_t)ssr_plan_pad(pl) - pl->n_fft) / pl->hop;
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -221,7 +244,7 @@ extern "C" int ssr_stft(const ssr_plan* pl, const float* wav, const int64_t* wav
   if (out_kind != SSR_STFT_MAG && out_kind != SSR_STFT_COMPLEX) return ssr_fail(SSR_ERR_INVALID_ARG, "bad out_kind");
   if (out_kind == SSR_STFT_COMPLEX && !out_b) return ssr_fail(SSR_ERR_INVALID_ARG, "complex output needs out_b");
   if (n_items <= 0) return SSR_OK;
-  if (int rc_dev = ssr_check_plan_device(pl)) return rc_dev;
+  if (int rc_dev = ssr_check_plan_device(pl, out_kind == SSR_STFT_COMPLEX)) return rc_dev;
   if (max_len < 1) return ssr_fail(SSR_ERR_INVALID_ARG, "empty signals");
   if (max_len >= (1 << 29)) return ssr_fail(SSR_ERR_UNSUPPORTED, "signals of 2^29 samples or more (4 GiB buffer views)");
   hipStream_t s = (hipStream_t)stream;

@@ -90,8 +90,9 @@ extern "C" int ssr_plan_set_lowpass_engine(ssr_plan* pl, int engine) {
   if (!pl) return ssr_fail(SSR_ERR_INVALID_ARG, "null plan");
   if (engine != SSR_LOWPASS_SEGMENTS && engine != SSR_LOWPASS_FUSED && engine != SSR_LOWPASS_CONV)
     return ssr_fail(SSR_ERR_INVALID_ARG, "unknown low-pass engine");
+  if (pl->ex && engine != SSR_LOWPASS_CONV) return ssr_fail(SSR_ERR_UNSUPPORTED, "a plan from ssr_plan_create_ex has the conv engine only");
   if (engine == SSR_LOWPASS_CONV) {
-    if (int rc_dev = ssr_check_plan_device(pl)) return rc_dev;
+    if (int rc_dev = ssr_check_plan_device(pl, true)) return rc_dev;
     if (int rc = ssr_tl_build(pl)) return rc;
   }
   if (engine == SSR_LOWPASS_FUSED && !lowpass_group_eligible(pl))
@@ -173,7 +174,7 @@ static int run_inverse(const ssr_plan* pl, const float* in, const int64_t* in_of
                        const int32_t* cut, const float* re, const float* im, const int64_t* frame_off,
                        const int64_t* out_off, int n_items, int max_len, int64_t total_rows, float* out,
                        void* workspace, size_t workspace_bytes, hipStream_t s) {
-  if (max_len <= pl->n_fft / 2) return ssr_fail(SSR_ERR_INVALID_ARG, "reflect padding needs len > n_fft/2");
+  if (int rc_len = ssr_check_max_len(pl, max_len)) return rc_len;
   if (max_len >= (1 << 29)) return ssr_fail(SSR_ERR_UNSUPPORTED, "signals of 2^29 samples or more (4 GiB buffer views)");
   if (!workspace || workspace_bytes < ssr_ola_workspace_bytes(pl, total_rows)) return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small");
   if (pl->lowpass_engine == SSR_LOWPASS_CONV)
@@ -220,7 +221,7 @@ extern "C" int ssr_fft_lowpass(const ssr_plan* pl, const float* in, const int64_
                                int64_t total_rows, float* out, void* workspace, size_t workspace_bytes, void* stream) {
   if (!pl || !in || !off || !len || !cut || !frame_off || !out) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
   if (n_items <= 0) return SSR_OK;
-  if (int rc_dev = ssr_check_plan_device(pl)) return rc_dev;
+  if (int rc_dev = ssr_check_plan_device(pl, true)) return rc_dev;
   return run_inverse(pl, in, off, len, cut, nullptr, nullptr, frame_off, off, n_items, max_len, total_rows, out, workspace,
                      workspace_bytes, (hipStream_t)stream);
 }
@@ -230,7 +231,7 @@ extern "C" int ssr_istft(const ssr_plan* pl, const float* re, const float* im, c
                          float* out, void* workspace, size_t workspace_bytes, void* stream) {
   if (!pl || !re || !im || !frame_off || !len || !out_off || !out) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
   if (n_items <= 0) return SSR_OK;
-  if (int rc_dev = ssr_check_plan_device(pl)) return rc_dev;
+  if (int rc_dev = ssr_check_plan_device(pl, true)) return rc_dev;
   return run_inverse(pl, nullptr, nullptr, len, nullptr, re, im, frame_off, out_off, n_items, max_len, total_rows, out,
                      workspace, workspace_bytes, (hipStream_t)stream);
 }

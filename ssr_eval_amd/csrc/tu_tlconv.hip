@@ -25,15 +25,16 @@ __global__ __launch_bounds__(256) void k_tl_fold(SsrTlFoldParams p, int blocks_p
 // W[j][k] = exp(-2 pi i j k / n); forward weights Re / Im (W[:, :F] * hann[:, None]) stored float32; inverse weights
 // Re / Im (conj(W) / n * hann[None, :]) stored float32.  The phase is reduced exactly (j k mod n) and evaluated in long double,
 // the product with the float64 window is a float64 product as numpy forms it, then one rounding to float32.
-static void tl_host_tables(int n, int ldw, std::vector<float>& wre_t, std::vector<float>& wim_t, std::vector<float>& ire_t,
-                           std::vector<float>& iim_t, std::vector<float>& w2) {
+// window: float64 [n] (librosa.filters.get_window(name, n_fft, fftbins=True) as the caller evaluated it) or nullptr = periodic Hann.
+static void tl_host_tables(int n, int ldw, const double* window, std::vector<float>& wre_t, std::vector<float>& wim_t,
+                           std::vector<float>& ire_t, std::vector<float>& iim_t, std::vector<float>& w2) {
   const int F = n / 2 + 1;
   std::vector<double> cs((size_t)n), sn((size_t)n), win((size_t)n);
   const long double two_pi = 6.283185307179586476925286766559005768L;
   for (int m = 0; m < n; ++m) {
     cs[m] = (double)cosl(two_pi * m / n);
     sn[m] = (double)sinl(two_pi * m / n);
-    win[m] = (double)(0.5L - 0.5L * cosl(two_pi * m / n));
+    win[m] = window ? window[m] : (double)(0.5L - 0.5L * cosl(two_pi * m / n));
   }
   // exact values where numpy's are exact too
   cs[0] = 1.0; sn[0] = 0.0;
@@ -61,11 +62,12 @@ static void tl_host_tables(int n, int ldw, std::vector<float>& wre_t, std::vecto
 
 static int tl_ldw(int n_fft) { return ((n_fft / 2 + 1 + SSR_TL_BN - 1) / SSR_TL_BN) * SSR_TL_BN; }
 
-extern "C" int ssr_tl_weights(int n_fft, float* fwd_re_t, float* fwd_im_t, float* inv_re_t, float* inv_im_t, float* w2) {
+extern "C" int ssr_tl_weights_ex(int n_fft, const double* window, float* fwd_re_t, float* fwd_im_t, float* inv_re_t, float* inv_im_t,
+                                 float* w2) {
   if (n_fft < 32 || n_fft > 4096 || n_fft % 32) return ssr_fail(SSR_ERR_UNSUPPORTED, "the conv engine needs n_fft = 32 m <= 4096");
   std::vector<float> a, b, c, d, e;
   const int ldw = tl_ldw(n_fft), F = n_fft / 2 + 1;
-  tl_host_tables(n_fft, ldw, a, b, c, d, e);
+  tl_host_tables(n_fft, ldw, window, a, b, c, d, e);
   for (int j = 0; j < n_fft; ++j)
     for (int k = 0; k < F; ++k) {
       if (fwd_re_t) fwd_re_t[(size_t)j * F + k] = a[(size_t)j * ldw + k];
@@ -77,6 +79,10 @@ extern "C" int ssr_tl_weights(int n_fft, float* fwd_re_t, float* fwd_im_t, float
   return SSR_OK;
 }
 
+extern "C" int ssr_tl_weights(int n_fft, float* fwd_re_t, float* fwd_im_t, float* inv_re_t, float* inv_im_t, float* w2) {
+  return ssr_tl_weights_ex(n_fft, nullptr, fwd_re_t, fwd_im_t, inv_re_t, inv_im_t, w2);
+}
+
 static std::mutex g_tl_mutex;
 int ssr_tl_build(ssr_plan* pl) {
   std::lock_guard<std::mutex> lock(g_tl_mutex);
@@ -85,7 +91,7 @@ int ssr_tl_build(ssr_plan* pl) {
     return ssr_fail(SSR_ERR_UNSUPPORTED, "the conv engine needs n_fft = 32 m <= 4096");
   std::vector<float> a, b, c, d, e;
   const int ldw = tl_ldw(pl->n_fft);
-  tl_host_tables(pl->n_fft, ldw, a, b, c, d, e);
+  tl_host_tables(pl->n_fft, ldw, pl->ex_window.empty() ? nullptr : pl->ex_window.data(), a, b, c, d, e);
   float* dev[5] = {};
   const std::vector<float>* src[5] = {&a, &b, &c, &d, &e};
   for (int i = 0; i < 5; ++i) {
@@ -121,6 +127,7 @@ static void tl_fill(const ssr_plan* pl, SsrTlParams& p, const int32_t* len, cons
                     int n_items, int max_len, int64_t total_rows, char* ws) {
   p.len = len; p.cut = cut; p.frame_off = frame_off;
   p.n_fft = pl->n_fft; p.hop = pl->hop; p.n_bins = pl->n_bins; p.n_items = n_items;
+  p.pad = ssr_plan_pad(pl); p.pad_reflect = pl->ex_pad_reflect;
   p.m_tiles = ssr_ceil_div(ssr_num_frames(pl, max_len), SSR_TL_BM);
   p.wre_t = pl->tl_wre_t; p.wim_t = pl->tl_wim_t; p.ldw = pl->tl_ldw; p.ire_t = pl->tl_ire_t; p.iim_t = pl->tl_iim_t;
   const size_t mat = (size_t)total_rows * pl->n_fft * sizeof(float);
@@ -131,7 +138,7 @@ static void tl_fill(const ssr_plan* pl, SsrTlParams& p, const int32_t* len, cons
 }
 
 static int tl_pad(const ssr_plan* pl, const SsrTlParams& p, const float* in, const int64_t* in_off, int max_len, hipStream_t s) {
-  SsrTlPadParams q{in, in_off, p.len, p.frame_off, pl->n_fft, pl->hop, (float*)p.xpad, p.pad_stride};
+  SsrTlPadParams q{in, in_off, p.len, p.frame_off, pl->n_fft, pl->hop, (float*)p.xpad, p.pad_stride, p.pad, p.pad_reflect};
   const int bpi = ssr_ceil_div((int64_t)max_len + pl->n_fft, 256);
   hipLaunchKernelGGL(k_tl_pad, dim3((unsigned)((int64_t)p.n_items * bpi)), dim3(256), 0, s, q, bpi);
   HIP_TRY(hipGetLastError());
@@ -144,6 +151,8 @@ int ssr_tl_run_inverse(const ssr_plan* pl, const float* in, const int64_t* in_of
                        int max_len, int64_t total_rows, float* out, void* workspace, size_t workspace_bytes, hipStream_t s) {
   if (!pl->tl_w2) return ssr_fail(SSR_ERR_INVALID_ARG, "conv engine tables missing (ssr_plan_set_lowpass_engine)");
   if (!workspace || workspace_bytes < ssr_tl_workspace_bytes(pl, total_rows)) return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small");
+  if (n_items > total_rows)            // (the padded copies are laid out for >= 1 frame per item: only a center = 0 batch can break that)
+    return ssr_fail(SSR_ERR_INVALID_ARG, "center = 0: every item of the batch needs len >= n_fft");
   SsrTlParams p{};
   tl_fill(pl, p, len, cut, frame_off, n_items, max_len, total_rows, (char*)workspace);
   int rc;
@@ -160,7 +169,7 @@ int ssr_tl_run_inverse(const ssr_plan* pl, const float* in, const int64_t* in_of
   static thread_local SsrLdsSlot slot;
   if ((rc = ssr_allow_lds((const void*)k_tl_gemm<SSR_TL_INV>, tl_lds_bytes(true), &slot))) return rc;
   if ((rc = tl_launch<SSR_TL_INV>(p, pl->n_fft / SSR_TL_BN, s))) return rc;
-  SsrTlFoldParams f{p.frames, frame_off, len, out_off, pl->n_fft, pl->hop, pl->tl_w2, out};
+  SsrTlFoldParams f{p.frames, frame_off, len, out_off, pl->n_fft, pl->hop, pl->tl_w2, out, p.pad, p.pad_reflect};
   const int bpi = ssr_ceil_div(max_len, 256);
   hipLaunchKernelGGL(k_tl_fold, dim3((unsigned)((int64_t)n_items * bpi)), dim3(256), 0, s, f, bpi);
   HIP_TRY(hipGetLastError());
@@ -172,7 +181,7 @@ int ssr_tl_run_inverse(const ssr_plan* pl, const float* in, const int64_t* in_of
 int ssr_tl_stft(const ssr_plan* pl, const float* wav, const int64_t* wav_off, const int32_t* wav_len, const int64_t* frame_off,
                 int n_items, int max_len, float* out_re, float* out_im, hipStream_t s) {
   if (!pl->tl_w2) return ssr_fail(SSR_ERR_INVALID_ARG, "conv engine tables missing (ssr_plan_set_lowpass_engine)");
-  if (max_len <= pl->n_fft / 2) return ssr_fail(SSR_ERR_INVALID_ARG, "reflect padding needs len > n_fft/2");
+  if (int rc_len = ssr_check_max_len(pl, max_len)) return rc_len;
   const int64_t pad_stride = (((int64_t)max_len + pl->n_fft + 3) / 4) * 4;
   const size_t bytes = (size_t)n_items * pad_stride * sizeof(float);
   void* pad = nullptr;
@@ -180,6 +189,7 @@ int ssr_tl_stft(const ssr_plan* pl, const float* wav, const int64_t* wav_off, co
   SsrTlParams p{};
   p.len = wav_len; p.cut = nullptr; p.frame_off = frame_off;
   p.n_fft = pl->n_fft; p.hop = pl->hop; p.n_bins = pl->n_bins; p.n_items = n_items;
+  p.pad = ssr_plan_pad(pl); p.pad_reflect = pl->ex_pad_reflect;
   p.m_tiles = ssr_ceil_div(ssr_num_frames(pl, max_len), SSR_TL_BM);
   p.wre_t = pl->tl_wre_t; p.wim_t = pl->tl_wim_t; p.ldw = pl->tl_ldw;
   p.xpad = (const float*)pad; p.pad_stride = pad_stride; p.out_re = out_re; p.out_im = out_im;

@@ -15,9 +15,7 @@ class FDomainHelper(torch.nn.Module):
     def __init__(self, window_size=2048, hop_size=441, center=True, pad_mode="reflect", window="hann",
                  freeze_parameters=True, subband=None, root=None, *, precision="f64", device=None, engine="conv"):
         super().__init__()
-        if not center or pad_mode != "reflect" or window != "hann":
-            raise NotImplementedError("libssrhip implements the configuration the reference instantiates: "
-                                      "center=True, pad_mode='reflect', window='hann'")
+        self.center, self.pad_mode, self.window = bool(center), pad_mode, window
         self.subband = subband
         div = 1 if subband is None else int(subband)          # dsp.py:40-59
         self.n_fft, self.hop = window_size // div, hop_size // div
@@ -25,8 +23,28 @@ class FDomainHelper(torch.nn.Module):
         # "conv": torchlibrosa's own arithmetic (dense float32 DFT products; n_fft must be a multiple of 32) - the default, as in
         # ssr_eval_amd.lowpass; "segments": float64 FFT (the exact transforms, faster)
         self.engine = engine if self.n_fft % 32 == 0 else "segments"
+        # Anything but the configuration the reference instantiates (center=True, "reflect", "hann" - lowpass.py:18) exists in
+        # torchlibrosa's own construction only: Conv1d weights from the named window, F.pad(mode=pad_mode) if center.  That is the
+        # conv engine with other tables (ssr_plan_create_ex).
+        self._ex = (not self.center) or pad_mode != "reflect" or window != "hann"
+        if self._ex:
+            if self.n_fft % 32 or self.n_fft > 4096:
+                raise NotImplementedError("center / pad_mode / window beyond the defaults need n_fft = 32 m <= 4096 (the conv engine)")
+            if pad_mode not in ("reflect", "constant"):
+                raise NotImplementedError("pad_mode %r (torch's 'reflect' and 'constant' are implemented)" % (pad_mode,))
+            self.engine = "conv"
+
+    def _window_array(self):
+        """librosa.filters.get_window(window, n_fft, fftbins=True): scipy's window of that name, periodic (torchlibrosa STFT.__init__)."""
+        if self.window == "hann":
+            return None
+        import scipy.signal
+        return np.asarray(scipy.signal.get_window(self.window, self.n_fft, fftbins=True), dtype=np.float64)
 
     def _plan(self):
+        if self._ex:
+            name = self.window if isinstance(self.window, (str, tuple, float, int)) else repr(self.window)
+            return B.get_plan_ex(self.n_fft, self.hop, name, self._window_array(), self.center, self.pad_mode, self._device)
         return B.get_plan(self.n_fft, self.hop, self.precision, self._device, lowpass_engine=self.engine)
 
     # ---- [B, n] helpers -------------------------------------------------------------------------------
@@ -40,7 +58,8 @@ class FDomainHelper(torch.nn.Module):
     def _istft(self, real, imag, length):
         """(real, imag) [B, 1, T, F] -> [B, length]."""
         if length is None:
-            length = self.hop * (real.shape[2] - 1)
+            # ISTFT._trim_edges(length=None): y[n_fft//2 : -n_fft//2] when centred, everything otherwise
+            length = self.hop * (real.shape[2] - 1) + (0 if self.center else self.n_fft)
         nb = real.shape[0]
         y = B.istft(self._plan(), [real[b, 0] for b in range(nb)], [imag[b, 0] for b in range(nb)], [int(length)] * nb)
         return torch.stack(y).to(real.device)

@@ -984,3 +984,103 @@ def test_conv_engine_other_transform_sizes_bit_exact_against_tl_chain(n_fft, hop
         np.testing.assert_array_equal(back, tl_chain.istft(wr, wi, len(x), n_fft, hop, weights=wts))
         assert np.abs(back - x).max() < 2e-6
     assert np.abs(B.fft_lowpass(plan, sigs[2:3], [0])[0].cpu().numpy()).max() == 0.0       # cut 0: silence
+
+
+def lib_tl_weights_ex(n_fft, window):
+    """ssr_tl_weights_ex: the tables of an ssr_plan_create_ex plan (window: float64 [n_fft] or None), oracle/tl_chain.py's layout."""
+    import ctypes as C
+    from ssr_eval_amd import _lib
+    F = n_fft // 2 + 1
+    a, b = np.empty((n_fft, F), np.float32), np.empty((n_fft, F), np.float32)
+    c, d = np.empty((n_fft, n_fft), np.float32), np.empty((n_fft, n_fft), np.float32)
+    w = None if window is None else np.ascontiguousarray(window, np.float64)
+    _lib.check(_lib.load().ssr_tl_weights_ex(n_fft, None if w is None else w.ctypes.data, *[v.ctypes.data_as(C.c_void_p) for v in (a, b, c, d)],
+                                             None))
+    return tuple(np.ascontiguousarray(v.T) for v in (a, b, c, d))
+
+
+EX_CASES = [("hann", False, "reflect"), ("hann", True, "constant"), ("hamming", True, "reflect"), ("hamming", False, "constant"),
+            (("kaiser", 8.0), True, "constant"), ("blackman", False, "reflect")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window,center,pad_mode", EX_CASES)
+@pytest.mark.parametrize("n_fft,hop", [(2048, 441), (512, 110)])
+def test_fdomain_helper_options_bit_exact_against_tl_chain(n_fft, hop, window, center, pad_mode):
+    """FDomainHelper(center=, pad_mode=, window=) beyond the defaults (ssr_eval/dsp.py:7-59 hands them to torchlibrosa's STFT / ISTFT):
+    ssr_plan_create_ex plans - complex STFT, ISTFT and the hard low-pass bit for bit against oracle/tl_chain.c with the same
+    window / padding / trimming, and the round trip STFT -> ISTFT returning the signal where the window sum is not degenerate."""
+    from ssr_eval_amd import backend as B
+    from oracle import tl_chain, stft as ostft
+    win = None if window == "hann" else ostft.window_array(window, n_fft)
+    wts = lib_tl_weights_ex(n_fft, win)
+    kw = dict(window=window, center=center)
+    plan = B.get_plan_ex(n_fft, hop, window, win, center, pad_mode)
+    assert plan.lib.ssr_num_frames(plan.handle, 20011) == plan.frames(20011)
+    rng = np.random.default_rng(n_fft + len(str(window)))
+    F = n_fft // 2 + 1
+    lens = [n_fft + 1 if (not center or pad_mode == "reflect") else 3, 3 * n_fft + 17, 9000, 20011]
+    cuts = [F, 1, F // 3, F - 1]
+    sigs = [(0.2 * rng.standard_normal(n)).astype(np.float32) for n in lens]
+    ys = B.fft_lowpass(plan, sigs, cuts)
+    for x, c, y in zip(sigs, cuts, ys):
+        want = tl_chain.stft_hard_lowpass(x, c, n_fft, hop, weights=wts, pad_mode=pad_mode, **kw)
+        np.testing.assert_array_equal(y.cpu().numpy(), want, err_msg="n=%d cut=%d" % (len(x), c))
+    re, im = B.stft(plan, sigs[1:], kind="complex", torch_style_pad=True)
+    for x, r, i in zip(sigs[1:], re, im):
+        wr, wi = tl_chain.stft(x, n_fft, hop, weights=wts, pad_mode=pad_mode, **kw)
+        assert r.shape == wr.shape
+        np.testing.assert_array_equal(r.cpu().numpy(), wr)
+        np.testing.assert_array_equal(i.cpu().numpy(), wi)
+        back = B.istft(plan, [r], [i], [len(x)])[0].cpu().numpy()
+        np.testing.assert_array_equal(back, tl_chain.istft(wr, wi, len(x), n_fft, hop, weights=wts, **kw))
+        # the inverse undoes the forward transform wherever every overlapping frame exists (away from un-padded / zero-padded edges)
+        T = wr.shape[0]
+        lo, hi = n_fft, min(len(x), (T - 1) * hop) - n_fft
+        assert hi <= lo or np.abs(back[lo:hi] - x[lo:hi]).max() < 5e-6
+        if not center:                                             # the slice past the overlap-added signal: zero-filled
+            end = (T - 1) * hop + n_fft
+            assert np.all(back[end:] == 0.0)
+
+
+@pytest.mark.gpu
+def test_fdomain_helper_options_module_api_and_refusals():
+    """The module API with the options on, against the oracle's torch-conv restatement (arithmetic class, not bit-exact), and the
+    entry points an ssr_plan_create_ex plan does not serve refusing loudly."""
+    import torch
+    from ssr_eval_amd import _lib, backend as B
+    from ssr_eval_amd.dsp import FDomainHelper
+    from oracle import stft as ostft
+    rng = np.random.default_rng(5)
+    x = (0.3 * rng.standard_normal((2, 12000))).astype(np.float32)
+    for window, center, pad_mode in [("hamming", False, "reflect"), ("hann", True, "constant")]:
+        h = FDomainHelper(window_size=1024, hop_size=256, center=center, pad_mode=pad_mode, window=window)
+        spec = h.complex_spectrogram(torch.from_numpy(x).cuda())
+        wr, wi = ostft.tl_stft_conv(x, 1024, 256, window=window, center=center, pad_mode=pad_mode)
+        assert spec.shape == (2, 2) + wr.shape[2:]
+        scale = np.abs(wr).max()
+        assert np.abs(spec[:, 0].cpu().numpy() - wr[:, 0]).max() < 2e-6 * scale
+        assert np.abs(spec[:, 1].cpu().numpy() - wi[:, 0]).max() < 2e-6 * scale
+        y = h.reverse_complex_spectrogram(spec, length=x.shape[1]).cpu().numpy()
+        want = ostft.tl_istft_conv(wr, wi, x.shape[1], 1024, 256, window=window, center=center)
+        assert np.abs(y - want).max() < 5e-6
+        # length=None: ISTFT._trim_edges keeps everything (un-centred) / drops n_fft//2 at both ends (centred)
+        T = wr.shape[2]
+        assert h.reverse_complex_spectrogram(spec).shape[1] == 256 * (T - 1) + (0 if center else 1024)
+        mag, cos, sin = h.wav_to_spectrogram_phase(torch.from_numpy(x[:, None, :]).cuda())
+        back = h.spectrogram_phase_to_wav(mag, cos, sin, x.shape[1])[:, 0].cpu().numpy()
+        assert np.abs(back[:, 1024:-2048] - x[:, 1024:-2048]).max() < 1e-5
+    with pytest.raises(NotImplementedError):
+        FDomainHelper(window_size=1000, hop_size=250, center=False)
+    with pytest.raises(NotImplementedError):
+        FDomainHelper(pad_mode="replicate")
+    with pytest.raises(ValueError):
+        FDomainHelper(center=False).complex_spectrogram(torch.zeros(1, 2047).cuda())
+    plan = B.get_plan_ex(1024, 256, "hamming", ostft.window_array("hamming", 1024), False, "reflect")
+    with pytest.raises(RuntimeError, match="ssr_plan_create_ex"):
+        B.stft(plan, [x[0]], kind="mag")
+    with pytest.raises(RuntimeError, match="ssr_plan_create_ex"):
+        B.pair_metrics(plan, [x[0]], [x[1]])
+    with pytest.raises(ValueError):
+        plan.set_lowpass_engine("segments")
+    assert plan.lib.ssr_plan_set_lowpass_engine(plan.handle, _lib.LOWPASS_SEGMENTS) == _lib.ERR_UNSUPPORTED

@@ -392,3 +392,68 @@ def test_resampy_restatement_known_answers():
     for k in range(1, 2000):
         acc += 1.0 / (48000 / 44100)
         assert tr[k] == acc
+
+
+@pytest.mark.parametrize("window,center,pad_mode", [("hann", False, "reflect"), ("hamming", True, "constant"), (("kaiser", 8.0), False, "constant"),
+                                                     ("blackman", True, "reflect")])
+def test_tl_restatement_with_helper_options(window, center, pad_mode):
+    """FDomainHelper's non-default arguments (dsp.py:7-59 -> torchlibrosa STFT / ISTFT(window, center, pad_mode)) in the oracle: the
+    float32 conv restatement and the fixed-order C restatement against the exact transform of the same frames (float64), frame
+    counts, ISTFT._trim_edges, and the round trip.  No reference-generated vector exists for these branches (the reference only
+    builds FDomainHelper()): this pins the oracle to the MATHEMATICAL transform, not to a torchlibrosa run."""
+    from oracle import stft as S, tl_chain
+    n_fft, hop = 512, 110
+    rng = np.random.default_rng(11)
+    x = (0.3 * rng.standard_normal(6000)).astype(np.float32)
+    win = S.window_array(window, n_fft)
+    if window == "hann":
+        np.testing.assert_array_equal(win, S.hann_periodic(n_fft))
+    pad = n_fft // 2 if center else 0
+    xp = np.pad(x.astype(np.float64), pad, mode=pad_mode) if center else x.astype(np.float64)
+    T = 1 + (len(xp) - n_fft) // hop
+    frames = np.stack([xp[t * hop:t * hop + n_fft] for t in range(T)])
+    exact = np.fft.rfft(frames * win[None, :], axis=1)
+    re, im = S.tl_stft_conv(x[None], n_fft, hop, window=window, center=center, pad_mode=pad_mode)
+    assert re.shape == (1, 1, T, n_fft // 2 + 1)
+    scale = np.abs(exact).max()
+    assert np.abs(re[0, 0] - exact.real).max() < 3e-6 * scale and np.abs(im[0, 0] - exact.imag).max() < 3e-6 * scale
+    cr, ci = tl_chain.stft(x, n_fft, hop, window=window, center=center, pad_mode=pad_mode)
+    assert cr.shape == (T, n_fft // 2 + 1)
+    assert np.abs(cr - exact.real).max() < 3e-6 * scale and np.abs(ci - exact.imag).max() < 3e-6 * scale
+    # inverse: exact overlap-add of the windowed inverse frames / window-sum, trimmed at `start`
+    length = len(x)
+    inv = np.fft.irfft(exact, n=n_fft, axis=1) * win[None, :]
+    L = (T - 1) * hop + n_fft
+    ola, wss = np.zeros(L), np.zeros(L)
+    for t in range(T):
+        ola[t * hop:t * hop + n_fft] += inv[t]
+        wss[t * hop:t * hop + n_fft] += win ** 2
+    want = (ola / np.maximum(wss, 1e-11))[pad:pad + length]
+    y = S.tl_istft_conv(re, im, length, n_fft, hop, window=window, center=center)[0]
+    yc = tl_chain.istft(cr, ci, length, n_fft, hop, window=window, center=center)
+    ok = wss[pad:pad + length][:len(want)] > 1e-3           # (where the window sum is tiny, float32 round-off is amplified without bound)
+    assert np.abs(y[:len(want)] - want)[ok].max() < 2e-5
+    assert np.abs(yc[:len(want)] - want)[ok].max() < 2e-5
+    assert np.all(y[len(want):] == 0.0) and np.all(yc[len(want):] == 0.0)        # past the overlap-added signal
+    assert (len(want) < length) == (not center)                                # 6000 = 49 * 110 + 512 + 98: 98 samples short un-centred
+    lo, hi = n_fft, min(length, (T - 1) * hop) - n_fft
+    assert np.abs(yc[lo:hi] - x[lo:hi]).max() < 5e-6
+    # hard low-pass through both restatements: same class
+    a = S.tl_istft_conv(*_cut(re, im, 60), length, n_fft, hop, window=window, center=center)[0]
+    b = tl_chain.stft_hard_lowpass(x, 60, n_fft, hop, window=window, center=center, pad_mode=pad_mode)
+    assert np.abs(a - b)[ok_full(ok, length)].max() < 2e-5
+
+
+def ok_full(ok, length):
+    m = np.zeros(length, bool)
+    m[:len(ok)] = ok
+    return m
+
+
+def _cut(re, im, cut):
+    """spectrogram_phase (eps 1e-8) -> mag[cut:] = 0 -> mag * cos, mag * sin in float32 (dsp.py:76-81, lowpass.py:24-25)."""
+    mag = np.sqrt(np.maximum(re * re + im * im, np.float32(1e-8)), dtype=np.float32)
+    c, s = re / mag, im / mag
+    mag = mag.copy()
+    mag[..., cut:] = 0
+    return mag * c, mag * s

@@ -326,19 +326,21 @@ class Cfg5:
         g = torch.Generator(device=dev).manual_seed(20220328 + rank)
         self.x = (0.1 * torch.randn((n, self.N_IN), generator=g, device=dev, dtype=torch.float32)).contiguous()
         self.tgt = (0.1 * torch.randn((n, N_SAMPLES), generator=g, device=dev, dtype=torch.float32)).contiguous()
-        self.s1 = B.ResampleBatch(B.Ragged.from_uniform(self.x), 44100, 16000)
+        # the two resample_poly stages in ONE kernel, the 44.1 kHz signal in LDS only (ssr_resample_poly_chain); --resample-chain
+        # two-calls runs them as two ssr_resample_poly launches through an 8.8 GB intermediate
+        self.chain = B.ResampleChainBatch(B.Ragged.from_uniform(self.x), 16000, 44100, 48000,
+                                          fused=None if getattr(a, "resample_chain", "fused") == "fused" else False)
+        self.s1, self.s2 = self.chain.s1, self.chain.s2
         assert int(self.s1.out_len[0]) == 176400
-        self.s2 = B.ResampleBatch(self.s1.out_ragged(), 48000, 44100)
         assert int(self.s2.out_len[0]) == N_SAMPLES
         self.plan = B.get_plan(N_FFT, HOP, a.precision, dev)
-        self.batch = B.PairBatch(self.plan, self.s2.out_ragged(), B.Ragged.from_uniform(self.tgt))
+        self.batch = B.PairBatch(self.plan, self.chain.out_ragged(), B.Ragged.from_uniform(self.tgt))
         self.units_per_step = n * N_SAMPLES
         self.cnt = torch.full((1,), float(n), dtype=torch.float64, device=dev)
         self.agg = torch.zeros(2, dtype=torch.float64, device=dev)
 
     def step(self):
-        self.s1.run()
-        self.s2.run()
+        self.chain.run()
         out = self.batch.run(self.B.M_LSD)
         torch.cat([out[:, 0].sum(0, keepdim=True), self.cnt], out=self.agg)
         return self.agg
@@ -354,20 +356,31 @@ class Cfg5:
     def report(self, a):
         it = 3
         n = a.utterances
-        ms1 = event_time_ms(lambda: self.s1.run(), it)
-        ms2 = event_time_ms(lambda: self.s2.run(), it)
+        # the resampling chain's algorithmic bytes are 4*(n_in + n_out_final) = 1,024,000 B / utterance
+        chain_alg = 4 * (64000 + 192000) * n
+        msc = event_time_ms(lambda: self.chain.run(), it)
+        fused = bool(self.chain.ran_fused)
+        ms1 = event_time_ms(lambda: self.chain.run_stage1(), it)          # the two stages as two launches through HBM
+        ms2 = event_time_ms(lambda: self.chain.run_stage2(), it)
+        self.chain.run()
         ms3 = event_time_ms(lambda: self.batch.run(self.B.M_LSD), it)
         stages = {"resample_441_160": (ms1, 4 * (64000 + 176400) * n), "resample_160_147": (ms2, 4 * (176400 + 192000) * n),
                   "stft+lsd": (ms3, (2 * N_SAMPLES * 4 + 32) * n)}
-        # the fused resampling chain's algorithmic bytes are 4*(n_in + n_out_final) = 1,024,000 B / utterance
-        chain_alg = 4 * (64000 + 192000) * n
-        roof = hbm_roofline("ssr_resample_poly x2 (k_resample_rc, both stages)", chain_alg, ms1 + ms2,
-                            "k_resample_rc stage 1+k_resample_rc stage 2" if a.utterances == 12500 else None,
-                            "the resampling chain is the HBM-side kernel of this config; per-stage read+write rates and the LSD "
-                            "stage are under extra.stage_ms / extra.stage_GBs")
+        if fused:
+            stages["resample_chain_fused"] = (msc, chain_alg)
+            roof = hbm_roofline("ssr_resample_poly_chain (k_resample_chain: both stages, the 44.1 kHz signal in LDS)", chain_alg, msc,
+                                "k_resample_chain" if a.utterances == 12500 else None,
+                                "the resampling chain is the HBM-side kernel of this config; the two stages as separate launches and "
+                                "the LSD stage are under extra.stage_ms / extra.stage_GBs")
+        else:
+            roof = hbm_roofline("ssr_resample_poly x2 (k_resample_rc, both stages)", chain_alg, ms1 + ms2,
+                                "k_resample_rc stage 1+k_resample_rc stage 2" if a.utterances == 12500 else None,
+                                "the resampling chain is the HBM-side kernel of this config; per-stage read+write rates and the LSD "
+                                "stage are under extra.stage_ms / extra.stage_GBs")
         extra = {"stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
                  "stage_GBs_read_plus_write": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) for k, v in stages.items()},
-                 "resample_only_output_samples_per_s": round(n * N_SAMPLES / ((ms1 + ms2) * 1e-3), 1)}
+                 "resample_chain": "fused (ssr_resample_poly_chain)" if fused else "two ssr_resample_poly calls",
+                 "resample_only_output_samples_per_s": round(n * N_SAMPLES / ((msc if fused else ms1 + ms2) * 1e-3), 1)}
         # side figure: the matrix-core mode of the resampler (ssr_resample_poly_mfma: fused multiply-adds, not SciPy's bits; the
         # timed region above runs the bit-exact kernel).  Its outputs replace the exact ones for this measurement only.
         try:
@@ -375,8 +388,8 @@ class Cfg5:
             lsd_exact = self.batch.run(B.M_LSD)[:, 0].clone()
             y_exact = self.s2.out.clone()
             self.s1.exact = self.s2.exact = False
-            mm1 = event_time_ms(lambda: self.s1.run(), it)
-            mm2 = event_time_ms(lambda: self.s2.run(), it)
+            mm1 = event_time_ms(lambda: self.chain.run_stage1(), it)
+            mm2 = event_time_ms(lambda: self.chain.run_stage2(), it)
             lsd_mfma = self.batch.run(B.M_LSD)[:, 0]
             extra["matrix_core_mode"] = {
                 "stage_ms": {"resample_441_160": round(mm1, 4), "resample_160_147": round(mm2, 4)},
@@ -387,8 +400,7 @@ class Cfg5:
                         "mode `value` is measured in"}
         finally:
             self.s1.exact = self.s2.exact = True
-            self.s1.run()
-            self.s2.run()
+            self.chain.run()
         return roof, extra
 
     def cpu_inputs(self, n):
@@ -979,6 +991,8 @@ def parse(argv=None):
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
     ap.add_argument("--lowpass-engine", dest="lowpass_engine", default="segments", choices=["segments", "fused", "conv"],
                     help="cfg3: overlap-add through the segment workspace (default, faster inside the pipeline) or fused in the transform kernel")
+    ap.add_argument("--resample-chain", dest="resample_chain", default="fused", choices=["fused", "two-calls"],
+                    help="cfg5: both resample_poly stages in one kernel (ssr_resample_poly_chain) or two ssr_resample_poly launches")
     ap.add_argument("--shard", default="balanced", choices=["balanced", "round-robin"], help="cfg4: how the fixed set is dealt to the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the cfg3 / cfg5 / API-true / end-to-end side figures")

@@ -245,6 +245,19 @@ int ssr_resample_poly(const float* in, const int64_t* in_off, const int32_t* in_
                       const int32_t* out_len, int n_items, int max_out_len, int up, int down, const float* taps,
                       int n_taps, int n_pre_remove, float* out, void* stream);
 
+/* K7 twice in one kernel (round 4): resample_poly(resample_poly(x, up1, down1), up2, down2) for float32 signals with the INTERMEDIATE
+ * signal held in LDS only - BASELINE cfg-5's 16 kHz -> 44.1 kHz -> 48 kHz chain (librosa.resample(res_type="polyphase") at
+ * ssr_eval/eval.py:144-150 behind a testee that itself up-sampled).  Both stages are the bit-exact kernel of ssr_resample_poly: the
+ * intermediate has SciPy's bits and so has the output - bit-identical to two ssr_resample_poly calls, at 12.8 GB of HBM traffic per
+ * 12,500 utterances of 4 s instead of 30.6 GB.  mid_len[i] (device) = the intermediate length of item i (ssr_resample_plan's n_out
+ * for stage 1); out_len / max_out_len refer to the final signal.  Plans (reduced up / down, taps, n_pre_remove) as for
+ * ssr_resample_poly.  SSR_ERR_UNSUPPORTED unless both plans have 21 taps per phase and 8 up1 = 24 down2 with up1 <= 448,
+ * up2 <= 160 (441/160 then 160/147 and its multiples): the caller then runs the two stages through ssr_resample_poly. */
+int ssr_resample_poly_chain(const float* in, const int64_t* in_off, const int32_t* in_len, const int32_t* mid_len,
+                            const int64_t* out_off, const int32_t* out_len, int n_items, int max_out_len, int up1, int down1,
+                            const float* taps1, int n_taps1, int n_pre_remove1, int up2, int down2, const float* taps2,
+                            int n_taps2, int n_pre_remove2, float* out, void* stream);
+
 /* K7 on the matrix cores (round 3): the same sums as ssr_resample_poly, evaluated as a dense (outputs x input window) by
  * (input window x 32 utterances) product on v_mfma_f32_32x32x2_f32 - float32 FUSED multiply-adds in ascending input index, one
  * rounding per tap where SciPy's upfirdn rounds product and sum separately.  NOT bit-identical to scipy.signal.resample_poly:

@@ -54,6 +54,7 @@ SIGNATURES = {
     "ssr_resample_plan": (_i, [_i64, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64), C.POINTER(_i),
                                C.POINTER(_i), C.POINTER(_i)]),
     "ssr_resample_poly": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "ssr_resample_poly_chain": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "ssr_resample_poly_mfma": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "ssr_resample_poly_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "ssr_resample_sinc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _vp, _vp, _i, _i, _i, C.c_double, C.c_double, _i,

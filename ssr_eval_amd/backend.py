@@ -602,7 +602,7 @@ class ResamplePlan:
 class ResampleBatch:
     """A ragged batch + cached output descriptors / buffer for repeated ssr_resample_poly calls (K7)."""
 
-    def __init__(self, ragged, up, down, exact=True):
+    def __init__(self, ragged, up, down, exact=True, alloc=True):
         dev = ragged.device
         self.r, self.rp = ragged, ResamplePlan.get(up, down, dev)
         self.exact = exact
@@ -614,10 +614,12 @@ class ResampleBatch:
         self.out_off = np.concatenate(([0], np.cumsum(self.out_len)[:-1])).astype(np.int64) if ragged.n else np.zeros(0, np.int64)
         self.out_off_d = torch.from_numpy(self.out_off).to(dev)
         self.out_len_d = torch.from_numpy(self.out_len.astype(np.int32)).to(dev)
-        self.out = torch.empty(int(self.out_len.sum()), dtype=ragged.data.dtype, device=dev)
+        self.out = torch.empty(int(self.out_len.sum()), dtype=ragged.data.dtype, device=dev) if alloc else None
 
     def run(self):
         r, rp = self.r, self.rp
+        if self.out is None:
+            self.out = torch.empty(int(self.out_len.sum()), dtype=r.data.dtype, device=r.device)
         if rp.identity:
             self.out.copy_(r.data)             # scipy returns x.copy() before designing any filter
         elif r.n and self.out_len.max() > 0:
@@ -635,6 +637,66 @@ class ResampleBatch:
 
     def out_ragged(self):
         return Ragged(self.out, self.out_off_d, self.out_len_d, self.out_len)
+
+
+class ResampleChainBatch:
+    """resample_poly(resample_poly(x, mid, orig), new, mid) for a ragged float32 batch - BASELINE cfg-5's 16 kHz -> 44.1 kHz -> 48 kHz.
+    Where the two plans fit ssr_resample_poly_chain (21-tap phases, 8 up1 = 24 down2: 441/160 then 160/147) ONE kernel runs both
+    stages and the intermediate signal never leaves LDS; otherwise the two stages run through ssr_resample_poly.  Same bits either
+    way (SciPy's).  `fused`: None = try the fused kernel, False = always two calls."""
+
+    def __init__(self, ragged, sr_orig, sr_mid, sr_new, fused=None):
+        self.r = ragged
+        self.s1 = ResampleBatch(ragged, sr_mid, sr_orig, alloc=False)
+        mid = Ragged(torch.empty(0, dtype=ragged.data.dtype, device=ragged.device), self.s1.out_off_d, self.s1.out_len_d,
+                     self.s1.out_len)                                          # geometry only: the buffer may never exist
+        self.s2 = ResampleBatch(mid, sr_new, sr_mid, alloc=False)
+        self.out_len, self.out_off, self.out_off_d, self.out_len_d = self.s2.out_len, self.s2.out_off, self.s2.out_off_d, self.s2.out_len_d
+        self.out = torch.empty(int(self.out_len.sum()), dtype=torch.float32, device=ragged.device)
+        self.s2.out = self.out
+        self.fused = fused
+        self.ran_fused = None
+        if ragged.data.dtype != torch.float32 or self.s1.rp.identity or self.s2.rp.identity:
+            self.fused = False
+
+    def run(self):
+        r, p1, p2 = self.r, self.s1.rp, self.s2.rp
+        if self.fused is not False and r.n and self.out_len.max() > 0:
+            rc = _lib.load().ssr_resample_poly_chain(
+                _vp(r.data), _vp(r.off), _vp(r.len), _vp(self.s1.out_len_d), _vp(self.out_off_d), _vp(self.out_len_d), r.n,
+                int(self.out_len.max()), p1.up, p1.down, _vp(p1.taps), int(p1.taps.numel()), p1.n_pre_remove,
+                p2.up, p2.down, _vp(p2.taps), int(p2.taps.numel()), p2.n_pre_remove, _vp(self.out), _stream())
+            if rc != _lib.ERR_UNSUPPORTED:
+                _lib.check(rc)
+                self.ran_fused = True
+                return self.out
+            if self.fused:
+                _lib.check(rc)
+        self.ran_fused = False
+        self.run_stage1()
+        return self.run_stage2()
+
+    def run_stage1(self):
+        """Stage 1 alone, into the intermediate buffer (allocated on first use)."""
+        return self.s1.run()
+
+    def run_stage2(self):
+        """Stage 2 alone, from the intermediate buffer run_stage1() filled."""
+        self.s2.r = self.s1.out_ragged()
+        return self.s2.run()
+
+    def out_ragged(self):
+        return Ragged(self.out, self.out_off_d, self.out_len_d, self.out_len)
+
+
+def resample_poly_chain(wavs, sr_orig, sr_mid, sr_new, device=None, fused=None):
+    """scipy.signal.resample_poly twice (sr_orig -> sr_mid -> sr_new) for a list of float32 waveforms; see ResampleChainBatch."""
+    dev = torch.device(device) if device is not None else default_device()
+    with torch.cuda.device(dev):
+        r = wavs if isinstance(wavs, Ragged) else Ragged.from_list(wavs, dev)
+        b = ResampleChainBatch(r, sr_orig, sr_mid, sr_new, fused=fused)
+        out = b.run()
+        return [out[b.out_off[i]:b.out_off[i] + b.out_len[i]] for i in range(r.n)]
 
 
 def resample_poly(wavs, up, down, device=None, exact=True):

@@ -6,6 +6,7 @@
 #include "ssr_resample.h"
 #include "ssr_resample_mfma.h"
 #include "ssr_resample_rc.h"
+#include "ssr_resample_chain.h"
 #include "ssr_sinc.h"
 
 __global__ __launch_bounds__(SSR_XC_NT) void k_xcorr(SsrXcorrParams p) {
@@ -124,6 +125,49 @@ static int resample_rc_launch(const float* in, const int64_t* in_off, const int3
     if (int rc = ssr_allow_lds((const void*)k_resample_rc<21, 1024>, lds, &slot2)) return rc;
     hipLaunchKernelGGL((k_resample_rc<21, 1024>), dim3((unsigned)grid), dim3(nt), lds, s, p);
   }
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
+}
+
+// Two residue-class stages in one kernel, the intermediate signal in LDS (ssr_resample_chain.h).
+template <int HPP> __global__ __launch_bounds__(SSR_RCC_NT, 6) void k_resample_chain(SsrResampleChainParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ssr_resample_chain_body<HPP>(p, smem);
+}
+extern "C" int ssr_resample_poly_chain(const float* in, const int64_t* in_off, const int32_t* in_len, const int32_t* mid_len,
+                                       const int64_t* out_off, const int32_t* out_len, int n_items, int max_out_len, int up1, int down1,
+                                       const float* taps1, int n_taps1, int n_pre_remove1, int up2, int down2, const float* taps2,
+                                       int n_taps2, int n_pre_remove2, float* out, void* stream) {
+  if (!in || !in_off || !in_len || !mid_len || !out_off || !out_len || !taps1 || !taps2 || !out) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (up1 < 1 || down1 < 1 || n_taps1 < 1 || up2 < 1 || down2 < 1 || n_taps2 < 1) return ssr_fail(SSR_ERR_INVALID_ARG, "bad resampling plan");
+  if (n_items <= 0 || max_out_len <= 0) return SSR_OK;
+#ifdef SSR_DEV_KNOBS
+  static const int off = getenv("SSR_NO_CHAIN") ? atoi(getenv("SSR_NO_CHAIN")) : 0;
+  if (off) return ssr_fail(SSR_ERR_UNSUPPORTED, "fused chain switched off");
+#endif
+  // geometry of the fused kernel: 21 taps per phase in both plans, a block of 8 stage-1 steps = 24 stage-2 steps, 441 / 2 x 160 lanes
+  const bool ok = (n_taps1 + up1 - 1) / up1 == 21 && (n_taps2 + up2 - 1) / up2 == 21 && up1 >= 33 && up1 <= SSR_RCC_NT1 &&
+                  SSR_RCC_G2 * up2 <= SSR_RCC_NT2 && up2 >= 33 &&
+                  (int64_t)SSR_RCC_JB1 * up1 == (int64_t)SSR_RCC_G2 * SSR_RCC_JB2 * down2;
+  if (!ok) return ssr_fail(SSR_ERR_UNSUPPORTED, "the fused chain needs 21-tap phases and 8 up1 = 24 down2 (e.g. 441/160 then 160/147)");
+  SsrResampleChainParams p{in, in_off, in_len, mid_len, out_off, out_len, up1, down1, n_taps1, n_pre_remove1, taps1,
+                           up2, down2, n_taps2, n_pre_remove2, taps2, 1, 1, 0, 0, out};
+  p.x_stage_floats = 2 * (((ssr_rc_pairs(up1, down1, 21, 1) + 31) / 32) * 32);
+  p.y_pairs = ((SSR_RCC_JB1 * up1 + 20 + 7) / 8) * 8;
+  const size_t lds = ((size_t)2 * p.x_stage_floats + (size_t)4 * p.y_pairs + 64) * sizeof(float);
+  if (lds > 80 * 1024) return ssr_fail(SSR_ERR_UNSUPPORTED, "the fused chain's windows exceed half a CU's LDS");
+  const int steps2 = ssr_ceil_div(max_out_len, up2), blocks = ssr_ceil_div(steps2, SSR_RCC_G2 * SSR_RCC_JB2);
+  // whole items where the batch is large; a chunk pays two extra iterations (the block before its first, the pipeline's lag)
+  int n_chunks = ssr_ceil_div(1024, n_items);
+  if (n_chunks > blocks / 8) n_chunks = blocks / 8;
+  if (n_chunks < 1) n_chunks = 1;
+  p.blocks_per_chunk = ssr_ceil_div(blocks, n_chunks);
+  p.n_chunks = ssr_ceil_div(blocks, p.blocks_per_chunk);
+  const int64_t grid = (int64_t)n_items * p.n_chunks;
+  if (grid > 0x7fffffff) return ssr_fail(SSR_ERR_UNSUPPORTED, "batch too large for one launch");
+  static thread_local SsrLdsSlot slot;
+  if (int rc = ssr_allow_lds((const void*)k_resample_chain<21>, lds, &slot)) return rc;
+  hipLaunchKernelGGL((k_resample_chain<21>), dim3((unsigned)grid), dim3(SSR_RCC_NT), lds, (hipStream_t)stream, p);
   HIP_TRY(hipGetLastError());
   return SSR_OK;
 }

@@ -1084,3 +1084,38 @@ def test_fdomain_helper_options_module_api_and_refusals():
     with pytest.raises(ValueError):
         plan.set_lowpass_engine("segments")
     assert plan.lib.ssr_plan_set_lowpass_engine(plan.handle, _lib.LOWPASS_SEGMENTS) == _lib.ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+def test_resample_chain_fused_bit_exact_vs_scipy_and_two_calls(golden):
+    """ssr_resample_poly_chain: 16 kHz -> 44.1 kHz -> 48 kHz in one kernel (the intermediate in LDS only) - SciPy's bits, ragged lengths
+    incl. ones shorter than a filter, than one block, and whole multiples of the block; the chunked launch (few items) and the
+    whole-item launch (many items) both covered; chains the kernel does not hold fall to two ssr_resample_poly calls."""
+    from ssr_eval_amd import backend as B
+    x = golden["rs_x16k"]
+    rng = np.random.default_rng(44100)
+    lens = [len(x), 777, 5, 1, 1280, 1281, 64000, 12803, 30011]
+    sig = [np.tile(x, 9)[:n].copy() if n <= 9 * len(x) else (0.1 * rng.standard_normal(n)).astype(np.float32) for n in lens]
+    want = [signal.resample_poly(signal.resample_poly(s, 441, 160), 160, 147) for s in sig]
+    b = B.ResampleChainBatch(B.Ragged.from_list(sig), 16000, 44100, 48000, fused=True)
+    out = b.run()
+    assert b.ran_fused is True
+    for i, w in enumerate(want):
+        got = out[b.out_off[i]:b.out_off[i] + b.out_len[i]].cpu().numpy()
+        assert got.shape == w.shape
+        np.testing.assert_array_equal(got, w, err_msg="item %d (n = %d)" % (i, lens[i]))
+    two = B.resample_poly_chain(sig, 16000, 44100, 48000, fused=False)
+    for t, w in zip(two, want):
+        np.testing.assert_array_equal(t.cpu().numpy(), w)
+    # many items: one workgroup per item
+    many = [(0.1 * rng.standard_normal(int(n))).astype(np.float32) for n in rng.integers(3000, 9000, 1100)]
+    got = B.resample_poly_chain(many, 16000, 44100, 48000)
+    for k in (0, 1, 549, 1098, 1099):
+        np.testing.assert_array_equal(got[k].cpu().numpy(), signal.resample_poly(signal.resample_poly(many[k], 441, 160), 160, 147))
+    # a chain outside the kernel's geometry (48 -> 44.1 -> 16 kHz: down-sampling plans): two calls, same API
+    b2 = B.ResampleChainBatch(B.Ragged.from_list(sig[:3]), 48000, 44100, 16000)
+    o2 = b2.run()
+    assert b2.ran_fused is False
+    np.testing.assert_array_equal(o2[:b2.out_len[0]].cpu().numpy(), signal.resample_poly(signal.resample_poly(sig[0], 147, 160), 160, 441))
+    with pytest.raises(RuntimeError):
+        B.ResampleChainBatch(B.Ragged.from_list(sig[:3]), 48000, 44100, 16000, fused=True).run()

@@ -26,7 +26,7 @@ for stats in sorted(glob.glob(src + "/stats_*/*kernel_stats.csv")):
     if os.path.exists(bj) and os.path.getsize(bj):
         summary.setdefault("bench_line_under_rocprof", {})[cfg] = json.load(open(bj))
 KEYS = ("k_stft_wave<double, false", "k_stft_wave<double, true", "k_ssim", "k_stft<double, 11")
-MORE = {"cfg3": ("k_lowpass_wave", "k_ola_paired", "k_ola(", "k_specred_wave"), "cfg3fused": ("k_lowpass_group",), "cfg5": ("k_resample<", "k_resample_rc"),
+MORE = {"cfg3": ("k_lowpass_wave", "k_ola_paired", "k_ola(", "k_specred_wave"), "cfg3fused": ("k_lowpass_group",), "cfg5": ("k_resample<", "k_resample_rc", "k_resample_chain"),
         "cfg3conv": ("k_tl_gemm<0>", "k_tl_gemm<2>", "k_tl_fold", "k_tl_pad"),
         "api": ("k_stft_r3_rot<double, false", "k_stft_r3_rot<double, true"), "sinc": ("k_resample_sinc",)}
 pm = {}

@@ -157,8 +157,7 @@ __device__ __forceinline__ void ssr_resample_chain_body(const SsrResampleChainPa
         const int wave = tid >> 6, lane = tid & 63;
         const float* src = x + lo + (lane >> 1) + ((lane & 1) ? down1 : 0);
         for (int i0 = wave * 32; i0 < n_pairs; i0 += (NT1 / 64) * 32)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i0),
-                                           (__attribute__((address_space(3))) void*)(a + 2 * i0), 4, 0, 0);
+          ssr_lds_dma_dword(src + i0, __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(a + 2 * i0)));
       } else {
         for (int i = tid; i < 2 * n_pairs; i += NT1) {
           const int gi = lo + (i >> 1) + ((i & 1) ? down1 : 0);

@@ -45,6 +45,15 @@ struct SsrResampleRcParams {
   float* out;
 };
 
+// LDS-DMA of one dword per lane: lane l's dword lands at LDS byte address `lds_wave_base` + 4 l (M0 = the wave-uniform base).
+// As inline asm, not __builtin_amdgcn_global_load_lds: with the builtin in flight the compiler's wait-count pass treats every
+// LDS wait of the loop as a wait for ALL outstanding LDS operations ("pending flat": s_waitcnt lgkmcnt(0) in front of every second
+// step of the multiply-add chains, i.e. the one-step-ahead ds_read prefetch was waited for at once).  The kernels order the
+// transfer themselves - counted s_waitcnt vmcnt before the barrier that publishes the stage.  M0 has no other user here.
+__device__ __forceinline__ void ssr_lds_dma_dword(const float* src_lane, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_wave_base), "v"(src_lane) : "memory");
+}
+
 // pairs a block's window holds: pair i = (x[lo + i], x[lo + i + down]), i < n_pairs; the chains of steps 0, 2, .., G JB - 2 start at
 // pair (q(r) - q(0)) + j down and read HPP pairs
 __host__ __device__ inline int ssr_rc_pairs(int up, int down, int hpp, int groups) {
@@ -109,8 +118,7 @@ __device__ __forceinline__ void ssr_resample_rc_body(const SsrResampleRcParams& 
       const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
       const float* src = x + lo + (lane >> 1) + ((lane & 1) ? down : 0);
       for (int i0 = wave * 32; i0 < n_pairs; i0 += nw * 32)               // wave-uniform trip count
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i0),
-                                         (__attribute__((address_space(3))) void*)(a + 2 * i0), 4, 0, 0);
+        ssr_lds_dma_dword(src + i0, __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(a + 2 * i0)));
     } else {
       for (int i = tid; i < 2 * n_pairs; i += nt) {
         const int g = lo + (i >> 1) + ((i & 1) ? down : 0);

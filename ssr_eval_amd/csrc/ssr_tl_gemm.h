@@ -80,9 +80,13 @@ __device__ __forceinline__ int64_t ssr_tl_pad_off(int64_t pad_stride, int64_t ro
   return pad_stride > 0 ? (int64_t)item * pad_stride : row0 * hop + (int64_t)item * n_fft;      // (T hop + n_fft >= len + 2 pad for every item)
 }
 
+// LDS-DMA, 16 bytes per lane: lane l's four floats land at LDS byte address `lds_wave_base` + 16 l (M0 = the wave-uniform base).
+// Inline asm rather than __builtin_amdgcn_global_load_lds: with the builtin in flight the compiler's wait-count pass makes EVERY LDS
+// wait of the loop a wait for all outstanding LDS operations (see ssr_resample_rc.h: ssr_lds_dma_dword); the kernel orders the
+// transfer itself (s_waitcnt vmcnt(0) before the barrier that publishes the stage).
 __device__ __forceinline__ void ssr_tl_glds16(const float* src, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+  const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(base), "v"(src) : "memory");
 }
 
 // separately rounded float32 operations (hipcc's default -ffp-contract=fast would fuse a * b + c; torch's tensor ops round each)
@@ -197,16 +201,28 @@ __device__ __forceinline__ void ssr_tl_gemm_body(const SsrTlParams& p, char* sme
       const float* as2 = INV ? st + A_FLOATS : st;
       const float* bs1 = st + (INV ? 2 : 1) * A_FLOATS + 32 * wave + fi;
       const float* bs2 = bs1 + B_FLOATS;
+      // One step = one k pair = four matrix instructions (256 cycles of the matrix pipe).  The operands of step s + 1 are requested
+      // BEFORE the instructions of step s are issued and first touched after them: the LDS round trip runs under a full step of
+      // matrix work (left to itself the compiler put every read right in front of its use - a wait per one or two instructions).
+      float fb1[2], fb2[2], fa10[2], fa11[2], fa20[2], fa21[2];
+      auto fetch = [&](int s, int slot) {
+        const int k = 2 * s + fk;
+        fb1[slot] = bs1[k * SSR_TL_BN]; fb2[slot] = bs2[k * SSR_TL_BN];
+        fa10[slot] = as1[fi * SSR_TL_LDA + k]; fa11[slot] = as1[(fi + 32) * SSR_TL_LDA + k];
+        if (INV) { fa20[slot] = as2[fi * SSR_TL_LDA + k]; fa21[slot] = as2[(fi + 32) * SSR_TL_LDA + k]; }
+      };
+      fetch(0, 0);
 #pragma unroll
       for (int s = 0; s < SSR_TL_BK / 2; ++s) {
-        const int k = 2 * s + fk;
-        const float b1v = bs1[k * SSR_TL_BN], b2v = bs2[k * SSR_TL_BN];
-        const float a10 = as1[fi * SSR_TL_LDA + k], a11 = as1[(fi + 32) * SSR_TL_LDA + k];
-        const float a20 = INV ? as2[fi * SSR_TL_LDA + k] : a10, a21 = INV ? as2[(fi + 32) * SSR_TL_LDA + k] : a11;
-        acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10, b1v, acc1[0], 0, 0, 0);
-        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a20, b2v, acc2[0], 0, 0, 0);
-        acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11, b1v, acc1[1], 0, 0, 0);
-        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a21, b2v, acc2[1], 0, 0, 0);
+        const int cur = s & 1;
+        if (s + 1 < SSR_TL_BK / 2) fetch(s + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const float a20 = INV ? fa20[cur] : fa10[cur], a21 = INV ? fa21[cur] : fa11[cur];
+        acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa10[cur], fb1[cur], acc1[0], 0, 0, 0);
+        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a20, fb2[cur], acc2[0], 0, 0, 0);
+        acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa11[cur], fb1[cur], acc1[1], 0, 0, 0);
+        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a21, fb2[cur], acc2[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       if ((chunk + 1) % (SSR_TL_KB / SSR_TL_BK) == 0 || chunk + 1 == n_chunks) {   // a chain ends: total += chain, restart from 0
 #pragma unroll

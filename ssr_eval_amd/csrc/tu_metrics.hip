@@ -273,7 +273,9 @@ static MultiWs multi_ws(const ssr_plan* pl, int n_items, int n_keys, int max_len
   // keys of an item per wave (they share the target's rows).  Measured on cfg-3 (6 such keys, 1024 items): 1 key per wave 4.37 ms
   // (20 GB of images at 4.6 TB/s: HBM-bound), 2 per wave 3.2-3.4 ms (90 VGPRs, five waves per SIMD), 3 per wave the same,
   // 6 per wave 5.11 ms (173 VGPRs: latency-bound at two waves per SIMD)
-  m.spec_kg = 2;
+  // after the round-4 packing of the float32 sequences (VALU-bound before, close to HBM-bound now): 2 per wave 2.92 ms, 3 per wave
+  // 2.77 ms - three where the keys divide by three (cfg-3: 6)
+  m.spec_kg = (n_spec > 0 && n_spec % 3 == 0) ? 3 : 2;
 #ifdef SSR_DEV_KNOBS
   if (getenv("SSR_SPEC_KG")) m.spec_kg = atoi(getenv("SSR_SPEC_KG"));
 #endif

@@ -42,8 +42,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                     agg[k].append((int(r.get("Dispatch_Id", 0) or 0), float(r["Counter_Value"])))
         for k, v in agg.items():
             vals = [x for _, x in sorted(v)]
-            if k in ("k_resample<", "k_resample_rc"):   # cfg-5 launches the two stages alternately: 441/160 first, then 160/147
-                for name, part in ((k.rstrip("<") + " stage 1", vals[0::2]), (k.rstrip("<") + " stage 2", vals[1::2])):
+            if k in ("k_resample<", "k_resample_rc"):   # cfg-5's two stages: 441/160, then 160/147
+                # (with the fused chain in the step the stages run in bench.py's report only: n x stage 1, then n x stage 2; before
+                # that they alternated inside the step)
+                halves = "k_resample_chain" in agg
+                parts = (vals[:len(vals) // 2], vals[len(vals) // 2:]) if halves else (vals[0::2], vals[1::2])
+                for name, part in ((k.rstrip("<") + " stage 1", parts[0]), (k.rstrip("<") + " stage 2", parts[1])):
                     if part:
                         part = sorted(part)
                         pm.setdefault(name, {})[c] = part[len(part) // 2]

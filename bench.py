@@ -239,6 +239,17 @@ class Cfg3:
                             tkey if dom == "fft_lowpass" and a.pairs == 1024 and a.precision == "f64" else None,
                             "per cutoff and 1024 utterances; algorithmic bytes: low-pass 2*n*4 per (utterance, cutoff), pair metrics "
                             "2*n*4+32 per pair (SURVEY 8(d))")
+        if engine == "conv" and dom == "fft_lowpass":
+            # the dense-DFT engine is bound by the fp32 matrix cores (MFMA where the DFT is deliberately cast as a GEMM):
+            # useful flops of the cut-bin-256 launch = frames x (forward 2 n_fft (2 cut) + inverse 2 n_fft (2 K)), K = cut + min(cut - 1, 1023)
+            c = CUT_BINS[3]
+            flops = n * (1 + N_SAMPLES // 441) * (2.0 * 2048 * 2 * c + 2.0 * 2048 * 2 * (c + min(c - 1, 1023)))
+            ach = flops / (ms_lp * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": lp_name, "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 5),
+                    "traffic": roof.get("traffic"), "traffic_source": roof.get("traffic_source"), "useful_flops_per_launch": flops,
+                    "kernel_ms": round(ms_lp, 4), "kernel_ms_source": roof["kernel_ms_source"],
+                    "note": "v_mfma_f32_32x32x2_f32 (exact float32 products, the reference's arithmetic class): dense peak 157.3 TFLOP/s; "
+                            "per cutoff (bin 256) and 1024 utterances, k_tl_pad + k_tl_gemm<0> + k_tl_gemm<2> + k_tl_fold; traffic = the forward product's PMC bytes"}
         extra = {"lowpass_engine": engine,
                  "stage_ms": {"fft_lowpass_one_cutoff(bin 256)": round(ms_lp, 4), "fft_lowpass_7_cutoffs": round(ms_lp_all, 4),
                               "pair_metrics_multi_7_keys": round(ms_multi, 4), "pair_metrics_one_key(round 3 path)": round(ms_pair, 4)},

@@ -412,11 +412,12 @@ class SSR_Eval_Helper:
         """eval.py:128-156 for one file."""
         return self.evaluate_files([file])[0]
 
-    def evaluate(self, limit_test_nums=-1, limit_test_speaker=-1, save_json=True, batch_files=128):
+    def evaluate(self, limit_test_nums=-1, limit_test_speaker=-1, save_json=True, batch_files=128, shard="round-robin"):
         """eval.py:171-227: walk speakers/files, evaluate, aggregate as mean of speaker means, write JSON.
         Files are evaluated `batch_files` at a time (one ragged launch sequence per batch).  With
-        torch.distributed initialised the (speaker, file) list is sharded round-robin over ranks and the
-        per-utterance rows are exchanged once (ssr_eval_amd.dist); every rank returns the full result."""
+        torch.distributed initialised the (speaker, file) list is sharded over the ranks - round-robin, or shard="balanced":
+        by audio duration read from the file headers, longest first to the lightest rank (every rank computes the
+        same deal) - and the per-utterance rows are exchanged once (ssr_eval_amd.dist); every rank returns the full result."""
         from datetime import datetime
         work = []                                                   # (speaker, file) in the reference's order
         speakers = []
@@ -434,9 +435,15 @@ class SSR_Eval_Helper:
             speakers.append(speaker)
             work += [(speaker, f) for f in files]
         rank, world = D.rank_world()
-        mine = D.shard_indices(len(work), rank, world)
+        if shard not in ("round-robin", "balanced"):
+            raise ValueError("shard must be 'round-robin' or 'balanced'")
+        from .io import decode_packed_async, duration_hint
+        if shard == "balanced" and world > 1:
+            weights = [int(round(1000.0 * duration_hint(os.path.join(self.test_data_root, *w)))) for w in work]      # milliseconds
+            mine = D.shard_indices_balanced(weights, rank, world)
+        else:
+            mine = D.shard_indices(len(work), rank, world)
         paths = [os.path.join(self.test_data_root, *work[i]) for i in mine]
-        from .io import decode_packed_async
         local = []
         step = max(1, int(batch_files))                            # ragged batches of files per launch sequence
         batches = [paths[b:b + step] for b in range(0, len(paths), step)]

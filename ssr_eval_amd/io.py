@@ -234,6 +234,26 @@ def _wav_pcm16_layout(path):
         return None
 
 
+def duration_hint(path):
+    """Seconds of audio in a file from its header alone (16-bit WAV / any FLAC with a known length), the file size in units of
+    16-bit 44.1 kHz mono otherwise - the weight length-balanced sharding deals by (ssr_eval_amd.dist.shard_indices_balanced); the
+    same value on every rank that sees the same tree."""
+    lay = _wav_pcm16_layout(path)
+    if lay is not None:
+        return lay[1] / (2.0 * lay[2] * max(lay[3], 1))
+    if _is_flac(path):
+        try:
+            sr, nch, bits, total = flac_info(path)
+            if total > 0 and sr > 0:
+                return total / float(sr)
+        except Exception:
+            pass
+    try:
+        return os.path.getsize(path) / (2.0 * 44100.0)
+    except OSError:
+        return 0.0
+
+
 class PackedBatch:
     """A batch of decoded files whose 16-bit PCM frames sit back to back in one page-locked arena (backend._Staging): the
     decoder threads read the files' data chunks STRAIGHT into it, so the batch crosses PCIe in one asynchronous copy with no

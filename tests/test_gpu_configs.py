@@ -475,7 +475,7 @@ print(json.dumps({"red": red.tolist(), "t": t.cpu().tolist(), "tab": tab.tolist(
 _TWO_RANK_EVAL = r"""
 import os, sys, json
 sys.path.insert(0, %r)
-rank = int(sys.argv[1]); world = int(sys.argv[2]); root = sys.argv[3]; port = sys.argv[4]
+rank = int(sys.argv[1]); world = int(sys.argv[2]); root = sys.argv[3]; port = sys.argv[4]; shard = sys.argv[5]
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
 import torch
 torch.cuda.set_device(0)                                  # both ranks share cuda:0; the exchange runs over gloo
@@ -485,7 +485,7 @@ if world > 1:
     D.init_from_env(backend="gloo")
 h = SSR_Eval_Helper(BasicTestee(), input_sr=44100, output_sr=44100, evaluation_sr=48000, test_data_root=root,
                     setting_fft={"cutoff_freq": [4000, 12000]}, setting_lowpass_filtering={"filter": ["cheby"], "cutoff_freq": [6000], "filter_order": [6]})
-res = h.evaluate(save_json=False, batch_files=5)
+res = h.evaluate(save_json=False, batch_files=5, shard=shard)
 print("RESULT" + json.dumps({"res": res, "allreduce_avg": h.last_allreduce_average.tolist()}))
 if world > 1:
     import torch.distributed as dist
@@ -511,8 +511,8 @@ def test_evaluate_sharded_two_processes_equals_single_process(tmp_path):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
 
-    def launch(rank, world, port):
-        return subprocess.Popen([sys.executable, "-c", code, str(rank), str(world), str(root), str(port)], stdout=subprocess.PIPE,
+    def launch(rank, world, port, shard="round-robin"):
+        return subprocess.Popen([sys.executable, "-c", code, str(rank), str(world), str(root), str(port), shard], stdout=subprocess.PIPE,
                                 stderr=subprocess.PIPE, text=True, env=env, cwd=str(tmp_path))
 
     def result(p):
@@ -523,6 +523,9 @@ def test_evaluate_sharded_two_processes_equals_single_process(tmp_path):
     port = 34500 + os.getpid() % 1000
     procs = [launch(r, 2, port) for r in range(2)]
     both = [result(p) for p in procs]
+    procs = [launch(r, 2, port + 1, "balanced") for r in range(2)]            # dealt by header duration instead of round-robin
+    balanced = [result(p) for p in procs]
+    assert balanced[0]["res"] == balanced[1]["res"]
     assert len(single["res"]["p360"]) == 4 and set(single["res"]["averaged"]) == {"proc_ch_12000_6_44100", "proc_fft_8000_44100", "proc_fft_24000_44100"}
     # every rank returns the SAME assembled result, bit for bit (the exchange transports float64 rows unchanged) ...
     assert both[0]["res"] == both[1]["res"]
@@ -541,6 +544,8 @@ def test_evaluate_sharded_two_processes_equals_single_process(tmp_path):
     assert worst <= 1e-12, worst
     assert sum(a[k] == b[k] for k in a) >= len(a) // 2
     np.testing.assert_allclose(both[0]["allreduce_avg"], single["allreduce_avg"], rtol=1e-12)
+    c = dict(flat(balanced[0]["res"]))
+    assert list(a) == list(c) and max(abs(a[k] - c[k]) / max(abs(a[k]), 1e-300) for k in a) <= 1e-12
 
 
 def test_cabi_allreduce_sums_two_rank_communicator():

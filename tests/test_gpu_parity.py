@@ -1112,6 +1112,15 @@ def test_resample_chain_fused_bit_exact_vs_scipy_and_two_calls(golden):
     got = B.resample_poly_chain(many, 16000, 44100, 48000)
     for k in (0, 1, 549, 1098, 1099):
         np.testing.assert_array_equal(got[k].cpu().numpy(), signal.resample_poly(signal.resample_poly(many[k], 441, 160), 160, 147))
+    # another input rate of the same geometry (8 kHz: 441/80 then 160/147) runs fused; 32 kHz (441/320: the input window no longer
+    # fits next to the pair buffers) falls to two calls - same bits either way
+    for sr_in, up1, down1, fused in ((8000, 441, 80, True), (32000, 441, 320, False)):
+        bx = B.ResampleChainBatch(B.Ragged.from_list(sig[:4] + sig[6:]), sr_in, 44100, 48000)
+        ox = bx.run()
+        assert bx.ran_fused is fused, (sr_in, bx.ran_fused)
+        for i, s in enumerate(sig[:4] + sig[6:]):
+            np.testing.assert_array_equal(ox[bx.out_off[i]:bx.out_off[i] + bx.out_len[i]].cpu().numpy(),
+                                          signal.resample_poly(signal.resample_poly(s, up1, down1), 160, 147), err_msg="%d Hz item %d" % (sr_in, i))
     # a chain outside the kernel's geometry (48 -> 44.1 -> 16 kHz: down-sampling plans): two calls, same API
     b2 = B.ResampleChainBatch(B.Ragged.from_list(sig[:3]), 48000, 44100, 16000)
     o2 = b2.run()

@@ -227,3 +227,31 @@ def test_length_balanced_sharding_of_the_vctk_shaped_set():
     rr = np.array([lens[np.arange(r, len(lens), 8)].sum() for r in range(8)], dtype=np.float64)
     bal = np.array([lens[D.shard_indices_balanced(lens, r, 8)].sum() for r in range(8)], dtype=np.float64)
     assert bal.max() / bal.mean() < rr.max() / rr.mean()
+
+
+def test_duration_hint_and_balanced_deal_of_a_file_tree(tmp_path):
+    """evaluate(shard="balanced") deals by the duration in the file headers: WAV (RIFF data size) and FLAC (STREAMINFO) agree on
+    what a second is, and the deal is a partition that every rank computes alike."""
+    import flac_fixture as FF
+    from ssr_eval_amd import dist as D
+    from ssr_eval_amd.io import duration_hint, write_wav
+    rng = np.random.default_rng(3)
+    paths, secs = [], []
+    for i, n in enumerate([44100, 22050, 132300, 8000, 66150, 99225]):
+        x = (0.1 * rng.standard_normal(n)).astype(np.float32)
+        p = str(tmp_path / ("f%d.%s" % (i, "flac" if i % 2 else "wav")))
+        if i % 2:
+            with open(p, "wb") as f:
+                f.write(FF.encode(np.round(x * 32767).astype(np.int64), 44100, bits=16))
+        else:
+            write_wav(p, x, 44100)
+        paths.append(p)
+        secs.append(n / 44100.0)
+    got = [duration_hint(p) for p in paths]
+    np.testing.assert_allclose(got, secs, rtol=1e-9)
+    w = [int(round(1000 * g)) for g in got]
+    parts = [D.shard_indices_balanced(w, r, 2) for r in range(2)]
+    assert sorted(np.concatenate(parts).tolist()) == list(range(6))
+    loads = [sum(w[i] for i in p) for p in parts]
+    assert max(loads) / (sum(loads) / 2.0) < 1.1
+    assert duration_hint(str(tmp_path / "missing.wav")) == 0.0

@@ -15,10 +15,11 @@ def one():
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(1)
     x = (0.1 * torch.randn((n, bench.N_SAMPLES), generator=g, device=dev)).contiguous()
-    plan = B.get_plan(2048, hop, "f64", dev)
+    prec = os.environ.get("PREC", "f64")
+    plan = B.get_plan(2048, hop, prec, dev)
     lb = B.LowpassBatch(plan, B.Ragged.from_uniform(x), [256] * n)
     ms = bench.event_time_ms(lambda: lb.run(), 10)
-    print(json.dumps({"lib": os.path.basename(os.environ.get("SSR_DEV_LIB", "default")), "hop": hop, "fft_lowpass_ms": round(ms, 4)}), flush=True)
+    print(json.dumps({"lib": os.path.basename(os.environ.get("SSR_DEV_LIB", "default")), "prec": prec, "hop": hop, "fft_lowpass_ms": round(ms, 4)}), flush=True)
 
 
 if __name__ == "__main__":

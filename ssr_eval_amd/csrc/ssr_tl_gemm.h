@@ -159,6 +159,9 @@ __device__ __forceinline__ void ssr_tl_gemm_body(const SsrTlParams& p, char* sme
     float* st = lds + stage * STAGE_FLOATS;
     float* bs = st + (INV ? 2 : 1) * A_FLOATS;
     const int k0 = chunk * SSR_TL_BK;
+#if defined(SSR_TL_EXP_NOB)             /* developer experiment (timing only, wrong results): B staged for the first chunks only */
+    if (chunk < 2)
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = 4 * wave + i, which = q >> 3, r = 2 * (q & 7) + brow;
@@ -169,6 +172,9 @@ __device__ __forceinline__ void ssr_tl_gemm_body(const SsrTlParams& p, char* sme
       ssr_tl_glds16(src, (char*)(bs + which * B_FLOATS + 2 * (q & 7) * SSR_TL_BN));
     }
     const bool in_k = k0 + ak < K;
+#if defined(SSR_TL_EXP_NOA)             /* developer experiment (timing only, wrong results): A loaded for the first chunks only */
+    if (chunk < 2)
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       ra1[j] = in_k ? a1p[j][k0] : 0.0f;

@@ -9,6 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools')); import devlib; devlib.select()   # SSR_DEV_LIB: alternative build  # noqa: E402,E702
 from ssr_eval_amd import backend as B, _lib  # noqa: E402
 from oracle import tl_chain, stft as ostft  # noqa: E402
 

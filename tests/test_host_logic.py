@@ -255,3 +255,33 @@ def test_duration_hint_and_balanced_deal_of_a_file_tree(tmp_path):
     loads = [sum(w[i] for i in p) for p in parts]
     assert max(loads) / (sum(loads) / 2.0) < 1.1
     assert duration_hint(str(tmp_path / "missing.wav")) == 0.0
+
+
+def test_cabi_round4_entry_points_validate_before_the_device():
+    """ssr_resample_poly_chain (null arguments, bad plans, a geometry the fused kernel does not hold -> SSR_ERR_UNSUPPORTED with the
+    reason), ssr_pair_metrics_multi, ssr_plan_create_ex and the FLAC entry points reject bad arguments on the host (fake non-null
+    pointers are never dereferenced; no GPU needed)."""
+    from ssr_eval_amd import _lib
+    lib = _lib.load()
+    p = C.c_void_p(0x1000)
+    ok_chain = (p, p, p, p, p, p, 4, 1000, 441, 160, p, 8821, 28, 160, 147, p, 3201, 11, p, None)
+    bad = list(ok_chain); bad[3] = None                                                   # mid_len missing
+    assert lib.ssr_resample_poly_chain(*bad) == _lib.ERR_INVALID_ARG
+    bad = list(ok_chain); bad[8] = 0                                                      # up1 = 0
+    assert lib.ssr_resample_poly_chain(*bad) == _lib.ERR_INVALID_ARG
+    bad = list(ok_chain); bad[6] = 0                                                      # empty batch: nothing to do
+    assert lib.ssr_resample_poly_chain(*bad) == 0
+    # 48 -> 44.1 -> 16 kHz (147/160 then 160/441): down-sampling plans have 221 and 441 taps per phase, not 21
+    assert lib.ssr_resample_poly_chain(p, p, p, p, p, p, 4, 1000, 147, 160, p, 3201, 10, 160, 441, p, 8821, 10, p, None) == _lib.ERR_UNSUPPORTED
+    assert b"21-tap" in lib.ssr_last_error()
+    # 21-tap phases but the wrong block geometry (3/2 then 160/147: 8 x 3 != 24 x 147)
+    assert lib.ssr_resample_poly_chain(p, p, p, p, p, p, 4, 1000, 441, 160, p, 8821, 28, 80, 147, p, 3201, 11, p, None) == _lib.ERR_UNSUPPORTED
+    assert lib.ssr_pair_metrics_multi(None, p, p, p, p, p, p, 2, 3, 4096, 18, 15, p, p, 1 << 20, None) == _lib.ERR_INVALID_ARG
+    assert lib.ssr_pair_metrics_multi_workspace_bytes(None, 2, 3, 4096, 18, 15) == 0
+    h = C.c_void_p()
+    assert lib.ssr_plan_create_ex(1, 441, None, 1, 0, C.byref(h)) == _lib.ERR_INVALID_ARG        # n_fft < 2
+    assert lib.ssr_plan_create_ex(2048, 441, None, 1, 7, C.byref(h)) == _lib.ERR_INVALID_ARG     # unknown pad mode
+    assert lib.ssr_plan_create_ex(2048, 441, None, 1, 0, None) == _lib.ERR_INVALID_ARG
+    sr, ch, b, md5, tot = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int64()
+    assert lib.ssr_flac_info(b"/nonexistent/x.flac", C.byref(sr), C.byref(ch), C.byref(b), C.byref(tot), C.byref(md5)) != 0
+    assert lib.ssr_flac_info(None, C.byref(sr), C.byref(ch), C.byref(b), C.byref(tot), C.byref(md5)) == _lib.ERR_INVALID_ARG

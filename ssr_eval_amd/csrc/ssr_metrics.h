@@ -153,18 +153,22 @@ SSR_DEV void ssr_ssim_row_load(const SsrSsimParams& p, SsrSsimRegs<CPT>& R, int 
   const int64_t ea = (int64_t)row_add * pitch + c_in0;                     // block-uniform element offsets of the rows
   const int64_t es = (int64_t)(sub ? row_sub : row_add) * pitch + c_in0;
   if constexpr (CONTIG) {
-    static_assert(!CONTIG || CPT == 4, "four consecutive columns per thread");
+    static_assert(!CONTIG || CPT == 4 || CPT == 8, "four or eight consecutive columns per thread");
     // (a quad past the strip's last column - narrow last strip - is clamped to the last aligned quad: never used, see apply)
     const int last4 = (ncol_in - 1) & ~3;
-    const unsigned c4 = (unsigned)((4 * tid < last4) ? 4 * tid : last4);
     // (the leaving rows come from the rings - x: registers, y: LDS; R.px[SET][2..3] are not loaded)
-    float q[2][4];
-    x.at4(ea, c4, q[0]); y.at4(ea, c4, q[1]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { R.px[SET][0][i] = q[0][i]; R.px[SET][1][i] = q[1][i]; }
+    for (int h = 0; h < CPT / 4; ++h) {
+      const int c0 = CPT * tid + 4 * h;
+      const unsigned c4 = (unsigned)((c0 < last4) ? c0 : last4);
+      float q[2][4];
+      x.at4(ea, c4, q[0]); y.at4(ea, c4, q[1]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { R.px[SET][0][4 * h + i] = q[0][i]; R.px[SET][1][4 * h + i] = q[1][i]; }
+    }
     int ce = SSR_SSIM_NT * CPT + tid;
     if (ce >= ncol_in) ce = ncol_in - 1;
-    R.px[SET][0][4] = x.at(ea, (unsigned)ce); R.px[SET][1][4] = y.at(ea, (unsigned)ce);
+    R.px[SET][0][CPT] = x.at(ea, (unsigned)ce); R.px[SET][1][CPT] = y.at(ea, (unsigned)ce);
     return;
   }
 #pragma unroll
@@ -201,15 +205,17 @@ SSR_DEV void ssr_ssim_row_apply(SsrSsimRegs<CPT>& R, int tid, bool sub, int ncol
 // step mod 7) - and takes their places in both rings.  No condition on the ring traffic: a thread past the strip's last column
 // moves clamped, never-used values, and threads without an extra column share one spare slot.  No condition on "is there a leaving
 // row yet" either: both rings start as zeros, and subtracting a zero row changes no bit of the sums.
-template <int SET, int SLOT>
-SSR_DEV void ssr_ssim_row_apply_contig(SsrSsimRegs<4>& R, float* yrow, int tid) {
-  constexpr int CPT = 4, VC = CPT + 1;
+template <int CPT, int SET, int SLOT>
+SSR_DEV void ssr_ssim_row_apply_contig(SsrSsimRegs<CPT>& R, float* yrow, int tid) {
+  constexpr int VC = CPT + 1;
   float* own = yrow + CPT * tid;
   float* ext = yrow + SSR_SSIM_NT * CPT + (tid < 7 ? tid : 7);
   float d[VC];
-  ssr_ld4(own, d);
+#pragma unroll
+  for (int h = 0; h < CPT / 4; ++h) ssr_ld4(own + 4 * h, d + 4 * h);
   d[CPT] = *ext;
-  ssr_st4(own, R.px[SET][1]);
+#pragma unroll
+  for (int h = 0; h < CPT / 4; ++h) ssr_st4(own + 4 * h, R.px[SET][1] + 4 * h);
   *ext = R.px[SET][1][CPT];
   // (columns past the strip's end: the loads were clamped to valid pixels, their sums are formed and never used)
 #pragma unroll
@@ -353,7 +359,7 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
       const float z4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
       for (int k = 0; k < W; ++k) {
         for (int i = 0; i < VC; ++i) R.ring[k][i] = 0.0f;
-        ssr_st4(L.yring + k * Lds::RW + CPT * tid, z4);
+        for (int h = 0; h < CPT / 4; ++h) ssr_st4(L.yring + k * Lds::RW + CPT * tid + 4 * h, z4);
         L.yring[k * Lds::RW + NT * CPT + (tid & 7)] = 0.0f;
       }
     }
@@ -365,14 +371,15 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
     // column sums cross the lanes one quantity at a time through the single L.col array.
 #define SSR_SSIM_STEP_C(s_, SET, SLOT)                                                                                       \
     SSR_WPHASE(blk, regs, {                                                                                                  \
-      ssr_ssim_row_apply_contig<SET, SLOT>(R, L.yring + (SLOT) * Lds::RW, tid);                                              \
+      ssr_ssim_row_apply_contig<CPT, SET, SLOT>(R, L.yring + (SLOT) * Lds::RW, tid);                                              \
       if ((s_) + 2 < n_steps && !SSR_SABL(4))                                                                                \
         ssr_ssim_row_load<CPT, true, SET>(p, R, tid, x, y, r0 + (s_) + 2, -1, c_in0, ncol_in);                               \
     });                                                                                                                      \
     if ((s_) >= W - 1) {                                                                                                     \
       SSR_UNROLL for (int q = 0; q < 4; ++q) {                                                                               \
         SSR_WPHASE(blk, regs, {             /* every lane publishes: columns past the strip's end carry finite, unused sums */ \
-          SSR_UNROLL for (int i = 0; i < CPT; ++i) L.col[ssr_ssim_slot<CPT>(CPT * tid + i)] = R.cs[i][q];                    \
+          /* (a lane's columns are read by its LEFT neighbour only, and only the first six of them) */                      \
+          SSR_UNROLL for (int i = 0; i < (CPT < 6 ? CPT : 6); ++i) L.col[ssr_ssim_slot<CPT>(CPT * tid + i)] = R.cs[i][q];    \
           L.col[ssr_ssim_slot<CPT>(NT * CPT + (tid < 7 ? tid : 7))] = R.cs[CPT][q];                                          \
         });                                                                                                                  \
         SSR_WPHASE(blk, regs, {                                                                                              \
@@ -380,11 +387,22 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
           SSR_UNROLL for (int d = 0; d < CPT + W - 1; ++d)                                                                   \
             v[d] = (d < CPT) ? R.cs[d < CPT ? d : 0][q]    /* the thread's own columns: already in its registers */         \
                              : L.col[ssr_ssim_slot<CPT>(CPT * tid + d)];                                                     \
-          /* four 7-wide windows over ten column sums: the shared core v3..v6, then v1 + v2 and v7 + v8 (11 additions) */   \
-          static_assert(CPT == 4 && W == 7, "window tree of the CONTIG variant");                                            \
-          const double core = (v[3] + v[4]) + (v[5] + v[6]);                                                                 \
-          const double wa = core + (v[1] + v[2]), wb = core + (v[7] + v[8]);                                                 \
-          const double wq[CPT] = {wa + v[0], wa + v[7], wb + v[2], wb + v[9]};                                               \
+          /* 7-wide windows in groups of four outputs over ten column sums: the shared core v3..v6, then v1 + v2 and       \
+             v7 + v8 (11 additions per group; the eight-column variant shares v5 + v6 and v7 + v8 between its two groups:   \
+             20) - the same association for every output whichever variant computes it */                                    \
+          static_assert((CPT == 4 || CPT == 8) && W == 7, "window tree of the CONTIG variant");                             \
+          double wq[CPT];                                                                                                    \
+          {                                                                                                                  \
+            const double p56 = v[5] + v[6], p78 = v[7] + v[8];                                                               \
+            const double core = (v[3] + v[4]) + p56;                                                                         \
+            const double wa = core + (v[1] + v[2]), wb = core + p78;                                                         \
+            wq[0] = wa + v[0]; wq[1] = wa + v[7]; wq[2] = wb + v[2]; wq[3] = wb + v[9];                                      \
+            if constexpr (CPT == 8) {                                                                                        \
+              const double core2 = p78 + (v[9] + v[10]);                                                                     \
+              const double wa2 = core2 + p56, wb2 = core2 + (v[11] + v[12]);                                                 \
+              wq[4] = wa2 + v[4]; wq[5] = wa2 + v[11]; wq[6] = wb2 + v[6]; wq[7] = wb2 + v[13];                              \
+            }                                                                                                                \
+          }                                                                                                                  \
           /* fold the quantity into the SSIM expression at once (ssr_ssim_value's stages): two live values per output.       \
              The thread's four float32 values of a row are added in float32 (values in [-1, 1]: 1e-7 per row, unbiased,    \
              against the 1e-5 bar on the mean) and join the float64 sum once. */                                             \

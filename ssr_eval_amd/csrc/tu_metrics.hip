@@ -6,8 +6,11 @@
 #ifndef SSR_SSIM_WAVES_PER_EU
 #define SSR_SSIM_WAVES_PER_EU 1
 #endif
+#ifndef SSR_SSIM8_WPE
+#define SSR_SSIM8_WPE 2
+#endif
 template <int CPT, bool CONTIG>
-__global__ __launch_bounds__(SSR_SSIM_NT, SSR_SSIM_WAVES_PER_EU) void k_ssim(SsrSsimParams p) {
+__global__ __launch_bounds__(SSR_SSIM_NT, CPT == 8 ? SSR_SSIM8_WPE : SSR_SSIM_WAVES_PER_EU) void k_ssim(SsrSsimParams p) {      // (eight columns: 256 VGPRs)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SsrBlk blk{(int)threadIdx.x};
   const int tiles = p.n_row_tiles * p.n_strips;
@@ -53,6 +56,7 @@ static SsimGeom ssim_geom(int max_rows, int n_bins, int n_items, bool aligned_ro
 #ifdef SSR_DEV_KNOBS
   static const int cpt_env = getenv("SSR_SSIM_CPT") ? atoi(getenv("SSR_SSIM_CPT")) : 0;
   if (cpt_env >= 1 && cpt_env <= SSR_SSIM_MAXCPT) g.cpt = cpt_env;
+  if (cpt_env == 8 && aligned_rows) g.cpt = 8;              // the eight-column CONTIG variant (experiment: VERDICT r3 item 5)
 #endif
   g.n_strips = n_bins > 6 ? ssr_ceil_div(n_bins - 6, ssr_ssim_strip_out(g.cpt)) : 1;
   return g;
@@ -124,6 +128,10 @@ static int launch_ssim(const float* x, const float* y, const int64_t* frame_off,
   // four consecutive columns per thread through aligned 16-byte loads: rows and both bases 16-byte aligned
   if (g.cpt == 4 && !no_contig && pitch > 0 && pitch % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
     return launch_ssim_inst<4, true>(p, grid, s);
+  if (g.cpt == 8) {
+    if (pitch > 0 && pitch % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) return launch_ssim_inst<8, true>(p, grid, s);
+    return ssr_fail(SSR_ERR_UNSUPPORTED, "the eight-column SSIM kernel needs 16-byte aligned rows");
+  }
   switch (g.cpt) {
     case 1: return launch_ssim_inst<1>(p, grid, s);
     case 2: return launch_ssim_inst<2>(p, grid, s);
@@ -359,6 +367,7 @@ extern "C" int ssr_pair_metrics_multi(const ssr_plan* pl, const float* est, cons
                     ssim_part + (size_t)key0 * n_items * m.n_tiles, pitch, n_items, (int64_t)(m.plane / sizeof(float))};
     const int grid = n_items * n_k * m.n_tiles;
     if (m.w.sg.cpt == 4) return launch_ssim_inst<4, true>(p, grid, s);
+    if (m.w.sg.cpt == 8) return launch_ssim_inst<8, true>(p, grid, s);
     switch (m.w.sg.cpt) {
       case 1: return launch_ssim_inst<1>(p, grid, s);
       case 2: return launch_ssim_inst<2>(p, grid, s);

@@ -255,8 +255,9 @@ extern "C" int emu_ssim(const float* x, const float* y, const int64_t* frame_off
                         int F, int pitch, int contig, int rows_per_tile, int n_row_tiles, int n_strips, int cpt, double* part) {
   SsrSsimParams p{x, y, frame_off, n_rows, F, rows_per_tile, n_row_tiles, n_strips, part, pitch};
   if (contig) {
-    if (cpt != 4 || pitch % 4 != 0 || pitch < F) return -2;
-    run_ssim<4, true>(p, n_items);
+    if ((cpt != 4 && cpt != 8) || pitch % 4 != 0 || pitch < F) return -2;
+    if (cpt == 4) run_ssim<4, true>(p, n_items);
+    else run_ssim<8, true>(p, n_items);
     return 0;
   }
   switch (cpt) {

@@ -100,6 +100,14 @@ def test_ssim_contiguous_columns_variant(shape):
         # the same float64 moments; this variant adds a thread's four float32 SSIM values of a row in float32 before they join the
         # float64 sum (<= 6e-8 worst case on the mean, ~1e-10 observed)
         assert abs(out_c[i, 3] - out_s[i, 3]) < 5e-9
+    # the eight-column variant of the same kernel (two aligned 16-byte reads per image row, six sums from LDS per eight outputs):
+    # the same window sums bit for bit, a lane's float32 row sum over eight values instead of four
+    sp_8, _ = E.ssim_parts(xs, ys, rows_per_tile=4, cpt=8, contig=True)
+    assert np.isfinite(sp_8).all()
+    out_8 = E.finalize(None, sp_8, T, shape[1], 8)
+    for i in range(2):
+        assert abs(out_8[i, 3] - ossim.structural_similarity(xs[i], ys[i])) < 2e-7
+        assert abs(out_8[i, 3] - out_c[i, 3]) < 3e-8
 
 
 def test_fft_lowpass_and_istft(golden):

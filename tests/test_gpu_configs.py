@@ -245,6 +245,11 @@ def test_cfg5_full_launch_2048_utterances_bit_exact():
     e1, e2 = (y1.double() ** 2).mean(dim=1), (y2.double() ** 2).mean(dim=1)
     assert float(e1.std() / e1.mean()) < 0.02 and float(e2.std() / e2.mean()) < 0.02
     assert np.isfinite(lsd).all() and lsd.std() / lsd.mean() < 0.01
+    # the same launch through the fused kernel (ssr_resample_poly_chain: what bench.py --config cfg5 times): EVERY sample of
+    # every utterance identical to the two-call result, compared on the device
+    chain = B.ResampleChainBatch(B.Ragged.from_uniform(x), 16000, 44100, 48000, fused=True)
+    yc = chain.run()
+    assert chain.ran_fused is True and torch.equal(yc, s2.out)
 
 
 def test_cfg5_bench_launch_12500_utterances_oracle_spot_checks():
@@ -274,6 +279,11 @@ def test_cfg5_bench_launch_12500_utterances_oracle_spot_checks():
     e1, e2 = (y1.double() ** 2).mean(dim=1), (y2.double() ** 2).mean(dim=1)
     assert float(e1.std() / e1.mean()) < 0.02 and float(e2.std() / e2.mean()) < 0.02
     assert float((e1 / e1.mean() - 1).abs().max()) < 0.1 and float((e2 / e2.mean() - 1).abs().max()) < 0.1
+    # the bench's launch of the FUSED chain (one workgroup of seven producer and five consumer waves per utterance, 52 iterations):
+    # all 2.4 G output samples identical to the two-call result
+    chain = B.ResampleChainBatch(B.Ragged.from_uniform(x), 16000, 44100, 48000, fused=True)
+    yc = chain.run()
+    assert chain.ran_fused is True and torch.equal(yc, s2.out)
 
 
 @pytest.mark.parametrize("hop", [441, 512])

@@ -131,7 +131,7 @@ __device__ __forceinline__ void ssr_resample_chain_body(const SsrResampleChainPa
   lds_float* carry = yb + 4 * p.y_pairs;                                // [2][32]
   const int YB = 2 * p.y_pairs;
   // stage 2's window of block b starts at intermediate index lo2(b) = qmin2 + b B - (HPP - 1); stage-1 block P covers the indices
-  // [P B + qmin2, (P + 1) B + qmin2): pair index of its sample (residue r, step s) in buffer P & 1 is r + s up1 + (HPP - 1)
+  // [P B + qmin2, (P + 1) B + qmin2): pair index of its sample (residue r, step s) in its iteration's buffer is r + s up1 + (HPP - 1)
   const int qmin2 = (int)(((unsigned)p.npr2 * (unsigned)down2) / (unsigned)up2);
 
   if (tid < NT1) {

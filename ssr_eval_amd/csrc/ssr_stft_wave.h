@@ -408,11 +408,18 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
               wa.st_raw2(xo + 2 * lane4 + 4 * (64 * b + 256 * (q0 + q)), e.x, e.y);
               wb.st_raw2(xo + 2 * lane4 + 4 * (64 * b + 256 * (q0 + q)), t.x, t.y);
 #else
+#if defined(SSR_EXP_STORE_NT)        /* developer experiment: streaming (nt) stores for the magnitude rows */
+              wa.st_raw_nt(xo + lane4 + 4 * (64 * b + 256 * (q0 + q)), e.x);
+              wa.st_raw_nt(xo + lane4 + 4 * (64 * b + 256 * (q0 + q + 1)), e.y);
+              wb.st_raw_nt(xo + lane4 + 4 * (64 * b + 256 * (q0 + q)), t.x);
+              wb.st_raw_nt(xo + lane4 + 4 * (64 * b + 256 * (q0 + q + 1)), t.y);
+#else
               wa.st_raw(xo + lane4 + 4 * (64 * b + 256 * (q0 + q)), e.x);
               wa.st_raw(xo + lane4 + 4 * (64 * b + 256 * (q0 + q + 1)), e.y);
 #if !defined(SSR_EXP_STORE_HALF)     /* developer ablation: only the estimate's row is written */
               wb.st_raw(xo + lane4 + 4 * (64 * b + 256 * (q0 + q)), t.x);
               wb.st_raw(xo + lane4 + 4 * (64 * b + 256 * (q0 + q + 1)), t.y);
+#endif
 #endif
 #endif
             }

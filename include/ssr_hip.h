@@ -92,11 +92,16 @@ int ssr_plan_query(const ssr_plan* plan, int* n_fft, int* hop, int* n_bins, int*
  *     DFT convolutions (nn.Conv1d with DFT x Hann weights computed in float64, stored float32); a hard-low-passed signal's stop band is
  *     that transform's round-off floor, and LSD / log-SISpec of the degraded input take its logarithm: against the float64 FFT engines
  *     above they differ by 2-7 % (LSD).  This engine runs the same dense products on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 =
- *     a float32 fused-multiply-add chain), accumulating in chains of 128 terms added in float32 - the fixed member of the class that
- *     oracle/tl_chain.c restates bit for bit - followed by F.fold's float32 overlap-add and window-sum division.  ssr_fft_lowpass,
+ *     a float32 fused-multiply-add chain) IN THE ACCUMULATION ORDER OF TORCH-CPU'S F.conv1d (oneDNN, AVX-512, >= 2 threads,
+ *     established bit for bit: tests/test_oracle.py::test_tl_chain_is_torch_conv1d_bit_for_bit): forward one chain of n_fft terms
+ *     per output (what torch runs for signals of >= 55 frames), inverse one chain per block of 256 channels of the mirrored
+ *     spectrum, the blocks added in float32 in order - oracle/tl_chain.c restates it, the kernels reproduce it bit for bit -
+ *     followed by F.fold's float32 overlap-add and window-sum division.  With the reference's own weight tables
+ *     (ssr_plan_set_tl_weights) a low-passed waveform of >= 55 frames IS the reference's, sample for sample.  ssr_fft_lowpass(_multi),
  *     ssr_istft and ssr_stft(SSR_STFT_COMPLEX) of such a plan all run it.  n_fft = 32 m.  Cost: 2 n_fft (2 cut) + 2 n_fft (4 cut)
  *     flops per frame instead of two FFTs (10-30x the time of the default engine), and ssr_ola_workspace_bytes grows to
- *     (4 n_fft + hop) floats per frame.  The Python mirror makes it the default of lowpass(_type="stft_hard") and FDomainHelper. */
+ *     ~(2 n_fft + 2 n_bins + hop) floats per frame.  The Python mirror makes it the default of lowpass(_type="stft_hard") and
+ *     FDomainHelper. */
 #define SSR_LOWPASS_SEGMENTS 0
 #define SSR_LOWPASS_FUSED 1
 #define SSR_LOWPASS_CONV 2
@@ -107,6 +112,16 @@ int ssr_plan_set_lowpass_engine(ssr_plan* plan, int engine);
  * HOST pointers (the one exception to the device-pointer convention; any may be NULL): a host-only introspection call, needs no GPU;
  * the parity tests feed these tables to oracle/tl_chain.c. */
 int ssr_tl_weights(int n_fft, float* fwd_re_t, float* fwd_im_t, float* inv_re_t, float* inv_im_t, float* w2);
+/* Replace the SSR_LOWPASS_CONV tables of a plan by the caller's (HOST pointers, torchlibrosa's own module layout):
+ *   fwd_re / fwd_im [n_bins][n_fft] = STFT.conv_real / conv_imag .weight[:, 0, :]   (torchlibrosa stft.py STFT.__init__)
+ *   inv_re / inv_im [n_fft][n_fft]  = ISTFT.conv_real / conv_imag .weight[:, :, 0]  (row = output sample, column = channel)
+ *   w2 [n_fft] = float32(window ** 2)                                              (ISTFT._get_ifft_window_sum_onnx / fold input)
+ * The Python mirror evaluates DFTBase.dft_matrix / idft_matrix with the module's own numpy expressions (np.power(omega, x * y) in
+ * complex128) and hands the float32 results over, so that the engine multiplies by the REFERENCE'S weights to the last bit (the
+ * library's own tables - exact phase reduction in long double - differ from numpy's in 1 ulp of ~0.5 % of the entries).
+ * Call it before the plan is shared between threads / before launches that should see the tables are enqueued. */
+int ssr_plan_set_tl_weights(ssr_plan* plan, const float* fwd_re, const float* fwd_im, const float* inv_re, const float* inv_im,
+                            const float* w2);
 /* The same for a caller-supplied window (HOST float64 [n_fft], NULL = periodic Hann): the tables of an ssr_plan_create_ex plan. */
 int ssr_tl_weights_ex(int n_fft, const double* window, float* fwd_re_t, float* fwd_im_t, float* inv_re_t, float* inv_im_t, float* w2);
 /* T = 1 + (n + 2 pad - n_fft) / hop, pad = n_fft / 2 (0 for a center = 0 plan; then T = 0 when n < n_fft)
@@ -226,6 +241,17 @@ size_t ssr_ola_workspace_bytes(const ssr_plan* plan, int64_t total_rows);
 int ssr_fft_lowpass(const ssr_plan* plan, const float* in, const int64_t* off, const int32_t* len, const int32_t* cut,
                     const int64_t* frame_off, int n_items, int max_len, int64_t total_rows, float* out,
                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* K6 for ONE batch and K cut-offs: SSR_Eval_Helper.lowpass_stft_hard (ssr_eval/eval.py:401-410) loops stft_hard_lowpass_v0 over the
+ * cutoffs of setting_fft on the same waveform.  cuts: HOST array of n_keys cut bins, each applied to every item of the batch
+ * (int(n_bins * (cutoff // 2) / int(fs / 2)) with the evaluator's one fs).  Key k's output goes to out + k * key_stride (elements),
+ * in the input's layout (same off / len).  On the SSR_LOWPASS_CONV engine the padded copy and the forward dense-DFT product are
+ * computed ONCE, at the largest cut (spectrogram_phase and mag * cos / mag * sin of a bin do not depend on the cut: every output is
+ * bit-identical to K ssr_fft_lowpass calls), followed by one inverse product per key over that key's channels; row tiles run over
+ * the whole batch (one cut per launch).  The FFT engines run K plain calls.  workspace: ssr_ola_workspace_bytes(plan, total_rows). */
+int ssr_fft_lowpass_multi(const ssr_plan* plan, const float* in, const int64_t* off, const int32_t* len, const int32_t* cuts,
+                          int n_keys, const int64_t* frame_off, int n_items, int max_len, int64_t total_rows, float* out,
+                          int64_t key_stride, void* workspace, size_t workspace_bytes, void* stream);
 
 /* K6'.  Inverse STFT: torchlibrosa ISTFT.forward(real, imag, length) as used by
  * FDomainHelper.spectrogram_phase_to_wav / reverse_complex_spectrogram (ssr_eval/dsp.py:67-70,107-119).

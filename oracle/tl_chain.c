@@ -1,20 +1,27 @@
-/* Oracle (TEST INFRASTRUCTURE): torchlibrosa's STFT -> hard low-pass -> ISTFT in the reference's arithmetic class, with the one
- * thing the published code leaves to the BLAS kernel - the float32 accumulation order of the dense DFT dot products - FIXED so
- * that a GPU kernel can be compared with it bit for bit:
+/* Oracle (TEST INFRASTRUCTURE): torchlibrosa's STFT -> hard low-pass -> ISTFT in the reference's arithmetic, with the one
+ * thing the published code leaves to the BLAS kernel - the float32 accumulation order of the dense DFT dot products - written
+ * out.  The order restated here is the one torch-CPU (2.10, oneDNN 3.7.1, AVX-512 host, >= 2 threads) runs for
+ * torchlibrosa's two convolutions, established by BIT-FOR-BIT comparison with F.conv1d in this container
+ * (tests/test_oracle.py::test_tl_chain_is_torch_conv1d_bit_for_bit; profiles/r05_lowpass_class_members.json):
  *
- *   a dot product over K terms is evaluated as chains of `kb` fused multiply-adds (ascending k, starting from 0.0f), the chains'
- *   results added to a float32 total in order ("K-blocked sgemm with FMA": what oneDNN / MKL kernels do, with kb their block).
+ *   STFT.forward  (F.conv1d, stride hop, kernel n_fft; signals of >= 55 frames):  ONE chain of n_fft fused multiply-adds per
+ *                 output, ascending sample index, starting from 0.0f                                             (kb = 0)
+ *   ISTFT.forward (the two 1x1 F.conv1d over the n_fft channels of the Hermitian-mirrored spectrum): chains of fused
+ *                 multiply-adds over BLOCKS OF 256 CHANNELS of the full spectrum (channel index / 256), ascending channel,
+ *                 each from 0.0f; the blocks' results added to a float32 total in ascending block order       (kbf = 256)
+ *                 - an all-zero channel adds exact zeros and is skipped.
+ * (Single-threaded torch blocks the inverse differently - 384 or 448 channels, by shape -, MKL sgemm 384 at 8 threads, OpenBLAS
+ * 512: other members of the same class, up to 0.8 % apart in LSD of the low-passed signal.)
  *
  * Everything else follows the published modules step by step (torchlibrosa 0.0.7-0.0.9 stft.py, as wrapped by
  * ssr_eval/dsp.py:21-39,76-81,107-119 and driven by ssr_eval/lowpass.py:17-28):
  *   STFT.forward     reflect pad n_fft/2, real = conv1d(x, W_re, stride hop), imag = conv1d(x, W_im)       float32
  *   spectrogram_phase mag = clamp(re*re + im*im, 1e-8)^0.5, cos = re / mag, sin = im / mag               float32, no contraction
  *   lowpass.py:24-25  mag[cut:] = 0;   ISTFT input = (mag * cos, mag * sin)
- *   ISTFT.forward    Hermitian mirror, s = conv_real(full_re) - conv_imag(full_im) (1x1 convs over n_fft channels; all-zero
- *                    channels add exact zeros and are skipped), F.fold (col2im: for a given output sample the frames are added
- *                    in DESCENDING frame order - the loop runs over the kernel offset), divided by the folded hann^2 (same order,
- *                    float32) clamped at 1e-11, trimmed to [n_fft/2, n_fft/2 + length).
- * The weight matrices are inputs (oracle/stft.py::tl_weights, or the tables libssrhip builds: ssr_tl_weights).
+ *   ISTFT.forward    Hermitian mirror, s = conv_real(full_re) - conv_imag(full_im), F.fold (col2im: for a given output sample
+ *                    the frames are added in DESCENDING frame order - the loop runs over the kernel offset), divided by the
+ *                    folded hann^2 (same order, float32) clamped at 1e-11, trimmed to [n_fft/2, n_fft/2 + length).
+ * The weight matrices are inputs (oracle/stft.py::tl_weights = torchlibrosa's own numpy construction).
  *
  * Build: gcc -O2 -mfma -ffp-contract=off -shared -fPIC (oracle/tl_chain.py).  fmaf() must be the correctly rounded one
  * (-mfma inlines vfmadd; glibc's software fmaf is also exact).
@@ -24,8 +31,9 @@
 #include <stdlib.h>
 #include <string.h>
 
-/* out[c] = sum_k a[k] * w[k * ldw + c], c < ncols, chains of kb terms.  acc / tot: scratch [ncols]. */
+/* out[c] = sum_k a[k] * w[k * ldw + c], c < ncols, chains of kb terms (kb <= 0: one chain).  acc / tot: scratch [ncols]. */
 static void chain_rows(const float* a, int K, const float* w, int64_t ldw, int ncols, int kb, float* acc, float* tot) {
+  if (kb <= 0) kb = K > 0 ? K : 1;
   for (int c = 0; c < ncols; ++c) tot[c] = 0.0f;
   for (int k0 = 0; k0 < K; k0 += kb) {
     const int k1 = k0 + kb < K ? k0 + kb : K;
@@ -69,39 +77,40 @@ void tl_chain_magphase_cut(float* re, float* im, int64_t rows, int nb, int cut, 
 }
 
 /* Inverse transform + fold + window-sum division + trim.  re / im: [T][nb] (bins >= nbz are taken as zero);
- * ire_t / iim_t: [n_fft][n_fft] TRANSPOSED inverse weights (row = bin k of the FULL spectrum, column = output sample);
+ * ire_t / iim_t: [n_fft][n_fft] TRANSPOSED inverse weights (row = channel k of the FULL spectrum, column = output sample);
+ * kbf: channels per chain block of the full spectrum (<= 0: one chain over all channels);
  * w2: window^2 float32 [n_fft]; out: [length]; start: first kept sample of the overlap-added signal (ISTFT._trim_edges: n_fft / 2
  * when the forward transform was centred, 0 otherwise); samples past its end are written as 0. */
 void tl_chain_istft(const float* re, const float* im, int T, int nb, int nbz, int n_fft, int hop, const float* ire_t,
-                    const float* iim_t, const float* w2, int kb, int length, int start, float* out) {
+                    const float* iim_t, const float* w2, int kbf, int length, int start, float* out) {
   const int half = n_fft / 2;
   if (nbz > nb) nbz = nb;
-  int mmax = nbz - 1 < half - 1 ? nbz - 1 : half - 1;       /* mirrored bins 1 .. mmax */
+  if (kbf <= 0) kbf = n_fft;
+  int mmax = nbz - 1 < half - 1 ? nbz - 1 : half - 1;       /* mirrored bins 1 .. mmax = channels n_fft - mmax .. n_fft - 1 */
   if (mmax < 0) mmax = 0;
   const int K = nbz + mmax;                                  /* non-zero channels of the full spectrum, ascending channel order */
-  float* fre = (float*)malloc(sizeof(float) * (K + 1));
-  float* fim = (float*)malloc(sizeof(float) * (K + 1));
-  float* wre = (float*)malloc(sizeof(float) * (size_t)(K + 1) * n_fft);   /* the K rows of the weight tables, compacted */
-  float* wim = (float*)malloc(sizeof(float) * (size_t)(K + 1) * n_fft);
-  for (int j = 0; j < K; ++j) {
-    const int ch = j < nbz ? j : n_fft - mmax + (j - nbz);
-    memcpy(wre + (size_t)j * n_fft, ire_t + (size_t)ch * n_fft, sizeof(float) * n_fft);
-    memcpy(wim + (size_t)j * n_fft, iim_t + (size_t)ch * n_fft, sizeof(float) * n_fft);
-  }
   float* s = (float*)malloc(sizeof(float) * (size_t)T * n_fft);
-  float* acc = (float*)malloc(sizeof(float) * n_fft);
-  float* sr = (float*)malloc(sizeof(float) * n_fft);
-  float* si = (float*)malloc(sizeof(float) * n_fft);
+  float* a1 = (float*)malloc(sizeof(float) * n_fft);
+  float* a2 = (float*)malloc(sizeof(float) * n_fft);
+  float* t1 = (float*)malloc(sizeof(float) * n_fft);
+  float* t2 = (float*)malloc(sizeof(float) * n_fft);
   for (int t = 0; t < T; ++t) {
     const float* r = re + (int64_t)t * nb;
     const float* i = im + (int64_t)t * nb;
+    for (int m = 0; m < n_fft; ++m) { t1[m] = 0.0f; t2[m] = 0.0f; a1[m] = 0.0f; a2[m] = 0.0f; }
+    int prev_block = -1;
     for (int j = 0; j < K; ++j) {
-      if (j < nbz) { fre[j] = r[j]; fim[j] = i[j]; }
-      else { const int src = mmax - (j - nbz); fre[j] = r[src]; fim[j] = -i[src]; }
+      const int src = j < nbz ? j : mmax - (j - nbz);        /* bin the channel's value comes from */
+      const int ch = j < nbz ? j : n_fft - src;              /* channel of the full spectrum */
+      const float fr = r[src], fi = j < nbz ? i[src] : -i[src];
+      if (ch / kbf != prev_block && prev_block >= 0)         /* a chain ends: total += chain, restart from 0 */
+        for (int m = 0; m < n_fft; ++m) { t1[m] = t1[m] + a1[m]; t2[m] = t2[m] + a2[m]; a1[m] = 0.0f; a2[m] = 0.0f; }
+      prev_block = ch / kbf;
+      const float* wr = ire_t + (size_t)ch * n_fft;
+      const float* wi = iim_t + (size_t)ch * n_fft;
+      for (int m = 0; m < n_fft; ++m) { a1[m] = fmaf(fr, wr[m], a1[m]); a2[m] = fmaf(fi, wi[m], a2[m]); }
     }
-    chain_rows(fre, K, wre, n_fft, n_fft, kb, acc, sr);
-    chain_rows(fim, K, wim, n_fft, n_fft, kb, acc, si);
-    for (int m = 0; m < n_fft; ++m) s[(size_t)t * n_fft + m] = sr[m] - si[m];
+    for (int m = 0; m < n_fft; ++m) s[(size_t)t * n_fft + m] = (t1[m] + a1[m]) - (t2[m] + a2[m]);
   }
   for (int p = 0; p < length; ++p) {
     const int q = p + start;
@@ -116,5 +125,5 @@ void tl_chain_istft(const float* re, const float* im, int T, int nb, int nbz, in
     if (ws < 1e-11f) ws = 1e-11f;
     out[p] = y / ws;
   }
-  free(fre); free(fim); free(wre); free(wim); free(s); free(acc); free(sr); free(si);
+  free(s); free(a1); free(a2); free(t1); free(t2);
 }

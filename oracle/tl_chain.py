@@ -1,6 +1,7 @@
-"""Oracle (test infrastructure): ctypes driver of oracle/tl_chain.c - torchlibrosa's dense float32 DFT low-pass with a FIXED
-accumulation order (chains of `kb` fused multiply-adds), the member of the reference's arithmetic class that the HIP
-`SSR_LOWPASS_CONV` engine computes bit for bit.  See the C file's header for the reference citations."""
+"""Oracle (test infrastructure): ctypes driver of oracle/tl_chain.c - torchlibrosa's dense float32 DFT low-pass with the
+accumulation order written out: the order torch-CPU's F.conv1d runs (forward: one chain of n_fft fused multiply-adds; inverse:
+chains over blocks of 256 channels of the full spectrum), which the HIP `SSR_LOWPASS_CONV` engine computes bit for bit.
+See the C file's header for the reference citations and how the order was established."""
 import ctypes as C
 import os
 import subprocess
@@ -12,7 +13,8 @@ from . import stft as _stft
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "tl_chain.c")
 SO = os.path.join(_HERE, "_build", "libtlchain.so")
-KB = 128          # chain length of the HIP engine (ssr_eval_amd/csrc/ssr_tl_gemm.h: SSR_TL_KB)
+KB_FWD = 0        # forward chain length: 0 = one chain over the n_fft samples of a frame (torch's strided conv1d, >= 55 frames)
+KB_INV = 256      # inverse: channels of the FULL spectrum per chain block (ssr_eval_amd/csrc/ssr_tl_gemm.h: SSR_TL_KBF)
 
 
 def build(force=False):
@@ -43,7 +45,7 @@ def transposed_weights(n_fft, weights=None, window="hann"):
     return (np.ascontiguousarray(fr.T), np.ascontiguousarray(fi.T), np.ascontiguousarray(ir.T), np.ascontiguousarray(ii.T), w2)
 
 
-def stft(x, n_fft=2048, hop=441, kb=KB, weights=None, nb=None, window="hann", center=True, pad_mode="reflect"):
+def stft(x, n_fft=2048, hop=441, kb=KB_FWD, weights=None, nb=None, window="hann", center=True, pad_mode="reflect"):
     """x [n] float32 -> (re, im) [T, nb] float32 (nb = n_fft//2+1 by default)."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     frt, fit, _, _, _ = transposed_weights(n_fft, weights, window)
@@ -65,22 +67,22 @@ def stft(x, n_fft=2048, hop=441, kb=KB, weights=None, nb=None, window="hann", ce
     return re, im
 
 
-def istft(re, im, length, n_fft=2048, hop=441, kb=KB, weights=None, nbz=None, window="hann", center=True):
+def istft(re, im, length, n_fft=2048, hop=441, kbf=KB_INV, weights=None, nbz=None, window="hann", center=True):
     re = np.ascontiguousarray(re, dtype=np.float32)
     im = np.ascontiguousarray(im, dtype=np.float32)
     T, nb = re.shape
     _, _, irt, iit, w2 = transposed_weights(n_fft, weights, window)
     out = np.empty(length, np.float32)
-    lib().tl_chain_istft(_f(re), _f(im), T, nb, nb if nbz is None else nbz, n_fft, hop, _f(irt), _f(iit), _f(w2), kb, length,
+    lib().tl_chain_istft(_f(re), _f(im), T, nb, nb if nbz is None else nbz, n_fft, hop, _f(irt), _f(iit), _f(w2), kbf, length,
                          n_fft // 2 if center else 0, _f(out))
     return out
 
 
-def stft_hard_lowpass(x, cut, n_fft=2048, hop=441, kb=KB, weights=None, window="hann", center=True, pad_mode="reflect"):
+def stft_hard_lowpass(x, cut, n_fft=2048, hop=441, kb=KB_FWD, kbf=KB_INV, weights=None, window="hann", center=True, pad_mode="reflect"):
     """ssr_eval/lowpass.py:17-28 with cut = the first zeroed bin."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     F = n_fft // 2 + 1
     cut = min(int(cut), F)
     re, im = stft(x, n_fft, hop, kb, weights, nb=cut, window=window, center=center, pad_mode=pad_mode)
     lib().tl_chain_magphase_cut(_f(re), _f(im), C.c_int64(re.shape[0]), cut, cut, C.c_float(1e-8))
-    return istft(re, im, len(x), n_fft, hop, kb, weights, window=window, center=center)
+    return istft(re, im, len(x), n_fft, hop, kbf, weights, window=window, center=center)

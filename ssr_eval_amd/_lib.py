@@ -28,6 +28,7 @@ SIGNATURES = {
     "ssr_plan_destroy": (_i, [_vp]),
     "ssr_plan_query": (_i, [_vp] + [C.POINTER(_i)] * 6),
     "ssr_plan_set_lowpass_engine": (_i, [_vp, _i]),
+    "ssr_plan_set_tl_weights": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "ssr_tl_weights": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "ssr_tl_weights_ex": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssr_num_frames": (_i64, [_vp, _i64]),
@@ -50,6 +51,7 @@ SIGNATURES = {
     "ssr_sispec_multichannel": (_i, [_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _sz, _vp]),
     "ssr_ola_workspace_bytes": (_sz, [_vp, _i64]),
     "ssr_fft_lowpass": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _vp, _vp, _sz, _vp]),
+    "ssr_fft_lowpass_multi": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i64, _vp, _i64, _vp, _sz, _vp]),
     "ssr_istft": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _vp, _vp, _sz, _vp]),
     "ssr_resample_plan": (_i, [_i64, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64), C.POINTER(_i),
                                C.POINTER(_i), C.POINTER(_i)]),

@@ -5,6 +5,7 @@ produced by the HIP kernels behind the C ABI.  Batches are ragged: one flat floa
 int64 offsets / int32 lengths, all resident in HBM.
 """
 import ctypes as C
+import functools
 import math
 import threading
 
@@ -38,6 +39,31 @@ def _stream():
 def num_frames(n, n_fft, hop):
     """T of a centred STFT (bit-exact integer)."""
     return 1 + (int(n) + 2 * (n_fft // 2) - n_fft) // hop
+
+
+@functools.lru_cache(maxsize=4)
+def _tl_dft_matrices(n):
+    """torchlibrosa DFTBase.dft_matrix / idft_matrix (stft.py): W[x, y] = omega ** (x y) with omega = exp(-/+ 2 pi i / n), evaluated
+    as the module evaluates it - numpy's complex128 power on the integer product grid - so that the float32 weights below are the
+    reference's to the last bit (ssr_eval/dsp.py:21-39 builds STFT / ISTFT, which build these)."""
+    x, y = np.meshgrid(np.arange(n), np.arange(n))
+    return np.power(np.exp(-2 * np.pi * 1j / n), x * y), np.power(np.exp(2 * np.pi * 1j / n), x * y)
+
+
+def tl_conv_weights(n_fft, window=None):
+    """The float32 Conv1d weights of torchlibrosa's STFT / ISTFT for a float64 window [n_fft] (None: periodic Hann =
+    librosa.filters.get_window("hann", n_fft, fftbins=True)), in the modules' layout:
+    (fwd_re, fwd_im [n_bins, n_fft]; inv_re, inv_im [n_fft (output sample), n_fft (channel)]; float32(window ** 2))."""
+    n, F = int(n_fft), int(n_fft) // 2 + 1
+    W, Wi = _tl_dft_matrices(n)
+    if window is None:
+        import scipy.signal
+        window = scipy.signal.get_window("hann", n, fftbins=True)
+    win = np.asarray(window, dtype=np.float64)
+    fw = W[:, :F] * win[:, None]                      # STFT.__init__: conv weights = (W[:, 0:out_channels] * window[:, None]).T
+    iw = (Wi / n) * win[None, :]                      # ISTFT.init_real_imag_conv: (W / n_fft * ifft_window[None, :]).T
+    c32 = lambda a: np.ascontiguousarray(a).astype(np.float32)          # noqa: E731
+    return (c32(np.real(fw).T), c32(np.imag(fw).T), c32(np.real(iw).T), c32(np.imag(iw).T), (win ** 2).astype(np.float32))
 
 
 class Plan:
@@ -74,8 +100,16 @@ class Plan:
             raise ValueError("this plan is shared through get_plan() under its engine; ask get_plan(..., lowpass_engine=%r)" % engine)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ssr_plan_set_lowpass_engine(self.handle, _ENGINES[engine]))
+            if engine == "conv":
+                self._upload_tl_weights(None)
         self.lowpass_engine = engine
         return self
+
+    def _upload_tl_weights(self, window):
+        """The conv engine multiplies by torchlibrosa's OWN weight values (tl_conv_weights: the module's numpy expressions), not by
+        the library's independently computed tables (1 ulp apart in ~0.5 % of the entries)."""
+        tabs = tl_conv_weights(self.n_fft, window)
+        _lib.check(self.lib.ssr_plan_set_tl_weights(self.handle, *[t.ctypes.data_as(C.c_void_p) for t in tabs]))
 
     def __del__(self):
         try:
@@ -110,7 +144,8 @@ class PlanEx(Plan):
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ssr_plan_create_ex(self.n_fft, self.hop, None if w is None else w.ctypes.data, int(self.center),
                                                    self._PAD[pad_mode], C.byref(h)))
-        self.handle = h
+            self.handle = h
+            self._upload_tl_weights(w)
         self.fft_len, self.bluestein = 0, False
         self.lowpass_engine = "conv"
 
@@ -501,9 +536,11 @@ class LowpassBatch:
             raise ValueError("the STFT-domain low-pass takes float32 signals (torchlibrosa's convolution does too)")
         self.plan, self.r = plan, ragged
         self.rows = _Rows(plan, ragged.lens_host, ragged.device)
-        self.cut = torch.from_numpy(np.asarray(cut_bins, dtype=np.int32)).to(ragged.device)
-        if self.cut.numel() != ragged.n:
+        cuts = np.asarray(cut_bins, dtype=np.int32).reshape(-1)
+        if cuts.size != ragged.n:
             raise ValueError("one cut bin per item")
+        self.uniform = int(cuts[0]) if cuts.size and bool((cuts == cuts[0]).all()) else None
+        self.cut = torch.from_numpy(cuts).to(ragged.device)
         self.ws_bytes = int(plan.lib.ssr_ola_workspace_bytes(plan.handle, self.rows.total))
         self.ws = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=ragged.device)
         # out: a caller-owned float32 buffer of the batch's size (e.g. one key's slice of a multi-key estimate buffer)
@@ -513,7 +550,14 @@ class LowpassBatch:
 
     def run(self):
         p, r = self.plan, self.r
-        if r.n:
+        if not r.n:
+            return self.out
+        if self.uniform is not None:
+            # one cut for the whole batch: the launch's row tiles run across item boundaries (ssr_fft_lowpass_multi with one key)
+            cuts = (C.c_int32 * 1)(self.uniform)
+            _lib.check(p.lib.ssr_fft_lowpass_multi(p.handle, _vp(r.data), _vp(r.off), _vp(r.len), cuts, 1, _vp(self.rows.off), r.n,
+                                                   r.max_len, self.rows.total, _vp(self.out), 0, _vp(self.ws), self.ws_bytes, _stream()))
+        else:
             _lib.check(p.lib.ssr_fft_lowpass(p.handle, _vp(r.data), _vp(r.off), _vp(r.len), _vp(self.cut), _vp(self.rows.off),
                                              r.n, r.max_len, self.rows.total, _vp(self.out), _vp(self.ws), self.ws_bytes,
                                              _stream()))
@@ -521,6 +565,50 @@ class LowpassBatch:
 
     def out_ragged(self):
         return Ragged(self.out, self.r.off, self.r.len, self.r.lens_host)
+
+
+class MultiLowpassBatch:
+    """One ragged batch, K cut bins applied to every item (SSR_Eval_Helper.lowpass_stft_hard's loop over setting_fft,
+    ssr_eval/eval.py:401-410): ssr_fft_lowpass_multi.  `run()` returns the [K, batch samples] float32 output (key-major; row k has
+    the input batch's layout); `out_ragged(k)` views key k as a Ragged batch for the metric stage.  On the conv engine the padded
+    copy and the forward product are computed once for the K keys."""
+
+    def __init__(self, plan, ragged, cut_bins, out=None):
+        _check_reflect(plan, ragged.lens_host)
+        if ragged.data.dtype != torch.float32:
+            raise ValueError("the STFT-domain low-pass takes float32 signals (torchlibrosa's convolution does too)")
+        self.plan, self.r = plan, ragged
+        self.rows = _Rows(plan, ragged.lens_host, ragged.device)
+        self.cuts = np.asarray(cut_bins, dtype=np.int32).reshape(-1)
+        self.n_keys = int(self.cuts.size)
+        self.ws_bytes = int(plan.lib.ssr_ola_workspace_bytes(plan.handle, self.rows.total))
+        self.ws = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=ragged.device)
+        total = ragged.data.numel()
+        if out is not None and (out.dtype != torch.float32 or out.numel() != self.n_keys * total or not out.is_contiguous()):
+            raise ValueError("out must be a contiguous float32 buffer of n_keys x the batch's size")
+        self.out = (out if out is not None else torch.empty(self.n_keys * total, dtype=torch.float32, device=ragged.device)).view(self.n_keys, total)
+
+    def run(self):
+        p, r = self.plan, self.r
+        if r.n and self.n_keys:
+            _lib.check(p.lib.ssr_fft_lowpass_multi(p.handle, _vp(r.data), _vp(r.off), _vp(r.len), self.cuts.ctypes.data_as(C.c_void_p),
+                                                   self.n_keys, _vp(self.rows.off), r.n, r.max_len, self.rows.total, _vp(self.out),
+                                                   r.data.numel(), _vp(self.ws), self.ws_bytes, _stream()))
+        return self.out
+
+    def out_ragged(self, k):
+        return Ragged(self.out[k], self.r.off, self.r.len, self.r.lens_host)
+
+
+def fft_lowpass_multi(plan, wavs, cut_bins):
+    """K hard low-passes of every waveform of a list: [[key 0's outputs], [key 1's], ...]."""
+    with torch.cuda.device(plan.device):
+        r = wavs if isinstance(wavs, Ragged) else Ragged.from_list(wavs, plan.device)
+        if r.n == 0:
+            return [[] for _ in cut_bins]
+        b = MultiLowpassBatch(plan, r, cut_bins)
+        out = b.run()
+        return [r.split(out[k]) for k in range(b.n_keys)]
 
 
 def fft_lowpass(plan, wavs, cut_bins):

@@ -120,5 +120,8 @@ size_t ssr_tl_workspace_bytes(const ssr_plan* pl, int64_t total_rows);
 int ssr_tl_run_inverse(const ssr_plan* pl, const float* in, const int64_t* in_off, const int32_t* len, const int32_t* cut,
                        const float* re, const float* im, const int64_t* frame_off, const int64_t* out_off, int n_items,
                        int max_len, int64_t total_rows, float* out, void* workspace, size_t workspace_bytes, hipStream_t s);
+int ssr_tl_run_multi(const ssr_plan* pl, const float* in, const int64_t* in_off, const int32_t* len, const int32_t* cuts_host,
+                     int n_keys, const int64_t* frame_off, int n_items, int max_len, int64_t total_rows, float* out,
+                     int64_t key_stride, void* workspace, size_t workspace_bytes, hipStream_t s);
 int ssr_tl_stft(const ssr_plan* pl, const float* wav, const int64_t* wav_off, const int32_t* wav_len, const int64_t* frame_off,
                 int n_items, int max_len, float* out_re, float* out_im, hipStream_t s);

@@ -226,6 +226,37 @@ extern "C" int ssr_fft_lowpass(const ssr_plan* pl, const float* in, const int64_
                      workspace_bytes, (hipStream_t)stream);
 }
 
+__global__ void k_fill_i32(int32_t* dst, int32_t v, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = v;
+}
+
+extern "C" int ssr_fft_lowpass_multi(const ssr_plan* pl, const float* in, const int64_t* off, const int32_t* len,
+                                     const int32_t* cuts_host, int n_keys, const int64_t* frame_off, int n_items, int max_len,
+                                     int64_t total_rows, float* out, int64_t key_stride, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  if (!pl || !in || !off || !len || !cuts_host || !frame_off || !out) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n_items <= 0 || n_keys <= 0) return SSR_OK;
+  if (int rc_dev = ssr_check_plan_device(pl, true)) return rc_dev;
+  if (int rc_len = ssr_check_max_len(pl, max_len)) return rc_len;
+  if (max_len >= (1 << 29)) return ssr_fail(SSR_ERR_UNSUPPORTED, "signals of 2^29 samples or more (4 GiB buffer views)");
+  hipStream_t s = (hipStream_t)stream;
+  if (pl->lowpass_engine == SSR_LOWPASS_CONV)
+    return ssr_tl_run_multi(pl, in, off, len, cuts_host, n_keys, frame_off, n_items, max_len, total_rows, out, key_stride, workspace,
+                            workspace_bytes, s);
+  // the FFT engines have nothing to share between keys (forward and inverse transform of a frame are one kernel): K plain calls
+  int32_t* cut = nullptr;
+  HIP_TRY(hipMallocAsync((void**)&cut, sizeof(int32_t) * (size_t)n_items, s));
+  int rc = SSR_OK;
+  for (int k = 0; k < n_keys && !rc; ++k) {
+    hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)ssr_ceil_div(n_items, 256)), dim3(256), 0, s, cut, cuts_host[k], n_items);
+    rc = run_inverse(pl, in, off, len, cut, nullptr, nullptr, frame_off, off, n_items, max_len, total_rows,
+                     out + (int64_t)k * key_stride, workspace, workspace_bytes, s);
+  }
+  (void)hipFreeAsync(cut, s);
+  return rc;
+}
+
 extern "C" int ssr_istft(const ssr_plan* pl, const float* re, const float* im, const int64_t* frame_off,
                          const int32_t* len, const int64_t* out_off, int n_items, int max_len, int64_t total_rows,
                          float* out, void* workspace, size_t workspace_bytes, void* stream) {

@@ -18,7 +18,7 @@ import torch
 
 from . import backend as B
 from . import dist as D
-from .lowpass import lowpass, lowpass_batch, stft_hard_lowpass_batch
+from .lowpass import lowpass, lowpass_batch, stft_hard_lowpass_multi
 from .metrics import AudioMetrics
 from .utils import dict_mean, write_json
 
@@ -152,8 +152,8 @@ class SSR_Eval_Helper:
 
     def lowpass_stft_hard(self, file, x, sr):
         keys, ratios = self._fft_plan_keys(sr)
-        ys = stft_hard_lowpass_batch([x] * len(keys), ratios, self._device)
-        return dict(zip(keys, ys))
+        ys = stft_hard_lowpass_multi([x], ratios, self._device)          # one call for the cutoffs of setting_fft
+        return {k: y[0] for k, y in zip(keys, ys)}
 
     def lowpass_subsampling(self, file, x, sr):
         ret = {}
@@ -286,10 +286,10 @@ class SSR_Eval_Helper:
         if self.setting_fft is not None:
             keys, ratios = self._fft_plan_keys(sr)
             src = xs if resident is None else resident
-            ys = stft_hard_lowpass_batch([x for x in src for _ in keys], ratios * len(xs), self._device, keep_on_device=keep_on_device)
+            ys = stft_hard_lowpass_multi(list(src), ratios, self._device, keep_on_device=keep_on_device)
             for i, ret in enumerate(rets):
                 for j, k in enumerate(keys):
-                    ret[k] = ys[i * len(keys) + j]
+                    ret[k] = ys[j][i]
         return rets
 
     def preprocess(self, file, sr):

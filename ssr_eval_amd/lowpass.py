@@ -18,11 +18,13 @@ from . import backend as B
 
 N_FFT, HOP = 2048, 441          # FDomainHelper() defaults used by the reference's global f_helper (lowpass.py:167)
 _precision = "f64"
-# Engine of the STFT-domain low-pass (include/ssr_hip.h: ssr_plan_set_lowpass_engine).  "conv" = the reference's arithmetic class
-# (torchlibrosa's dense float32 DFT convolutions, on the fp32 matrix cores): the degraded input's stop band - the transform's
-# round-off floor - sits where the reference's does, so LSD / log-SISpec of the degraded input agree with the reference's to the
-# spread of the class itself instead of 2-7 % off.  "segments" / "fused" = float64 FFT engines: the exact
-# low-pass, 10-30x faster, for callers that want the ideal filter rather than the reference's numbers.
+# Engine of the STFT-domain low-pass (include/ssr_hip.h: ssr_plan_set_lowpass_engine).  "conv" = the reference's arithmetic
+# (torchlibrosa's dense float32 DFT convolutions with the module's own weights, accumulated in torch-CPU's F.conv1d order, on the
+# fp32 matrix cores): for a signal of >= 55 frames (0.55 s at 44.1 kHz) the degraded waveform is the reference's bit for bit, so
+# its stop band - the transform's round-off floor, whose logarithm LSD / log-SISpec take - is the reference's too (DESIGN.md
+# section 4); shorter signals, where torch switches its forward convolution to another summation order, agree to the spread of
+# the arithmetic class.  "segments" / "fused" = float64 FFT engines: the exact low-pass, 10-30x faster, 2-7 % off in LSD of the
+# degraded input - for callers that want the ideal filter rather than the reference's numbers.
 DEFAULT_ENGINE = "conv"
 
 
@@ -43,6 +45,16 @@ def stft_hard_lowpass_batch(datas, ratios, device=None, keep_on_device=False, en
     ys = B.fft_lowpass(plan, [d if isinstance(d, torch.Tensor) else np.asarray(d, np.float32) for d in datas],
                        [cut_bin(r) for r in ratios])
     return list(ys) if keep_on_device else [y.cpu().numpy() for y in ys]
+
+
+def stft_hard_lowpass_multi(datas, ratios, device=None, keep_on_device=False, engine=None):
+    """Every waveform of `datas` low-passed at EVERY ratio of `ratios` - the loop of SSR_Eval_Helper.lowpass_stft_hard over
+    setting_fft (ssr_eval/eval.py:401-410) for a batch of files: [[outputs at ratios[0]], [at ratios[1]], ...].  One
+    ssr_fft_lowpass_multi call: on the conv engine the padded copy and the forward dense-DFT product are shared by the ratios."""
+    plan = B.get_plan(N_FFT, HOP, _precision, device, lowpass_engine=engine or DEFAULT_ENGINE)
+    ys = B.fft_lowpass_multi(plan, [d if isinstance(d, torch.Tensor) else np.asarray(d, np.float32) for d in datas],
+                             [cut_bin(r) for r in ratios])
+    return [list(y) if keep_on_device else [v.cpu().numpy() for v in y] for y in ys]
 
 
 def align_length(x, y):

@@ -1,5 +1,6 @@
-"""Developer tool: the SSR_LOWPASS_CONV engine against oracle/tl_chain.c (bit-exact expected) and its time per launch."""
-import ctypes as C
+"""Developer tool: the SSR_LOWPASS_CONV engine against oracle/tl_chain.c and torch-CPU's own conv1d (bit-exact expected) and its
+time per launch.  PARITY=0 skips the checks; UTT = utterances of the timing runs (default 1024 x 4 s @ 48 kHz = BASELINE cfg-3);
+with a -DSSR_DEV_KNOBS build (SSR_DEV_LIB) VARIANTS="128:2,128:3,64:2" times the inverse product's tile variants."""
 import os
 import sys
 import time
@@ -10,74 +11,101 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tools')); import devlib; devlib.select()   # SSR_DEV_LIB: alternative build  # noqa: E402,E702
-from ssr_eval_amd import backend as B, _lib  # noqa: E402
+from ssr_eval_amd import backend as B  # noqa: E402
 from oracle import tl_chain, stft as ostft  # noqa: E402
 
+CUTS = (42, 85, 170, 256, 341, 512, 683)
 
-def lib_weights(n_fft):
-    lib = _lib.load()
-    F = n_fft // 2 + 1
-    a, b = np.empty((n_fft, F), np.float32), np.empty((n_fft, F), np.float32)
-    c, d = np.empty((n_fft, n_fft), np.float32), np.empty((n_fft, n_fft), np.float32)
-    w2 = np.empty(n_fft, np.float32)
-    _lib.check(lib.ssr_tl_weights(n_fft, *[x.ctypes.data_as(C.c_void_p) for x in (a, b, c, d, w2)]))
-    # oracle layout: fwd [F, n_fft], inv [n_fft(sample), n_fft(channel)]
-    return (np.ascontiguousarray(a.T), np.ascontiguousarray(b.T), np.ascontiguousarray(c.T), np.ascontiguousarray(d.T)), w2
+
+def torch_conv_lowpass(x, cut):
+    """stft_hard_lowpass_v0 through the published torchlibrosa arithmetic on torch-CPU (oracle restatement of the modules)."""
+    re, im = ostft.tl_stft_conv(x[None])
+    mag = np.clip(re ** 2 + im ** 2, np.float32(1e-8), np.inf) ** np.float32(0.5)
+    c, s_ = re / mag, im / mag
+    mag[..., cut:] = 0
+    return ostft.tl_istft_conv(mag * c, mag * s_, len(x))[0]
+
+
+def report(what, got, want):
+    got = got.cpu().numpy() if isinstance(got, torch.Tensor) else got
+    print("%-46s mismatching %d / %d, max |diff| %.3e" % (what, int((got != want).sum()), want.size, float(np.abs(got - want).max())), flush=True)
+
+
+def parity(plan):
+    n_fft, hop = plan.n_fft, plan.hop
+    rng = np.random.default_rng(5)
+    lens = [30000, 12345, 48000, 1500, 28223, 26001]
+    cuts = [85, 683, 256, 1025, 42, 557]
+    sigs = [(0.1 * rng.standard_normal(n)).astype(np.float32) for n in lens]
+    ys = B.fft_lowpass(plan, sigs, cuts)                       # per-item cuts
+    for x, c, y in zip(sigs, cuts, ys):
+        report("per-item cut n=%d cut=%d vs tl_chain" % (len(x), c), y, tl_chain.stft_hard_lowpass(x, c, n_fft, hop))
+    ys = B.fft_lowpass(plan, sigs, [341] * len(sigs))          # one cut: row tiles across items
+    for x, y in zip(sigs, ys):
+        report("uniform cut 341 n=%d vs tl_chain" % len(x), y, tl_chain.stft_hard_lowpass(x, 341, n_fft, hop))
+    yk = B.fft_lowpass_multi(plan, sigs, CUTS)
+    for c, ys in zip(CUTS, yk):
+        bad = sum(int((y.cpu().numpy() != tl_chain.stft_hard_lowpass(x, c, n_fft, hop)).sum()) for x, y in zip(sigs, ys))
+        print("multi cut %4d vs tl_chain: %d mismatching samples over %d signals" % (c, bad, len(sigs)), flush=True)
+    torch.set_num_threads(8)
+    for x, c in ((sigs[0], 85), (sigs[2], 683), (sigs[5], 557)):
+        y = B.fft_lowpass(plan, [x], [c])[0]
+        report("n=%d cut=%d vs TORCH conv1d (8 threads)" % (len(x), c), y, torch_conv_lowpass(x, c))
+    re, im = B.stft(plan, sigs[:3], kind="complex", torch_style_pad=True)
+    for x, r, i in zip(sigs[:3], re, im):
+        wr, wi = tl_chain.stft(x, n_fft, hop)
+        report("stft complex n=%d re" % len(x), r, wr)
+        report("stft complex n=%d im" % len(x), i, wi)
+    wr, wi = tl_chain.stft(sigs[0], n_fft, hop)
+    y = B.istft(plan, [torch.from_numpy(wr)], [torch.from_numpy(wi)], [lens[0]])[0]
+    report("istft", y, tl_chain.istft(wr, wi, lens[0], n_fft, hop))
+    print("istft round trip err %.3e" % float(np.abs(y.cpu().numpy() - sigs[0]).max()))
+
+
+def timeit(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.time() - t) / reps
 
 
 def main():
     n_fft, hop = 2048, 441
-    wts, w2 = lib_weights(n_fft)
-    ref = ostft.tl_weights(n_fft)
-    for name, x, y in zip(("fwd_re", "fwd_im", "inv_re", "inv_im"), wts, ref):
-        print("weights", name, "identical", float((x == y).mean()), "max diff", float(np.abs(x - y).max()))
     plan = B.get_plan(n_fft, hop, "f64", lowpass_engine="conv")
-    rng = np.random.default_rng(5)
-    lens = [30000, 12345, 48000, 1500, 28223]
-    cuts = [85, 683, 256, 1025, 42]
-    sigs = [(0.1 * rng.standard_normal(n)).astype(np.float32) for n in lens]
-    ys = B.fft_lowpass(plan, sigs, cuts)
-    torch.cuda.synchronize()
-    for x, c, y in zip(sigs, cuts, ys):
-        want = tl_chain.stft_hard_lowpass(x, c, n_fft, hop, weights=wts)
-        got = y.cpu().numpy()
-        print("lowpass n=%d cut=%d: max |diff| %.3e, mismatching samples %d / %d, max |y| %.3f" % (
-            len(x), c, np.abs(got - want).max(), int((got != want).sum()), len(x), np.abs(want).max()))
-    # stft complex
-    re, im = B.stft(plan, sigs[:2], kind="complex", torch_style_pad=True)
-    for x, r, i in zip(sigs[:2], re, im):
-        wr, wi = tl_chain.stft(x, n_fft, hop, weights=wts)
-        print("stft: mismatches re %d im %d of %d" % (int((r.cpu().numpy() != wr).sum()), int((i.cpu().numpy() != wi).sum()), wr.size))
-    # istft of given spectra
-    wr, wi = tl_chain.stft(sigs[0], n_fft, hop, weights=wts)
-    y = B.istft(plan, [torch.from_numpy(wr)], [torch.from_numpy(wi)], [lens[0]])[0].cpu().numpy()
-    want = tl_chain.istft(wr, wi, lens[0], n_fft, hop, weights=wts)
-    print("istft: mismatches %d of %d, max diff %.3e, round trip err %.3e" % (int((y != want).sum()), len(y), np.abs(y - want).max(), np.abs(y - sigs[0]).max()))
-    # timing: 256 x 4 s @ 48 kHz per cut
-    n_utt = int(os.environ.get("UTT", 256))
+    if os.environ.get("PARITY", "1") != "0":
+        parity(plan)
+    n_utt = int(os.environ.get("UTT", 1024))
     g = torch.Generator(device="cuda").manual_seed(1)
     data = 0.1 * torch.randn(n_utt, 192000, device="cuda", generator=g)
-    wavs = [data[i] for i in range(n_utt)]
-    for cut in (42, 85, 170, 256, 341, 512, 683, 1025):
-        B.fft_lowpass(plan, wavs, [cut] * n_utt)
-        torch.cuda.synchronize()
-        t = time.time()
-        for _ in range(3):
-            B.fft_lowpass(plan, wavs, [cut] * n_utt)
-        torch.cuda.synchronize()
-        dt = (time.time() - t) / 3
-        T = 1 + 192000 // hop
-        K = cut + min(cut - 1, 1023)
-        flops = n_utt * T * (2.0 * 2048 * 2 * cut + 2.0 * 2048 * 2 * K)
-        print("cut %4d: %.2f ms per %d utterances, %.1f TFLOP/s useful" % (cut, dt * 1e3, n_utt, flops / dt / 1e12))
-    p64 = B.get_plan(n_fft, hop, "f64")
-    B.fft_lowpass(p64, wavs, [256] * n_utt)
-    torch.cuda.synchronize()
-    t = time.time()
-    for _ in range(3):
-        B.fft_lowpass(p64, wavs, [256] * n_utt)
-    torch.cuda.synchronize()
-    print("float64 FFT engine: %.2f ms" % ((time.time() - t) / 3 * 1e3))
+    r = B.Ragged.from_uniform(data)
+    T = 1 + 192000 // hop
+    variants = [v.split(":") for v in os.environ.get("VARIANTS", "").split(",") if v] or [(None, None)]
+    for bm, ns in variants:
+        if bm is not None:
+            os.environ["SSR_TL_BM"], os.environ["SSR_TL_NS"] = bm, ns
+        print("== inverse tile rows %s, stages %s" % (bm or "default", ns or "default"), flush=True)
+        for cut in [int(v) for v in os.environ.get("CUTS_TIMED", "42,85,170,256,341,512,683,1025").split(",") if v]:
+            b = B.LowpassBatch(plan, r, [cut] * n_utt)
+            dt = timeit(b.run)
+            K = cut + min(cut - 1, 1023)
+            flops = n_utt * T * (2.0 * 2048 * 2 * cut + 2.0 * 2048 * 2 * K)
+            print("cut %4d: %7.2f ms per %d utterances, %.1f TFLOP/s useful" % (cut, dt * 1e3, n_utt, flops / dt / 1e12), flush=True)
+            del b
+        if os.environ.get("MULTI", "1") == "0":
+            continue
+        m = B.MultiLowpassBatch(plan, r, CUTS)
+        dt = timeit(m.run, reps=2)
+        flops = n_utt * T * (2.0 * 2048 * 2 * max(CUTS) + sum(2.0 * 2048 * 2 * (c + c - 1) for c in CUTS))
+        print("multi %s: %.2f ms per %d utterances x %d keys = %.1f k pairs/s of degradation alone, %.1f TFLOP/s" % (
+            CUTS, dt * 1e3, n_utt, len(CUTS), n_utt * len(CUTS) / dt / 1e3, flops / dt / 1e12), flush=True)
+        del m
+    if os.environ.get("MULTI", "1") != "0":
+        p64 = B.get_plan(n_fft, hop, "f64")
+        b = B.LowpassBatch(p64, r, [256] * n_utt)
+        print("float64 FFT engine: %.2f ms" % (timeit(b.run) * 1e3))
 
 
 if __name__ == "__main__":

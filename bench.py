@@ -180,33 +180,37 @@ class Cfg3:
     metric = "utterance-pairs/sec (full metric set + FFT low-pass degradation, cutoff sweep {2k..32k}, 48kHz, n_fft=2048)"
     unit = "pairs/s"
 
+    @staticmethod
+    def engine_of(a):
+        """--lowpass-engine, by default the PRODUCT's default (ssr_eval_amd.lowpass.DEFAULT_ENGINE = "conv": the reference's arithmetic)."""
+        import importlib
+        L = importlib.import_module("ssr_eval_amd.lowpass")      # (the package attribute `lowpass` is the function)
+        return getattr(a, "lowpass_engine", None) or L.DEFAULT_ENGINE
+
     def __init__(self, a, dev, rank):
         from ssr_eval_amd import backend as B
         self.B, self.a, self.dev = B, a, dev
+        self.engine = self.engine_of(a)
         g = torch.Generator(device=dev).manual_seed(20220328 + rank)
         n = a.pairs
         self.tgt = (0.1 * torch.randn((n, N_SAMPLES), generator=g, device=dev, dtype=torch.float32)).contiguous()
         tr = B.Ragged.from_uniform(self.tgt)
-        self.lp_plan = B.get_plan(2048, 441, a.precision, dev, lowpass_engine=getattr(a, "lowpass_engine", "segments"))   # FDomainHelper() of ssr_eval/lowpass.py:167
+        self.lp_plan = B.get_plan(2048, 441, a.precision, dev, lowpass_engine=self.engine)   # FDomainHelper() of ssr_eval/lowpass.py:167
         self.plan = B.get_plan(N_FFT, HOP, a.precision, dev)
-        # the seven cutoffs run one after the other on the stream and share the low-pass output / workspace buffers; only
-        # the cut-bin descriptor changes
-        # ONE estimate buffer, key-major [7][n][samples]: cutoff k's low-pass writes plane k; the metric stage is ONE
-        # ssr_pair_metrics_multi launch sequence over the 7 keys (each target transformed and stored once: 8 real transforms and 8
-        # magnitude images per target instead of 14 and 14 - ssr_eval/eval.py:136-154 scores every key against the same target)
+        # ONE estimate buffer, key-major [7][n][samples]: ONE ssr_fft_lowpass_multi call fills it (eval.py:401-410 loops the cutoffs
+        # over the same waveform: on the conv engine the padded copy and the forward dense-DFT product are shared by the 7 keys),
+        # then ONE ssr_pair_metrics_multi launch sequence scores the 7 keys (each target transformed and stored once -
+        # ssr_eval/eval.py:136-154 scores every key against the same target)
         K = len(CUT_BINS)
         self.est = torch.empty((K, n, N_SAMPLES), dtype=torch.float32, device=dev)
-        self.lps = [B.LowpassBatch(self.lp_plan, tr, [c] * n, out=self.est[k].reshape(-1)) for k, c in enumerate(CUT_BINS)]
-        for lp in self.lps[1:]:
-            lp.ws = self.lps[0].ws                      # the cutoffs run one after the other on the stream: one workspace
+        self.mlp = B.MultiLowpassBatch(self.lp_plan, tr, CUT_BINS, out=self.est.view(-1))
         self.batch = B.MultiPairBatch(self.plan, B.Ragged.from_uniform(self.est.view(K * n, N_SAMPLES)), tr, K)
         self.units_per_step = n * K
         self.cnt = torch.full((1,), float(self.units_per_step), dtype=torch.float64, device=dev)
         self.agg = torch.zeros(5, dtype=torch.float64, device=dev)
 
     def step(self):
-        for lp in self.lps:
-            lp.run()                                     # est[k] <- fft_lowpass(target, cut k)
+        self.mlp.run()                                   # est[k] <- fft_lowpass(target, cut k), k = 0 .. 6
         acc = self.batch.run(self.B.M_ALL).sum((0, 1))
         torch.cat([acc, self.cnt], out=self.agg)
         return self.agg
@@ -214,80 +218,92 @@ class Cfg3:
     def config(self, world):
         a = self.a
         return {"workload": "cfg-3: %d synthetic 48 kHz 4 s float32 targets per GPU resident in HBM x 7 cutoffs "
-                            "(cut bins %s of FDomainHelper 2048/441 at fs 48 kHz): est[k] = ssr_fft_lowpass(target, cut k) (engine: %s), then "
-                            "LSD + log-SISpec + SISpec + SSIM of the 7 keys at STFT 2048/512 through ONE ssr_pair_metrics_multi call, "
-                            "transform precision %s" % (a.pairs, CUT_BINS, getattr(a, "lowpass_engine", "segments"), a.precision),
-                "lowpass_engine": getattr(a, "lowpass_engine", "segments"),
+                            "(cut bins %s of FDomainHelper 2048/441 at fs 48 kHz): est[k] = stft_hard low-pass(target, cut k) through ONE "
+                            "ssr_fft_lowpass_multi call (engine: %s%s), then LSD + log-SISpec + SISpec + SSIM of the 7 keys at STFT 2048/512 "
+                            "through ONE ssr_pair_metrics_multi call, metric transform precision %s" % (
+                                a.pairs, CUT_BINS, self.engine, " = the product default, torchlibrosa's float32 dense-DFT arithmetic on the "
+                                "fp32 matrix cores" if self.engine == "conv" else "", a.precision),
+                "lowpass_engine": self.engine,
                 "targets_per_gpu": a.pairs, "cutoffs_hz": CUTOFFS_HZ, "cut_bins": CUT_BINS, "samples_per_utterance": N_SAMPLES,
                 "parallelism": "utterance-sharded x%d, one float64 all-reduce (40 B) per step" % world}
+
+    @staticmethod
+    def conv_flops(n, cuts, shared_forward=True):
+        """Useful flops of the dense-DFT low-pass of n utterances: per frame forward 2 n_fft (2 cut) + inverse 2 n_fft (2 K),
+        K = cut + min(cut - 1, 1023) channels of the mirrored spectrum; the forward product once at the largest cut when shared."""
+        rows = n * (1 + N_SAMPLES // 441)
+        fwd = max(cuts) if shared_forward else sum(cuts)
+        return rows * 2.0 * 2048 * 2 * (fwd + sum(c + min(c - 1, 1023) for c in cuts))
 
     def report(self, a):
         B, batch = self.B, self.batch
         it, K, n = 3, len(CUT_BINS), a.pairs
-        engine = getattr(a, "lowpass_engine", "segments")
-        ms_lp = event_time_ms(lambda: self.lps[3].run(), it)
-        ms_lp_all = event_time_ms(lambda: [lp.run() for lp in self.lps], it)
+        engine = self.engine
+        tr = B.Ragged.from_uniform(self.tgt)
+        ms_lp_all = event_time_ms(lambda: self.mlp.run(), it)
+        one = B.LowpassBatch(self.lp_plan, tr, [CUT_BINS[3]] * n, out=self.est[3].reshape(-1))
+        one.ws = self.mlp.ws
+        ms_lp = event_time_ms(lambda: one.run(), it)
         ms_multi = event_time_ms(lambda: batch.run(B.M_ALL), it)
-        per_key = B.PairBatch(self.plan, B.Ragged.from_uniform(self.est[3]), B.Ragged.from_uniform(self.tgt))
+        per_key = B.PairBatch(self.plan, B.Ragged.from_uniform(self.est[3]), tr)
         ms_pair = event_time_ms(lambda: per_key.run(B.M_ALL), it)       # what one key cost before ssr_pair_metrics_multi
-        stages = {"fft_lowpass": (ms_lp, 2 * N_SAMPLES * 4 * n), "pair_metrics_multi/7": (ms_multi / K, (2 * N_SAMPLES * 4 + 32) * n)}
-        dom = max(stages, key=lambda k: stages[k][0])
-        tkey = {"segments": "k_lowpass_wave+k_ola_paired", "fused": "k_lowpass_group", "conv": "k_tl_gemm"}[engine]
-        lp_name = {"segments": "ssr_fft_lowpass(k_lowpass_wave+k_ola_paired)", "fused": "ssr_fft_lowpass(k_lowpass_group: transforms + overlap-add in one kernel)",
-                   "conv": "ssr_fft_lowpass(conv engine: k_tl_gemm forward + inverse, k_tl_fold)"}[engine]
-        roof = hbm_roofline(lp_name if dom == "fft_lowpass" else "ssr_pair_metrics_multi (7 keys, per key)", stages[dom][1], stages[dom][0],
-                            tkey if dom == "fft_lowpass" and a.pairs == 1024 and a.precision == "f64" else None,
-                            "per cutoff and 1024 utterances; algorithmic bytes: low-pass 2*n*4 per (utterance, cutoff), pair metrics "
-                            "2*n*4+32 per pair (SURVEY 8(d))")
-        if engine == "conv" and dom == "fft_lowpass":
-            # the dense-DFT engine is bound by the fp32 matrix cores (MFMA where the DFT is deliberately cast as a GEMM):
-            # useful flops of the cut-bin-256 launch = frames x (forward 2 n_fft (2 cut) + inverse 2 n_fft (2 K)), K = cut + min(cut - 1, 1023)
-            c = CUT_BINS[3]
-            flops = n * (1 + N_SAMPLES // 441) * (2.0 * 2048 * 2 * c + 2.0 * 2048 * 2 * (c + min(c - 1, 1023)))
-            ach = flops / (ms_lp * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": lp_name, "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 5),
-                    "traffic": roof.get("traffic"), "traffic_source": roof.get("traffic_source"), "useful_flops_per_launch": flops,
-                    "kernel_ms": round(ms_lp, 4), "kernel_ms_source": roof["kernel_ms_source"],
-                    "note": "v_mfma_f32_32x32x2_f32 (exact float32 products, the reference's arithmetic class): dense peak 157.3 TFLOP/s; "
-                            "per cutoff (bin 256) and 1024 utterances, k_tl_pad + k_tl_gemm<0> + k_tl_gemm<2> + k_tl_fold; traffic = the forward product's PMC bytes"}
+        self.mlp.run()                                                  # (restore plane 3)
+        if engine == "conv":
+            # the dense-DFT engine is bound by the fp32 matrix cores (SURVEY 8(d): MFMA where the DFT is deliberately cast as a GEMM)
+            flops = self.conv_flops(n, CUT_BINS)
+            ach = flops / (ms_lp_all * 1e-3) / 1e12
+            counts = {"k_tl_pad": 1, "k_tl_fwd": 1, "k_tl_inv": K, "k_tl_fold": K}
+            traffic, src = None, None
+            if a.pairs == 1024:
+                parts = {k: pmc_traffic(k) for k in counts}
+                if all(v[0] is not None for v in parts.values()):
+                    traffic, src = sum(counts[k] * parts[k][0] for k in counts), parts["k_tl_inv"][1]
+            roof = {"bound": "mfma_f32", "kernel": "ssr_fft_lowpass_multi launch sequence: k_tl_pad + k_tl_fwd<0> (once, cut 683) + 7 x (k_tl_inv + k_tl_fold)",
+                    "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 5),
+                    "traffic": traffic, "traffic_source": src, "useful_flops_per_launch_sequence": flops,
+                    "algorithmic_bytes_per_launch_sequence": int(2 * N_SAMPLES * 4 * n * K),
+                    "kernel_ms": round(ms_lp_all, 4),
+                    "kernel_ms_source": "hip_events on the launch stream around the ONE C-ABI call (its kernels one by one: the rocprofv3 "
+                                        "summary of the same command under profiles/)",
+                    "note": "v_mfma_f32_32x32x2_f32 (exact float32 products in torch-CPU's conv1d accumulation order: the reference's "
+                            "arithmetic, bit for bit): dense peak 157.3 TFLOP/s.  Useful flops per frame: forward 2 n_fft (2 x 683) ONCE for the 7 "
+                            "keys + inverse 2 n_fft (2 K_k) per key, K = 2 cut - 1 channels of the mirrored spectrum; the sequence's time "
+                            "includes the overlap-add (k_tl_fold) and padding kernels.  HBM-wise the same sequence moves 2 n 4 bytes per "
+                            "(utterance, cutoff) algorithmically (SURVEY 8(d)): %.4f of 8 TB/s - not the bound." % (
+                                2 * N_SAMPLES * 4 * n * K / (ms_lp_all * 1e-3) / 1e9 / HBM_PEAK_GBS)}
+        else:
+            stages = {"fft_lowpass": (ms_lp, 2 * N_SAMPLES * 4 * n), "pair_metrics_multi/7": (ms_multi / K, (2 * N_SAMPLES * 4 + 32) * n)}
+            dom = max(stages, key=lambda k: stages[k][0])
+            tkey = {"segments": "k_lowpass_wave+k_ola_paired", "fused": "k_lowpass_group"}[engine]
+            lp_name = {"segments": "ssr_fft_lowpass(k_lowpass_wave+k_ola_paired)",
+                       "fused": "ssr_fft_lowpass(k_lowpass_group: transforms + overlap-add in one kernel)"}[engine]
+            roof = hbm_roofline(lp_name if dom == "fft_lowpass" else "ssr_pair_metrics_multi (7 keys, per key)", stages[dom][1], stages[dom][0],
+                                tkey if dom == "fft_lowpass" and a.pairs == 1024 and a.precision == "f64" else None,
+                                "per cutoff and 1024 utterances; algorithmic bytes: low-pass 2*n*4 per (utterance, cutoff), pair metrics "
+                                "2*n*4+32 per pair (SURVEY 8(d))")
         extra = {"lowpass_engine": engine,
-                 "stage_ms": {"fft_lowpass_one_cutoff(bin 256)": round(ms_lp, 4), "fft_lowpass_7_cutoffs": round(ms_lp_all, 4),
+                 "stage_ms": {"fft_lowpass_one_cutoff(bin 256, own forward product)": round(ms_lp, 4), "fft_lowpass_multi_7_cutoffs": round(ms_lp_all, 4),
                               "pair_metrics_multi_7_keys": round(ms_multi, 4), "pair_metrics_one_key(round 3 path)": round(ms_pair, 4)},
                  "metric_stage_speedup_vs_7_pair_calls": round(K * ms_pair / ms_multi, 3),
-                 "fft_lowpass_utterances_per_s": round(n / (ms_lp * 1e-3), 1),
-                 "fft_lowpass_algorithmic_GBs": round(stages["fft_lowpass"][1] / (ms_lp * 1e-3) / 1e9, 1)}
-        if engine != "conv" and not getattr(a, "no_conv_side", False):
-            # the reference-arithmetic engine (the default of lowpass(_type="stft_hard")) on the same batch, next to the timed one
+                 "fft_lowpass_utterance_cutoffs_per_s": round(n * K / (ms_lp_all * 1e-3), 1)}
+        if engine == "conv":
+            extra["conv_engine_one_cutoff_useful_TFLOPs(bin 256)"] = round(self.conv_flops(n, [CUT_BINS[3]]) / (ms_lp * 1e-3) / 1e12, 1)
+        if not getattr(a, "no_conv_side", False):
+            # SIDE figures: the float64 / float32 FFT engines on the same batch - the exact low-pass, 2-7 % off the reference's LSD of
+            # the degraded input (profiles/r05_cfg3_engines.json), for callers that want speed rather than the reference's numbers
             try:
-                cplan = B.get_plan(2048, 441, a.precision, self.dev, lowpass_engine="conv")
-                tr = B.Ragged.from_uniform(self.tgt)
-                ms = []
-                for k, c in enumerate(CUT_BINS):
-                    lp = B.LowpassBatch(cplan, tr, [c] * n, out=self.est[k].reshape(-1))
-                    ms.append(event_time_ms(lambda: lp.run(), 1))
-                    del lp
-                flops = sum(n * (1 + N_SAMPLES // 441) * (2.0 * 2048 * 2 * c + 2.0 * 2048 * 2 * (c + min(c - 1, 1023))) for c in CUT_BINS)
-                extra["conv_engine(reference arithmetic: dense float32 DFT on the matrix cores)"] = {
-                    "ms_per_cutoff": [round(v, 3) for v in ms], "ms_7_cutoffs": round(sum(ms), 3),
-                    "useful_TFLOPs": round(flops / (sum(ms) * 1e-3) / 1e12, 1), "fp32_mfma_peak_TFLOPs": 157.3,
-                    "cfg3_pairs_per_s_with_it": round(n * K / ((sum(ms) + ms_multi) * 1e-3), 1)}
-                # the float32 FFT engine (SSR_F32 plan, same kernels in float32): faster than the float64 one and CLOSER to the
-                # reference's float32 arithmetic (LSD +1.9 % mean against +3.7 %: profiles/r04_cfg3_engines.json), still outside
-                # the class bar the conv engine meets (1.5 %)
-                if a.precision == "f64":
-                    fplan = B.get_plan(2048, 441, "f32", self.dev, lowpass_engine="segments")
-                    ms32 = []
-                    for k, c in enumerate(CUT_BINS):
-                        lp = B.LowpassBatch(fplan, tr, [c] * n, out=self.est[k].reshape(-1))
-                        ms32.append(event_time_ms(lambda: lp.run(), 2))
-                        del lp
-                    extra["float32_fft_engine(SSR_F32 plan)"] = {
-                        "ms_per_cutoff": [round(v, 3) for v in ms32], "ms_7_cutoffs": round(sum(ms32), 3),
-                        "cfg3_pairs_per_s_with_it": round(n * K / ((sum(ms32) + ms_multi) * 1e-3), 1)}
-                for lp in self.lps:
-                    lp.run()                             # (restore the timed engine's estimates)
+                for label, prec in (("float64_fft_engine(segments)", a.precision), ("float32_fft_engine(SSR_F32 plan)", "f32")):
+                    if engine != "conv" and prec == a.precision:
+                        continue
+                    fplan = B.get_plan(2048, 441, prec, self.dev, lowpass_engine="segments")
+                    m2 = B.MultiLowpassBatch(fplan, tr, CUT_BINS, out=self.est.view(-1))
+                    ms2 = event_time_ms(lambda: m2.run(), 2)
+                    extra[label] = {"ms_7_cutoffs": round(ms2, 3), "cfg3_pairs_per_s_with_it": round(n * K / ((ms2 + ms_multi) * 1e-3), 1),
+                                    "note": "NOT the reference's arithmetic: LSD of the degraded input 2-7 % high"}
+                    del m2
+                self.mlp.run()                           # (restore the timed engine's estimates)
             except Exception as e:                       # a side figure must not take the line down
-                extra["conv_engine_error"] = repr(e)
+                extra["side_engine_error"] = repr(e)
         return roof, extra
 
     def cpu_inputs(self, n):
@@ -301,39 +317,49 @@ class Cfg3:
         r = om.evaluation(est, tgt, n_fft=N_FFT, hop=HOP)
         return r["lsd"], r["ssim"]
 
-    cpu_desc = "(utterance, cutoff) pairs of the same workload (oracle stft_hard low-pass 2048/441 + 4 metrics at 2048/512)"
+    cpu_desc = "(utterance, cutoff) pairs of the same workload (oracle stft_hard low-pass 2048/441 = the published torchlibrosa conv1d arithmetic + 4 metrics at 2048/512)"
 
     def parity(self, out_vals, n, first):
         """CPU-baseline items first .. first + n - 1 (item i = target i mod pairs at cutoff i mod 7): max relative error of
         (LSD, SSIM) of the pair (HIP-degraded, target) against the oracle's metrics of THAT pair - the stop band of a
         low-passed signal is round-off, so the two sides must look at the same degraded signal - and, recorded on the
-        side, the degraded signal itself against the oracle's torchlibrosa restatement (max abs difference)."""
+        side, the degraded signal itself against the oracle's torchlibrosa restatement (torch-CPU conv1d, >= 2 threads: samples
+        that differ, max abs difference) and the PIPELINE (low-pass -> metrics) of the timed engine and of the float64 FFT engine
+        against the reference's arithmetic."""
         from oracle import lowpass as olp, metrics as om
-        B, worst, self.parity_lowpass_max_abs = self.B, 0.0, 0.0
-        dev_ideal, dev_conv = [0.0, 0.0], [0.0, 0.0]
-        cplan = B.get_plan(2048, 441, self.a.precision, self.dev, lowpass_engine="conv")
-        for i in range(first, first + n):
-            j, c = i % self.a.pairs, i % 7
-            t = B.Ragged.from_uniform(self.tgt[j:j + 1])
-            lp = B.LowpassBatch(self.lp_plan, t, [CUT_BINS[c]])
-            est = lp.run().cpu().numpy().copy()
-            tgt = self.tgt[j].cpu().numpy()
-            got = B.PairBatch(self.plan, lp.out_ragged(), t).run(B.M_ALL)[0].cpu().numpy()
-            want = om.evaluation(est, tgt, n_fft=N_FFT, hop=HOP)
-            worst = max(worst, abs(got[0] - want["lsd"]) / abs(want["lsd"]), abs(got[3] - want["ssim"]) / abs(want["ssim"]))
-            ref_est = olp.lowpass(tgt, CUTOFFS_HZ[c], SR, 1, "stft_hard")        # the published torchlibrosa arithmetic on torch-CPU
-            self.parity_lowpass_max_abs = max(self.parity_lowpass_max_abs, float(np.abs(est - ref_est).max()))
-            # the PIPELINE against the reference's arithmetic: this run's engine, and the conv engine
-            ref = om.evaluation(ref_est, tgt, n_fft=N_FFT, hop=HOP)
-            lpc = B.LowpassBatch(cplan, t, [CUT_BINS[c]])
-            lpc.run()
-            gc = B.PairBatch(self.plan, lpc.out_ragged(), t).run(B.M_ALL)[0].cpu().numpy()
-            for dst, g in ((dev_ideal, got), (dev_conv, gc)):
-                dst[0] = max(dst[0], abs(g[0] / ref["lsd"] - 1))
-                dst[1] = max(dst[1], abs(g[1] - ref["log_sispec"]))
-        self.pipeline_dev = {"timed_engine(%s)" % getattr(self.a, "lowpass_engine", "segments"): {"lsd_rel_max": dev_ideal[0], "log_sispec_abs_max_db": dev_ideal[1]},
-                             "conv_engine": {"lsd_rel_max": dev_conv[0], "log_sispec_abs_max_db": dev_conv[1]},
-                             "against": "published torchlibrosa low-pass (float32 conv1d, torch-CPU) -> oracle metrics, same targets"}
+        B, worst, self.parity_lowpass_max_abs, self.parity_lowpass_samples_differing = self.B, 0.0, 0.0, 0
+        dev_timed, dev_f64 = [0.0, 0.0], [0.0, 0.0]
+        old_threads = torch.get_num_threads()
+        torch.set_num_threads(max(2, old_threads))
+        fplan = B.get_plan(2048, 441, self.a.precision, self.dev, lowpass_engine="segments")
+        try:
+            for i in range(first, first + n):
+                j, c = i % self.a.pairs, i % 7
+                t = B.Ragged.from_uniform(self.tgt[j:j + 1])
+                lp = B.LowpassBatch(self.lp_plan, t, [CUT_BINS[c]])
+                est = lp.run().cpu().numpy().copy()
+                # (the timed step's own output plane holds the same samples)
+                assert torch.equal(self.est[c, j].cpu(), torch.from_numpy(est)), "ssr_fft_lowpass_multi differs from ssr_fft_lowpass"
+                tgt = self.tgt[j].cpu().numpy()
+                got = B.PairBatch(self.plan, lp.out_ragged(), t).run(B.M_ALL)[0].cpu().numpy()
+                want = om.evaluation(est, tgt, n_fft=N_FFT, hop=HOP)
+                worst = max(worst, abs(got[0] - want["lsd"]) / abs(want["lsd"]), abs(got[3] - want["ssim"]) / abs(want["ssim"]))
+                ref_est = olp.lowpass(tgt, CUTOFFS_HZ[c], SR, 1, "stft_hard")        # the published torchlibrosa arithmetic on torch-CPU
+                self.parity_lowpass_max_abs = max(self.parity_lowpass_max_abs, float(np.abs(est - ref_est).max()))
+                self.parity_lowpass_samples_differing += int((est != ref_est).sum())
+                ref = om.evaluation(ref_est, tgt, n_fft=N_FFT, hop=HOP)
+                lpf = B.LowpassBatch(fplan, t, [CUT_BINS[c]])
+                lpf.run()
+                gf = B.PairBatch(self.plan, lpf.out_ragged(), t).run(B.M_ALL)[0].cpu().numpy()
+                for dst, g in ((dev_timed, got), (dev_f64, gf)):
+                    dst[0] = max(dst[0], abs(g[0] / ref["lsd"] - 1))
+                    dst[1] = max(dst[1], abs(g[1] - ref["log_sispec"]))
+        finally:
+            torch.set_num_threads(old_threads)
+        self.pipeline_dev = {"timed_engine(%s)" % self.engine: {"lsd_rel_max": dev_timed[0], "log_sispec_abs_max_db": dev_timed[1]},
+                             "float64_fft_engine(side figure)": {"lsd_rel_max": dev_f64[0], "log_sispec_abs_max_db": dev_f64[1]},
+                             "lowpass_samples_differing_from_torch_conv1d": self.parity_lowpass_samples_differing,
+                             "against": "published torchlibrosa low-pass (float32 conv1d, torch-CPU, >= 2 threads) -> oracle metrics, same targets"}
         return worst
 
 
@@ -1013,8 +1039,9 @@ def parse(argv=None):
     ap.add_argument("--pairs", type=int, default=1024, help="cfg2/cfg3: pairs (targets) per GPU per step (BASELINE: 1024)")
     ap.add_argument("--utterances", type=int, default=12500, help="cfg5: utterances per GPU per step (100k over 8 GPUs)")
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--lowpass-engine", dest="lowpass_engine", default="segments", choices=["segments", "fused", "conv"],
-                    help="cfg3: overlap-add through the segment workspace (default, faster inside the pipeline) or fused in the transform kernel")
+    ap.add_argument("--lowpass-engine", dest="lowpass_engine", default=None, choices=["segments", "fused", "conv"],
+                    help="cfg3: engine of the STFT-domain low-pass; default = the product's (ssr_eval_amd.lowpass.DEFAULT_ENGINE = conv: the "
+                         "reference's float32 dense-DFT arithmetic on the matrix cores); segments / fused = float64 FFT (exact, not the reference's)")
     ap.add_argument("--resample-chain", dest="resample_chain", default="fused", choices=["fused", "two-calls"],
                     help="cfg5: both resample_poly stages in one kernel (ssr_resample_poly_chain) or two ssr_resample_poly launches")
     ap.add_argument("--shard", default="balanced", choices=["balanced", "round-robin"], help="cfg4: how the fixed set is dealt to the ranks")

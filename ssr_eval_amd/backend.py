@@ -536,17 +536,24 @@ class LowpassBatch:
             raise ValueError("the STFT-domain low-pass takes float32 signals (torchlibrosa's convolution does too)")
         self.plan, self.r = plan, ragged
         self.rows = _Rows(plan, ragged.lens_host, ragged.device)
-        cuts = np.asarray(cut_bins, dtype=np.int32).reshape(-1)
-        if cuts.size != ragged.n:
-            raise ValueError("one cut bin per item")
-        self.uniform = int(cuts[0]) if cuts.size and bool((cuts == cuts[0]).all()) else None
-        self.cut = torch.from_numpy(cuts).to(ragged.device)
+        self.set_cuts(cut_bins)
         self.ws_bytes = int(plan.lib.ssr_ola_workspace_bytes(plan.handle, self.rows.total))
         self.ws = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=ragged.device)
         # out: a caller-owned float32 buffer of the batch's size (e.g. one key's slice of a multi-key estimate buffer)
         if out is not None and (out.dtype != torch.float32 or out.numel() != ragged.data.numel() or not out.is_contiguous()):
             raise ValueError("out must be a contiguous float32 buffer of the batch's size")
         self.out = out if out is not None else torch.empty_like(ragged.data)
+
+    def set_cuts(self, cut_bins):
+        """One cut bin per item (a scalar: the same for every item).  A batch with ONE cut runs through ssr_fft_lowpass_multi (row
+        tiles across item boundaries), per-item cuts through ssr_fft_lowpass."""
+        cuts = np.asarray(cut_bins, dtype=np.int32).reshape(-1)
+        if cuts.size == 1 and self.r.n != 1:
+            cuts = np.repeat(cuts, self.r.n)
+        if cuts.size != self.r.n:
+            raise ValueError("one cut bin per item")
+        self.uniform = int(cuts[0]) if cuts.size and bool((cuts == cuts[0]).all()) else None
+        self.cut = torch.from_numpy(cuts).to(self.r.device)
 
     def run(self):
         p, r = self.plan, self.r

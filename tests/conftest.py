@@ -88,11 +88,16 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
 
 
 # ---- the arithmetic class of the STFT-domain low-pass --------------------------------------------------
-# Measured on CPU by tests/test_oracle.py::test_lowpass_arithmetic_class_sensitivity (profiles/r04_lowpass_class_sensitivity.json):
-# members of the reference's class (torchlibrosa's float32 dense-DFT products under different accumulation orders) differ from
-# each other by up to 3.4 % in LSD and 0.013 dB in log-SISpec of the degraded input; the HIP conv engine's member (chains of 128
-# fused multiply-adds) sits within 1.04 % / 0.0135 dB of torch-CPU's; the float64-FFT idealisation is 2.4-7 % off in LSD.
-CLASS_LSD_RTOL = 0.015
+# Measured on CPU (tools/exp_class_members.py -> profiles/r05_lowpass_class_members.json; tests/test_oracle.py): the REAL members of
+# the reference's class - torchlibrosa's float32 inverse product through every float32 GEMM this image has: torch F.conv1d (oneDNN)
+# at 1 / 2 / 4 / 8 / 16 threads, torch.mm (MKL) at 1 / 8 threads, numpy @ (OpenBLAS) - differ from each other by up to 0.77 % in LSD
+# of the degraded input (2 signals x 7 cutoffs) and 0.004 dB in log-SISpec; a Hermitian-folded inverse (half the flops) sits 1.0-1.9 %
+# away - outside, not built; the float64-FFT idealisation 2.4-7 %.  The HIP conv engine IS the multi-threaded conv1d member bit
+# for bit for signals of >= 55 frames, so a comparison with THAT member is held to the north_star bar (test_gpu_configs.py strict
+# leg, test_gpu_parity.py::test_conv_lowpass_is_the_references_waveform); the bar below = 2 x the real spread, for comparisons with
+# OTHER members: torch at one thread (forked oracle workers), or signals below 55 frames, where torch's forward convolution
+# switches to another summation order.
+CLASS_LSD_RTOL = 0.0155
 CLASS_LOGSI_ATOL_DB = 0.03
 CLASS_LOG = []       # dicts: what, lsd_rel, logsi_abs
 

@@ -30,15 +30,19 @@ def _vec(d):
     return np.array([d[k] for k in KEYS])
 
 
-def lib_tl_weights(n_fft):
-    """The conv engine's weight tables as libssrhip builds them, in oracle/tl_chain.py's layout (ssr_tl_weights is host code)."""
-    import ctypes as C
-    from ssr_eval_amd import _lib
-    F = n_fft // 2 + 1
-    a, b = np.empty((n_fft, F), np.float32), np.empty((n_fft, F), np.float32)
-    c, d = np.empty((n_fft, n_fft), np.float32), np.empty((n_fft, n_fft), np.float32)
-    _lib.check(_lib.load().ssr_tl_weights(n_fft, *[v.ctypes.data_as(C.c_void_p) for v in (a, b, c, d)], None))
-    return tuple(np.ascontiguousarray(v.T) for v in (a, b, c, d))
+def test_conv_engine_multiplies_by_torchlibrosas_own_weights():
+    """The Python mirror hands the conv engine the weight tables torchlibrosa's modules would hold (backend.tl_conv_weights: the
+    numpy expressions of DFTBase.dft_matrix / idft_matrix, STFT.__init__, ISTFT.init_real_imag_conv) - bit for bit the oracle's
+    restatement of the same construction, which is what oracle/tl_chain.c is fed by default in the tests below."""
+    from ssr_eval_amd import backend as B
+    from oracle import stft as ostft
+    import scipy.signal
+    for n_fft, window in ((2048, "hann"), (512, "hamming")):
+        win = None if window == "hann" else scipy.signal.get_window(window, n_fft, fftbins=True)
+        got = B.tl_conv_weights(n_fft, win)
+        for a, b in zip(got[:4], ostft.tl_weights(n_fft, window)):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(got[4], (ostft.window_array(window, n_fft) ** 2).astype(np.float32))
 
 
 def assert_sispec_parity(got, ref32, exact, what=""):
@@ -251,24 +255,121 @@ def test_fft_lowpass_matches_reference_vectors(golden):
     import importlib
     L = importlib.import_module("ssr_eval_amd.lowpass")
     assert L.DEFAULT_ENGINE == "conv"
-    wts = lib_tl_weights(2048)
     x = golden["lp_x"]
     for hc, fs in [(4000, 44100), (12000, 44100), (6000, 48000)]:
-        # default engine = the reference's arithmetic class: the vector of the imported reference (published torchlibrosa code on
-        # torch-CPU) to float32 dot-product round-off, and the fixed-order member oracle/tl_chain.c BIT FOR BIT
+        # default engine = the reference's arithmetic: the vector of the imported reference (published torchlibrosa code on
+        # torch-CPU; 21 frames, where torch runs its forward convolution in another order) to float32 dot-product round-off,
+        # and oracle/tl_chain.c (= torch's order from 55 frames on) BIT FOR BIT
         y = lowpass(x, hc, fs, order=1, _type="stft_hard")
         assert y.dtype == np.float32 and y.shape == x.shape
         np.testing.assert_allclose(y, golden["lp_y_%d_%d" % (hc, fs)], atol=2e-7)
-        np.testing.assert_array_equal(y, tl_chain.stft_hard_lowpass(x, olp.cut_bin(hc, fs), weights=wts))
+        np.testing.assert_array_equal(y, tl_chain.stft_hard_lowpass(x, olp.cut_bin(hc, fs)))
         # the float64 engine = the exact low-pass (the oracle's idealisation at 3e-8)
         y64 = L.stft_hard_lowpass_v0(x, hc / int(fs / 2), engine="segments")
         np.testing.assert_allclose(y64, olp.lowpass(x, hc, fs, 1, "stft_hard", arithmetic="ideal"), atol=3e-8)
         np.testing.assert_allclose(y64, y, atol=2e-7)
     sigs, ratios = [x, x[:1500], x[:4321]], [0.2, 0.5, 0.9]
     for xi, r, y, y64 in zip(sigs, ratios, stft_hard_lowpass_batch(sigs, ratios), stft_hard_lowpass_batch(sigs, ratios, engine="segments")):
-        np.testing.assert_array_equal(y, tl_chain.stft_hard_lowpass(xi, int(1025 * r), weights=wts))
+        np.testing.assert_array_equal(y, tl_chain.stft_hard_lowpass(xi, int(1025 * r)))
         np.testing.assert_allclose(y, olp.stft_hard_lowpass(xi, r), atol=2e-7)
         np.testing.assert_allclose(y64, olp.stft_hard_lowpass(xi, r, arithmetic="ideal"), atol=3e-8)
+
+
+def _torch_conv_is_the_pinned_member():
+    """see tests/test_oracle.py: torch-CPU's conv1d is the member oracle/tl_chain.c restates on an AVX-512 host, torch 2.10"""
+    return torch.backends.cpu.get_cpu_capability() == "AVX512" and torch.__version__.startswith("2.10")
+
+
+def _torch_conv_lowpass(x, cut, threads=8):
+    """stft_hard_lowpass_v0 through the published torchlibrosa modules on torch-CPU (the oracle's restatement of the modules; the
+    float32 magnitude / phase arithmetic in IEEE operations)."""
+    from oracle import stft as ostft
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        re, im = ostft.tl_stft_conv(x[None])
+        mag = np.clip(re ** 2 + im ** 2, np.float32(1e-8), np.inf) ** np.float32(0.5)
+        c, s_ = re / mag, im / mag
+        mag[..., cut:] = 0
+        return ostft.tl_istft_conv(mag * c, mag * s_, len(x))[0]
+    finally:
+        torch.set_num_threads(old)
+
+
+def test_conv_lowpass_is_the_references_waveform():
+    """Round 5: the conv engine accumulates in torch-CPU's own order and multiplies by torchlibrosa's own weights, so for signals of
+    >= 55 frames its output IS what the reference's code computes:
+      * every sample equal to oracle/tl_chain.c (always) and to F.conv1d-based torchlibrosa run LIVE on this box's CPU (where torch
+        is the pinned member: AVX-512, >= 2 threads) - per-item cuts, one cut, and the K-cutoff entry;
+      * against the vectors of the IMPORTED reference (tests/golden/reference_vectors_r5.npz): <= 3 % of the samples one ulp apart
+        (<= 6e-8) - torch's `** 0.5` is MKL's vector square root, 0.7 % of whose results are one ulp low
+        (tests/test_oracle.py::test_round5_reference_vectors_and_torchs_square_root); the kernel's sqrtf is correctly rounded."""
+    import json
+    from ssr_eval_amd import backend as B
+    from ssr_eval_amd.lowpass import lowpass, stft_hard_lowpass_multi
+    from oracle import lowpass as olp, tl_chain
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors_r5.npz"))
+    from ssr_eval_amd.backend import tl_conv_weights
+    import hashlib
+    h = hashlib.sha256()
+    for t in tl_conv_weights(2048)[:4]:
+        h.update(np.ascontiguousarray(t).tobytes())
+    assert h.hexdigest() == str(g["tables_sha256"]), "numpy's DFT tables on this host differ from the generating host's"
+    for name, seed, n, cuts in json.loads(str(g["lp5_cases"])):
+        if name == "noise":
+            x = (0.1 * np.random.default_rng(seed).standard_normal(n)).astype(np.float32)
+        else:
+            x = g["lp5_%s_x" % name]
+        for hc, fs in cuts:
+            y, want = lowpass(x, hc, fs, order=1, _type="stft_hard"), g["lp5_%s_%d_%d" % (name, hc, fs)]
+            np.testing.assert_array_equal(y, tl_chain.stft_hard_lowpass(x, olp.cut_bin(hc, fs)))
+            assert (y != want).mean() < 0.03 and np.abs(y - want).max() <= 6e-8, (name, hc, fs)
+            if _torch_conv_is_the_pinned_member():
+                np.testing.assert_array_equal(y, _torch_conv_lowpass(x, olp.cut_bin(hc, fs)))
+    # cfg-3 in small: SSR_Eval_Helper.lowpass_stft_hard's sweep in ONE call (shared forward product), metrics of every key
+    seed, n = [int(v) for v in g["c35_seed_n"]]
+    x = (0.1 * np.random.default_rng(seed).standard_normal(n)).astype(np.float32)
+    keys = [str(k) for k in g["c35_keys"]]
+    ratios = [(int(k.split("_")[2]) // 2) / 24000 for k in keys]
+    ys = stft_hard_lowpass_multi([x, x[:27001]], ratios)
+    plan = B.get_plan(2048, 512, "f64")
+    for k, r, yk, want in zip(keys, ratios, ys, g["c35_metrics_2048_512"]):
+        cut = min(int(1025 * r), 1025)
+        np.testing.assert_array_equal(yk[0], tl_chain.stft_hard_lowpass(x, cut), err_msg=k)
+        np.testing.assert_array_equal(yk[1], tl_chain.stft_hard_lowpass(x[:27001], cut), err_msg=k)
+        yr = g["c35_y_" + k]
+        assert (yk[0] != yr).mean() < 0.03 and np.abs(yk[0] - yr).max() <= 6e-8, k
+        m = B.pair_metrics(plan, [yk[0]], [x])[0].cpu().numpy()
+        assert abs(m[0] - want[0]) <= 1e-4 * want[0] + 1e-8 and abs(m[1] - want[1]) <= 2e-3 + 1e-4 * abs(want[1]), (k, m, want)
+        assert abs(m[2] - want[2]) <= 1e-4 * abs(want[2]) + 1e-4 and abs(m[3] - want[3]) <= 1e-5 * want[3], (k, m, want)
+        # on the reference's own waveform the metric kernels give the reference's numbers at the north_star bar
+        m = B.pair_metrics(plan, [yr], [x])[0].cpu().numpy()
+        np.testing.assert_allclose(m[[0, 3]], want[[0, 3]], rtol=1e-5, atol=1e-9)
+
+
+def test_fft_lowpass_multi_equals_single_calls():
+    """ssr_fft_lowpass_multi (one batch, K cuts; padded copy and forward product shared on the conv engine) against K
+    ssr_fft_lowpass calls: every sample equal, ragged batches including an item torch's padding refuses to frame... (skipped by
+    the entry points alike), cuts 0 and n_bins, both engine families; and per-item cuts (a tile never spans two items) against
+    one-cut launches (tiles across items)."""
+    from ssr_eval_amd import backend as B
+    rng = np.random.default_rng(77)
+    lens = [30000, 1025, 12345, 2048, 48001, 5000]
+    sigs = [(0.1 * rng.standard_normal(n)).astype(np.float32) for n in lens]
+    cuts = [0, 1, 42, 256, 257, 683, 1024, 1025]
+    for engine in ("conv", "segments"):
+        plan = B.get_plan(2048, 441, "f64", lowpass_engine=engine)
+        multi = B.fft_lowpass_multi(plan, sigs, cuts)
+        for c, ys in zip(cuts, multi):
+            single = B.fft_lowpass(plan, sigs, [c] * len(sigs))
+            for a, b in zip(ys, single):
+                assert torch.equal(a, b), (engine, c)
+        # per-item cuts: each item against the one-cut launch of its cut
+        per_item = [cuts[(3 * i + 1) % len(cuts)] for i in range(len(sigs))]
+        ys = B.fft_lowpass(plan, sigs, per_item)
+        for i, (c, y) in enumerate(zip(per_item, ys)):
+            assert torch.equal(y, multi[cuts.index(c)][i]), (engine, i, c)
+    assert B.fft_lowpass_multi(B.get_plan(2048, 441, "f64", lowpass_engine="conv"), [], cuts) == [[] for _ in cuts]
 
 
 def test_fdomain_helper_api(golden):
@@ -962,10 +1063,9 @@ def test_residue_class_resampler_random_rate_pairs_bit_exact(seed):
 def test_conv_engine_other_transform_sizes_bit_exact_against_tl_chain(n_fft, hop):
     """The conv (reference-arithmetic) low-pass engine away from FDomainHelper's 2048 / 441: its sub-band variants
     (FDomainHelper(subband=2 / 4): 1024 / 220, 512 / 110, ssr_eval/dsp.py:40-59), librosa's 2048 / 512 and a small plan - low-pass
-    at several cuts, ISTFT of given spectra and the complex STFT, all bit for bit against oracle/tl_chain.c fed the library's tables."""
+    at several cuts, ISTFT of given spectra and the complex STFT, all bit for bit against oracle/tl_chain.c."""
     from ssr_eval_amd import backend as B
     from oracle import tl_chain
-    wts = lib_tl_weights(n_fft)
     plan = B.get_plan(n_fft, hop, "f64", lowpass_engine="conv")
     rng = np.random.default_rng(n_fft)
     F = n_fft // 2 + 1
@@ -974,29 +1074,16 @@ def test_conv_engine_other_transform_sizes_bit_exact_against_tl_chain(n_fft, hop
     sigs = [(0.2 * rng.standard_normal(n)).astype(np.float32) for n in lens]
     ys = B.fft_lowpass(plan, sigs, cuts)
     for x, c, y in zip(sigs, cuts, ys):
-        np.testing.assert_array_equal(y.cpu().numpy(), tl_chain.stft_hard_lowpass(x, c, n_fft, hop, weights=wts), err_msg="n=%d cut=%d" % (len(x), c))
+        np.testing.assert_array_equal(y.cpu().numpy(), tl_chain.stft_hard_lowpass(x, c, n_fft, hop), err_msg="n=%d cut=%d" % (len(x), c))
     re, im = B.stft(plan, sigs[1:3], kind="complex", torch_style_pad=True)
     for x, r, i in zip(sigs[1:3], re, im):
-        wr, wi = tl_chain.stft(x, n_fft, hop, weights=wts)
+        wr, wi = tl_chain.stft(x, n_fft, hop)
         np.testing.assert_array_equal(r.cpu().numpy(), wr)
         np.testing.assert_array_equal(i.cpu().numpy(), wi)
         back = B.istft(plan, [r], [i], [len(x)])[0].cpu().numpy()
-        np.testing.assert_array_equal(back, tl_chain.istft(wr, wi, len(x), n_fft, hop, weights=wts))
+        np.testing.assert_array_equal(back, tl_chain.istft(wr, wi, len(x), n_fft, hop))
         assert np.abs(back - x).max() < 2e-6
     assert np.abs(B.fft_lowpass(plan, sigs[2:3], [0])[0].cpu().numpy()).max() == 0.0       # cut 0: silence
-
-
-def lib_tl_weights_ex(n_fft, window):
-    """ssr_tl_weights_ex: the tables of an ssr_plan_create_ex plan (window: float64 [n_fft] or None), oracle/tl_chain.py's layout."""
-    import ctypes as C
-    from ssr_eval_amd import _lib
-    F = n_fft // 2 + 1
-    a, b = np.empty((n_fft, F), np.float32), np.empty((n_fft, F), np.float32)
-    c, d = np.empty((n_fft, n_fft), np.float32), np.empty((n_fft, n_fft), np.float32)
-    w = None if window is None else np.ascontiguousarray(window, np.float64)
-    _lib.check(_lib.load().ssr_tl_weights_ex(n_fft, None if w is None else w.ctypes.data, *[v.ctypes.data_as(C.c_void_p) for v in (a, b, c, d)],
-                                             None))
-    return tuple(np.ascontiguousarray(v.T) for v in (a, b, c, d))
 
 
 EX_CASES = [("hann", False, "reflect"), ("hann", True, "constant"), ("hamming", True, "reflect"), ("hamming", False, "constant"),
@@ -1013,7 +1100,6 @@ def test_fdomain_helper_options_bit_exact_against_tl_chain(n_fft, hop, window, c
     from ssr_eval_amd import backend as B
     from oracle import tl_chain, stft as ostft
     win = None if window == "hann" else ostft.window_array(window, n_fft)
-    wts = lib_tl_weights_ex(n_fft, win)
     kw = dict(window=window, center=center)
     plan = B.get_plan_ex(n_fft, hop, window, win, center, pad_mode)
     assert plan.lib.ssr_num_frames(plan.handle, 20011) == plan.frames(20011)
@@ -1024,16 +1110,16 @@ def test_fdomain_helper_options_bit_exact_against_tl_chain(n_fft, hop, window, c
     sigs = [(0.2 * rng.standard_normal(n)).astype(np.float32) for n in lens]
     ys = B.fft_lowpass(plan, sigs, cuts)
     for x, c, y in zip(sigs, cuts, ys):
-        want = tl_chain.stft_hard_lowpass(x, c, n_fft, hop, weights=wts, pad_mode=pad_mode, **kw)
+        want = tl_chain.stft_hard_lowpass(x, c, n_fft, hop, pad_mode=pad_mode, **kw)
         np.testing.assert_array_equal(y.cpu().numpy(), want, err_msg="n=%d cut=%d" % (len(x), c))
     re, im = B.stft(plan, sigs[1:], kind="complex", torch_style_pad=True)
     for x, r, i in zip(sigs[1:], re, im):
-        wr, wi = tl_chain.stft(x, n_fft, hop, weights=wts, pad_mode=pad_mode, **kw)
+        wr, wi = tl_chain.stft(x, n_fft, hop, pad_mode=pad_mode, **kw)
         assert r.shape == wr.shape
         np.testing.assert_array_equal(r.cpu().numpy(), wr)
         np.testing.assert_array_equal(i.cpu().numpy(), wi)
         back = B.istft(plan, [r], [i], [len(x)])[0].cpu().numpy()
-        np.testing.assert_array_equal(back, tl_chain.istft(wr, wi, len(x), n_fft, hop, weights=wts, **kw))
+        np.testing.assert_array_equal(back, tl_chain.istft(wr, wi, len(x), n_fft, hop, **kw))
         # the inverse undoes the forward transform wherever every overlapping frame exists (away from un-padded / zero-padded edges)
         T = wr.shape[0]
         lo, hi = n_fft, min(len(x), (T - 1) * hop) - n_fft

@@ -19,7 +19,7 @@ def main():
     tr = B.Ragged.from_uniform(tgt)
     lp = B.LowpassBatch(B.get_plan(2048, 441, "f64", dev), tr, [256] * n)
     batch = B.PairBatch(B.get_plan(2048, 512, "f64", dev), lp.out_ragged(), tr)
-    cuts = [torch.full((n,), c, dtype=torch.int32, device=dev) for c in bench.CUT_BINS]
+    cuts = list(bench.CUT_BINS)
     BIGLDS = int(os.environ.get("BIG_LDS", "0"))     # a tiny launch of a kernel with 139 KB of LDS per workgroup after every low-pass
     if BIGLDS:
         small = (0.1 * torch.randn((2, 30000), generator=g, device=dev)).contiguous()
@@ -30,7 +30,7 @@ def main():
         scratch_a = torch.zeros(COOL * 1024 * 1024 // 4, dtype=torch.float32, device=dev); scratch_b = torch.empty_like(scratch_a)
     def seq(evs=None):
         for c in cuts:
-            lp.cut = c
+            lp.set_cuts(c)
             if evs is not None: evs.append(torch.cuda.Event(enable_timing=True)); evs[-1].record()
             lp.run()
             if BIGLDS:

@@ -7,8 +7,10 @@ image has is run on the same low-pass and the metrics of the degraded signal are
   np_openblas          numpy float32 @ (OpenBLAS sgemm)
   fold_mm_t{1,8}, fold_np   the same libraries on the Hermitian-FOLDED inverse (bins 0..c-1 only, weights of bins >= 1 doubled:
                        half the flops)
-  chain{32,...,2048}   oracle/tl_chain.c with that chain length (compact channel order)
-Prints per cut: LSD relative to conv at 8 threads, log-SISpec difference in dB; and the spread of the real members.
+  blocks{64,...,2048}  oracle/tl_chain.c: fused-multiply-add chains over blocks of that many channels of the FULL spectrum
+                       (256 = what the HIP conv engine runs; it is conv_t{2..16} bit for bit)
+Prints per cut: LSD relative to conv at 8 threads (per cent), and for the restated members the fraction of samples that differ from
+conv_t8; writes the table (with log-SISpec differences in dB) to $OUT (default profiles/r05_lowpass_class_members.json).
 """
 import json
 import os
@@ -76,8 +78,8 @@ def inverse_members(R, I, cut, length):
     out["np_openblas"] = finish(torch.from_numpy(s), T, length)
     s = (ir[:, :cut] * g[None, :]) @ R.T[:cut] - (ii[:, :cut] * g[None, :]) @ I.T[:cut]
     out["fold_np"] = finish(torch.from_numpy(np.ascontiguousarray(s)), T, length)
-    for kb in (32, 64, 128, 256, 512, 2048):
-        out["chain%d" % kb] = tl_chain.istft(R, I, length, N_FFT, HOP, kb=kb, nbz=cut)
+    for kb in (64, 128, 256, 384, 512, 2048):
+        out["blocks%d" % kb] = tl_chain.istft(R, I, length, N_FFT, HOP, kbf=kb, nbz=cut)
     return out
 
 
@@ -95,16 +97,28 @@ def main():
                 m = om.evaluation(y.astype(np.float32), x, n_fft=2048, hop=512)
                 ms[k] = (m["lsd"], m["log_sispec"])
             ref = ms["conv_t8"]
-            row = {"sig": si, "cut": cut, "ref_lsd": ref[0]}
+            row = {"sig": si, "cut": cut, "ref_lsd": ref[0], "members[lsd_rel, log_sispec_db, samples_differing_from_conv_t8]": {}}
             for k, v in ms.items():
                 row[k] = (v[0] / ref[0] - 1, v[1] - ref[1])
+                row["members[lsd_rel, log_sispec_db, samples_differing_from_conv_t8]"][k] = [
+                    v[0] / ref[0] - 1, v[1] - ref[1], float((mem[k] != mem["conv_t8"]).mean())]
             table.append(row)
             real = [k for k in ms if k.startswith(("conv", "mm_", "mmcompact", "np_"))]
             lsds = [ms[k][0] for k in real]
             print("sig %d cut %3d | real spread %.3f %% | " % (si, cut, 100 * (max(lsds) - min(lsds)) / ref[0]) +
                   " ".join("%s %+.2f" % (k, 100 * row[k][0]) for k in ms if k != "conv_t8"), flush=True)
-    with open(os.environ.get("OUT", "/tmp/class_members.json"), "w") as f:
-        json.dump(table, f, indent=1)
+    real = lambda k: k.startswith(("conv", "mm_", "np_"))          # noqa: E731  (full-matrix products of real libraries)
+    spread = max(max(r[k][0] for k in r if isinstance(r[k], tuple) and real(k)) - min(r[k][0] for k in r if isinstance(r[k], tuple) and real(k))
+                 for r in table)
+    hip = max(r["members[lsd_rel, log_sispec_db, samples_differing_from_conv_t8]"]["blocks256"][2] for r in table)
+    slim = [{k: v for k, v in r.items() if not isinstance(v, tuple)} for r in table]
+    with open(os.environ.get("OUT", os.path.join(ROOT, "profiles", "r05_lowpass_class_members.json")), "w") as f:
+        json.dump({"note": "LSD (relative to torch F.conv1d at 8 threads) / log-SISpec (dB difference) of a hard-low-passed 1 s noise target, "
+                           "48 kHz, metrics at 2048/512, per float32 GEMM implementation of torchlibrosa's ISTFT; torch %s, numpy %s, %d cores" % (
+                               torch.__version__, np.__version__, os.cpu_count()),
+                   "largest_lsd_spread_of_real_full_matrix_members": spread,
+                   "largest_fraction_of_samples_where_blocks256_differs_from_conv_t8": hip, "rows": slim}, f, indent=1)
+    print("largest LSD spread of the real full-matrix members: %.3f %%; blocks256 differs from conv_t8 in %.4f of the samples" % (100 * spread, hip))
 
 
 if __name__ == "__main__":

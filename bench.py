@@ -88,11 +88,48 @@ def pmc_traffic(kernel_key):
     return None, None
 
 
+_HBM_MEASURED = {}
+
+
+def measured_hbm_peak():
+    """What THIS box sustains on a plain streaming read and on a copy (tools/ubench/hbm_probe.hip: 16-byte accesses, four
+    independent loads in flight per lane, 2 GiB buffers - past the 256 MB Infinity Cache), timed with HIP events in this process:
+    the measured ceiling SURVEY 8(d) asks to quote next to the 8 TB/s data-sheet peak (MI355X_MICROARCH.md: 6.29 TB/s on a
+    float4 copy).  {"read_GBs", "copy_GBs"} (copy counts bytes read + bytes written) or {} when the probe library is missing."""
+    if _HBM_MEASURED or not torch.cuda.is_available():
+        return _HBM_MEASURED
+    path = os.path.join(ROOT, "tools", "_build", "libhbmprobe.so")
+    try:
+        import ctypes as C
+        lib = C.CDLL(path)
+        lib.hbm_probe_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        nbytes = 2 << 30
+        a = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda").normal_()
+        b = torch.empty_like(a)
+        stream = torch.cuda.current_stream().cuda_stream
+        best = {}
+        for mode, name, moved in ((0, "read_GBs", nbytes), (1, "copy_GBs", 2 * nbytes)):
+            for blocks in (2048, 4096, 8192):
+                ms = event_time_ms(lambda: lib.hbm_probe_launch(a.data_ptr(), b.data_ptr(), nbytes, mode, blocks, stream), 5)
+                best[name] = max(best.get(name, 0.0), round(moved / (ms * 1e-3) / 1e9, 1))
+        del a, b
+        torch.cuda.empty_cache()
+        _HBM_MEASURED.update(best)
+    except Exception as e:                               # the probe is a convenience: the line survives without it
+        _HBM_MEASURED["error"] = repr(e)
+    return _HBM_MEASURED
+
+
 def hbm_roofline(kernel, alg_bytes, ms, traffic_key=None, note=None):
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     traffic, src = pmc_traffic(traffic_key) if traffic_key else (None, None)
+    meas = measured_hbm_peak()
     r = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": src,
+         "frac": round(achieved / HBM_PEAK_GBS, 5),
+         "peak_measured": meas.get("read_GBs"), "peak_measured_copy": meas.get("copy_GBs"),
+         "frac_of_measured": round(achieved / meas["read_GBs"], 5) if meas.get("read_GBs") else None,
+         "peak_measured_source": "streaming read / copy of 2 GiB with 16-byte accesses in this process (tools/ubench/hbm_probe.hip)",
+         "traffic": traffic, "traffic_source": src,
          "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(ms, 4),
          "kernel_ms_source": "hip_events on the launch stream, 3-10 iterations on this box (the rocprofv3 average of the same command: profiles/)"}
     if note:
@@ -427,6 +464,11 @@ class Cfg5:
                                 "k_resample_rc stage 1+k_resample_rc stage 2" if a.utterances == 12500 else None,
                                 "the resampling chain is the HBM-side kernel of this config; per-stage read+write rates and the LSD "
                                 "stage are under extra.stage_ms / extra.stage_GBs")
+        # the kernel most of the step's TIME goes to is the LSD stage's transform, not the chain: its roofline object rides along
+        roof["time_dominant_kernel"] = hbm_roofline(
+            "ssr_stft_pair(k_stft_wave<double, false, true, false>: resampled signal and target -> LSD)", (2 * N_SAMPLES * 4 + 32) * n, ms3,
+            "k_stft_wave<double, false, true, false>" if a.utterances == 12500 else None,
+            "%.0f %% of the step's kernel time; algorithmic bytes 2*n*4+32 per pair" % (100 * ms3 / ((msc if fused else ms1 + ms2) + ms3)))
         extra = {"stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
                  "stage_GBs_read_plus_write": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) for k, v in stages.items()},
                  "resample_chain": "fused (ssr_resample_poly_chain)" if fused else "two ssr_resample_poly calls",
@@ -530,6 +572,7 @@ class Cfg4:
             gi = torch.from_numpy(self.mine.astype(np.float64)).to(dev)
             self.fake_out = torch.stack([gi, 0.5 * gi, gi * gi * 1e-3, torch.cos(gi)], dim=1)
         self.lens_local = ml
+        self.collective = getattr(a, "collective", "allgather")
         self.n_spk = len(self.SPEAKER_COUNTS)
         self.spk_local = torch.from_numpy(spk[self.mine]).to(dev)
         self.cnt_local = torch.bincount(self.spk_local, minlength=self.n_spk).to(torch.float64)
@@ -553,7 +596,9 @@ class Cfg4:
         self.buf[:, 4] = self.cnt_local
         self.pack[:len(self.mine), 1:] = out
         self.pack[self.cap:] = self.buf
-        if self.world > 1:
+        if self.world > 1 and self.collective == "allreduce":
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)                       # BASELINE cfg-4's collective: 320 B of float64 sums
+        elif self.world > 1:
             dist.all_gather_into_tensor(self.gathered.view(-1, 5), self.pack)      # RCCL over xGMI: the step's only collective
             torch.sum(self.gathered[:, self.cap:], dim=0, out=self.buf)           # ranks added in rank order, on every rank alike
         return self.buf
@@ -579,9 +624,10 @@ class Cfg4:
         import torch.distributed as dist
         B = self.B
         if self.fake:
-            g = self.gathered[:, :self.cap].reshape(-1, 5).cpu().numpy() if self.world > 1 else self.pack[:self.cap].cpu().numpy()
+            gathered = self.world > 1 and self.collective == "allgather"
+            g = self.gathered[:, :self.cap].reshape(-1, 5).cpu().numpy() if gathered else self.pack[:self.cap].cpu().numpy()
             return None, {"allgather_rows_received": int((g[:, 0] >= 0).sum()), "shard_utterances": int(len(self.mine)),
-                          "shard_balance_max_over_mean": round(self.shard_balance, 5)}
+                          "shard_balance_max_over_mean": round(self.shard_balance, 5), "collective": self.collective if self.world > 1 else None}
         ms_all = event_time_ms(lambda: self.batch.run(B.M_ALL), 3)
         ms_stft = event_time_ms(lambda: self.batch.run(B.M_ALL, stages=1), 3)
         alg = int((2 * self.lens_local * 4 + 32).sum())                  # each pair's own n
@@ -591,9 +637,13 @@ class Cfg4:
         extra = {"shard_utterances": int(len(self.mine)), "shard_samples": int(self.lens_local.sum()),
                  "stage_ms_rank0": {"pair_metrics": round(ms_all, 4), "stft+lsd+sispec": round(ms_stft, 4)},
                  "shard": self.shard, "shard_balance_max_over_mean": round(self.shard_balance, 5),
-                 "allgather_payload_bytes_per_rank": int(self.pack.numel() * 8), "collectives_per_step": 1 if self.world > 1 else 0}
+                 "collective": self.collective if self.world > 1 else None,
+                 "collective_payload_bytes_per_rank": int(self.pack.numel() * 8) if self.collective == "allgather" else int(self.buf.numel() * 8),
+                 "collectives_per_step": 1 if self.world > 1 else 0}
         if self.world > 1:                                               # every rank calls report() for this workload
+            scratch = self.buf.clone()
             extra["allgather_latency_us"] = round(1e3 * event_time_ms(lambda: dist.all_gather_into_tensor(self.gathered.view(-1, 5), self.pack), 20), 2)
+            extra["allreduce_latency_us"] = round(1e3 * event_time_ms(lambda: dist.all_reduce(scratch, op=dist.ReduceOp.SUM), 20), 2)
             g = self.gathered[:, :self.cap].reshape(-1, 5).cpu().numpy()
             extra["allgather_rows_received"] = int((g[:, 0] >= 0).sum())
         return roof, extra
@@ -624,7 +674,10 @@ class Skeleton:
     parity = None
 
     def __init__(self, a, dev, rank):
-        self.a, self.units_per_step = a, 10
+        # units per rank and step as the selected config counts them (cfg5: 12,500 utterances x 192,000 output samples per GPU =
+        # 100 k utterances over 8 GPUs; cfg2 / cfg3: the pairs), 10 for the plain launcher test
+        self.a = a
+        self.units_per_step = {"cfg5": a.utterances * N_SAMPLES, "cfg3": a.pairs * len(CUT_BINS)}.get(a.config, 10 if a.pairs == 1024 else a.pairs)
         self.agg = torch.tensor([float(rank + 1), 1.0], dtype=torch.float64, device=dev)
         self.rank = rank
 
@@ -1045,6 +1098,10 @@ def parse(argv=None):
     ap.add_argument("--resample-chain", dest="resample_chain", default="fused", choices=["fused", "two-calls"],
                     help="cfg5: both resample_poly stages in one kernel (ssr_resample_poly_chain) or two ssr_resample_poly launches")
     ap.add_argument("--shard", default="balanced", choices=["balanced", "round-robin"], help="cfg4: how the fixed set is dealt to the ranks")
+    ap.add_argument("--collective", default="allgather", choices=["allgather", "allreduce"],
+                    help="cfg4: the step's one collective - allgather (default): per-utterance rows + per-speaker sums, added in rank order "
+                         "on every rank (what evaluate() needs for its JSON); allreduce: the per-speaker [sums, count] block only, one RCCL "
+                         "all-reduce (the collective BASELINE cfg-4 names)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the cfg3 / cfg5 / API-true / end-to-end side figures")
     ap.add_argument("--_cpu-skeleton", dest="cpu_skeleton", action="store_true", help=argparse.SUPPRESS)

@@ -735,7 +735,7 @@ class ResampleBatch:
 
 
 class ResampleChainBatch:
-    """resample_poly(resample_poly(x, mid, orig), new, mid) for a ragged float32 batch - BASELINE cfg-5's 16 kHz -> 44.1 kHz -> 48 kHz.
+    """resample_poly(resample_poly(x, mid, orig), new, mid) for a ragged float32 (or float64: two calls) batch - BASELINE cfg-5's 16 kHz -> 44.1 kHz -> 48 kHz.
     Where the two plans fit ssr_resample_poly_chain (21-tap phases, 8 up1 = 24 down2: 441/160 then 160/147) ONE kernel runs both
     stages and the intermediate signal never leaves LDS; otherwise the two stages run through ssr_resample_poly.  Same bits either
     way (SciPy's).  `fused`: None = try the fused kernel, False = always two calls."""
@@ -747,7 +747,8 @@ class ResampleChainBatch:
                      self.s1.out_len)                                          # geometry only: the buffer may never exist
         self.s2 = ResampleBatch(mid, sr_new, sr_mid, alloc=False)
         self.out_len, self.out_off, self.out_off_d, self.out_len_d = self.s2.out_len, self.s2.out_off, self.s2.out_off_d, self.s2.out_len_d
-        self.out = torch.empty(int(self.out_len.sum()), dtype=torch.float32, device=ragged.device)
+        # (a float64 batch runs the two stages in float64 - what SciPy does per dtype - and so is its output: ADVICE r4)
+        self.out = torch.empty(int(self.out_len.sum()), dtype=ragged.data.dtype, device=ragged.device)
         self.s2.out = self.out
         self.fused = fused
         self.ran_fused = None

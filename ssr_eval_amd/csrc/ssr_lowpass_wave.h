@@ -49,13 +49,7 @@ template <typename T, typename REGS>
 SSR_DEV void ssr_lowpass_wave_prefetch(REGS& R, int tid, const SsrView<float>& vs, int g, int hop, int n, int n_frames) {
   const int ta = (2 * g < n_frames) ? 2 * g : n_frames - 1;
   const int tb = (2 * g + 1 < n_frames) ? 2 * g + 1 : n_frames - 1;      // a missing frame re-reads the last one
-#if defined(SSR_LPW_EXP_SAMEIN)       /* developer experiment (timing only, wrong results): every unit reads the item's first frames */
-  const int base_a = SSR_W_N + (g & 1) * 0, base_b = SSR_W_N + hop;
-#elif defined(SSR_LPW_EXP_SAMEALL)    /* developer experiment (timing only, wrong results): every unit of every item reads the same lines */
-  const int base_a = SSR_W_N, base_b = SSR_W_N + hop; (void)ta; (void)tb;
-#else
   const int base_a = ta * hop - SSR_W_N / 2, base_b = tb * hop - SSR_W_N / 2;
-#endif
   if (base_a >= 0 && base_b + SSR_W_N <= n) {                             // wave-uniform: both frames inside the signal
     SSR_UNROLL for (int r = 0; r < SSR_W_P; ++r) {
       R.pa[r] = vs.at(SSR_UIDX(tid + 64 * r), base_a);
@@ -160,11 +154,7 @@ SSR_BODY void ssr_lowpass_wave_body(const SsrLowpassParams<T>& p, BLK& blk, int 
     blk = blk0; ssr_launder(blk);
     if constexpr (PAIRED) {
       const int stride = ssr_seg_stride(N, hop), shift = (2 * g * hop) & 3;           // row layout: ssr_lowpass.h
-#if defined(SSR_LPW_EXP_NOSTORE)      /* developer experiment (timing only, wrong results): the segment stores fall to the range check */
-      const SsrRwView<float> vseg(p.frames + row0 * N + (int64_t)g * stride + shift, 0);
-#else
       const SsrRwView<float> vseg(p.frames + row0 * N + (int64_t)g * stride + shift, N + hop);
-#endif
       // window; frame ta to the exchange array (its first hop samples stay in .y), frame tb stays in .x
       SSR_WPHASE(blk, regs, {
         SSR_SCHED_BARRIER() SSR_W_LOAD_WIN;

@@ -124,11 +124,7 @@ SSR_DEV void ssr_resample_compute(const SsrResampleParamsT<S>& p, int tid, int i
       SSR_UNROLL4 for (int k = 0; k < hpp; ++k) {
         const S hv = (hi < h_len) ? h[hi] : (S)0;
         hi -= up;
-#if defined(SSR_EXP_RESAMPLE_FMA) && !defined(SSR_HOST_EMU)   /* developer measurement: fused multiply-add (NOT SciPy's bits) */
-        SSR_UNROLL for (int j = 0; j < J; ++j) acc[j] = (S)__builtin_fmaf((float)xw[xb[j] + k], (float)hv, (float)acc[j]);
-#else
         SSR_UNROLL for (int j = 0; j < J; ++j) acc[j] = ssr_fadd_rn(acc[j], ssr_fmul_rn(xw[xb[j] + k], hv));
-#endif
       }
       SSR_UNROLL for (int j = 0; j < J; ++j) {
         const int64_t m = mf + (int64_t)j * up;

@@ -251,13 +251,8 @@ __device__ __forceinline__ void ssr_resample_chain_body(const SsrResampleChainPa
           const int mb = 4 * (Cb * SB2 + ps * 6) * up2;                   // wave-uniform part
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-#if defined(SSR_EXP_STORE_NT)        /* developer experiment: streaming (nt) stores for the output */
-            vy.st_raw_nt(vo0 + mb + 8 * c * up2, acc[c].x);
-            vy.st_raw_nt(vo0 + mb + 4 * (2 * c + 1) * up2, acc[c].y);
-#else
             vy.st_raw(vo0 + mb + 8 * c * up2, acc[c].x);
             vy.st_raw(vo0 + mb + 4 * (2 * c + 1) * up2, acc[c].y);
-#endif
           }
         }
       }

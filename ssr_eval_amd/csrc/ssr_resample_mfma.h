@@ -110,11 +110,6 @@ SSR_DEV float ssr_resample_mfma_a(const float* hl, int pad, int up, int down, in
   return ((unsigned)ii < (unsigned)hpp) ? hl[ssr_rmf_slot(ph + ii * up, pad)] : 0.0f;
 }
 
-#if defined(SSR_DEV_KNOBS) && defined(SSR_EXP_RMF)   // timing-only ablations (wrong results): 1 no stores, 2 no tap gather, 4 no MFMA, 8 no window traffic
-#define SSR_RMF_ABL(bit) ((SSR_EXP_RMF) & (bit))
-#else
-#define SSR_RMF_ABL(bit) 0
-#endif
 // MAXCH: 64-sample chunks of a window a lane can prefetch per utterance (5: windows up to 320 samples - 441 / 160 and 160 / 147;
 // SSR_RMF_MAXCH = 7 for the down-sampling plans: sixteen more registers and sixteen more guarded requests per pass)
 template <int MAXCH, typename BLK>
@@ -169,7 +164,7 @@ SSR_BODY void ssr_resample_mfma_body(const SsrResampleMfmaParams& p, BLK& blk, i
   for (int idx = first; idx < total; idx += stride) {
     const bool more = idx + stride < total;
     const SsrResampleMfmaPass nxt = more ? ssr_resample_mfma_pass(p, g, idx + stride) : cur;
-    SSR_WPHASE(blk, regs, { if (more && !SSR_RMF_ABL(8)) SSR_RMF_FETCH(nxt); });      // (registers only: no barrier)
+    SSR_WPHASE(blk, regs, { if (more) SSR_RMF_FETCH(nxt); });      // (registers only: no barrier)
     // ---- the pass's tiles: wave w, round r -> block 4 r + w
     for (int r4 = 0; r4 < NB; r4 += SSR_RMF_WAVES) {
       SSR_WPHASE(blk, regs, {
@@ -196,13 +191,12 @@ SSR_BODY void ssr_resample_mfma_body(const SsrResampleMfmaParams& p, BLK& blk, i
             float a4[4]; float b4[4];
             SSR_UNROLL for (int u = 0; u < 4; ++u) {
               const bool in_taps = (unsigned)(ii - 2 * u) < (unsigned)hpp;
-              const float tv = SSR_RMF_ABL(2) ? 1.0f : L.hl[ssr_rmf_slot(ph + (in_taps ? ii - 2 * u : 0) * up, pad)];
+              const float tv = L.hl[ssr_rmf_slot(ph + (in_taps ? ii - 2 * u : 0) * up, pad)];
               a4[u] = in_taps ? tv : 0.0f;
               b4[u] = xrow[2 * (kap + u)];
             }
             SSR_UNROLL for (int u = 0; u < 4; ++u) {
-              if (SSR_RMF_ABL(4)) acc[u] += a4[u] * b4[u];
-              else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u], b4[u], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u], b4[u], acc, 0, 0, 0);
             }
             ii -= 8;
           }
@@ -237,7 +231,7 @@ SSR_BODY void ssr_resample_mfma_body(const SsrResampleMfmaParams& p, BLK& blk, i
           const int64_t m = mb + (lane & 31);
           SSR_UNROLL for (int pr = 0; pr < 16; ++pr) {
             const int jj = 2 * pr + (lane >> 5);
-            if (m < L.ol[jj] && !(SSR_RMF_ABL(1) && m != 0)) p.rp.out[L.oo[jj] + m] = tb[jj * (T + 1) + (lane & 31)];
+            if (m < L.ol[jj]) p.rp.out[L.oo[jj] + m] = tb[jj * (T + 1) + (lane & 31)];
           }
         }
       });
@@ -245,7 +239,7 @@ SSR_BODY void ssr_resample_mfma_body(const SsrResampleMfmaParams& p, BLK& blk, i
     SSR_PHASE(blk, regs, {});                          // every wave is done with the windows and the descriptors
     SSR_PHASE(blk, regs, {
       if (more) {
-        if (!SSR_RMF_ABL(8)) SSR_RMF_PUT();
+        SSR_RMF_PUT();
         SSR_RMF_DESC(nxt);
       }
     });

@@ -70,16 +70,8 @@ __device__ __forceinline__ void ssr_resample_rc_body(const SsrResampleRcParams& 
   const int item = (int)blockIdx.x / p.n_chunks, chunk = (int)blockIdx.x % p.n_chunks;
   const int up = p.up, down = p.down;
   const int n_in = p.in_len[item], n_out = p.out_len[item];
-#if defined(SSR_RC_EXP_SAMEIN)       /* developer experiment (timing only): every workgroup reads item 0's samples */
-  const float* x = p.in + p.in_off[0];
-#else
   const float* x = p.in + p.in_off[item];
-#endif
-#if defined(SSR_RC_EXP_SAMEOUT)      /* developer experiment (timing only): every workgroup writes item 0's output */
-  float* y = p.out + p.out_off[0];
-#else
   float* y = p.out + p.out_off[item];
-#endif
   const int steps = (n_out + up - 1) / up;                              // outputs r + j up, j < steps
   const int G = p.groups, SB = G * JB;                                  // steps per block
   const int blk0 = chunk * p.blocks_per_chunk;

@@ -230,18 +230,10 @@ SSR_DEV void ssr_wave_prefetch(const SsrStftParams<T>& p, REGS& R, int tid, cons
   const int t_c = (u < n_frames) ? u : n_frames - 1;
   const int base = t_c * p.hop - SSR_W_N / 2;
   if (base >= 0 && base + SSR_W_N <= n) {            // wave-uniform: the frame lies fully inside the signal
-#if defined(SSR_EXP_LOAD_X4) && !defined(SSR_HOST_EMU)   /* developer ablation: 8 wide loads per signal; the frame's samples land
-                                                            permuted (timing only - same values, same statistics) */
-    SSR_UNROLL for (int r = 0; r < SSR_W_P / 4; ++r) {
-      if (WHICH & 1) va.at4(SSR_UIDX(4 * tid + 256 * r), base & ~3, R.pa + 4 * r);
-      if (WHICH & 2) vb.at4(SSR_UIDX(4 * tid + 256 * r), base & ~3, R.pb + 4 * r);
-    }
-#else
     SSR_UNROLL for (int r = 0; r < SSR_W_P; ++r) {
       if (WHICH & 1) R.pa[r] = va.at(SSR_UIDX(tid + 64 * r), base);
       if (WHICH & 2) R.pb[r] = vb.at(SSR_UIDX(tid + 64 * r), base);
     }
-#endif
   } else {
     SSR_UNROLL for (int r = 0; r < SSR_W_P; ++r) {
       const unsigned m = SSR_UIDX(ssr_reflect(base + tid + 64 * r, n));
@@ -399,29 +391,10 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
               e = f2_make(e0, e1); t = f2_make(t0, t1);
             }
             if (store) {
-#if defined(SSR_EXP_STORE_OOR)       /* developer ablation: the stores are issued, the buffer range check drops them */
-              const int xo = 0x40000000;
-#else
-              const int xo = 0;
-#endif
-#if defined(SSR_EXP_STORE_X2)        /* developer ablation (with SSR_EXP_STORE_OOR): half as many, twice as wide */
-              wa.st_raw2(xo + 2 * lane4 + 4 * (64 * b + 256 * (q0 + q)), e.x, e.y);
-              wb.st_raw2(xo + 2 * lane4 + 4 * (64 * b + 256 * (q0 + q)), t.x, t.y);
-#else
-#if defined(SSR_EXP_STORE_NT)        /* developer experiment: streaming (nt) stores for the magnitude rows */
-              wa.st_raw_nt(xo + lane4 + 4 * (64 * b + 256 * (q0 + q)), e.x);
-              wa.st_raw_nt(xo + lane4 + 4 * (64 * b + 256 * (q0 + q + 1)), e.y);
-              wb.st_raw_nt(xo + lane4 + 4 * (64 * b + 256 * (q0 + q)), t.x);
-              wb.st_raw_nt(xo + lane4 + 4 * (64 * b + 256 * (q0 + q + 1)), t.y);
-#else
-              wa.st_raw(xo + lane4 + 4 * (64 * b + 256 * (q0 + q)), e.x);
-              wa.st_raw(xo + lane4 + 4 * (64 * b + 256 * (q0 + q + 1)), e.y);
-#if !defined(SSR_EXP_STORE_HALF)     /* developer ablation: only the estimate's row is written */
-              wb.st_raw(xo + lane4 + 4 * (64 * b + 256 * (q0 + q)), t.x);
-              wb.st_raw(xo + lane4 + 4 * (64 * b + 256 * (q0 + q + 1)), t.y);
-#endif
-#endif
-#endif
+              wa.st_raw(lane4 + 4 * (64 * b + 256 * (q0 + q)), e.x);
+              wa.st_raw(lane4 + 4 * (64 * b + 256 * (q0 + q + 1)), e.y);
+              wb.st_raw(lane4 + 4 * (64 * b + 256 * (q0 + q)), t.x);
+              wb.st_raw(lane4 + 4 * (64 * b + 256 * (q0 + q + 1)), t.y);
             }
           }
           if (b == 1 && q0 + G == 4) {

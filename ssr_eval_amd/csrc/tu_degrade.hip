@@ -141,6 +141,9 @@ extern "C" int ssr_resample_poly_chain(const float* in, const int64_t* in_off, c
   if (!in || !in_off || !in_len || !mid_len || !out_off || !out_len || !taps1 || !taps2 || !out) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
   if (up1 < 1 || down1 < 1 || n_taps1 < 1 || up2 < 1 || down2 < 1 || n_taps2 < 1) return ssr_fail(SSR_ERR_INVALID_ARG, "bad resampling plan");
   if (n_items <= 0 || max_out_len <= 0) return SSR_OK;
+  // the kernel forms 32-bit byte offsets into an item's output (and parks idle consumer lanes at byte 0x40000000): items of 2^28
+  // samples or more take the two-call path (ssr_resample_poly rejects 2^29 itself)
+  if (max_out_len >= (1 << 28)) return ssr_fail(SSR_ERR_UNSUPPORTED, "the fused chain handles outputs below 2^28 samples per item");
 #ifdef SSR_DEV_KNOBS
   static const int off = getenv("SSR_NO_CHAIN") ? atoi(getenv("SSR_NO_CHAIN")) : 0;
   if (off) return ssr_fail(SSR_ERR_UNSUPPORTED, "fused chain switched off");

@@ -128,10 +128,12 @@ static int launch_ssim(const float* x, const float* y, const int64_t* frame_off,
   // four consecutive columns per thread through aligned 16-byte loads: rows and both bases 16-byte aligned
   if (g.cpt == 4 && !no_contig && pitch > 0 && pitch % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
     return launch_ssim_inst<4, true>(p, grid, s);
+#ifdef SSR_DEV_KNOBS          /* the eight-column experiment (slower, 80 B of scratch per lane): profiling builds only */
   if (g.cpt == 8) {
     if (pitch > 0 && pitch % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) return launch_ssim_inst<8, true>(p, grid, s);
     return ssr_fail(SSR_ERR_UNSUPPORTED, "the eight-column SSIM kernel needs 16-byte aligned rows");
   }
+#endif
   switch (g.cpt) {
     case 1: return launch_ssim_inst<1>(p, grid, s);
     case 2: return launch_ssim_inst<2>(p, grid, s);
@@ -367,7 +369,9 @@ extern "C" int ssr_pair_metrics_multi(const ssr_plan* pl, const float* est, cons
                     ssim_part + (size_t)key0 * n_items * m.n_tiles, pitch, n_items, (int64_t)(m.plane / sizeof(float))};
     const int grid = n_items * n_k * m.n_tiles;
     if (m.w.sg.cpt == 4) return launch_ssim_inst<4, true>(p, grid, s);
+#ifdef SSR_DEV_KNOBS
     if (m.w.sg.cpt == 8) return launch_ssim_inst<8, true>(p, grid, s);
+#endif
     switch (m.w.sg.cpt) {
       case 1: return launch_ssim_inst<1>(p, grid, s);
       case 2: return launch_ssim_inst<2>(p, grid, s);

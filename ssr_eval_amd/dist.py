@@ -7,9 +7,9 @@ The path shards naturally (every (utterance, degradation) pair is independent, s
   hundred bytes; latency-bound), from which every rank forms the mean of per-speaker means;
 * ``allgather_rows``  - ONE padded all-gather of the per-utterance metric rows (for the per-file JSON
   block and for a bit-identical np.mean in the reference's order);
-* ``gather_rows_and_speaker_sums`` (round 4) - both in ONE all-gather: the speaker sums ride behind the rows
-  and are added in rank order on every rank (at 8 GPUs a cfg-4 step is ~2 ms of kernels: two blocking
-  collectives per step would show);
+* ``gather_rows_and_speaker_sums`` (round 4) - both in ONE all-gather (behind one 24-byte MAX all-reduce that agrees on width and
+  largest shard): the speaker sums ride behind the rows and are added in rank order on every rank (at 8 GPUs a cfg-4 step is
+  ~2 ms of kernels: every further blocking collective per step would show);
 * ``shard_indices_balanced`` - length-balanced dealing (longest first to the least-loaded rank).
 
 Backend "nccl" IS RCCL on ROCm; CPU tests use "gloo" with world_size 2.
@@ -121,10 +121,12 @@ def allgather_rows(local_rows, global_index, n_total):
 
 
 def gather_rows_and_speaker_sums(local_rows, global_index, n_total, speaker_ids, n_speakers):
-    """The path's WHOLE exchange in ONE collective (ssr_eval/eval.py:200-216 needs the per-file rows for the JSON block and the
-    per-speaker sums + counts for the aggregate): every rank appends its [n_speakers, K + 1] speaker_sums rows to its padded
-    per-utterance rows, ONE all-gather moves both, and every rank adds the gathered speaker blocks in rank order - a fixed order,
-    so the aggregate is bit-identical on every rank (an all-reduce leaves the order to the library).
+    """The path's whole data exchange in ONE all-gather (ssr_eval/eval.py:200-216 needs the per-file rows for the JSON block and
+    the per-speaker sums + counts for the aggregate), behind one 24-byte MAX all-reduce that agrees on the row width and the
+    largest shard: every rank appends its [n_speakers, K + 1] speaker_sums rows to its padded per-utterance rows, the all-gather
+    moves both, and every rank adds the gathered speaker blocks in rank order - a fixed order, so the aggregate is bit-identical
+    on every rank (an all-reduce leaves the order to the library).  Two blocking collectives per evaluation in all (three in
+    round 4; evaluate() adds one all_gather_object for the file names of the JSON block).
     -> (table [n_total, K], speaker buffer [n_speakers, K + 1])."""
     local_rows = np.asarray(local_rows, dtype=np.float64)
     local_rows = local_rows.reshape(len(global_index), -1) if local_rows.size else np.empty((len(global_index), 0))
@@ -134,15 +136,16 @@ def gather_rows_and_speaker_sums(local_rows, global_index, n_total, speaker_ids,
         return allgather_rows(local_rows, global_index, n_total), sums
     owns = len(global_index) > 0
     K = local_rows.shape[1]
-    kk = torch.tensor([K if owns else -1, -K if owns else -(1 << 60)], dtype=torch.int64, device=_comm_device())
-    dist.all_reduce(kk, op=dist.ReduceOp.MAX)        # (width agreement, as in allgather_rows: a mismatch raises on EVERY rank)
+    # ONE 24-byte MAX all-reduce carries the width agreement (as in allgather_rows: a mismatch raises on EVERY rank) and the largest
+    # shard (balanced shards may exceed ceil(n / world) by a few rows) - then ONE all-gather carries everything else
+    kk = torch.tensor([K if owns else -1, -K if owns else -(1 << 60), len(global_index)], dtype=torch.int64, device=_comm_device())
+    dist.all_reduce(kk, op=dist.ReduceOp.MAX)
     k_max, k_min = int(kk[0].item()), -int(kk[1].item())
     if k_max >= 0 and k_min != k_max:
         raise ValueError("gather_rows_and_speaker_sums: ranks disagree on the row width (%d .. %d columns): the shards were "
                          "evaluated with different keys or metrics" % (k_min, k_max))
     K = max(k_max, 0)
-    cap = -(-n_total // world)
-    cap = int(allreduce_max_int(max(cap, len(global_index))))       # (balanced shards may exceed ceil(n / world) by a few rows)
+    cap = max(-(-n_total // world), int(kk[2].item()))
     pack = torch.full((cap + n_speakers, K + 1), float("nan"), dtype=torch.float64)
     pack[:cap, 0] = -1.0
     if owns:

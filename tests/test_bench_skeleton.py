@@ -81,3 +81,33 @@ def test_cfg4_strong_scaling_shards_and_collectives_gloo():
     want = np.mean([vals[s:s + c].mean(axis=0) for s, c in zip(np.cumsum([0] + counts[:-1]), counts)], axis=0)
     for n in (1, 2, 3):
         np.testing.assert_allclose(means[n], want, rtol=1e-12, atol=1e-12)
+
+
+def test_true_world_size_8_launcher_and_accounting_gloo():
+    """The driver's 8-GPU launch, on CPU: eight gloo ranks through bench.py's own launcher for cfg-2, cfg-5 and cfg-4 - one JSON
+    line from rank 0, n_gpus = the ranks that joined, MAX-over-ranks time, whole-job units: cfg-2 8 x 1024 pairs per step (weak),
+    cfg-5 8 x 12,500 utterances = 100 k x 192,000 samples per step (weak), cfg-4 the 2,937-utterance set per step whatever N
+    (strong), with either collective - BASELINE cfg-4 names the all-reduce, evaluate() needs the all-gather."""
+    import numpy as np
+    r = _bench("--config", "cfg2", "--gpus", "8", "--steps", "2", "--warmup", "1", "--pairs", "1000", "--_cpu-skeleton")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak"
+    assert abs(d["value"] - 8 * 1000 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-3
+    assert d["extra"]["job_means"] == [4.5]                           # (1 + ... + 8) / 8: all eight ranks' sums arrived
+    r = _bench("--config", "cfg5", "--gpus", "8", "--steps", "2", "--warmup", "1", "--_cpu-skeleton")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 8 and abs(d["value"] - 100000 * 192000 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-3
+    means = {}
+    for coll in ("allgather", "allreduce"):
+        r = _bench("--config", "cfg4", "--gpus", "8", "--steps", "2", "--warmup", "1", "--collective", coll, "--_cpu-skeleton")
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+        assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["extra"]["collective"] == coll
+        assert abs(d["value"] - 2937 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-3
+        assert d["extra"]["shard_balance_max_over_mean"] <= 1.01 and abs(d["extra"]["shard_utterances"] - 2937 / 8) <= 8
+        if coll == "allgather":
+            assert d["extra"]["allgather_rows_received"] == 2937
+        means[coll] = np.array(d["extra"]["job_means"])
+    np.testing.assert_allclose(means["allreduce"], means["allgather"], rtol=1e-12, atol=1e-12)

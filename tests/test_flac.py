@@ -171,3 +171,32 @@ def test_decoder_survives_corrupted_streams(tmp_path):
             x = pcm[it % len(streams)]
             np.testing.assert_array_equal(out[:x.size].reshape(x.shape), x)       # MD5 on: a pass means the very samples
     assert passed[2] == 0
+
+
+def test_verify_flac_tree_tool(tmp_path, capsys):
+    """tools/verify_flac_tree.py: the one command a holder of the VCTK test set runs before evaluate() - every stream decoded with
+    MD5 verification, per-file format lines, exit status 0 on a clean tree, 1 when a stream's samples do not hash to its STREAMINFO
+    digest (a flipped residual bit), 2 on a tree without FLAC files."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("verify_flac_tree", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                   "tools", "verify_flac_tree.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    (tmp_path / "p360").mkdir()
+    (tmp_path / "p361").mkdir()
+    a = FF.encode(_signal(6000, 1, 16, 1), 48000, 16, 1152)
+    b = FF.encode(_signal(5000, 2, 24, 2), 44100, 24, 4096)
+    (tmp_path / "p360" / "a.flac").write_bytes(a)
+    (tmp_path / "p361" / "b.flac").write_bytes(b)
+    assert tool.main([str(tmp_path)]) == 0
+    out = capsys.readouterr().out
+    assert "a.flac: 48000 Hz, 1 ch, 16 bit, 6000 frames" in out and "b.flac: 44100 Hz, 2 ch, 24 bit, 5000 frames" in out
+    assert "2 file(s), 0 failed, 11000 frames" in out
+    bad = bytearray(a)
+    bad[len(bad) // 2] ^= 0x10                                   # inside a frame: CRC-16 / MD5 catch it
+    (tmp_path / "p361" / "c.flac").write_bytes(bytes(bad))
+    assert tool.main([str(tmp_path), "--quiet"]) == 1
+    out = capsys.readouterr().out
+    assert "FAIL" in out and "c.flac" in out and "3 file(s), 1 failed" in out
+    (tmp_path / "empty").mkdir()
+    assert tool.main([str(tmp_path / "empty")]) == 2

@@ -254,6 +254,7 @@ class Cfg3:
 
     def config(self, world):
         a = self.a
+        self.engine = self.engine_of(a)                  # (config() is also called on a bare shell of the class)
         return {"workload": "cfg-3: %d synthetic 48 kHz 4 s float32 targets per GPU resident in HBM x 7 cutoffs "
                             "(cut bins %s of FDomainHelper 2048/441 at fs 48 kHz): est[k] = stft_hard low-pass(target, cut k) through ONE "
                             "ssr_fft_lowpass_multi call (engine: %s%s), then LSD + log-SISpec + SISpec + SSIM of the 7 keys at STFT 2048/512 "

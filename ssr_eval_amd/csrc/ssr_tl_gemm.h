@@ -16,7 +16,8 @@
 // Two kernels, both "dual GEMMs" (out1 = A1 . B1, out2 = A2 . B2), K in chunks of 16, operands double-buffered in LDS:
 //   k_tl_fwd: A1 = A2 = the frames (rows of the padded signal at stride hop, read where they lie), B1 / B2 = Re / Im weights
 //            [n_fft][bins].  128 (frames) x 128 (bins) per workgroup of four waves, wave = 64 x 64 of both products: eight 32 x 32
-//            accumulators, no chain totals (one chain).  The lane that ends with re[t][k] also holds im[t][k], so
+//            accumulators, no chain totals (one chain); a tile with at most 64 bins left (the last one of most cuts) is split 4 x 1:
+//            wave = 32 x 64, half the matrix instructions, no idle wave.  The lane that ends with re[t][k] also holds im[t][k], so
 //            spectrogram_phase, the cut and mag * cos / mag * sin (dsp.py:76-81,112-116; lowpass.py:24-25) run in the epilogue,
 //            which stores (R, I) TRANSPOSED - [bin][row], four consecutive rows per lane and store - so that the inverse product
 //            can stream its A tiles with LDS-DMA.  The mirrored half of the spectrum is never materialised.
@@ -192,7 +193,11 @@ __device__ __forceinline__ void ssr_tl_fwd_body(const SsrTlParams& p, float* lds
   const int n0 = ct * SSR_TL_BN;
   const int n_cols = MODE == SSR_TL_FWD_STFT ? p.n_bins : c;
   if (n0 >= n_cols) return;
-  const bool wave_on = n0 + 64 * wc < n_cols;          // a wave whose 64 columns lie past the bins only stages
+  // Wave layout of the tile: 2 x 2 waves of 64 rows x 64 columns - or, when the tile holds no more than 64 columns (the last column
+  // tile of most cuts: 683 = 5 x 128 + 43), 4 x 1 waves of 32 rows x 64 columns: half the matrix instructions per wave, no idle wave
+  const bool narrow = n_cols - n0 <= 64;
+  const int row0 = narrow ? 32 * wave : 64 * wr, col0 = narrow ? 0 : 64 * wc;
+  const bool wave_on = n0 + col0 < n_cols;             // a wave whose 64 columns lie past the bins only stages
 
   // ---- staging assignments ------------------------------------------------------------------------------------
   // A: thread -> k = tid % 16, rows tid / 16 + 16 j (j < 8); rows outside the tile's own range re-read a row inside it (never stored)
@@ -242,25 +247,32 @@ __device__ __forceinline__ void ssr_tl_fwd_body(const SsrTlParams& p, float* lds
   // operands of one step (one k pair = eight matrix instructions, 512 cycles of the matrix pipe): two register sets, the set of step
   // s + 1 is requested BEFORE the matrix instructions of step s are issued and first touched after them
   float fa0[2], fa1[2], fb10[2], fb11[2], fb20[2], fb21[2];
-  auto fetch = [&](int stage, int s, int slot) {
+  auto fetch = [&](int stage, int s, int slot, auto narrow_tag) {
+    constexpr bool NARROW = decltype(narrow_tag)::value;
     const float* st = lds + stage * STAGE_FLOATS;
-    const float* as = st + (64 * wr + fi) * SSR_TL_LDA;
-    const float* bs1 = st + A_FLOATS + 64 * wc + fi;
+    const float* as = st + (row0 + fi) * SSR_TL_LDA;
+    const float* bs1 = st + A_FLOATS + col0 + fi;
     const float* bs2 = bs1 + B_FLOATS;
     const int k = 2 * s + fk;
-    fa0[slot] = as[k]; fa1[slot] = as[32 * SSR_TL_LDA + k];
+    fa0[slot] = as[k];
+    if (!NARROW) fa1[slot] = as[32 * SSR_TL_LDA + k];
     fb10[slot] = bs1[k * SSR_TL_BN]; fb20[slot] = bs2[k * SSR_TL_BN];
     fb11[slot] = bs1[k * SSR_TL_BN + 32]; fb21[slot] = bs2[k * SSR_TL_BN + 32];
   };
-  auto mfma8 = [&](int cur) {
+  auto mfma8 = [&](int cur, auto narrow_tag) {
+    constexpr bool NARROW = decltype(narrow_tag)::value;
     acc1[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cur], fb10[cur], acc1[0][0], 0, 0, 0);
     acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cur], fb20[cur], acc2[0][0], 0, 0, 0);
-    acc1[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cur], fb10[cur], acc1[1][0], 0, 0, 0);
-    acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cur], fb20[cur], acc2[1][0], 0, 0, 0);
+    if (!NARROW) {
+      acc1[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cur], fb10[cur], acc1[1][0], 0, 0, 0);
+      acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cur], fb20[cur], acc2[1][0], 0, 0, 0);
+    }
     acc1[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cur], fb11[cur], acc1[0][1], 0, 0, 0);
     acc2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cur], fb21[cur], acc2[0][1], 0, 0, 0);
-    acc1[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cur], fb11[cur], acc1[1][1], 0, 0, 0);
-    acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cur], fb21[cur], acc2[1][1], 0, 0, 0);
+    if (!NARROW) {
+      acc1[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cur], fb11[cur], acc1[1][1], 0, 0, 0);
+      acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cur], fb21[cur], acc2[1][1], 0, 0, 0);
+    }
   };
 
   // ---- the pipeline: three stages, ONE barrier per chunk, in the MIDDLE of the chunk's eight steps (see k_tl_inv) -------------------
@@ -278,18 +290,18 @@ __device__ __forceinline__ void ssr_tl_fwd_body(const SsrTlParams& p, float* lds
   for (int j = 0; j < 8; ++j) load_a(j, 1);
   ssr_tl_wait_vm<12>();                                 // chunk 0's transfers have landed (chunk 1's four + eight loads may be in flight)
   __syncthreads();
-  if (wave_on) fetch(0, 0, 0);
+  if (wave_on) fetch(0, 0, 0, std::false_type{});
   int stage = 0;
-  auto chunk_body = [&](int chunk, auto more_tag, auto on_tag) {
+  auto chunk_body = [&](int chunk, auto more_tag, auto on_tag, auto narrow_tag) {
     constexpr bool MORE = decltype(more_tag)::value;     // chunk + 2 exists: request it in the second half
     constexpr bool ON = decltype(on_tag)::value;         // this wave multiplies (else it only stages)
     const int st1 = stage == 2 ? 0 : stage + 1, st2 = stage == 0 ? 2 : stage - 1;     // stages of chunks c + 1, c + 2
     if (ON) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        fetch(stage, s + 1, (s + 1) & 1);
+        fetch(stage, s + 1, (s + 1) & 1, narrow_tag);
         __builtin_amdgcn_sched_barrier(0);
-        mfma8(s & 1);
+        mfma8(s & 1, narrow_tag);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -306,35 +318,40 @@ __device__ __forceinline__ void ssr_tl_fwd_body(const SsrTlParams& p, float* lds
         load_a(2 * (s - 4) + 1, chunk + 2);
       }
       if (ON) {
-        if (s < 7) fetch(stage, s + 1, (s + 1) & 1);
-        else if (chunk + 1 < n_chunks) fetch(st1, 0, 0);
+        if (s < 7) fetch(stage, s + 1, (s + 1) & 1, narrow_tag);
+        else if (chunk + 1 < n_chunks) fetch(st1, 0, 0, narrow_tag);
         __builtin_amdgcn_sched_barrier(0);
-        mfma8(s & 1);
+        mfma8(s & 1, narrow_tag);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     stage = st1;
   };
-  if (wave_on) {
+  if (wave_on && !narrow) {
     int chunk = 0;
-    for (; chunk + 2 < n_chunks; ++chunk) chunk_body(chunk, std::true_type{}, std::true_type{});
-    for (; chunk < n_chunks; ++chunk) chunk_body(chunk, std::false_type{}, std::true_type{});
+    for (; chunk + 2 < n_chunks; ++chunk) chunk_body(chunk, std::true_type{}, std::true_type{}, std::false_type{});
+    for (; chunk < n_chunks; ++chunk) chunk_body(chunk, std::false_type{}, std::true_type{}, std::false_type{});
+  } else if (wave_on) {
+    int chunk = 0;
+    for (; chunk + 2 < n_chunks; ++chunk) chunk_body(chunk, std::true_type{}, std::true_type{}, std::true_type{});
+    for (; chunk < n_chunks; ++chunk) chunk_body(chunk, std::false_type{}, std::true_type{}, std::true_type{});
   } else {
     int chunk = 0;
-    for (; chunk + 2 < n_chunks; ++chunk) chunk_body(chunk, std::true_type{}, std::false_type{});
-    for (; chunk < n_chunks; ++chunk) chunk_body(chunk, std::false_type{}, std::false_type{});
+    for (; chunk + 2 < n_chunks; ++chunk) chunk_body(chunk, std::true_type{}, std::false_type{}, std::false_type{});
+    for (; chunk < n_chunks; ++chunk) chunk_body(chunk, std::false_type{}, std::false_type{}, std::false_type{});
   }
   if (!wave_on) return;
 
   // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -------------------------------
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const int col = n0 + 64 * wc + 32 * h + fi;
+    const int col = n0 + col0 + 32 * h + fi;
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int64_t rq = tl.lo + 64 * wr + 32 * g + 8 * j + 4 * fk;       // rows rq .. rq + 3 (rq is a multiple of 4)
+        if (g == 1 && narrow) continue;                                  // (32 rows per wave in the narrow layout)
+        const int64_t rq = tl.lo + row0 + 32 * g + 8 * j + 4 * fk;          // rows rq .. rq + 3 (rq is a multiple of 4)
         if (MODE == SSR_TL_FWD_STFT) {
           if (col < p.n_bins)
 #pragma unroll
@@ -657,27 +674,52 @@ __device__ __forceinline__ void ssr_tl_pack_body(const SsrTlPackParams& p, float
   }
 }
 
-// F.fold + / clamp(folded window^2, 1e-11) + trim (ISTFT._overlap_add_divide_window_sum, _trim_edges): one thread per output sample.
+// F.fold + / clamp(folded window^2, 1e-11) + trim (ISTFT._overlap_add_divide_window_sum, _trim_edges).
 struct SsrTlFoldParams {
   const float* frames; const int64_t* frame_off; const int32_t* len; const int64_t* out_off; int n_fft, hop;
   const float* w2; float* out; int pad, pad_reflect;
 };
-__device__ __forceinline__ void ssr_tl_fold_body(const SsrTlFoldParams& p, int item, int s) {
+// FOUR output samples per thread, 256 apart (s0, s0 + 256, ...): their frame rows are independent chains of loads, so a thread keeps
+// up to twenty requests in flight instead of five; each sample's sums run in the same order as before (frames in descending order).
+__device__ __forceinline__ void ssr_tl_fold_body(const SsrTlFoldParams& p, int item, int s0) {
   const int len = p.len[item];
-  if (s >= len) return;
+  if (s0 >= len) return;
   float* out = p.out + p.out_off[item];
-  if (!ssr_tl_item_ok(len, p.n_fft, p.pad, p.pad_reflect)) { out[s] = 0.0f; return; }
-  const int T = ssr_tl_frames_of(len, p.n_fft, p.hop, p.pad);
-  const int q = s + p.pad;                             // ISTFT._trim_edges: start = n_fft / 2 if center else 0
-  int t = q / p.hop;
-  t = t < T - 1 ? t : T - 1;
+  const bool ok = ssr_tl_item_ok(len, p.n_fft, p.pad, p.pad_reflect);
+  const int T = ok ? ssr_tl_frames_of(len, p.n_fft, p.hop, p.pad) : 1;
   const float* fr = p.frames + p.frame_off[item] * (int64_t)p.n_fft;
-  if (q >= (T - 1) * p.hop + p.n_fft) { out[s] = 0.0f; return; }     // past the overlap-added signal (the slice ends there; zero-filled)
-  float y = 0.0f, ws = 0.0f;
-  for (; t >= 0 && q - t * p.hop < p.n_fft; --t) {
-    y = ssr_tl_add(y, fr[(int64_t)t * p.n_fft + (q - t * p.hop)]);
-    ws = ssr_tl_add(ws, p.w2[q - t * p.hop]);
+  const int end = (T - 1) * p.hop + p.n_fft;          // samples of the overlap-added signal
+  float y[4], ws[4];
+  int q[4], t[4];
+  bool live[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int s = s0 + 256 * j;
+    q[j] = s + p.pad;                                  // ISTFT._trim_edges: start = n_fft / 2 if center else 0
+    live[j] = ok && s < len && q[j] < end;             // (past the overlap-added signal the slice ends: zero-filled)
+    int tt = q[j] / p.hop;
+    t[j] = tt < T - 1 ? tt : T - 1;
+    y[j] = 0.0f; ws[j] = 0.0f;
   }
-  ws = ws < 1e-11f ? 1e-11f : ws;
-  out[s] = y / ws;
+  // a sample lies in at most ceil(n_fft / hop) frames; the chains advance together, a finished one idles
+  for (bool any = true; any;) {
+    any = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool go = live[j] && t[j] >= 0 && q[j] - t[j] * p.hop < p.n_fft;
+      if (go) {
+        y[j] = ssr_tl_add(y[j], fr[(int64_t)t[j] * p.n_fft + (q[j] - t[j] * p.hop)]);
+        ws[j] = ssr_tl_add(ws[j], p.w2[q[j] - t[j] * p.hop]);
+        --t[j];
+        any = true;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int s = s0 + 256 * j;
+    if (s >= len) continue;
+    const float w = ws[j] < 1e-11f ? 1e-11f : ws[j];
+    out[s] = live[j] ? y[j] / w : 0.0f;
+  }
 }

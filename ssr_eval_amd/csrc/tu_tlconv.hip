@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void k_tl_pack(SsrTlPackParams p) {
   ssr_tl_pack_body(p, tile);
 }
 __global__ __launch_bounds__(256) void k_tl_fold(SsrTlFoldParams p, int blocks_per_item) {
-  ssr_tl_fold_body(p, blockIdx.x / blocks_per_item, (blockIdx.x % blocks_per_item) * 256 + threadIdx.x);
+  ssr_tl_fold_body(p, blockIdx.x / blocks_per_item, (blockIdx.x % blocks_per_item) * 1024 + threadIdx.x);     // 1024 samples per block
 }
 
 // ---- tables: torchlibrosa's Conv1d weights (DFTBase.dft_matrix / idft_matrix, STFT.__init__, ISTFT.init_real_imag_conv) ----------
@@ -242,7 +242,7 @@ static int tl_pad(const ssr_plan* pl, const SsrTlParams& p, const float* in, con
 }
 static int tl_fold(const ssr_plan* pl, const SsrTlParams& p, const int64_t* out_off, int max_len, float* out, hipStream_t s) {
   SsrTlFoldParams f{p.frames, p.frame_off, p.len, out_off, pl->n_fft, pl->hop, pl->tl_w2, out, p.pad, p.pad_reflect};
-  const int bpi = ssr_ceil_div(max_len, 256);
+  const int bpi = ssr_ceil_div(max_len, 1024);
   hipLaunchKernelGGL(k_tl_fold, dim3((unsigned)((int64_t)p.n_items * bpi)), dim3(256), 0, s, f, bpi);
   HIP_TRY(hipGetLastError());
   return SSR_OK;

@@ -195,7 +195,7 @@ def test_cfg3_pipeline_against_reference_arithmetic():
                 for c, yk in enumerate(ys):
                     ref = olp.lowpass(tgt_h[t], CUTOFFS[c], 48000, 1, "stft_hard")
                     strict["samples_differing"] += int((yk[0].cpu().numpy() != ref).sum())
-                    got = B.pair_metrics(mplan, [yk[0]], [tgt[t]])[0].cpu().numpy()
+                    got = B.pair_metrics(mplan, [yk[0]], [tgt[t]])[0]
                     wv = _vec(om.evaluation(ref, tgt_h[t], n_fft=2048, hop=512))
                     strict["lsd_rel_max"] = max(strict["lsd_rel_max"], float(abs(got[0] / wv[0] - 1)))
                     strict["items"] += 1

@@ -339,11 +339,12 @@ def test_conv_lowpass_is_the_references_waveform():
         np.testing.assert_array_equal(yk[1], tl_chain.stft_hard_lowpass(x[:27001], cut), err_msg=k)
         yr = g["c35_y_" + k]
         assert (yk[0] != yr).mean() < 0.03 and np.abs(yk[0] - yr).max() <= 6e-8, k
-        m = B.pair_metrics(plan, [yk[0]], [x])[0].cpu().numpy()
-        assert abs(m[0] - want[0]) <= 1e-4 * want[0] + 1e-8 and abs(m[1] - want[1]) <= 2e-3 + 1e-4 * abs(want[1]), (k, m, want)
-        assert abs(m[2] - want[2]) <= 1e-4 * abs(want[2]) + 1e-4 and abs(m[3] - want[3]) <= 1e-5 * want[3], (k, m, want)
+        m = B.pair_metrics(plan, [yk[0]], [x])[0]
+        assert abs(m[0] - want[0]) <= 1e-4 * want[0] + 1e-8 and abs(m[3] - want[3]) <= 1e-5 * want[3], (k, m, want)
+        if cut < 1025:      # (no cut at all: estimate = target to round-off, SISpec is the ratio of two round-off energies - SURVEY 8(c))
+            assert abs(m[1] - want[1]) <= 2e-3 + 1e-4 * abs(want[1]) and abs(m[2] - want[2]) <= 1e-4 * abs(want[2]) + 1e-4, (k, m, want)
         # on the reference's own waveform the metric kernels give the reference's numbers at the north_star bar
-        m = B.pair_metrics(plan, [yr], [x])[0].cpu().numpy()
+        m = B.pair_metrics(plan, [yr], [x])[0]
         np.testing.assert_allclose(m[[0, 3]], want[[0, 3]], rtol=1e-5, atol=1e-9)
 
 

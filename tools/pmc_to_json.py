@@ -9,7 +9,11 @@ summary = {"source": "rocprofv3 --kernel-trace --stats -- python bench.py --conf
                      "(cfg2 with its side figures, the others --no-side); PMC: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
                      "--kernel-trace passes per config and for tools/exp_api_true.py / tools/exp_sinc.py (tools/collect_profiles_r03.sh)",
            "kernels": {}}
-if tag >= "r04":
+if tag >= "r05":
+    summary["source"] = summary["source"].replace("collect_profiles_r03.sh", "collect_profiles_r05.sh") + \
+        "; cfg3 = the product default engine (conv, ONE ssr_fft_lowpass_multi call per step); cfg3f64 = bench.py --config cfg3 --lowpass-engine segments; " \
+        "k_tl_* traffic = the MEAN over the launches of a step (seven inverse products at seven cuts)"
+elif tag >= "r04":
     summary["source"] = summary["source"].replace("collect_profiles_r03.sh", "collect_profiles_r04.sh") + "; cfg3conv = bench.py --config cfg3 --lowpass-engine conv"
 for stats in sorted(glob.glob(src + "/stats_*/*kernel_stats.csv")):
     cfg = os.path.basename(os.path.dirname(stats)).replace("stats_", "")
@@ -26,7 +30,9 @@ for stats in sorted(glob.glob(src + "/stats_*/*kernel_stats.csv")):
     if os.path.exists(bj) and os.path.getsize(bj):
         summary.setdefault("bench_line_under_rocprof", {})[cfg] = json.load(open(bj))
 KEYS = ("k_stft_wave<double, false", "k_stft_wave<double, true", "k_ssim", "k_stft<double, 11")
-MORE = {"cfg3": ("k_lowpass_wave", "k_ola_paired", "k_ola(", "k_specred_wave"), "cfg3fused": ("k_lowpass_group",), "cfg5": ("k_resample<", "k_resample_rc", "k_resample_chain"),
+MORE = {"cfg3": ("k_lowpass_wave", "k_ola_paired", "k_ola(", "k_specred_wave") if tag < "r05" else ("k_tl_fwd", "k_tl_inv", "k_tl_fold", "k_tl_pad", "k_specred_wave"),
+        "cfg3f64": ("k_lowpass_wave", "k_ola_paired", "k_ola("),
+        "cfg3fused": ("k_lowpass_group",), "cfg5": ("k_resample<", "k_resample_rc", "k_resample_chain"),
         "cfg3conv": ("k_tl_gemm<0>", "k_tl_gemm<2>", "k_tl_fold", "k_tl_pad"),
         "api": ("k_stft_r3_rot<double, false", "k_stft_r3_rot<double, true"), "sinc": ("k_resample_sinc",)}
 pm = {}
@@ -54,6 +60,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 continue
             if k == "k_resample_sinc":        # one launch per rate pair of tools/exp_sinc.py: report the first pair (44.1 -> 48 kHz)
                 pm.setdefault(k + " 44.1->48 kHz, 128 files", {})[c] = vals[0]
+                continue
+            if k.startswith("k_tl_"):             # launches of a step differ (seven cuts): the mean is what a step's sum needs
+                pm.setdefault(k, {})[c] = sum(vals) / len(vals)
                 continue
             vals = sorted(vals)
             pm.setdefault(k, {})[c] = vals[len(vals) // 2]

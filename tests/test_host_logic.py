@@ -180,6 +180,26 @@ def test_cabi_round3_entry_points_validate_before_the_device():
     assert b"ssr_resample_poly" in lib.ssr_last_error()
 
 
+def test_cabi_round5_entry_points_validate_before_the_device():
+    """ssr_fft_lowpass_multi and ssr_plan_set_tl_weights reject null arguments on the host, an empty batch / key list is a no-op, and the
+    Python mirror's weight construction (backend.tl_conv_weights = torchlibrosa's numpy expressions) is the oracle's, bit for bit."""
+    from ssr_eval_amd import _lib, backend as B
+    from oracle import stft as ostft
+    lib = _lib.load()
+    p = C.c_void_p(0x1000)
+    cuts = (C.c_int32 * 2)(10, 20)
+    assert lib.ssr_fft_lowpass_multi(None, p, p, p, cuts, 2, p, 1, 100, 10, p, 100, p, 1 << 20, None) == -1
+    assert lib.ssr_fft_lowpass_multi(p, p, p, p, None, 2, p, 1, 100, 10, p, 100, p, 1 << 20, None) == -1
+    assert lib.ssr_fft_lowpass_multi(p, p, p, p, cuts, 0, p, 1, 100, 10, p, 100, p, 1 << 20, None) == 0     # no key: nothing to do
+    assert lib.ssr_fft_lowpass_multi(p, p, p, p, cuts, 2, p, 0, 100, 10, p, 100, p, 1 << 20, None) == 0     # empty batch
+    assert lib.ssr_plan_set_tl_weights(None, p, p, p, p, p) == -1
+    assert lib.ssr_plan_set_tl_weights(p, None, p, p, p, p) == -1
+    got = B.tl_conv_weights(256)
+    for a, b in zip(got[:4], ostft.tl_weights(256)):
+        assert a.dtype == np.float32 and np.array_equal(a, b)
+    assert got[0].shape == (129, 256) and got[2].shape == (256, 256) and got[4].shape == (256,)
+
+
 def test_wav_decode_mono_stereo_and_batch(tmp_path):
     """io.read_audio on 16-bit mono / stereo PCM and the pooled decode_batch; Ragged.from_list packing on the host device."""
     import torch

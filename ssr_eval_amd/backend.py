@@ -5,7 +5,6 @@ produced by the HIP kernels behind the C ABI.  Batches are ragged: one flat floa
 int64 offsets / int32 lengths, all resident in HBM.
 """
 import ctypes as C
-import functools
 import math
 import threading
 
@@ -41,7 +40,6 @@ def num_frames(n, n_fft, hop):
     return 1 + (int(n) + 2 * (n_fft // 2) - n_fft) // hop
 
 
-@functools.lru_cache(maxsize=4)
 def _tl_dft_matrices(n):
     """torchlibrosa DFTBase.dft_matrix / idft_matrix (stft.py): W[x, y] = omega ** (x y) with omega = exp(-/+ 2 pi i / n), evaluated
     as the module evaluates it - numpy's complex128 power on the integer product grid - so that the float32 weights below are the

@@ -72,6 +72,8 @@ def test_cfg2_full_batch_1024_pairs():
     full = batch.run(B.M_ALL).cpu().numpy().copy()
     assert full.shape == (N, 4) and np.isfinite(full).all()
     spots = [0, 1, 255, 256, 511, 512, 777, 1023]                   # spread over the whole grid
+    if (os.cpu_count() or 1) >= 16:                                 # a 16-core box checks 32 of the 1024 pairs
+        spots = sorted(set(spots) | set(range(17, 1024, 43)))[:32]
     _check_rows(full[spots], _oracle_many([(est[i].cpu().numpy(), tgt[i].cpu().numpy()) for i in spots]), "cfg2")
     # the bench's mask (LSD + SSIM) gives the same two numbers, the other two stay NaN
     two = batch.run(B.M_LSD | B.M_SSIM).cpu().numpy()

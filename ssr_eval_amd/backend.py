@@ -43,9 +43,12 @@ def num_frames(n, n_fft, hop):
 def _tl_dft_matrices(n):
     """torchlibrosa DFTBase.dft_matrix / idft_matrix (stft.py): W[x, y] = omega ** (x y) with omega = exp(-/+ 2 pi i / n), evaluated
     as the module evaluates it - numpy's complex128 power on the integer product grid - so that the float32 weights below are the
-    reference's to the last bit (ssr_eval/dsp.py:21-39 builds STFT / ISTFT, which build these)."""
+    reference's to the last bit (ssr_eval/dsp.py:21-39 builds STFT / ISTFT, which build these).  The power is a function of the
+    exponent alone, so it is taken once per DISTINCT product x y (a quarter of the grid) and gathered: the same values, 3-4x sooner."""
     x, y = np.meshgrid(np.arange(n), np.arange(n))
-    return np.power(np.exp(-2 * np.pi * 1j / n), x * y), np.power(np.exp(2 * np.pi * 1j / n), x * y)
+    k, inv = np.unique(x * y, return_inverse=True)
+    inv = inv.reshape(n, n)
+    return np.power(np.exp(-2 * np.pi * 1j / n), k)[inv], np.power(np.exp(2 * np.pi * 1j / n), k)[inv]
 
 
 def tl_conv_weights(n_fft, window=None):

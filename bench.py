@@ -120,6 +120,31 @@ def measured_hbm_peak():
     return _HBM_MEASURED
 
 
+def fp64_mix_ceiling():
+    """tools/_build/fp64_mix (tools/ubench/fp64_mix.hip, built by __graft_entry__.build()): units/s of a kernel with k_stft_wave's FP64
+    instruction mix and LDS exchange pattern and no global memory, and the FP64 matrix-instruction rate - measured on this box."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "_build", "fp64_mix")
+    if not os.path.exists(exe):
+        return {}
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=90).stdout
+        r = {}
+        m = re.search(r"LDS exchanges/unit, 2 wave\(s\)/SIMD: ([0-9.]+) M units/s.*?clock ([0-9]+) MHz", out)
+        if m:
+            r["units_M_per_s_2_waves"], r["clock_MHz"] = float(m.group(1)), int(m.group(2))
+        m = re.search(r"FP64 mix alone\s*, 2 wave\(s\)/SIMD: ([0-9.]+) M units/s", out)
+        if m:
+            r["units_M_per_s_2_waves_without_lds"] = float(m.group(1))
+        m = re.search(r"v_mfma_f64_16x16x4_f64, 2 wave\(s\)/SIMD: ([0-9.]+) shader cycles", out)
+        if m:
+            r["mfma_f64_16x16x4_cycles_per_instruction_and_simd"] = float(m.group(1))
+        return r
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def hbm_roofline(kernel, alg_bytes, ms, traffic_key=None, note=None):
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     traffic, src = pmc_traffic(traffic_key) if traffic_key else (None, None)
@@ -183,11 +208,18 @@ class Cfg2:
         fft_tflops = 2 * 376 * 2.5 * 2048 * 11 * a.pairs / (ms_stft * 1e-3) / 1e12   # 42.4 MFLOP of real-FFT work per pair
         dom = ("ssr_stft_pair(k_stft_wave)", ms_stft, "k_stft_wave<double, false") if ms_stft >= ms_ssim else ("ssr_ssim(k_ssim)", ms_ssim, "k_ssim")
         default_wl = a.pairs == 1024 and a.precision == "f64"
+        ceil = fp64_mix_ceiling() if default_wl else {}
+        units_s = 376 * a.pairs / (ms_stft * 1e-3)                 # frame pairs per second of the transform kernel
         roof = hbm_roofline(dom[0], alg, dom[1], dom[2] if default_wl else None,
                             "fused path is compute-side (f64 FFT + f64 SSIM moments); secondary: STFT kernel runs at %.2f TFLOP/s "
-                            "of real-FFT work = %.3f of the f64 vector peak at 2.4 GHz (the chip sustains 1.7-2.0 GHz under FP64 "
-                            "load; by instruction count the kernel issues FP64 at 70 %% of that rate: DESIGN.md section 3)"
-                            % (fft_tflops, fft_tflops / FP64_PEAK_TFLOPS))
+                            "of real-FFT work = %.3f of the f64 vector peak at 2.4 GHz; %.1f M frame pairs/s%s"
+                            % (fft_tflops, fft_tflops / FP64_PEAK_TFLOPS, units_s / 1e6,
+                               " = %.2f of the %.1f M/s a kernel with its hot loop's FP64 instruction mix and LDS exchanges, ideal ILP and no "
+                               "global memory sustains on this box at two waves per SIMD (tools/ubench/fp64_mix, run in this process's shadow: "
+                               "the ceiling of the mix, not of the kernel's whole instruction stream - profiles/r05_notes.md section 3)"
+                               % (units_s / 1e6 / ceil["units_M_per_s_2_waves"], ceil["units_M_per_s_2_waves"]) if ceil.get("units_M_per_s_2_waves") else ""))
+        if ceil:
+            roof["fp64_mix_ceiling"] = ceil
         extra = {"stage_ms": {"stft+lsd": round(ms_stft, 4), "ssim": round(ms_ssim, 4), "finalize": round(ms_fin, 4)},
                  "full_metric_set_pairs_per_s_per_gpu": round(a.pairs / (ms_all4 * 1e-3), 1)}
         return roof, extra

@@ -205,6 +205,76 @@ def get_plan(n_fft, hop, precision="f64", device=None, lowpass_engine="segments"
         return p
 
 
+class _DescRing:
+    """Page-locked staging for the descriptor uploads (offsets, lengths, cut bins: a few KB per launch sequence): ONE 4 MB block used
+    as a ring, so that an upload costs a memcpy and an asynchronous copy.  (tensor.pin_memory() per upload looked free and was not:
+    while launches are queued ahead of the GPU every earlier staging block is still waiting for its copy, the caching host allocator
+    has nothing to hand back and goes to hipHostMalloc - ~1 ms each, visible as idle gaps in front of every stage in the kernel
+    trace.)  The ring has two halves; on entering a half the host waits for the events recorded when it last left it (one per stream
+    that copied out of it) - hundreds of launch sequences earlier."""
+    SIZE = 1 << 22
+    _by_dev, _lock = {}, threading.Lock()
+
+    def __init__(self):
+        self.buf = torch.empty(self.SIZE, dtype=torch.uint8, pin_memory=True)
+        self.host = self.buf.numpy()
+        self.pos, self.half = 0, 0
+        self.streams = {}                       # streams that copied out of the current half
+        self.guard = [[], []]                   # events to wait for before a half is written again
+        self.lock = threading.Lock()
+
+    @classmethod
+    def get(cls, idx):
+        with cls._lock:
+            r = cls._by_dev.get(idx)
+            if r is None:
+                r = cls._by_dev[idx] = cls()
+            return r
+
+    def put(self, a, dev):
+        nbytes = a.nbytes
+        room = (nbytes + 63) & ~63
+        with self.lock:
+            pos = self.pos
+            if pos + room > (self.half + 1) * (self.SIZE // 2):          # leave this half: remember what must finish first
+                evs = []
+                for st in self.streams.values():
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    evs.append(ev)
+                self.guard[self.half], self.streams = evs, {}
+                self.half ^= 1
+                pos = self.half * (self.SIZE // 2)
+                for ev in self.guard[self.half]:
+                    ev.synchronize()
+                self.guard[self.half] = []
+            self.pos = pos + room
+            st = torch.cuda.current_stream(dev)
+            self.streams[st.cuda_stream] = st
+            self.host[pos:pos + nbytes] = a.reshape(-1).view(np.uint8)
+            src = self.buf[pos:pos + nbytes].view(_TORCH_OF[a.dtype.type]).view(a.shape)
+            out = torch.empty(a.shape, dtype=src.dtype, device=dev)
+            out.copy_(src, non_blocking=True)
+            return out
+
+
+_TORCH_OF = {np.int32: torch.int32, np.int64: torch.int64, np.float32: torch.float32, np.float64: torch.float64,
+             np.int16: torch.int16, np.uint8: torch.uint8}
+
+
+def _h2d(a, dev):
+    """Host ndarray -> device tensor WITHOUT a stream synchronisation: through page-locked memory (_DescRing) and an asynchronous
+    copy.  (A pageable source makes the runtime order the copy behind everything queued on the stream and makes the host wait for
+    it - every descriptor upload was a full GPU drain: rocprofv3 showed an evaluate() pass with 42 ms of kernels in 65 ms of wall
+    clock.)"""
+    a = np.ascontiguousarray(a)
+    dev = torch.device(dev)
+    if dev.type != "cuda" or a.size == 0 or a.nbytes > _DescRing.SIZE // 8 or a.dtype.type not in _TORCH_OF:
+        return torch.from_numpy(a).to(dev)
+    with torch.cuda.device(dev):
+        return _DescRing.get(torch.cuda.current_device()).put(a, dev)
+
+
 def _is_f64(a):
     return (a.dtype == torch.float64) if isinstance(a, torch.Tensor) else (getattr(a, "dtype", None) == np.float64)
 
@@ -244,8 +314,8 @@ class Ragged:
                     a0 = arrays[0]
                     data = torch.empty(0, dtype=dtype, device=a0.device).set_(a0.untyped_storage(), a0.storage_offset(), (total,), (1,))
                     off = np.concatenate(([0], np.cumsum(lens)[:-1]))
-                    desc = torch.from_numpy(off.astype(np.int64)).to(a0.device, non_blocking=True)
-                    return Ragged(data, desc, torch.from_numpy(lens.astype(np.int32)).to(a0.device, non_blocking=True), lens)
+                    desc = _h2d(off.astype(np.int64), a0.device)
+                    return Ragged(data, desc, _h2d(lens.astype(np.int32), a0.device), lens)
         ts = []
         for a in arrays:
             t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
@@ -257,8 +327,7 @@ class Ragged:
             raise ValueError("signal too long")
         data = torch.cat(ts) if len(ts) else torch.empty(0, dtype=dtype, device=dev)
         off = np.concatenate(([0], np.cumsum(lens)[:-1])) if len(ts) else np.zeros(0, np.int64)
-        return Ragged(data, torch.from_numpy(off.astype(np.int64)).to(dev),
-                      torch.from_numpy(lens.astype(np.int32)).to(dev), lens)
+        return Ragged(data, _h2d(off.astype(np.int64), dev), _h2d(lens.astype(np.int32), dev), lens)
 
     @staticmethod
     def from_list_keep64(arrays, device=None):
@@ -291,7 +360,7 @@ class _Rows:
         self.max_T = int(self.T.max()) if len(self.T) else 0
         off = np.concatenate(([0], np.cumsum(self.T)[:-1])) if len(self.T) else np.zeros(0, np.int64)
         self.off_host = off
-        self.off = torch.from_numpy(off.astype(np.int64)).to(device)
+        self.off = _h2d(off.astype(np.int64), device)
 
 
 def _check_reflect(plan, lens_host):
@@ -393,20 +462,36 @@ class MultiPairBatch:
         return self.out
 
 
-def pair_metrics_multi(plan, est_lists, tgt_list, mask=M_ALL):
-    """est_lists: K lists (one per key) of n waveforms; tgt_list: n targets -> [n, K, 4] float64."""
+class Pending:
+    """A device result on its way to the host: the copy into page-locked memory is queued behind the launch sequence that produces
+    it, and calling the object waits for THAT copy only (an event) and returns the ndarray - the host can queue the next batch's
+    launches in between."""
+
+    def __init__(self, t):
+        self.host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        self.host.copy_(t, non_blocking=True)
+        self.ev = torch.cuda.Event()
+        self.ev.record(torch.cuda.current_stream(t.device))
+
+    def __call__(self):
+        self.ev.synchronize()
+        return self.host.numpy()
+
+
+def pair_metrics_multi(plan, est_lists, tgt_list, mask=M_ALL, deferred=False):
+    """est_lists: K lists (one per key) of n waveforms; tgt_list: n targets -> [n, K, 4] float64 (deferred: a Pending)."""
     with torch.cuda.device(plan.device):
         flat = [e for key in est_lists for e in key]
         b = MultiPairBatch(plan, Ragged.from_list(flat, plan.device), Ragged.from_list(tgt_list, plan.device), len(est_lists))
-        return b.run(mask).cpu().numpy()
+        return Pending(b.run(mask)) if deferred else b.run(mask).cpu().numpy()
 
 
-def pair_metrics(plan, est_list, tgt_list, mask=M_ALL):
+def pair_metrics(plan, est_list, tgt_list, mask=M_ALL, deferred=False):
     """[n, 4] float64 (lsd, log_sispec, sispec, ssim) for lists of equal-length (est, target) waveforms.
-    float64 signals stay float64 (ssr_pair_metrics_est64 / ssr_pair_metrics_f64)."""
+    float64 signals stay float64 (ssr_pair_metrics_est64 / ssr_pair_metrics_f64).  deferred: a Pending instead of the ndarray."""
     with torch.cuda.device(plan.device):
         b = PairBatch(plan, Ragged.from_list_keep64(est_list, plan.device), Ragged.from_list_keep64(tgt_list, plan.device))
-        return b.run(mask).cpu().numpy()
+        return Pending(b.run(mask)) if deferred else b.run(mask).cpu().numpy()
 
 
 def stft(plan, wavs, kind="mag", torch_style_pad=False):
@@ -515,8 +600,8 @@ def spectrogram_metrics(est_sps, tgt_sps, mask=M_ALL):
             raise ValueError("win_size exceeds image extent")
         x = torch.cat([e.reshape(-1) for e in es])
         y = torch.cat([t.reshape(-1) for t in ts])
-        off = torch.from_numpy(np.concatenate(([0], np.cumsum(T)[:-1])).astype(np.int64)).to(dev)
-        rows = torch.from_numpy(T.astype(np.int32)).to(dev)
+        off = _h2d(np.concatenate(([0], np.cumsum(T)[:-1])).astype(np.int64), dev)
+        rows = _h2d(T.astype(np.int32), dev)
         n, max_T = len(es), int(T.max())
         ws_bytes = int(lib.ssr_spectrogram_metrics_workspace_bytes(n, max_T, F))
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
@@ -554,7 +639,7 @@ class LowpassBatch:
         if cuts.size != self.r.n:
             raise ValueError("one cut bin per item")
         self.uniform = int(cuts[0]) if cuts.size and bool((cuts == cuts[0]).all()) else None
-        self.cut = torch.from_numpy(cuts).to(self.r.device)
+        self.cut = _h2d(cuts, self.r.device)
 
     def run(self):
         p, r = self.plan, self.r
@@ -649,8 +734,8 @@ def istft(plan, res, ims, lengths):
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
         # descriptor tensors must stay referenced until the launch has been enqueued: a temporary would be
         # returned to the caching allocator (and its block re-used by the next temporary) before the call
-        lens_d = torch.from_numpy(lens.astype(np.int32)).to(dev)
-        out_off_d = torch.from_numpy(out_off).to(dev)
+        lens_d = _h2d(lens.astype(np.int32), dev)
+        out_off_d = _h2d(out_off, dev)
         _lib.check(plan.lib.ssr_istft(plan.handle, _vp(re), _vp(im), _vp(rows.off), _vp(lens_d), _vp(out_off_d), len(lens),
                                       int(lens.max()), rows.total, _vp(out), _vp(ws), ws_bytes, _stream()))
         return [out[out_off[i]:out_off[i] + lens[i]] for i in range(len(lens))]
@@ -708,8 +793,8 @@ class ResampleBatch:
         else:
             self.out_len = np.array([self.rp.n_out(n) for n in ragged.lens_host], dtype=np.int64)
         self.out_off = np.concatenate(([0], np.cumsum(self.out_len)[:-1])).astype(np.int64) if ragged.n else np.zeros(0, np.int64)
-        self.out_off_d = torch.from_numpy(self.out_off).to(dev)
-        self.out_len_d = torch.from_numpy(self.out_len.astype(np.int32)).to(dev)
+        self.out_off_d = _h2d(self.out_off, dev)
+        self.out_len_d = _h2d(self.out_len.astype(np.int32), dev)
         self.out = torch.empty(int(self.out_len.sum()), dtype=ragged.data.dtype, device=dev) if alloc else None
 
     def run(self):
@@ -884,8 +969,8 @@ def resample_sinc(wavs, sr_orig, sr_new, res_type="kaiser_best", device=None, fi
         out_off = np.concatenate(([0], np.cumsum(want)[:-1])).astype(np.int64) if r.n else np.zeros(0, np.int64)
         out = torch.zeros(int(want.sum()), dtype=torch.float32, device=dev)       # fix_length pads with zeros
         if r.n and out_len.max() > 0:
-            out_off_d = torch.from_numpy(out_off).to(dev)
-            out_len_d = torch.from_numpy(out_len.astype(np.int32)).to(dev)
+            out_off_d = _h2d(out_off, dev)
+            out_len_d = _h2d(out_len.astype(np.int32), dev)
             tr = sp.time_register(int(out_len.max()))
             _lib.check(_lib.load().ssr_resample_sinc(_vp(r.data), _vp(r.off), _vp(r.len), _vp(out_off_d), _vp(out_len_d), r.n,
                                                      int(out_len.max()), _vp(tr), int(tr.numel()), _vp(sp.win), _vp(sp.delta),
@@ -936,12 +1021,34 @@ class _Staging:
             self.ev[k] = ev
 
 
+_upload_streams = {}
+
+
+def _h2d_arena(arena, total, dev, sent):
+    """A page-locked int16 arena -> device buffer on the device's UPLOAD stream: the bus transfer of a batch runs under the kernels
+    of the batch before it instead of queueing behind them (6 ms of an evaluate() pass over 367 files).  The current stream waits
+    for the copy (an event, no host wait); the buffer is allocated in the upload stream's pool and handed to the current stream
+    with record_stream, so neither pool re-uses it early.  sent(): called once the copy is queued (the arena's re-use event)."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    side = _upload_streams.get(idx)
+    if side is None:
+        side = _upload_streams[idx] = torch.cuda.Stream(device=idx)
+    cur = torch.cuda.current_stream(idx)
+    with torch.cuda.stream(side):
+        d16 = torch.empty(total, dtype=torch.int16, device=dev)
+        d16.copy_(arena[:total], non_blocking=True)
+        sent()
+    cur.wait_stream(side)
+    d16.record_stream(cur)
+    return d16
+
+
 def _pcm_to_float(d16, in_off, frames, chans, dev):
     """int16 device buffer + host descriptors -> (flat float32 mono device buffer, host out offsets)."""
     n = len(frames)
     out_off = np.concatenate(([0], np.cumsum(frames)[:-1]))
-    desc = torch.from_numpy(np.concatenate((in_off, out_off)).astype(np.int64)).to(dev, non_blocking=True)
-    desc32 = torch.from_numpy(np.concatenate((frames.astype(np.int32), chans.astype(np.int32)))).to(dev, non_blocking=True)
+    desc = _h2d(np.concatenate((in_off, out_off)).astype(np.int64), dev)
+    desc32 = _h2d(np.concatenate((frames.astype(np.int32), chans.astype(np.int32))), dev)
     flat = torch.empty(int(frames.sum()), dtype=torch.float32, device=dev)
     _lib.check(_lib.load().ssr_pcm16_to_float(_vp(d16), _vp(desc[:n]), _vp(desc32[:n]), _vp(desc32[n:]), n, int(frames.max()),
                                               _vp(flat), _vp(desc[n:]), _stream()))
@@ -959,9 +1066,7 @@ def upload_decoded(raw, device=None):
         out = [None] * len(raw.paths)
         with torch.cuda.device(dev):
             if raw.total:                      # the arena's copy (and its event) first: nothing else touches this batch's arena
-                d16 = torch.empty(raw.total, dtype=torch.int16, device=dev)
-                d16.copy_(raw.arena[:raw.total], non_blocking=True)
-                raw.staging.sent(raw.k)
+                d16 = _h2d_arena(raw.arena, raw.total, dev, lambda: raw.staging.sent(raw.k))
                 flat, out_off = _pcm_to_float(d16, raw.in_off, raw.frames, raw.chans, dev)
                 for j, i in enumerate(raw.pcm_idx):
                     out[i] = flat[out_off[j]:out_off[j] + raw.frames[j]]
@@ -987,9 +1092,7 @@ def upload_decoded(raw, device=None):
             in_off = np.concatenate(([0], np.cumsum(sizes)[:-1]))
             for i, o in zip(pcm, in_off):
                 host[o:o + raw[i].pcm.shape[0]] = raw[i].pcm
-            d16 = torch.empty(total, dtype=torch.int16, device=dev)
-            d16.copy_(arena[:total], non_blocking=True)
-            st.sent(k)
+            d16 = _h2d_arena(arena, total, dev, lambda: st.sent(k))
             flat, out_off = _pcm_to_float(d16, in_off, frames, chans, dev)
             for j, i in enumerate(pcm):
                 out[i] = flat[out_off[j]:out_off[j] + frames[j]]

@@ -62,54 +62,61 @@ class AudioMetrics:
         """{lsd, log_sispec, sispec, ssim} for one (estimate, target) pair (metrics.py:51-107)."""
         return self.evaluation_batch([est], [target])[0]
 
-    def evaluation_batch(self, ests, targets, mask=B.M_ALL, resident=False):
-        """The same four metrics for lists of pairs, one fused launch sequence for the whole batch."""
+    def evaluation_batch(self, ests, targets, mask=B.M_ALL, resident=False, deferred=False):
+        """The same four metrics for lists of pairs, one fused launch sequence for the whole batch.
+        deferred: the launches are queued and a function is returned that waits for the values and builds the list (the caller
+        queues its next batch in between)."""
         pairs = [self._prepare_pair(e, t, resident) for e, t in zip(ests, targets)]
         # A float64 estimate (IIR-degraded input passed through a testee, eval.py:138-150) makes the reference's est
         # spectrogram - and with it every metric - float64; float64 targets (arrays decoded as float64 by the caller)
         # likewise.  Pairs are grouped by dtype combination and each group runs its own launch sequence:
         # 0 = both float32, 1 = float64 estimate / float32 target, 2 = float64 target (estimate widened if needed).
         kind = [2 if B._is_f64(p[1]) else (1 if B._is_f64(p[0]) else 0) for p in pairs]
-        out = [None] * len(pairs)
+        groups = []
         for want in (0, 1, 2):
             idx = [i for i, f in enumerate(kind) if f == want]
-            if not idx:
-                continue
-            vals = B.pair_metrics(self._plan(), [pairs[i][0] for i in idx], [pairs[i][1] for i in idx], mask)
-            for i, row in zip(idx, vals):
-                d = {}
-                for k, v in zip(_KEYS, row):
-                    if not np.isnan(v) or (mask & (1 << _KEYS.index(k))):
-                        # float32 pairs: lsd / sispec are float32 tensors in the reference (float() of fp32), ssim float64
-                        d[k] = float(v) if (k == "ssim" or want) else float(np.float32(v))
-                out[i] = d
-        return out
+            if idx:
+                groups.append((want, idx, B.pair_metrics(self._plan(), [pairs[i][0] for i in idx], [pairs[i][1] for i in idx], mask,
+                                                         deferred=True)))
 
-    def evaluation_multi(self, ests_by_key, targets, mask=B.M_ALL, resident=False):
+        def finish():
+            out = [None] * len(pairs)
+            for want, idx, pending in groups:
+                for i, row in zip(idx, pending()):
+                    # float32 pairs: lsd / sispec are float32 tensors in the reference (float() of fp32), ssim float64
+                    out[i] = self._row_dict(row, mask, bool(want))
+            return out
+        return finish if deferred else finish()
+
+    @staticmethod
+    def _row_dict(row, mask, wide):
+        d = {}
+        for k, v in zip(_KEYS, row):
+            if not np.isnan(v) or (mask & (1 << _KEYS.index(k))):
+                d[k] = float(v) if (k == "ssim" or wide) else float(np.float32(v))
+        return d
+
+    def evaluation_multi(self, ests_by_key, targets, mask=B.M_ALL, resident=False, deferred=False):
         """K estimates per target (the degradation keys of a file, ssr_eval/eval.py:136-154): ests_by_key = K lists of n
         waveforms, targets = n waveforms -> n lists of K dicts.  One ssr_pair_metrics_multi launch sequence: every target is
         transformed once.  Needs float32 signals and, per item, one truncated length for all keys (metrics.py:89-90) - otherwise
-        (or for K = 1) the pairs go through evaluation_batch."""
+        (or for K = 1) the pairs go through evaluation_batch.  deferred: as evaluation_batch."""
         K, n = len(ests_by_key), len(targets)
         pairs = [[self._prepare_pair(ests_by_key[k][i], targets[i], resident) for i in range(n)] for k in range(K)]
         same_len = all(len({pairs[k][i][0].shape[0] for k in range(K)}) == 1 for i in range(n))
         f32 = not any(B._is_f64(pairs[k][i][0]) or B._is_f64(pairs[k][i][1]) for k in range(K) for i in range(n))
         if K < 2 or n == 0 or not same_len or not f32:
             flat = self.evaluation_batch([ests_by_key[k][i] for i in range(n) for k in range(K)],
-                                         [targets[i] for i in range(n) for _ in range(K)], mask, resident)
-            return [flat[i * K:(i + 1) * K] for i in range(n)]
-        vals = B.pair_metrics_multi(self._plan(), [[pairs[k][i][0] for i in range(n)] for k in range(K)], [pairs[0][i][1] for i in range(n)], mask)
-        out = []
-        for i in range(n):
-            row = []
-            for k in range(K):
-                d = {}
-                for name, v in zip(_KEYS, vals[i, k]):
-                    if not np.isnan(v) or (mask & (1 << _KEYS.index(name))):
-                        d[name] = float(v) if name == "ssim" else float(np.float32(v))
-                row.append(d)
-            out.append(row)
-        return out
+                                         [targets[i] for i in range(n) for _ in range(K)], mask, resident, deferred=True)
+            finish = lambda: (lambda rows: [rows[i * K:(i + 1) * K] for i in range(n)])(flat())    # noqa: E731
+            return finish if deferred else finish()
+        pending = B.pair_metrics_multi(self._plan(), [[pairs[k][i][0] for i in range(n)] for k in range(K)],
+                                       [pairs[0][i][1] for i in range(n)], mask, deferred=True)
+
+        def finish():
+            vals = pending()
+            return [[self._row_dict(vals[i, k], mask, False) for k in range(K)] for i in range(n)]
+        return finish if deferred else finish()
 
     # ---- reductions on [B, C, T, F] tensors (est first)
     @staticmethod

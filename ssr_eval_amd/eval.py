@@ -26,6 +26,17 @@ from .utils import dict_mean, write_json
 _METRIC_KEYS = ("lsd", "log_sispec", "sispec", "ssim")
 
 
+def pipeline_batches(paths, step):
+    """The file batches of one evaluate() pass: `step` files per launch sequence, except that the first two batches hold a quarter
+    and a half of `step` (pipeline fill: the GPU has work after a quarter of a batch's file reads and bus transfer).  Per-file
+    results do not depend on how the files are batched."""
+    batches, b = [], 0
+    for size in (max(1, step // 4), max(1, step // 2)):
+        if len(paths) - b > step:
+            batches.append(paths[b:b + size]); b += size
+    return batches + [paths[c:c + step] for c in range(b, len(paths), step)]
+
+
 class BasicTestee:
     """Plugin base class (ssr_eval/eval.py:17-52): subclass and override ``infer``."""
 
@@ -464,13 +475,7 @@ class SSR_Eval_Helper:
         paths = [os.path.join(self.test_data_root, *work[i]) for i in mine]
         local = []
         step = max(1, int(batch_files))                            # ragged batches of files per launch sequence
-        # (pipeline fill: the first two batches hold a quarter and a half of `step`, so the GPU has work after a quarter of a
-        # batch's file reads and bus transfer; per-file results do not depend on how the files are batched)
-        batches, b = [], 0
-        for size in (max(1, step // 4), max(1, step // 2)):
-            if len(paths) - b > step:
-                batches.append(paths[b:b + size]); b += size
-        batches += [paths[c:c + step] for c in range(b, len(paths), step)]
+        batches = pipeline_batches(paths, step)
         # the file reads of batch k+1 (straight into a page-locked arena) run under the GPU work of batch k
         ahead = decode_packed_async(batches[0], self._device) if batches else None
         # ... and the host work of batch k+1 (descriptors, launches) under the GPU work of batch k: a batch's metric values are

@@ -732,6 +732,50 @@ def test_resident_path_equals_ndarray_testee_path(tmp_path):
                 assert v.pop("extra_metric") == 1.5 and v == base[spk][f][k]
 
 
+def test_pipelined_pass_equals_file_by_file_and_the_descriptor_ring_wraps(tmp_path):
+    """Round 5's host pipeline: evaluate() queues a batch's launches and collects its metric values one batch later, uploads
+    descriptors through a page-locked ring and the PCM on its own stream.  (1) Whatever the batching (1, 3, 64 files per launch
+    sequence; file by file through evaluate_single, which waits for each file), every number is the same, bit for bit.  (2) The
+    ring: thousands of uploads (several times its 4 MB) interleaved with kernels that read them arrive intact."""
+    from ssr_eval_amd import SSR_Eval_Helper, BasicTestee, backend as B
+    from ssr_eval_amd.io import write_wav
+    rng = np.random.default_rng(77)
+    root = tmp_path / "set"
+    for s, c in (("p200", 6), ("p201", 5), ("s5", 3)):
+        (root / s).mkdir(parents=True)
+        for i in range(c):
+            write_wav(str(root / s / ("u%d.wav" % i)), 0.1 * rng.standard_normal(int(rng.integers(30000, 90000))), 44100)
+    h = SSR_Eval_Helper(BasicTestee(), input_sr=44100, output_sr=44100, evaluation_sr=48000, test_data_root=str(root),
+                        setting_fft={"cutoff_freq": [4000, 12000]}, setting_subsampling={"cutoff_freq": [8000]})
+    base = h.evaluate(save_json=False, batch_files=64)
+    for bf in (1, 3, 5):
+        assert h.evaluate(save_json=False, batch_files=bf) == base
+    for spk in ("p200", "p201", "s5"):
+        for f in sorted(os.listdir(root / spk)):
+            assert h.evaluate_single(str(root / spk / f)) == base[spk][f]
+    # (2)
+    dev = B.default_device()
+    ring = B._DescRing.get(torch.cuda.current_device())
+    start_half, flips, kept = ring.half, 0, []
+    for i in range(2600):                                           # 2600 x 4 KB = 2.5 rings
+        a = rng.integers(-2 ** 31, 2 ** 31 - 1, size=512, dtype=np.int64)
+        t = B._h2d(a, dev)
+        if i % 2 == 0:
+            t = t + 1                                               # a kernel behind the copy, on the same stream
+            a = a + 1
+        if i % 100 == 0 or i > 2590:
+            kept.append((a, t))
+        flips += ring.half != start_half; start_half = ring.half
+    assert flips >= 4
+    for a, t in kept:
+        np.testing.assert_array_equal(t.cpu().numpy(), a)
+    for dt in (np.int32, np.float64, np.float32):
+        a = rng.standard_normal(37).astype(dt)
+        np.testing.assert_array_equal(B._h2d(a, dev).cpu().numpy(), a)
+    big = rng.integers(0, 100, size=B._DescRing.SIZE // 8 // 8 + 1, dtype=np.int64)   # above the ring's per-upload limit: the plain copy
+    np.testing.assert_array_equal(B._h2d(big, dev).cpu().numpy(), big)
+
+
 def test_load_audio_is_librosa_load_shaped(tmp_path):
     """load_audio / load_audio_batch: decode + mono + kaiser_best to the requested rate (librosa.load semantics), batched."""
     from ssr_eval_amd.io import write_wav, load_audio, load_audio_batch, read_audio

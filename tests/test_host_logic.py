@@ -305,3 +305,18 @@ def test_cabi_round4_entry_points_validate_before_the_device():
     sr, ch, b, md5, tot = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int64()
     assert lib.ssr_flac_info(b"/nonexistent/x.flac", C.byref(sr), C.byref(ch), C.byref(b), C.byref(tot), C.byref(md5)) != 0
     assert lib.ssr_flac_info(None, C.byref(sr), C.byref(ch), C.byref(b), C.byref(tot), C.byref(md5)) == _lib.ERR_INVALID_ARG
+
+
+def test_pipeline_batches_cover_every_file_once_in_order():
+    """evaluate()'s batching (round 5: two short pipeline-fill batches, then `step` files each): every file exactly once, in the
+    reference's order (eval.py:171-199 walks speakers and files in sorted order), no empty batch, no batch above `step`."""
+    from ssr_eval_amd.eval import pipeline_batches
+    for n in (0, 1, 5, 63, 64, 65, 129, 200, 367, 2937):
+        for step in (1, 5, 64, 128, 512):
+            paths = list(range(n))
+            batches = pipeline_batches(paths, step)
+            assert [p for b in batches for p in b] == paths
+            assert all(0 < len(b) <= step for b in batches)
+            if n > step and step >= 4:
+                assert len(batches[0]) == step // 4                 # the GPU starts after a quarter of a batch's reads
+    assert [len(b) for b in pipeline_batches(list(range(367)), 64)] == [16, 32, 64, 64, 64, 64, 63]

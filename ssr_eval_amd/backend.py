@@ -289,11 +289,20 @@ class Ragged:
         self.n = len(self.lens_host)
         self.max_len = int(self.lens_host.max()) if self.n else 0
         self.device = data.device
+        self.packed = True                      # the signals sit back to back in `data` (from_list(allow_gaps=True) may say otherwise)
 
     @staticmethod
-    def from_list(arrays, device=None, dtype=torch.float32):
+    def from_list(arrays, device=None, dtype=torch.float32, allow_gaps=False):
+        """allow_gaps (callers that only hand data / off / len to a kernel: the metric stage): views into ONE device buffer in
+        increasing address order are taken where they lie even with unused samples between them - `off` says where each starts
+        (est[:m] / target[:m] of metrics.py:89-90 cut a sample off an item here and there, which used to send the whole batch
+        through a per-signal `.to()` and a concatenation).  Such a batch is not `packed`: split() refuses it."""
         dev = torch.device(device) if device is not None else default_device()
         arrays = list(arrays)
+        if allow_gaps and len(arrays) > 1:
+            g = Ragged._from_views_with_gaps(arrays, dev, dtype)
+            if g is not None:
+                return g
         # Views that already sit back to back in ONE device buffer (the output of an earlier launch: upload_decoded,
         # resample_sinc, fft_lowpass, resample_poly ...) are taken as they are: no per-signal transfer call, no concatenation.
         if len(arrays) > 1 and all(isinstance(a, torch.Tensor) and a.is_cuda and a.dtype == dtype and a.dim() == 1 and a.is_contiguous()
@@ -330,10 +339,36 @@ class Ragged:
         return Ragged(data, _h2d(off.astype(np.int64), dev), _h2d(lens.astype(np.int32), dev), lens)
 
     @staticmethod
-    def from_list_keep64(arrays, device=None):
+    def _from_views_with_gaps(arrays, dev, dtype):
+        a0 = arrays[0]
+        if not (isinstance(a0, torch.Tensor) and a0.is_cuda):
+            return None
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        es, st = a0.element_size(), a0.untyped_storage()
+        st0, p0, end = st.data_ptr(), a0.data_ptr(), a0.data_ptr()
+        off, lens = [], []
+        for a in arrays:
+            if not (isinstance(a, torch.Tensor) and a.dtype == dtype and a.dim() == 1 and a.is_contiguous() and a.device == a0.device
+                    and a.untyped_storage().data_ptr() == st0):
+                return None
+            p = a.data_ptr()
+            if p < end:                                  # out of order or overlapping: not this path
+                return None
+            off.append((p - p0) // es); lens.append(a.shape[0])
+            end = p + a.shape[0] * es
+        lens = np.array(lens, dtype=np.int64)
+        if a0.device.index != idx or end > st0 + st.nbytes() or lens.sum() == 0 or lens.max() >= 2 ** 31:
+            return None
+        data = torch.empty(0, dtype=dtype, device=a0.device).set_(st, a0.storage_offset(), ((end - p0) // es,), (1,))
+        r = Ragged(data, _h2d(np.array(off, dtype=np.int64), a0.device), _h2d(lens.astype(np.int32), a0.device), lens)
+        r.packed = bool(off[-1] + lens[-1] == lens.sum())
+        return r
+
+    @staticmethod
+    def from_list_keep64(arrays, device=None, allow_gaps=False):
         """float64 batch if ANY signal is float64 (exact for the float32 ones), else float32."""
         arrays = list(arrays)
-        return Ragged.from_list(arrays, device, torch.float64 if any(_is_f64(a) for a in arrays) else torch.float32)
+        return Ragged.from_list(arrays, device, torch.float64 if any(_is_f64(a) for a in arrays) else torch.float32, allow_gaps)
 
     @staticmethod
     def from_uniform(x):
@@ -346,6 +381,8 @@ class Ragged:
         return Ragged(x.view(-1), off, lens, np.full(N, n, dtype=np.int64))
 
     def split(self, flat=None):
+        if not self.packed:
+            raise ValueError("a batch of views with gaps has no packed layout to split")
         flat = self.data if flat is None else flat
         o = np.concatenate(([0], np.cumsum(self.lens_host)))
         return [flat[o[i]:o[i + 1]] for i in range(self.n)]
@@ -482,7 +519,8 @@ def pair_metrics_multi(plan, est_lists, tgt_list, mask=M_ALL, deferred=False):
     """est_lists: K lists (one per key) of n waveforms; tgt_list: n targets -> [n, K, 4] float64 (deferred: a Pending)."""
     with torch.cuda.device(plan.device):
         flat = [e for key in est_lists for e in key]
-        b = MultiPairBatch(plan, Ragged.from_list(flat, plan.device), Ragged.from_list(tgt_list, plan.device), len(est_lists))
+        b = MultiPairBatch(plan, Ragged.from_list(flat, plan.device, allow_gaps=True), Ragged.from_list(tgt_list, plan.device, allow_gaps=True),
+                           len(est_lists))
         return Pending(b.run(mask)) if deferred else b.run(mask).cpu().numpy()
 
 
@@ -490,7 +528,8 @@ def pair_metrics(plan, est_list, tgt_list, mask=M_ALL, deferred=False):
     """[n, 4] float64 (lsd, log_sispec, sispec, ssim) for lists of equal-length (est, target) waveforms.
     float64 signals stay float64 (ssr_pair_metrics_est64 / ssr_pair_metrics_f64).  deferred: a Pending instead of the ndarray."""
     with torch.cuda.device(plan.device):
-        b = PairBatch(plan, Ragged.from_list_keep64(est_list, plan.device), Ragged.from_list_keep64(tgt_list, plan.device))
+        b = PairBatch(plan, Ragged.from_list_keep64(est_list, plan.device, allow_gaps=True),
+                      Ragged.from_list_keep64(tgt_list, plan.device, allow_gaps=True))
         return Pending(b.run(mask)) if deferred else b.run(mask).cpu().numpy()
 
 
@@ -989,6 +1028,8 @@ class _Staging:
     def __init__(self):
         self.buf = [None, None]
         self.ev = [None, None]
+        self.twin = [None, None]                # the arenas' device-side twins and the events behind their last readers (_h2d_arena)
+        self.done = [None, None]
         self.k = 0
         self.lock = threading.Lock()
 
@@ -1024,23 +1065,36 @@ class _Staging:
 _upload_streams = {}
 
 
-def _h2d_arena(arena, total, dev, sent):
-    """A page-locked int16 arena -> device buffer on the device's UPLOAD stream: the bus transfer of a batch runs under the kernels
-    of the batch before it instead of queueing behind them (6 ms of an evaluate() pass over 367 files).  The current stream waits
-    for the copy (an event, no host wait); the buffer is allocated in the upload stream's pool and handed to the current stream
-    with record_stream, so neither pool re-uses it early.  sent(): called once the copy is queued (the arena's re-use event)."""
+def _h2d_arena(st, k, arena, total, dev):
+    """Page-locked int16 arena k of staging pair `st` -> its device twin, on the device's UPLOAD stream: the bus transfer of a batch
+    runs under the kernels of the batch before it instead of queueing behind them (6 ms of an evaluate() pass over 367 files).  The
+    twin is a persistent buffer (grown when a batch needs more): a fresh torch.empty per batch on the upload stream's pool cost the
+    launching thread 2-3 ms per batch (the pool cannot re-use a block whose last reader on the OTHER stream has not finished, so it
+    went to hipMalloc).  Ordering, all on the GPU: the upload stream waits for the event recorded behind the last kernel that read
+    the twin (consumed()), the current stream waits for the copy.  -> (the twin's first `total` elements, consumed)."""
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     side = _upload_streams.get(idx)
     if side is None:
         side = _upload_streams[idx] = torch.cuda.Stream(device=idx)
     cur = torch.cuda.current_stream(idx)
+    with st.lock:
+        twin, done = st.twin[k], st.done[k]
+    if twin is None or twin.numel() < total or twin.device.index != idx:
+        twin = torch.empty(max(total, 1 << 22), dtype=torch.int16, device=dev)       # (its old self is freed stream-ordered, on `cur`)
+        side.wait_stream(cur)
+    if done is not None:
+        side.wait_event(done)
     with torch.cuda.stream(side):
-        d16 = torch.empty(total, dtype=torch.int16, device=dev)
-        d16.copy_(arena[:total], non_blocking=True)
-        sent()
+        twin[:total].copy_(arena[:total], non_blocking=True)
+        st.sent(k)
     cur.wait_stream(side)
-    d16.record_stream(cur)
-    return d16
+
+    def consumed():
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        with st.lock:
+            st.twin[k], st.done[k] = twin, ev
+    return twin[:total], consumed
 
 
 def _pcm_to_float(d16, in_off, frames, chans, dev):
@@ -1066,8 +1120,9 @@ def upload_decoded(raw, device=None):
         out = [None] * len(raw.paths)
         with torch.cuda.device(dev):
             if raw.total:                      # the arena's copy (and its event) first: nothing else touches this batch's arena
-                d16 = _h2d_arena(raw.arena, raw.total, dev, lambda: raw.staging.sent(raw.k))
+                d16, consumed = _h2d_arena(raw.staging, raw.k, raw.arena, raw.total, dev)
                 flat, out_off = _pcm_to_float(d16, raw.in_off, raw.frames, raw.chans, dev)
+                consumed()
                 for j, i in enumerate(raw.pcm_idx):
                     out[i] = flat[out_off[j]:out_off[j] + raw.frames[j]]
             for i, r in zip(raw.other_idx, raw.others):           # (these go through the "list" arenas, a separate pair)
@@ -1092,8 +1147,9 @@ def upload_decoded(raw, device=None):
             in_off = np.concatenate(([0], np.cumsum(sizes)[:-1]))
             for i, o in zip(pcm, in_off):
                 host[o:o + raw[i].pcm.shape[0]] = raw[i].pcm
-            d16 = _h2d_arena(arena, total, dev, lambda: st.sent(k))
+            d16, consumed = _h2d_arena(st, k, arena, total, dev)
             flat, out_off = _pcm_to_float(d16, in_off, frames, chans, dev)
+            consumed()
             for j, i in enumerate(pcm):
                 out[i] = flat[out_off[j]:out_off[j] + frames[j]]
     return out

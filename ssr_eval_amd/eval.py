@@ -442,8 +442,8 @@ class SSR_Eval_Helper:
     def evaluate(self, limit_test_nums=-1, limit_test_speaker=-1, save_json=True, batch_files=64, shard="round-robin"):
         """eval.py:171-227: walk speakers/files, evaluate, aggregate as mean of speaker means, write JSON.
         Files are evaluated `batch_files` at a time (one ragged launch sequence per batch; 64: enough rows to fill the chip, and
-        enough batches that the host's queueing of one hides under the GPU work of the one before - 7.3 k files/s against 6.4 k at
-        128 and 6.0 k at 256 on the 367-file bench tree).  With
+        enough batches that the host's queueing of one hides under the GPU work of the one before - 7.4-7.7 k files/s on the
+        367-file bench tree, 7.2 k at 128).  With
         torch.distributed initialised the (speaker, file) list is sharded over the ranks - round-robin, or shard="balanced":
         by audio duration read from the file headers, longest first to the lightest rank (every rank computes the
         same deal) - and the per-utterance rows are exchanged once (ssr_eval_amd.dist); every rank returns the full result."""
@@ -480,11 +480,13 @@ class SSR_Eval_Helper:
         ahead = decode_packed_async(batches[0], self._device) if batches else None
         # ... and the host work of batch k+1 (descriptors, launches) under the GPU work of batch k: a batch's metric values are
         # collected only after the next batch has been queued (no host wait in between - backend._h2d, backend.Pending)
+        # (the reads of batch k+1 are started AFTER batch k has been queued: sixteen reader threads next to the launching thread
+        # cost it 2-3 ms per batch; they run while it waits for batch k-1's values instead)
         collect = None
         for k, batch in enumerate(batches):
             decoded = ahead()
-            ahead = decode_packed_async(batches[k + 1], self._device) if k + 1 < len(batches) else None
             queued = self.evaluate_files(batch, decoded, deferred=True)
+            ahead = decode_packed_async(batches[k + 1], self._device) if k + 1 < len(batches) else None
             if collect is not None:
                 local += collect()
             collect = queued

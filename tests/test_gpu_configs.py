@@ -774,6 +774,29 @@ def test_pipelined_pass_equals_file_by_file_and_the_descriptor_ring_wraps(tmp_pa
         np.testing.assert_array_equal(B._h2d(a, dev).cpu().numpy(), a)
     big = rng.integers(0, 100, size=B._DescRing.SIZE // 8 // 8 + 1, dtype=np.int64)   # above the ring's per-upload limit: the plain copy
     np.testing.assert_array_equal(B._h2d(big, dev).cpu().numpy(), big)
+    # (3) the metric stage takes views with gaps where they lie (est[:m] / target[:m] cut samples off items of one buffer)
+    plan = B.get_plan(2048, 512, "f64")
+    lens = [30000, 41234, 25000, 52001]
+    buf_e = 0.1 * torch.randn(sum(lens) + 64, device="cuda")
+    buf_t = buf_e + 0.01 * torch.randn_like(buf_e)
+    offs = np.concatenate(([0], np.cumsum(lens)[:-1]))
+    cut = [0, 3, 1, 7]                                              # samples dropped at the end of each item
+    ev = [buf_e[o:o + n - c] for o, n, c in zip(offs, lens, cut)]
+    tv = [buf_t[o:o + n - c] for o, n, c in zip(offs, lens, cut)]
+    r = B.Ragged.from_list(ev, dev, allow_gaps=True)
+    assert not r.packed and r.data.data_ptr() == buf_e.data_ptr() and B.Ragged.from_list(ev, dev).data.data_ptr() != buf_e.data_ptr()
+    with pytest.raises(ValueError):
+        r.split()
+    np.testing.assert_array_equal(B.pair_metrics(plan, ev, tv), B.pair_metrics(plan, [e.clone() for e in ev], [t.clone() for t in tv]))
+    multi = B.pair_metrics_multi(plan, [ev, [e * 0.5 for e in ev]], tv)          # key 0: views with gaps, key 1: separate tensors -> copied
+    np.testing.assert_array_equal(multi[:, 0], B.pair_metrics(plan, ev, tv))
+    ev2 = torch.cat([torch.cat(ev), torch.cat([e * 0.5 for e in ev])])           # both keys in one buffer, key-major, then cut again
+    o2 = np.concatenate(([0], np.cumsum([e.shape[0] for e in ev] * 2)[:-1]))
+    views = [ev2[o:o + n - 2] for o, n in zip(o2, [e.shape[0] for e in ev] * 2)]
+    tv2 = [t[:t.shape[0] - 2] for t in tv]
+    got = B.pair_metrics_multi(plan, [views[:4], views[4:]], tv2)
+    np.testing.assert_array_equal(got[:, 0], B.pair_metrics(plan, [v.clone() for v in views[:4]], [t.clone() for t in tv2]))
+    np.testing.assert_array_equal(got[:, 1], B.pair_metrics(plan, [v.clone() for v in views[4:]], [t.clone() for t in tv2]))
 
 
 def test_load_audio_is_librosa_load_shaped(tmp_path):

@@ -1068,10 +1068,9 @@ _upload_streams = {}
 def _h2d_arena(st, k, arena, total, dev):
     """Page-locked int16 arena k of staging pair `st` -> its device twin, on the device's UPLOAD stream: the bus transfer of a batch
     runs under the kernels of the batch before it instead of queueing behind them (6 ms of an evaluate() pass over 367 files).  The
-    twin is a persistent buffer (grown when a batch needs more): a fresh torch.empty per batch on the upload stream's pool cost the
-    launching thread 2-3 ms per batch (the pool cannot re-use a block whose last reader on the OTHER stream has not finished, so it
-    went to hipMalloc).  Ordering, all on the GPU: the upload stream waits for the event recorded behind the last kernel that read
-    the twin (consumed()), the current stream waits for the copy.  -> (the twin's first `total` elements, consumed)."""
+    twin is a persistent buffer (grown when a batch needs more), so no allocation crosses the two streams' pools.  Ordering, all on
+    the GPU: the upload stream waits for the event recorded behind the last kernel that read the twin (consumed()), the current
+    stream waits for the copy.  -> (the twin's first `total` elements, consumed)."""
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     side = _upload_streams.get(idx)
     if side is None:

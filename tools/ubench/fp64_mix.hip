@@ -13,7 +13,7 @@
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-template <bool WITH_LDS> __global__ __launch_bounds__(64) void k_mix(unsigned long long* out, int units, double seed) {
+template <bool WITH_LDS, int MODE = 0> __global__ __launch_bounds__(64) void k_mix(unsigned long long* out, int units, double seed) {
   __shared__ double lds[64 * 16];          // 16 rows of 64 lanes: element e of lane l at e * 64 + l (conflict-free, as the kernel's exchanges)
   double x[32];
 #pragma unroll
@@ -40,16 +40,27 @@ template <bool WITH_LDS> __global__ __launch_bounds__(64) void k_mix(unsigned lo
       for (int k = 0; k < 16; ++k) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(x[(ph * 16 + k) & 31]) : "v"(f[k & 3]));
       if (WITH_LDS) {
 #pragma unroll
-        for (int k = 0; k < 20; ++k)           // elements (2k, 2k + 1) mod 16: row group (2k mod 16) / 4, rows 64 and 128 eight-byte units apart
-          asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(base[((2 * k) & 15) >> 2]), "v"(x[k & 31]), "v"(x[(k + 7) & 31]),
-                       "n"(((2 * k) & 3) * 64), "n"(((2 * k + 1) & 3) * 64) : "memory");
+        for (int k = 0; k < 20; ++k) {         // elements (2k, 2k + 1) mod 16: row group (2k mod 16) / 4, rows 64 and 128 eight-byte units apart
+          if (MODE & 2) {                      // MODE bit 1: two ds_write_b64 instead of one ds_write2_b64
+            asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(base[((2 * k) & 15) >> 2]), "v"(x[k & 31]), "n"(((2 * k) & 3) * 512) : "memory");
+            asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(base[((2 * k) & 15) >> 2]), "v"(x[(k + 7) & 31]), "n"(((2 * k + 1) & 3) * 512) : "memory");
+          } else {
+            asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(base[((2 * k) & 15) >> 2]), "v"(x[k & 31]), "v"(x[(k + 7) & 31]),
+                         "n"(((2 * k) & 3) * 64), "n"(((2 * k + 1) & 3) * 64) : "memory");
+          }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-          d2 v;                                    // (a 128-bit result: two doubles)
-          asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(base[((2 * k) & 15) >> 2]), "n"(((2 * k) & 3) * 64),
-                       "n"(((2 * k + 1) & 3) * 64) : "memory");
-          x[(2 * k) & 31] = v.x; x[(2 * k + 1) & 31] = v.y;
+          if (MODE & 1) {                          // MODE bit 0: two ds_read_b64 (256 B/clk in the guide's table) instead of one ds_read2_b64 (128)
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(x[(2 * k) & 31]) : "v"(base[((2 * k) & 15) >> 2]), "n"(((2 * k) & 3) * 512) : "memory");
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(x[(2 * k + 1) & 31]) : "v"(base[((2 * k) & 15) >> 2]), "n"(((2 * k + 1) & 3) * 512) : "memory");
+          } else {
+            d2 v;                                  // (a 128-bit result: two doubles)
+            asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(base[((2 * k) & 15) >> 2]), "n"(((2 * k) & 3) * 64),
+                         "n"(((2 * k + 1) & 3) * 64) : "memory");
+            x[(2 * k) & 31] = v.x; x[(2 * k + 1) & 31] = v.y;
+          }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
@@ -109,6 +120,24 @@ int main() {
              with_lds ? "FP64 mix + 4 LDS exchanges/unit" : "FP64 mix alone              ", wps, units_s / 1e6,
              (double)cmax / ((double)units * per_unit_f64 * wps), 100.0 * h[0] / h[1], units_s * per_unit_f64 * 64 / 1e12);
     }
+  // the same unit with the exchanges' DS instructions split: reads as 2 x ds_read_b64, writes as 2 x ds_write_b64, both (2 waves per SIMD)
+  for (int mode = 1; mode <= 3; ++mode) {
+    const int blocks = 256 * 4 * 2;
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEvent_t e0, e1;
+      (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+      (void)hipEventRecord(e0);
+      if (mode == 1) k_mix<true, 1><<<blocks, 64>>>(d, units, 1.0); else if (mode == 2) k_mix<true, 2><<<blocks, 64>>>(d, units, 1.0); else k_mix<true, 3><<<blocks, 64>>>(d, units, 1.0);
+      (void)hipEventRecord(e1);
+      (void)hipEventSynchronize(e1);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      best = ms < best ? ms : best;
+    }
+    printf("DS variant %d (%s, %s), 2 waves/SIMD: %.1f M units/s\n", mode, (mode & 1) ? "2 x ds_read_b64" : "ds_read2_b64", (mode & 2) ? "2 x ds_write_b64" : "ds_write2_b64",
+           (double)blocks * units / (best * 1e-3) / 1e6);
+  }
   for (int wps = 1; wps <= 2; ++wps) {
     const int blocks = 256 * 4 * wps, iters = 4000;
     k_mfma64<<<blocks, 64>>>(d, 10, 1.0);

@@ -137,6 +137,9 @@ def fp64_mix_ceiling():
         m = re.search(r"FP64 mix alone\s*, 2 wave\(s\)/SIMD: ([0-9.]+) M units/s", out)
         if m:
             r["units_M_per_s_2_waves_without_lds"] = float(m.group(1))
+        m = re.search(r"DS variant 2 .*?: ([0-9.]+) M units/s", out)
+        if m:                                           # the same unit with its exchange stores as single ds_write_b64 (profiles/r05_notes.md section 8)
+            r["units_M_per_s_2_waves_split_writes"] = float(m.group(1))
         m = re.search(r"v_mfma_f64_16x16x4_f64, 2 wave\(s\)/SIMD: ([0-9.]+) shader cycles", out)
         if m:
             r["mfma_f64_16x16x4_cycles_per_instruction_and_simd"] = float(m.group(1))

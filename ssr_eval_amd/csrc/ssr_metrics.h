@@ -275,6 +275,15 @@ SSR_DEV double ssr_ssim_value(double sx, double sy, double sq, double sxy) {
 // Vertical pass: thread owns STRIDED input columns (coalesced loads, running 7-row sums in registers) and
 // publishes the four column sums through LDS.  Horizontal pass: thread owns CPT CONTIGUOUS outputs, reads
 // CPT+6 column sums per quantity once and slides the 7-wide window across them.
+// A store of the column-sum hand-off, as a volatile LDS access: the compiler does not pair volatile stores into ds_write2_b64, so each
+// sum leaves as its own ds_write_b64.  (tools/ubench/fp64_mix: an exchange written with ds_write_b64 costs a third of the same bytes
+// written with ds_write2_b64; here, where the LDS pipe is ~65 % busy next to the VALU's ~69 %: 0.924 -> 0.908 ms per 1024 pairs, three
+// alternations on one box, the same values - profiles/r05_notes.md section 8.)
+#ifndef SSR_HOST_EMU
+#define SSR_SSIM_ST(arr, idx, val) (*(volatile __attribute__((address_space(3))) double*)(&(arr)[idx]) = (val))
+#else
+#define SSR_SSIM_ST(arr, idx, val) ((arr)[idx] = (val))
+#endif
 template <int CPT, bool CONTIG, typename BLK>
 SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item, char* lds_base) {
   constexpr int NT = SSR_SSIM_NT, PW = SsrSsimLds<CPT, CONTIG>::PW, VC = CPT + 1, W = SSR_SSIM_WIN;
@@ -379,7 +388,7 @@ SSR_BODY void ssr_ssim_body(const SsrSsimParams& p, BLK& blk, int tile, int item
       SSR_UNROLL for (int q = 0; q < 4; ++q) {                                                                               \
         SSR_WPHASE(blk, regs, {             /* every lane publishes: columns past the strip's end carry finite, unused sums */ \
           /* (a lane's columns are read by its LEFT neighbour only, and only the first six of them) */                      \
-          SSR_UNROLL for (int i = 0; i < (CPT < 6 ? CPT : 6); ++i) L.col[ssr_ssim_slot<CPT>(CPT * tid + i)] = R.cs[i][q];    \
+          SSR_UNROLL for (int i = 0; i < (CPT < 6 ? CPT : 6); ++i) SSR_SSIM_ST(L.col, ssr_ssim_slot<CPT>(CPT * tid + i), R.cs[i][q]); \
           L.col[ssr_ssim_slot<CPT>(NT * CPT + (tid < 7 ? tid : 7))] = R.cs[CPT][q];                                          \
         });                                                                                                                  \
         SSR_WPHASE(blk, regs, {                                                                                              \

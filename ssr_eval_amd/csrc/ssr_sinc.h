@@ -29,8 +29,10 @@
 //     the table reads scatter again, the input still comes from LDS.
 #pragma once
 #include "ssr_block.h"
+#include <type_traits>
 
 constexpr int SSR_SINC_NT = 256;
+constexpr int SSR_SINC_AHEAD = 4;       // taps whose operands are requested ahead of their use (ssr_sinc_one's uniform-offset loop)
 
 struct SsrSincParams {
   const float* in;
@@ -50,7 +52,28 @@ struct SsrSincParams {
   int m;                    // a block = (64 / pw) m periods = (64 / pw) m period outputs
   int max_room;             // most taps a wing can have: nwin / index_step (+1)
   int lds_floats;           // floats of LDS the launch provides for the input window
+  // device launches only (ssr_resample_sinc builds it per call, ssr_sinc_table_body): the two tables re-ordered by filter phase,
+  // tab[offset * tab_r + i] = {win, delta}[offset + i * index_step] (zeros past the table's end), tab_rows = index_step + 1 rows
+  const double* tab;
+  int tab_r, tab_rows;
 };
+
+struct alignas(16) SsrSincPair { double w, d; };
+struct alignas(64) SsrSincQuad { SsrSincPair e[4]; };
+
+// Round 5: the phase-major copy of the interpolation tables.  The taps of ONE output walk the tables with a stride of index_step
+// entries (4 KB for kaiser_best): 2 x 129 different cache lines per output, fetched by scalar loads whose latency five waves per
+// SIMD could not hide (one tap per ~500 cycles and wave; the kernel ran at the rate that model predicts).  Re-ordered by phase the
+// taps of an output are consecutive 16-byte {win, delta} pairs, read four taps ahead with vector loads.
+SSR_HD int ssr_sinc_tab_r(int max_room) { return (max_room + 3) / 4 * 4 + 4; }     // row length: whole quads + one quad of read-ahead
+SSR_DEV void ssr_sinc_table_body(const SsrSincParams& p, int64_t e) {
+  if (e >= (int64_t)p.tab_rows * p.tab_r) return;
+  const int offset = (int)(e / p.tab_r), i = (int)(e - (int64_t)offset * p.tab_r);
+  const int64_t idx = offset + (int64_t)i * p.index_step;
+  double* t = const_cast<double*>(p.tab) + 2 * e;
+  t[0] = idx < p.nwin ? p.win[idx] : 0.0;
+  t[1] = idx < p.nwin ? p.delta[idx] : 0.0;
+}
 
 // One output, input through `xs` (xs[pad(s - lo)] = x[s]; lo = 0, no pad and xs = x: straight from global memory).
 template <bool PAD, bool STAGED>
@@ -69,21 +92,58 @@ SSR_DEV float ssr_sinc_one(const SsrSincParams& p, const SsrView<double>& vwin, 
     const int cnt = room < avail ? room : avail;
     const int x0 = (wing == 0 ? n : n + 1) - lo, dx = wing == 0 ? -1 : 1;
 #ifndef SSR_HOST_EMU
-    // One phase per wave: the lanes' table offsets are equal (they can differ by one entry where the accumulated time register
-    // crosses a table boundary).  When they are, the table entries are wave-uniform: SCALAR loads (one request per wave and
-    // tap instead of two 64-lane gathers), and the loop runs to the uniform tap count `room` with no per-lane condition at
-    // all: a tap beyond the signal's end reads one of the zeros staged around it, and y + w * 0 is y (resampy skips that
-    // tap; only the sign of an exact zero could differ).
-    const int offset_u = __builtin_amdgcn_readfirstlane(offset);
-    if (STAGED && __builtin_amdgcn_ballot_w64(offset != offset_u) == 0ull) {
-      const int room_u = (p.nwin - offset_u) / p.index_step;
-      SSR_UNROLL4 for (int i = 0; i < room_u; ++i) {
-        const int idx = offset_u + i * p.index_step;
-        const double weight = ssr_fadd_rn(p.win[idx], ssr_fmul_rn(eta, p.delta[idx]));
-        const int xi = x0 + dx * i;
-        const double xv = (double)xs[PAD ? xi + (xi >> 5) : xi];
-        y = (float)ssr_fadd_rn((double)y, ssr_fmul_rn(weight, xv));
-      }
+    // The taps' table entries come from the phase-major table (consecutive 16-byte pairs along the taps), four taps ahead of their use.
+    // One phase per wave (the usual geometry): the lanes' offsets are equal and the entries wave-uniform - ONE scalar load
+    // (s_load_dwordx16) per four taps.  Where they are not equal - the accumulated time register straddles a table boundary
+    // (exactly integral index_frac in exact arithmetic: every fifth phase of 44.1 -> 48 kHz splits its lanes between two neighbouring
+    // entries), or the wave holds several phases (pw > 1) - each lane reads ITS row with vector loads.  (Until round 5 the strided
+    // scalar loads waited ~one L2 round trip per tap, and the unequal case gathered win[] / delta[] 4 KB apart per tap: a fifth of
+    // the outputs took most of the kernel's time.  The uniform entries as broadcast VECTOR loads were no faster than that: a
+    // broadcast load still returns 1 KB per wave through the 64 B/clk vector-memory return path.)
+    // The loop runs to a wave-uniform tap count with no per-lane condition on the signal's ends: a tap beyond them reads one of the
+    // zeros staged around the signal, and y + w * 0 is y (resampy skips that tap; only the sign of an exact zero could differ).
+    if (STAGED) {
+      const int o1 = __builtin_amdgcn_readfirstlane(offset);
+      const bool uniform = __builtin_amdgcn_ballot_w64(offset != o1) == 0ull;
+      // (read as doubles: type-based alias analysis then knows that the float stores of the outputs cannot touch them, which is
+      // what lets the compiler use scalar loads; an aggregate copy of a quad became 16-byte vector loads)
+      const double* ta = p.tab + 2 * (int64_t)o1 * p.tab_r;               // wave-uniform
+      const double* tl = p.tab + 2 * (int64_t)offset * p.tab_r;           // the lane's own row
+      const int room_u = uniform ? (p.nwin - o1) / p.index_step : p.max_room - 1;     // (max_room - 1 = the wing of offset 0: the longest)
+      // taps i .. i + 3 use entries c.e[0..3] and input samples a0..a3; the entries AND the samples of the next four taps are
+      // requested before these four are computed (with a few waves per SIMD nothing else hides a load's latency)
+      auto xat = [&](int i) { const int xi = x0 + dx * i; return xs[PAD ? xi + (xi >> 5) : xi]; };
+      auto wing_loop = [&](auto own_tag) {
+        constexpr bool OWN = decltype(own_tag)::value;
+        // OWN rows: a lane's wing can be shorter than the loop - (nwin - offset) / index_step taps - and the entry behind its last one is
+        // a real entry of the row unless it lies past the table's end: the lane's weight is forced to zero there, y + 0 * x is y.
+        const double* t = OWN ? tl : ta;
+        auto tap = [&](const SsrSincPair& c, float xv32, int i) {
+          double weight = ssr_fadd_rn(c.w, ssr_fmul_rn(eta, c.d));
+          if (OWN) weight = (i < room) ? weight : 0.0;
+          y = (float)ssr_fadd_rn((double)y, ssr_fmul_rn(weight, (double)xv32));
+        };
+        auto quad = [&](int q) {
+          SsrSincQuad a;
+          SSR_UNROLL for (int k = 0; k < 4; ++k) { a.e[k].w = t[8 * q + 2 * k]; a.e[k].d = t[8 * q + 2 * k + 1]; }
+          return a;
+        };
+        SsrSincQuad c = quad(0);
+        float a0 = xat(0), a1 = xat(1), a2 = xat(2), a3 = xat(3);        // (staged zeros surround the signal: always readable)
+        int i = 0;
+        for (; i + 4 <= room_u; i += 4) {
+          const SsrSincQuad n = quad(i / 4 + 1);
+          const float b0 = xat(i + 4), b1 = xat(i + 5), b2 = xat(i + 6), b3 = xat(i + 7);
+          tap(c.e[0], a0, i); tap(c.e[1], a1, i + 1); tap(c.e[2], a2, i + 2); tap(c.e[3], a3, i + 3);
+          c = n;
+          a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+        }
+        if (i < room_u) tap(c.e[0], a0, i);
+        if (i + 1 < room_u) tap(c.e[1], a1, i + 1);
+        if (i + 2 < room_u) tap(c.e[2], a2, i + 2);
+      };
+      if (uniform) wing_loop(std::false_type{});
+      else wing_loop(std::true_type{});
     } else
 #endif
     for (int i = 0; i < cnt; ++i) {
@@ -111,8 +171,10 @@ SSR_BODY void ssr_sinc_block_body(const SsrSincParams& p, BLK& blk, int item, in
   const float* x = p.in + p.in_off[item];
   const SsrView<double> vwin(p.win, p.nwin), vdelta(p.delta, p.nwin);
   // input window of the block: every index a tap of one of its outputs can touch
-  const int lo = (int)p.time_reg[t0] - (p.max_room - 1);
-  const int hi = (int)p.time_reg[t1 - 1] + p.max_room;
+  // (+ SSR_SINC_AHEAD samples either side: the uniform-offset loop requests the samples of the next four taps before it knows whether
+  // the wing has that many)
+  const int lo = (int)p.time_reg[t0] - (p.max_room - 1) - SSR_SINC_AHEAD;
+  const int hi = (int)p.time_reg[t1 - 1] + p.max_room + SSR_SINC_AHEAD;
   const int W = hi - lo + 1;
   const bool staged = (PAD ? W + (W >> 5) + 1 : W) <= p.lds_floats;   // (the host's geometry guarantees it; a safety net otherwise)
   SSR_REGS(int, regs, blk);
@@ -144,7 +206,7 @@ struct SsrSincGeometry { int period, pw, m, max_room, lds_floats, outputs_per_bl
 SSR_HD SsrSincGeometry ssr_sinc_geometry(int period_hint, double ratio, int nwin, int index_step, int lds_cap_floats) {
   SsrSincGeometry g;
   g.max_room = nwin / index_step + 1;
-  const int halo = 2 * g.max_room + 4;
+  const int halo = 2 * g.max_room + 4 + 2 * SSR_SINC_AHEAD;
   int P = period_hint > 1 ? period_hint : 1, pw = 1;
   const double b = (double)P / ratio;                            // input samples per period
   const double cap = (double)lds_cap_floats * 32.0 / 33.0 - 2.0; // (room for the pad words)

@@ -45,6 +45,10 @@ __global__ __launch_bounds__(SSR_SINC_NT) void k_resample_sinc(SsrSincParams p, 
   ssr_sinc_block_body<PAD>(p, blk, blockIdx.x / blocks_per_item, blockIdx.x % blocks_per_item, smem);
 }
 
+__global__ __launch_bounds__(256) void k_sinc_table(SsrSincParams p) {
+  ssr_sinc_table_body(p, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+
 template <int G, typename X>
 __global__ __launch_bounds__(64) void k_sosfiltfilt(SsrIirParamsT<X> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -298,9 +302,21 @@ extern "C" int ssr_resample_sinc(const float* in, const int64_t* in_off, const i
   if (lds > 160 * 1024) return ssr_fail(SSR_ERR_UNSUPPORTED, "input window of one block exceeds the LDS (extreme down-sampling ratio)");
   static thread_local SsrLdsSlot slot[2];
   if (int rc = ssr_allow_lds(g.pad ? (const void*)k_resample_sinc<true> : (const void*)k_resample_sinc<false>, lds, &slot[g.pad])) return rc;
-  if (g.pad) hipLaunchKernelGGL(k_resample_sinc<true>, dim3((unsigned)((int64_t)n_items * bpi)), dim3(SSR_SINC_NT), lds, (hipStream_t)stream, p, bpi);
-  else hipLaunchKernelGGL(k_resample_sinc<false>, dim3((unsigned)((int64_t)n_items * bpi)), dim3(SSR_SINC_NT), lds, (hipStream_t)stream, p, bpi);
-  HIP_TRY(hipGetLastError());
+  // the phase-major copy of the two tables (about the tables' own size: 0.5 MB for kaiser_best), stream-ordered scratch of this call
+  p.tab_r = ssr_sinc_tab_r(g.max_room);
+  p.tab_rows = index_step + 1;
+  const int64_t entries = (int64_t)p.tab_rows * p.tab_r;
+  if (entries * 16 >= ((int64_t)1 << 31)) return ssr_fail(SSR_ERR_UNSUPPORTED, "interpolation table of 2 GiB or more");
+  hipStream_t s = (hipStream_t)stream;
+  void* tab = nullptr;
+  HIP_TRY(hipMallocAsync(&tab, (size_t)entries * 16, s));
+  p.tab = (const double*)tab;
+  hipLaunchKernelGGL(k_sinc_table, dim3((unsigned)ssr_ceil_div(entries, 256)), dim3(256), 0, s, p);
+  if (g.pad) hipLaunchKernelGGL(k_resample_sinc<true>, dim3((unsigned)((int64_t)n_items * bpi)), dim3(SSR_SINC_NT), lds, s, p, bpi);
+  else hipLaunchKernelGGL(k_resample_sinc<false>, dim3((unsigned)((int64_t)n_items * bpi)), dim3(SSR_SINC_NT), lds, s, p, bpi);
+  const hipError_t launched = hipGetLastError();
+  (void)hipFreeAsync(tab, s);
+  HIP_TRY(launched);
   return SSR_OK;
 }
 

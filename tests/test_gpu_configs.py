@@ -651,6 +651,11 @@ def test_sinc_resampler_bit_exact_vs_restatement_gpu(sr_orig, sr_new):
         assert y.dtype == torch.float32 and tuple(y.shape) == want.shape          # ceil(n * ratio): fix_length applied
         np.testing.assert_array_equal(y.cpu().numpy(), want)                      # bit-identical to the NumPy restatement
     assert [tuple(y.shape) for y in B.resample_sinc(sigs, 48000, 48000)] == [x.shape for x in sigs]
+    if (sr_orig, sr_new) in ((44100, 48000), (48000, 44100)):
+        # a long signal: the accumulated time register drifts further, more waves find their lanes split between two neighbouring
+        # table entries (round 5: those waves read both rows of the phase-major table instead of falling to the gather loop)
+        x = (0.2 * rng.standard_normal(400000)).astype(np.float32)
+        np.testing.assert_array_equal(B.resample_sinc([x], sr_orig, sr_new)[0].cpu().numpy(), orsy.librosa_resample_kaiser(x, sr_orig, sr_new))
 
 
 def test_pcm16_upload_is_the_host_decode(tmp_path):

@@ -92,6 +92,30 @@ __global__ __launch_bounds__(64) void k_mfma64(unsigned long long* out, int iter
   if (a0.x + a1.x + a2.x + a3.x == 12345.678) out[0] = 0;
 }
 
+// issue rate of the two conversions (the windowed-sinc resampler issues three per tap next to four FP64 add / mul): WHICH 0 =
+// v_cvt_f64_f32, 1 = v_cvt_f32_f64, 2 = v_add_f64 (the yardstick), 32 independent registers
+template <int WHICH> __global__ __launch_bounds__(64) void k_cvt(unsigned long long* out, int iters, double seed) {
+  double x[32];
+  float f[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) { x[i] = seed + threadIdx.x + i; f[i] = (float)x[i]; }
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int u = 0; u < iters; ++u) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      if (WHICH == 0) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(x[i]) : "v"(f[i]));
+      else if (WHICH == 1) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(f[i]) : "v"(x[i]));
+      else asm volatile("v_add_f64 %0, %0, %1" : "+v"(x[i]) : "v"(seed));
+    }
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) s += x[i] + f[i];
+  if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+  if (s == 12345.678) out[0] = 0;
+}
+
 int main() {
   unsigned long long* d;
   (void)hipMalloc(&d, 1 << 22);
@@ -137,6 +161,19 @@ int main() {
     }
     printf("DS variant %d (%s, %s), 2 waves/SIMD: %.1f M units/s\n", mode, (mode & 1) ? "2 x ds_read_b64" : "ds_read2_b64", (mode & 2) ? "2 x ds_write_b64" : "ds_write2_b64",
            (double)blocks * units / (best * 1e-3) / 1e6);
+  }
+  for (int which = 0; which < 3; ++which) {
+    const int blocks = 256 * 4 * 2, iters = 2000;
+    for (int rep = 0; rep < 2; ++rep) {
+      if (which == 0) k_cvt<0><<<blocks, 64>>>(d, rep ? iters : 10, 1.0); else if (which == 1) k_cvt<1><<<blocks, 64>>>(d, rep ? iters : 10, 1.0);
+      else k_cvt<2><<<blocks, 64>>>(d, rep ? iters : 10, 1.0);
+      (void)hipDeviceSynchronize();
+    }
+    (void)hipMemcpy(h, d, sizeof(unsigned long long) * blocks, hipMemcpyDeviceToHost);
+    unsigned long long cmax = 0;
+    for (int b = 0; b < blocks; ++b) cmax = h[b] > cmax ? h[b] : cmax;
+    printf("%s, 2 waves/SIMD: %.2f shader cycles per instruction and SIMD\n", which == 0 ? "v_cvt_f64_f32" : which == 1 ? "v_cvt_f32_f64" : "v_add_f64    ",
+           (double)cmax / ((double)iters * 32 * 2));
   }
   for (int wps = 1; wps <= 2; ++wps) {
     const int blocks = 256 * 4 * wps, iters = 4000;

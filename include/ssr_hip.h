@@ -368,6 +368,18 @@ int ssr_sosfiltfilt_f64(const double* x, const int64_t* off, const int32_t* len,
                     const double* sos, const double* zi, int n_sections, int edge, double* y, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* The same for n_designs filters over ONE batch in one launch (round 5): SSR_Eval_Helper.preprocess applies every
+ * (filter type, cutoff, order) of setting_lowpass_filtering to the same waveform (ssr_eval/eval.py:243-258, three nested loops).
+ * The recurrence is serial in time - a launch is latency-bound (~85 ns per sample step) and occupies 1/8 wave per utterance - so
+ * 36 designs one after the other took 36 x that latency (94 % of an evaluate() pass with IIR settings); side by side they take it once.
+ * sos: DEVICE [n_designs][8][6] (rows >= n_sections[d] unused), zi: DEVICE [n_designs][8][2]; n_sections, edge: HOST [n_designs]
+ * (n_sections <= 8, n_designs <= 48); y: [n_designs][y_stride] float64, design d's output in x's ragged layout from d * y_stride.
+ * Every output bit-identical to the single-design call. */
+size_t ssr_sosfiltfilt_multi_workspace_bytes(int64_t total_len, int n_items, const int32_t* edge, int n_designs);
+int ssr_sosfiltfilt_multi(const float* x, const int64_t* off, const int32_t* len, int n_items, int64_t total_len,
+                          const double* sos, const double* zi, const int32_t* n_sections, const int32_t* edge, int n_designs,
+                          double* y, int64_t y_stride, void* workspace, size_t workspace_bytes, void* stream);
+
 /* A12 / SURVEY 8(e).  The path's one collective: the per-speaker [metric sums ..., count] buffer summed over ranks in
  * float64 (what SSR_Eval_Helper.evaluate's mean-of-speaker-means needs from the other shards, ssr_eval/eval.py:200-216) -
  * ncclAllReduce(sum, double) over RCCL / xGMI, in place, on `stream`.  RCCL is resolved with dlopen at the first call

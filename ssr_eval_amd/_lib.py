@@ -70,6 +70,8 @@ SIGNATURES = {
     "ssr_sosfiltfilt_workspace_bytes": (_sz, [_i64, _i, _i]),
     "ssr_sosfiltfilt": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "ssr_sosfiltfilt_f64": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "ssr_sosfiltfilt_multi_workspace_bytes": (_sz, [_i64, _i, _vp, _i]),
+    "ssr_sosfiltfilt_multi": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _i64, _vp, _sz, _vp]),
     "ssr_comm_unique_id": (_i, [_vp]),
     "ssr_comm_init_rank": (_i, [_vp, _i, _i, C.POINTER(C.c_void_p)]),
     "ssr_comm_destroy": (_i, [_vp]),

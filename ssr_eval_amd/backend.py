@@ -1163,8 +1163,7 @@ def sosfiltfilt(sos, wavs, device=None):
     if sos.ndim != 2 or sos.shape[1] != 6:
         raise ValueError("sos must have shape (n_sections, 6)")
     n_sections = sos.shape[0]
-    ntaps = 2 * n_sections + 1 - min(int((sos[:, 2] == 0).sum()), int((sos[:, 5] == 0).sum()))
-    edge = 3 * ntaps
+    edge = _sos_edge(sos)
     with torch.cuda.device(dev):
         r = wavs if isinstance(wavs, Ragged) else Ragged.from_list_keep64(wavs, dev)
         if r.n == 0:
@@ -1173,8 +1172,8 @@ def sosfiltfilt(sos, wavs, device=None):
             raise ValueError("The length of the input vector x must be greater than padlen, which is %d." % edge)
         lib = _lib.load()
         total = int(r.lens_host.sum())
-        sos_d = torch.from_numpy(sos).to(dev)
-        zi_d = torch.from_numpy(np.ascontiguousarray(sosfilt_zi(sos), dtype=np.float64)).to(dev)
+        sos_d = _h2d(sos, dev)
+        zi_d = _h2d(np.ascontiguousarray(sosfilt_zi(sos), dtype=np.float64), dev)
         ws_bytes = int(lib.ssr_sosfiltfilt_workspace_bytes(total, r.n, edge))
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
         y = torch.empty(total, dtype=torch.float64, device=dev)
@@ -1182,6 +1181,59 @@ def sosfiltfilt(sos, wavs, device=None):
         _lib.check(fn(_vp(r.data), _vp(r.off), _vp(r.len), r.n, total, _vp(sos_d), _vp(zi_d), n_sections, edge, _vp(y), _vp(ws),
                       ws_bytes, _stream()))
         return r.split(y)
+
+
+def _sos_edge(sos):
+    n_sections = sos.shape[0]
+    ntaps = 2 * n_sections + 1 - min(int((sos[:, 2] == 0).sum()), int((sos[:, 5] == 0).sum()))
+    return 3 * ntaps
+
+
+SOS_MULTI_MAX_DESIGNS, SOS_MULTI_MAX_DOUBLES = 48, 1 << 29       # designs per launch (the C ABI's limit); output doubles per launch (4 GiB)
+
+
+def sosfiltfilt_multi(sos_list, wavs, device=None):
+    """scipy.signal.sosfiltfilt(sos, x) for EVERY design of sos_list over one list of float32 waveforms: ssr_sosfiltfilt_multi, the
+    designs side by side in one launch (a launch is latency-bound - the recurrence is serial in time - and fills an eighth of a wave
+    per utterance: one design after the other costs the same latency each time).  -> [design][signal] float64 device tensors, every one
+    bit-identical to sosfiltfilt(sos, ...).  Designs of more than 8 sections and float64 signals go through sosfiltfilt()."""
+    from scipy.signal import sosfilt_zi
+    dev = torch.device(device) if device is not None else default_device()
+    sos_list = [np.ascontiguousarray(s_, dtype=np.float64) for s_ in sos_list]
+    for s_ in sos_list:
+        if s_.ndim != 2 or s_.shape[1] != 6:
+            raise ValueError("sos must have shape (n_sections, 6)")
+    with torch.cuda.device(dev):
+        r = wavs if isinstance(wavs, Ragged) else Ragged.from_list_keep64(wavs, dev)
+        if r.n == 0:
+            return [[] for _ in sos_list]
+        if r.data.dtype != torch.float32 or any(s_.shape[0] > 8 for s_ in sos_list) or not r.packed:
+            return [sosfiltfilt(s_, r if r.packed else wavs, dev) for s_ in sos_list]
+        edges = [_sos_edge(s_) for s_ in sos_list]
+        if int(r.lens_host.min()) <= max(edges):
+            raise ValueError("The length of the input vector x must be greater than padlen, which is %d." % max(edges))
+        lib = _lib.load()
+        total = int(r.lens_host.sum())
+        per_launch = max(1, min(SOS_MULTI_MAX_DESIGNS, SOS_MULTI_MAX_DOUBLES // max(total, 1)))
+        out = []
+        for d0 in range(0, len(sos_list), per_launch):
+            chunk = sos_list[d0:d0 + per_launch]
+            D = len(chunk)
+            sos_h, zi_h = np.zeros((D, 8, 6)), np.zeros((D, 8, 2))
+            for d, s_ in enumerate(chunk):
+                sos_h[d, :s_.shape[0]] = s_
+                zi_h[d, :s_.shape[0]] = sosfilt_zi(s_)
+            ns = np.array([s_.shape[0] for s_ in chunk], dtype=np.int32)
+            eg = np.array(edges[d0:d0 + D], dtype=np.int32)
+            sos_d, zi_d = _h2d(sos_h, dev), _h2d(zi_h, dev)
+            ws_bytes = int(lib.ssr_sosfiltfilt_multi_workspace_bytes(total, r.n, eg.ctypes.data_as(C.c_void_p), D))
+            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+            y = torch.empty((D, total), dtype=torch.float64, device=dev)
+            _lib.check(lib.ssr_sosfiltfilt_multi(_vp(r.data), _vp(r.off), _vp(r.len), r.n, total, _vp(sos_d), _vp(zi_d),
+                                                 ns.ctypes.data_as(C.c_void_p), eg.ctypes.data_as(C.c_void_p), D, _vp(y), total, _vp(ws),
+                                                 ws_bytes, _stream()))
+            out += [r.split(y[d]) for d in range(D)]
+        return out
 
 
 def xcorr_argmax(a_list, b_list, device=None):

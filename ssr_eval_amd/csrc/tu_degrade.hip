@@ -55,6 +55,29 @@ __global__ __launch_bounds__(64) void k_sosfiltfilt(SsrIirParamsT<X> p) {
   ssr_iir_wave<G, X>(p, blockIdx.x, threadIdx.x, smem);
 }
 
+// K designs in one launch (ssr_sosfiltfilt_multi): workgroup -> (design, group of utterances); the design's parameters are
+// wave-uniform values read from the kernel arguments.
+constexpr int SSR_IIR_MAXD = 48;
+struct SsrIirMultiParams {
+  SsrIirParams base;                     // x, off, len, n_items; sos / zi / fwd / y = the first design's
+  int n_designs, wgs_per_design;
+  int64_t y_stride;                      // doubles between the designs' outputs
+  int n_sections[SSR_IIR_MAXD], edge[SSR_IIR_MAXD];
+  int64_t fwd_off[SSR_IIR_MAXD];         // doubles
+};
+__global__ __launch_bounds__(64) void k_sosfiltfilt_multi(SsrIirMultiParams mp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int d = blockIdx.x / mp.wgs_per_design, wg = blockIdx.x % mp.wgs_per_design;
+  SsrIirParams p = mp.base;
+  p.sos += (int64_t)d * 8 * 6;
+  p.zi += (int64_t)d * 8 * 2;
+  p.n_sections = mp.n_sections[d];
+  p.edge = mp.edge[d];
+  p.fwd += mp.fwd_off[d];
+  p.y += (int64_t)d * mp.y_stride;
+  ssr_iir_wave<8, float>(p, wg, threadIdx.x, smem);
+}
+
 // ----------------------------------------------------------------------------------------------------
 static int64_t gcd64(int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a; }
 
@@ -384,6 +407,47 @@ extern "C" int ssr_sosfiltfilt(const float* x, const int64_t* off, const int32_t
                                const double* sos, const double* zi, int n_sections, int edge, double* y,
                                void* workspace, size_t workspace_bytes, void* stream) {
   return sosfiltfilt_t<float>(x, off, len, n_items, total_len, sos, zi, n_sections, edge, y, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t ssr_sosfiltfilt_multi_workspace_bytes(int64_t total_len, int n_items, const int32_t* edge, int n_designs) {
+  if (total_len <= 0 || n_items <= 0 || !edge || n_designs <= 0) return 0;
+  size_t b = 0;
+  for (int d = 0; d < n_designs; ++d) b += ssr_sosfiltfilt_workspace_bytes(total_len, n_items, edge[d] < 0 ? 0 : edge[d]);
+  return b;
+}
+
+extern "C" int ssr_sosfiltfilt_multi(const float* x, const int64_t* off, const int32_t* len, int n_items, int64_t total_len,
+                                     const double* sos, const double* zi, const int32_t* n_sections, const int32_t* edge,
+                                     int n_designs, double* y, int64_t y_stride, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  if (!x || !off || !len || !sos || !zi || !n_sections || !edge || !y) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  if (n_designs < 1 || n_designs > SSR_IIR_MAXD) return ssr_fail(SSR_ERR_UNSUPPORTED, "1 to 48 designs per call");
+  if (y_stride < total_len) return ssr_fail(SSR_ERR_INVALID_ARG, "y_stride smaller than the batch");
+  for (int d = 0; d < n_designs; ++d) {
+    if (n_sections[d] < 1 || n_sections[d] > 8) return ssr_fail(SSR_ERR_UNSUPPORTED, "n_sections must be in [1, 8] (ssr_sosfiltfilt takes up to 16)");
+    if (edge[d] < 0) return ssr_fail(SSR_ERR_INVALID_ARG, "negative edge");
+  }
+  if (n_items <= 0) return SSR_OK;
+  if (!workspace || workspace_bytes < ssr_sosfiltfilt_multi_workspace_bytes(total_len, n_items, edge, n_designs))
+    return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small");
+  SsrIirMultiParams mp;
+  mp.base = SsrIirParams{x, off, len, sos, zi, 0, 0, n_items, (double*)workspace, y};
+  mp.n_designs = n_designs;
+  const int per_wave = 8 * SSR_IIR_U;
+  mp.wgs_per_design = ssr_ceil_div(n_items, per_wave);
+  mp.y_stride = y_stride;
+  int64_t fo = 0;
+  for (int d = 0; d < n_designs; ++d) {
+    mp.n_sections[d] = n_sections[d]; mp.edge[d] = edge[d]; mp.fwd_off[d] = fo;
+    fo += (int64_t)(ssr_sosfiltfilt_workspace_bytes(total_len, n_items, edge[d]) / sizeof(double));
+  }
+  if ((int64_t)mp.wgs_per_design * n_designs > 0x7fffffff) return ssr_fail(SSR_ERR_UNSUPPORTED, "batch too large for one launch");
+  const size_t lds = (size_t)per_wave * 4 * SSR_IIR_CH * sizeof(double);
+  static thread_local SsrLdsSlot slot;
+  if (int rc = ssr_allow_lds((const void*)k_sosfiltfilt_multi, lds, &slot)) return rc;
+  hipLaunchKernelGGL(k_sosfiltfilt_multi, dim3((unsigned)(mp.wgs_per_design * n_designs)), dim3(64), lds, (hipStream_t)stream, mp);
+  HIP_TRY(hipGetLastError());
+  return SSR_OK;
 }
 
 extern "C" int ssr_sosfiltfilt_f64(const double* x, const int64_t* off, const int32_t* len, int n_items, int64_t total_len,

@@ -19,7 +19,7 @@ import torch
 
 from . import backend as B
 from . import dist as D
-from .lowpass import lowpass, lowpass_batch, stft_hard_lowpass_multi
+from .lowpass import lowpass, lowpass_batch, lowpass_iir_multi, stft_hard_lowpass_multi
 from .metrics import AudioMetrics
 from .utils import dict_mean, write_json
 
@@ -274,6 +274,9 @@ class SSR_Eval_Helper:
                 ret[key] = y
         lp = self.setting_lowpass_filtering
         if lp is not None:
+            # every (filter, cutoff, order) of the setting over the same waveforms: ONE launch with the designs side by side
+            # (lowpass_iir_multi; one after the other they were 94 % of a pass - profiles/r05_notes.md section 9)
+            keys, specs = [], []
             for word, tag, ftype in (("butter", "bw", "butter"), ("cheby", "ch", "cheby1"), ("ellip", "el", "ellip"),
                                      ("bessel", "bessel", "bessel")):
                 if word not in lp["filter"]:
@@ -282,8 +285,10 @@ class SSR_Eval_Helper:
                     for order in lp["filter_order"]:
                         if low_rate == sr:
                             low_rate -= 1
-                        put("proc_%s_%s_%s_%s" % (tag, low_rate, order, sr),
-                            lowpass_batch(xs, low_rate // 2, sr, order=order, _type=ftype, keep_on_device=keep_on_device))
+                        keys.append("proc_%s_%s_%s_%s" % (tag, low_rate, order, sr))
+                        specs.append((low_rate // 2, order, ftype))
+            for key, ys in zip(keys, lowpass_iir_multi(xs, specs, sr, keep_on_device=keep_on_device)):
+                put(key, ys)
         if self.setting_subsampling is not None:
             for low_rate in self.setting_subsampling["cutoff_freq"]:
                 if low_rate == sr:

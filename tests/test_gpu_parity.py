@@ -613,6 +613,45 @@ def test_sosfiltfilt_bit_exact(golden, ftype, order, band):
         np.testing.assert_array_equal(lowpass(sigs64[0], 4000, 44100, order=order, _type=ftype), olp.lowpass(sigs64[0], 4000, 44100, order, ftype))
 
 
+def test_sosfiltfilt_multi_is_every_design_bit_for_bit(golden):
+    """ssr_sosfiltfilt_multi (round 5: SSR_Eval_Helper.preprocess's filter x cutoff x order loops in one launch): 4 filter types x 3
+    cutoffs x orders 2 / 4 / 8 / 10 (1-5 sections, different padding lengths) over one ragged batch - every output equals SciPy's
+    and the single-design launch's; through lowpass_iir_multi the values of lowpass_batch; more designs than a launch takes (chunking);
+    float64 signals and a 9-section design fall back to the single-design path with the same values."""
+    from ssr_eval_amd import backend as B
+    from ssr_eval_amd.lowpass import lowpass_batch, lowpass_iir_multi
+    from oracle import lowpass as olp
+    rng = np.random.default_rng(99)
+    x = golden["ss_x"]
+    sigs = [x, x[:701], np.tile(x, 3)] + [rng.standard_normal(int(n)).astype(np.float32) for n in rng.integers(300, 5000, 14)]
+    specs = [(hc, order, ft) for ft in ("butter", "cheby1", "ellip", "bessel") for hc in (2000, 4000, 8000) for order in (2, 4, 8, 10)]
+    designs = [olp.iir_sos(hc, 44100, order, ft) for hc, order, ft in specs]
+    assert sorted({d.shape[0] for d in designs}) == [1, 2, 4, 5]
+    got = B.sosfiltfilt_multi(designs, sigs)
+    assert len(got) == 48
+    for sos, per_design in zip(designs, got):
+        for s_, g in zip(sigs, per_design):
+            assert g.dtype == torch.float64
+            np.testing.assert_array_equal(g.cpu().numpy(), signal.sosfiltfilt(sos, s_))
+    one = B.sosfiltfilt(designs[17], sigs)
+    for a, b in zip(one, got[17]):
+        assert torch.equal(a, b)
+    multi = lowpass_iir_multi(sigs, [(hc, order, ft[:5]) for hc, order, ft in specs[:7]], 44100)      # ("cheby" in "cheby1": the reference's dispatch)
+    for (hc, order, ft), ys in zip(specs[:7], multi):
+        for a, b in zip(ys, lowpass_batch(sigs, hc, 44100, order=order, _type=ft)):
+            np.testing.assert_array_equal(a, b)
+    many = B.sosfiltfilt_multi(designs + designs[:5], sigs[:4])                                       # 53 designs: two launches
+    for k in (0, 47, 48, 52):
+        np.testing.assert_array_equal(many[k][2].cpu().numpy(), signal.sosfiltfilt((designs + designs[:5])[k], sigs[2]))
+    sigs64 = [s_.astype(np.float64) * 1.0000000321 for s_ in sigs[:4]]
+    for sos, per_design in zip(designs[:3], B.sosfiltfilt_multi(designs[:3], sigs64)):
+        for s_, g in zip(sigs64, per_design):
+            np.testing.assert_array_equal(g.cpu().numpy(), signal.sosfiltfilt(sos, s_))
+    big = signal.butter(18, 0.2, output="sos")                                                        # 9 sections
+    for s_, g in zip(sigs[:3], B.sosfiltfilt_multi([big, designs[0]], sigs[:3])[0]):
+        np.testing.assert_array_equal(g.cpu().numpy(), signal.sosfiltfilt(big, s_))
+
+
 def test_iir_lowpass_matches_reference_vectors(golden):
     from ssr_eval_amd.lowpass import lowpass, bandpass
     from oracle import lowpass as olp

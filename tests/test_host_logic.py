@@ -194,6 +194,18 @@ def test_cabi_round5_entry_points_validate_before_the_device():
     assert lib.ssr_fft_lowpass_multi(p, p, p, p, cuts, 2, p, 0, 100, 10, p, 100, p, 1 << 20, None) == 0     # empty batch
     assert lib.ssr_plan_set_tl_weights(None, p, p, p, p, p) == -1
     assert lib.ssr_plan_set_tl_weights(p, None, p, p, p, p) == -1
+    # ssr_sosfiltfilt_multi: null arguments, design count and section count limits, workspace size - all before any launch
+    ns, eg = (C.c_int32 * 3)(1, 2, 4), (C.c_int32 * 3)(9, 15, 27)
+    need = lib.ssr_sosfiltfilt_multi_workspace_bytes(1000, 2, eg, 3)
+    assert need >= 8 * (3 * 1000 + 2 * 2 * (9 + 15 + 27)) and lib.ssr_sosfiltfilt_multi_workspace_bytes(1000, 2, None, 3) == 0
+    assert lib.ssr_sosfiltfilt_multi(None, p, p, 2, 1000, p, p, ns, eg, 3, p, 1000, p, need, None) == -1
+    assert lib.ssr_sosfiltfilt_multi(p, p, p, 2, 1000, p, p, None, eg, 3, p, 1000, p, need, None) == -1
+    assert lib.ssr_sosfiltfilt_multi(p, p, p, 2, 1000, p, p, ns, eg, 0, p, 1000, p, need, None) == -2        # 1 .. 48 designs
+    assert lib.ssr_sosfiltfilt_multi(p, p, p, 2, 1000, p, p, ns, eg, 49, p, 1000, p, need, None) == -2
+    assert lib.ssr_sosfiltfilt_multi(p, p, p, 2, 1000, p, p, (C.c_int32 * 3)(1, 9, 4), eg, 3, p, 1000, p, need, None) == -2   # > 8 sections
+    assert lib.ssr_sosfiltfilt_multi(p, p, p, 2, 1000, p, p, ns, eg, 3, p, 999, p, need, None) == -1         # y_stride < the batch
+    assert lib.ssr_sosfiltfilt_multi(p, p, p, 2, 1000, p, p, ns, eg, 3, p, 1000, p, need - 1, None) == -4    # workspace too small
+    assert lib.ssr_sosfiltfilt_multi(p, p, p, 0, 1000, p, p, ns, eg, 3, p, 1000, p, need, None) == 0         # empty batch
     got = B.tl_conv_weights(256)
     for a, b in zip(got[:4], ostft.tl_weights(256)):
         assert a.dtype == np.float32 and np.array_equal(a, b)

@@ -68,8 +68,12 @@ def main():
                 n = int(rng.integers(int(1.5 * 44100), 9 * 44100))
                 write_wav(os.path.join(root, "p%03d" % (360 + s), "u%03d.wav" % i), 0.1 * rng.standard_normal(n), 44100)
                 n_files += 1
-        h = SSR_Eval_Helper(BasicTestee(), input_sr=44100, output_sr=44100, evaluation_sr=48000, test_data_root=root,
-                            setting_fft={"cutoff_freq": [12000]})
+        kw = {"setting_fft": {"cutoff_freq": [12000]}}
+        if os.environ.get("IIR"):              # the zero-phase IIR degradations as well: IIR="butter,cheby,ellip,bessel:4000,8000,12000:2,4,8"
+            f, c, o = os.environ["IIR"].split(":")
+            kw["setting_lowpass_filtering"] = {"filter": f.split(","), "cutoff_freq": [int(v) for v in c.split(",")],
+                                               "filter_order": [int(v) for v in o.split(",")]}
+        h = SSR_Eval_Helper(BasicTestee(), input_sr=44100, output_sr=44100, evaluation_sr=48000, test_data_root=root, **kw)
         bf = int(os.environ.get("BATCH_FILES", 128))
         h.evaluate(limit_test_nums=2, limit_test_speaker=1, save_json=False)
         h.evaluate(save_json=False, batch_files=bf)
@@ -88,6 +92,8 @@ def main():
             host_profile(h, bf)
         print("evaluate(): %d files, batch_files %d, median %.1f files/s, passes %s, averaged lsd %.6f" % (
             n_files, bf, n_files / float(np.median(times)), ["%.4f" % t for t in times], res["averaged"]["proc_fft_24000_44100"]["lsd"]), flush=True)
+        if os.environ.get("IIR"):
+            print("keys: %d; e.g. %s" % (len(res["averaged"]), {k: round(v["lsd"], 6) for k, v in list(res["averaged"].items())[:3]}), flush=True)
     finally:
         shutil.rmtree(root, ignore_errors=True)
 

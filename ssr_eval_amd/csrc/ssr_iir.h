@@ -88,6 +88,21 @@ SSR_DEV double ssr_dpp_from_lower_lane(double v) {
   return b.d;
 }
 
+// Input of lane s at a step: lane 0 of a group takes the staged sample `x_in`, the others lane s-1's output of the previous step.
+// G == 16 (a group = a whole DPP row): ONE update_dpp per half whose out-of-row value is x_in - no select on the step's dependent chain.
+template <int G> SSR_DEV double ssr_iir_xin(double yout_prev, double x_in, int s) {
+  if constexpr (G == 16) {
+    union { double d; int i[2]; } a, o, b;
+    a.d = yout_prev; o.d = x_in;
+    b.i[0] = __builtin_amdgcn_update_dpp(o.i[0], a.i[0], 0x111, 0xf, 0xf, false);
+    b.i[1] = __builtin_amdgcn_update_dpp(o.i[1], a.i[1], 0x111, 0xf, 0xf, false);
+    return b.d;
+  } else {
+    const double from_lower = ssr_dpp_from_lower_lane(yout_prev);
+    return (s == 0) ? x_in : from_lower;
+  }
+}
+
 // Per-lane view of one utterance slot.  A lane can serve U utterances at once (independent recurrences
 // interleaved in one instruction stream); measured on MI355X the step time grows almost linearly with U, so
 // U = 1 is the default.
@@ -158,8 +173,7 @@ SSR_DEV void ssr_iir_pass(const SsrIirParamsT<X>& p, int s, SsrIirSlot<G, X> (&s
         for (int k = 0; k < 8; ++k) {
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            const double from_lower = ssr_dpp_from_lower_lane(sl[u].yout);   // lane s-1's output of step t-1
-            const double xin = (s == 0) ? x8[u][k] : from_lower;
+            const double xin = ssr_iir_xin<G>(sl[u].yout, x8[u][k], s);       // lane s-1's output of step t-1 (lane 0: the sample)
             sl[u].yout = ssr_iir_step(xin, b0, b1, b2, a1, a2, sl[u].z0, sl[u].z1);
             if (s == S - 1) sl[u].out_buf[(t0 + k - s) & (2 * CH - 1)] = sl[u].yout;
           }
@@ -170,8 +184,7 @@ SSR_DEV void ssr_iir_pass(const SsrIirParamsT<X>& p, int s, SsrIirSlot<G, X> (&s
           const int n = t0 + k - s;                                // sample this lane filters at this step
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            const double from_lower = ssr_dpp_from_lower_lane(sl[u].yout);
-            const double xin = (s == 0) ? x8[u][k] : from_lower;
+            const double xin = ssr_iir_xin<G>(sl[u].yout, x8[u][k], s);
             double nz0 = sl[u].z0, nz1 = sl[u].z1;
             const double yo = ssr_iir_step(xin, b0, b1, b2, a1, a2, nz0, nz1);
             const bool on = (s < S) && (n >= 0) && (n < sl[u].ne);

@@ -58,6 +58,10 @@ __global__ __launch_bounds__(64) void k_sosfiltfilt(SsrIirParamsT<X> p) {
 // K designs in one launch (ssr_sosfiltfilt_multi): workgroup -> (design, group of utterances); the design's parameters are
 // wave-uniform values read from the kernel arguments.
 constexpr int SSR_IIR_MAXD = 48;
+// lanes per utterance of the multi-design launch: 16 = a whole DPP row per utterance (four per wave), where the step's input comes from ONE
+// update_dpp with the staged sample as the out-of-row value - no select on the dependent chain: 123 ms against 151 ms per launch of 36
+// designs x 128 files with 8-lane groups (the same outputs; profiles/r05_notes.md section 9)
+constexpr int SSR_IIR_MULTI_G = 16;
 struct SsrIirMultiParams {
   SsrIirParams base;                     // x, off, len, n_items; sos / zi / fwd / y = the first design's
   int n_designs, wgs_per_design;
@@ -65,6 +69,7 @@ struct SsrIirMultiParams {
   int n_sections[SSR_IIR_MAXD], edge[SSR_IIR_MAXD];
   int64_t fwd_off[SSR_IIR_MAXD];         // doubles
 };
+template <int G>
 __global__ __launch_bounds__(64) void k_sosfiltfilt_multi(SsrIirMultiParams mp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int d = blockIdx.x / mp.wgs_per_design, wg = blockIdx.x % mp.wgs_per_design;
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(64) void k_sosfiltfilt_multi(SsrIirMultiParams mp) 
   p.edge = mp.edge[d];
   p.fwd += mp.fwd_off[d];
   p.y += (int64_t)d * mp.y_stride;
-  ssr_iir_wave<8, float>(p, wg, threadIdx.x, smem);
+  ssr_iir_wave<G, float>(p, wg, threadIdx.x, smem);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -433,7 +438,8 @@ extern "C" int ssr_sosfiltfilt_multi(const float* x, const int64_t* off, const i
   SsrIirMultiParams mp;
   mp.base = SsrIirParams{x, off, len, sos, zi, 0, 0, n_items, (double*)workspace, y};
   mp.n_designs = n_designs;
-  const int per_wave = 8 * SSR_IIR_U;
+  constexpr int G = SSR_IIR_MULTI_G;
+  const int per_wave = (64 / G) * SSR_IIR_U;
   mp.wgs_per_design = ssr_ceil_div(n_items, per_wave);
   mp.y_stride = y_stride;
   int64_t fo = 0;
@@ -444,8 +450,8 @@ extern "C" int ssr_sosfiltfilt_multi(const float* x, const int64_t* off, const i
   if ((int64_t)mp.wgs_per_design * n_designs > 0x7fffffff) return ssr_fail(SSR_ERR_UNSUPPORTED, "batch too large for one launch");
   const size_t lds = (size_t)per_wave * 4 * SSR_IIR_CH * sizeof(double);
   static thread_local SsrLdsSlot slot;
-  if (int rc = ssr_allow_lds((const void*)k_sosfiltfilt_multi, lds, &slot)) return rc;
-  hipLaunchKernelGGL(k_sosfiltfilt_multi, dim3((unsigned)(mp.wgs_per_design * n_designs)), dim3(64), lds, (hipStream_t)stream, mp);
+  if (int rc = ssr_allow_lds((const void*)k_sosfiltfilt_multi<G>, lds, &slot)) return rc;
+  hipLaunchKernelGGL(k_sosfiltfilt_multi<G>, dim3((unsigned)(mp.wgs_per_design * n_designs)), dim3(64), lds, (hipStream_t)stream, mp);
   HIP_TRY(hipGetLastError());
   return SSR_OK;
 }

@@ -393,7 +393,9 @@ static int sosfiltfilt_t(const X* x, const int64_t* off, const int32_t* len, int
     return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small");
   SsrIirParamsT<X> p{x, off, len, sos, zi, n_sections, edge, n_items, (double*)workspace, y};
   hipStream_t s = (hipStream_t)stream;
-  if (n_sections <= 8) {
+  // 16-lane groups (four utterances per wave, the select-free step of ssr_iir_xin<16>) while that leaves at most one wave per SIMD;
+  // eight-lane groups pack twice the utterances per wave beyond that
+  if (n_sections <= 8 && n_items > 4096) {
     const int per_wave = 8 * SSR_IIR_U;                           // utterances per one-wave workgroup
     const size_t lds = (size_t)per_wave * 4 * SSR_IIR_CH * sizeof(double);
     static thread_local SsrLdsSlot slot;

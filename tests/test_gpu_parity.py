@@ -611,6 +611,12 @@ def test_sosfiltfilt_bit_exact(golden, ftype, order, band):
     if not band:
         from ssr_eval_amd.lowpass import lowpass
         np.testing.assert_array_equal(lowpass(sigs64[0], 4000, 44100, order=order, _type=ftype), olp.lowpass(sigs64[0], 4000, 44100, order, ftype))
+    if ftype == "butter" and not band and sos.shape[0] <= 8:
+        # more than 4096 utterances: the launch packs eight utterances per wave (8-lane groups) instead of four (16-lane groups)
+        many = [rng.standard_normal(int(n)).astype(np.float32) for n in rng.integers(3 * (2 * sos.shape[0] + 1) + 5, 120, 4100)]
+        got = B.sosfiltfilt(sos, many)
+        for k in list(range(0, 4100, 97)) + [4095, 4096, 4099]:
+            np.testing.assert_array_equal(got[k].cpu().numpy(), signal.sosfiltfilt(sos, many[k]))
 
 
 def test_sosfiltfilt_multi_is_every_design_bit_for_bit(golden):

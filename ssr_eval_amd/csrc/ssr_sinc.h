@@ -158,6 +158,34 @@ SSR_DEV float ssr_sinc_one(const SsrSincParams& p, const SsrView<double>& vwin, 
   return y;
 }
 
+#ifdef SSR_HOST_EMU
+// Scalar statement of what a lane of the device's phase-major loops computes for one output (tests/emu): the lane's own row of `tab`,
+// the loop run to the longest wing (max_room - 1 taps) with a zero weight past the lane's own wing, input samples outside the signal
+// read as the staged zeros.  Must equal ssr_sinc_one (which skips those taps) up to the sign of an exact zero.
+static inline float ssr_sinc_one_tab_host(const SsrSincParams& p, const float* x, int n_in, int64_t t) {
+  const double tr = p.time_reg[t];
+  const int n = (int)tr;
+  double frac = ssr_fmul_rn(p.scale, ssr_fadd_rn(tr, -(double)n));
+  float y = 0.0f;
+  for (int wing = 0; wing < 2; ++wing) {
+    const double index_frac = ssr_fmul_rn(frac, (double)p.num_table);
+    const int offset = (int)index_frac;
+    const double eta = ssr_fadd_rn(index_frac, -(double)offset);
+    const int room = (p.nwin - offset) / p.index_step;
+    const double* row = p.tab + 2 * (int64_t)offset * p.tab_r;
+    for (int i = 0; i < p.max_room - 1; ++i) {
+      double weight = ssr_fadd_rn(row[2 * i], ssr_fmul_rn(eta, row[2 * i + 1]));
+      if (i >= room) weight = 0.0;
+      const int64_t xi = wing == 0 ? (int64_t)n - i : (int64_t)n + 1 + i;
+      const double xv = (xi >= 0 && xi < n_in) ? (double)x[xi] : 0.0;
+      y = (float)ssr_fadd_rn((double)y, ssr_fmul_rn(weight, xv));
+    }
+    frac = ssr_fadd_rn(p.scale, -frac);
+  }
+  return y;
+}
+#endif
+
 // grid = n_items * blocks_per_item workgroups of SSR_SINC_NT threads; dynamic LDS: lds_floats floats
 template <bool PAD, typename BLK>
 SSR_BODY void ssr_sinc_block_body(const SsrSincParams& p, BLK& blk, int item, int block, char* lds_base) {

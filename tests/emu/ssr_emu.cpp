@@ -494,6 +494,23 @@ extern "C" int emu_resample_sinc(const float* in, const int64_t* in_off, const i
   return g.period * 1000000 + g.pw * 10000 + g.pad * 1000 + (g.m < 1000 ? g.m : 999);   // geometry actually used
 }
 
+// the device's phase-major table (ssr_sinc_table_body) and the per-lane-row tap loop, stated sequentially
+extern "C" int emu_resample_sinc_tab(const float* in, const int64_t* in_off, const int32_t* in_len, const int64_t* out_off,
+                                     const int32_t* out_len, int n_items, const double* tr, const double* win, const double* delta,
+                                     int n_win, int num_table, int index_step, double scale, float* out) {
+  SsrSincParams p{in, in_off, in_len, out_off, out_len, tr, win, delta, n_win, num_table, index_step, scale, out, 1, 1, 1,
+                  n_win / index_step + 1, 0};
+  p.tab_r = ssr_sinc_tab_r(p.max_room);
+  p.tab_rows = index_step + 1;
+  std::vector<double> tab((size_t)p.tab_rows * p.tab_r * 2, -12345.0);
+  p.tab = tab.data();
+  for (int64_t e = 0; e < (int64_t)p.tab_rows * p.tab_r; ++e) ssr_sinc_table_body(p, e);
+  for (int item = 0; item < n_items; ++item)
+    for (int64_t t = 0; t < out_len[item]; ++t)
+      out[out_off[item] + t] = ssr_sinc_one_tab_host(p, in + in_off[item], in_len[item], t);
+  return p.tab_r;
+}
+
 // ---- zero-phase IIR (sequential statement of the wavefront kernel's arithmetic) -------------------------------
 extern "C" int emu_sosfiltfilt(const float* x, const int64_t* off, const int32_t* len, int n_items, const double* sos,
                                const double* zi, int n_sections, int edge, double* fwd, double* y) {

@@ -298,6 +298,24 @@ def xcorr_argmax(a_list, b_list):
     return out
 
 
+def resample_sinc_tab(sigs, sr_orig, sr_new, name="kaiser_best"):
+    """The device's round-5 tap loop on the host: phase-major table built by ssr_sinc_table_body, every output from its own row
+    with the loop run to the longest wing (ssr_sinc_one_tab_host)."""
+    from oracle import resampy as orsy
+    ratio = float(sr_new) / sr_orig
+    win, delta, num_table, step, scale = orsy.filter_tables(ratio, name)
+    a, off, lens = ragged(sigs)
+    out_len = np.array([int(int(n) * ratio) for n in lens], np.int32)
+    out_off = np.concatenate(([0], np.cumsum(out_len)[:-1])).astype(np.int64)
+    tr = orsy.time_register(int(out_len.max()), ratio)
+    out = np.full(int(out_len.sum()), np.nan, np.float32)
+    rc = lib().emu_resample_sinc_tab(_p(a, C.c_float), _p(off, C.c_int64), _p(lens, C.c_int32), _p(out_off, C.c_int64),
+                                     _p(out_len, C.c_int32), len(lens), _p(tr, C.c_double), _p(win, C.c_double), _p(delta, C.c_double),
+                                     len(win), num_table, step, C.c_double(scale), _p(out, C.c_float))
+    assert rc >= 8 and rc % 4 == 0
+    return [out[out_off[i]:out_off[i] + out_len[i]] for i in range(len(lens))]
+
+
 def resample_sinc(sigs, sr_orig, sr_new, name="kaiser_best", phase_period=None, lds_cap_floats=12288, geometry=None):
     """ssr_sinc.h on the host: tables / time register from the oracle module's published-parameter restatement.
     phase_period: None = what the product passes (a of sr_new / sr_orig = a / b); geometry: a list that receives (period, m)."""

@@ -39,7 +39,7 @@ template <typename T, int P> struct SsrR3RotLds {
   }
 };
 
-template <typename T, bool SUMS, int NQ, int P> struct SsrR3RotRegs : SsrRnWaveRegs<T, SUMS, NQ, P> {
+template <typename T, bool SUMS, int NQ, int P, typename SA = float> struct SsrR3RotRegs : SsrRnWaveRegs<T, SUMS, NQ, P, SA> {
   double sums[6];
 };
 
@@ -58,16 +58,20 @@ template <typename T> SSR_DEV cx<T> ssr_r3_combine3(const T* y0p, const T* y1p, 
 // round in which the last job of unit U runs
 SSR_DEV int ssr_r3_rot_done_round(int U) { return (3 * U + 2) >> 2; }
 
-// grid = n_items * n_chunks workgroups of 256 threads; PAIR mode, float32 signals, n_fft = 3 q.
-template <typename T, bool SUMS, int NQ, int P, typename BLK>
+// grid = n_items * n_chunks workgroups of 256 threads; PAIR mode, n_fft = 3 q.  IN64 = 0: float32 signals; SSR_IN_EST64 (round 5): the
+// estimate as float64 samples (p.a64) with the float64 estimate arithmetic of ssr_pair_bin<T, SSR_IN_EST64> - what an IIR-degraded
+// input carries into the metrics (ssr_eval/eval.py:138-150); the target stays float32.
+template <typename T, bool SUMS, int NQ, int P, int IN64 = 0, typename BLK>
 SSR_BODY void ssr_stft_r3_rot_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
+  static_assert(IN64 == 0 || IN64 == SSR_IN_EST64, "float32 pairs, or a float64 estimate against a float32 target");
+  using SA = typename SsrSample<(IN64 & 1) != 0>::type;
   constexpr bool SPLIT = true;
   constexpr int NT = 64 * SSR_R3ROT_WAVES, NI = 4 * NQ;
   constexpr int PB = P / 8, M = 64 * P, PN = ssr_rn_wave_pn<P>();
   constexpr int NQO = (P == 32) ? NQ : 4;
   static_assert(NQ == 3 || NQ == 4, "q <= 768 or q <= 1024");
   static_assert(P == 32 || (P == 24 && NQ == 3), "M = 1536 holds the chirp-z of q <= 768 only");
-  using Regs = SsrR3RotRegs<T, SUMS, NQ, P>;
+  using Regs = SsrR3RotRegs<T, SUMS, NQ, P, SA>;
   SsrR3RotLds<T, P> L(lds_base);
   const int n_fft = p.n_fft, hop = p.hop, F = n_fft / 2 + 1, q = n_fft / 3;
   const int n = p.len[item];
@@ -79,7 +83,10 @@ SSR_BODY void ssr_stft_r3_rot_body(const SsrStftParams<T>& p, BLK& blk, int chun
   double* part = p.part ? p.part + ((int64_t)item * p.n_chunks + chunk) * SSR_NPART : nullptr;
   const int mask = SUMS ? p.metric_mask : (p.metric_mask & SSR_M_LSD);
   const bool want_lsd = mask & SSR_M_LSD;
-  const SsrView<float> va(p.a + p.a_off[item], n), vb(p.b + p.b_off[item], n);
+  const SA* sa;
+  if constexpr (IN64 & 1) sa = p.a64 + p.a_off[item]; else sa = p.a + p.a_off[item];
+  const SsrView<SA> va(sa, n);
+  const SsrView<float> vb(p.b + p.b_off[item], n);
   const SsrView<cx<T>> vbf(p.bfilt, M), vch(p.chirp, n_fft), vt(p.tw, M + (P == 32 ? SSR_W_TWP : SSR_W24_TWP));
   const int64_t OP = p.out_pitch ? p.out_pitch : F;      // floats between output rows
   const bool store = p.out_kind == SSR_OUT_MAG;
@@ -184,7 +191,7 @@ SSR_BODY void ssr_stft_r3_rot_body(const SsrStftParams<T>& p, BLK& blk, int chun
           const cx<T> zk = ssr_r3_combine3<T>(yb[0], yb[1], yb[2], q, K);
           const cx<T> zn = ssr_r3_combine3<T>(yb[0], yb[1], yb[2], q, Kn);
           float ev, tv;
-          ssr_pair_bin<T, 0, true>(mask, acc, zk, zn, a_nz, b_nz, ev, tv);
+          ssr_pair_bin<T, IN64, IN64 == 0>(mask, acc, zk, zn, a_nz, b_nz, ev, tv);
           if (store) { ra0[K] = ev; if (rb0 != nullptr) rb0[K] = tv; }
         }
         if (want_lsd) SSR_WAVE_SUM_STORE(tid, NT, acc[0], L.sc1 + 4 * e);

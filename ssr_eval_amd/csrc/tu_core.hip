@@ -128,7 +128,10 @@ template <typename T> int ssr_launch_stft(const ssr_plan* pl, SsrStftParams<T>& 
   const DevTables<T>& d = ssr_tables_of<T>(pl);
   p.window = d.window_h; p.tw = d.tw; p.wchirp = d.wchirp; p.bfilt = d.bfilt; p.chirp = d.chirp;
   const bool in64 = p.a64 != nullptr;
-  if (!in64 && p.mode == SSR_MODE_PAIR && ssr_stft_rn_wave_radix(pl)) {
+  // float64 ESTIMATE against a float32 target at n_fft = 3 q, q <= 768 (AudioMetrics(48000) behind an IIR degradation): the rotating
+  // four-wave engine has an IN64 variant (round 5); every other float64 combination runs the block engines
+  const bool est64_rot = in64 && p.b64 == nullptr && sizeof(T) == 8 && ssr_stft_rn_wave_radix(pl) == 3 && pl->weng.m == 1536;   // (SSR_W24_N, ssr_fft24.h)
+  if ((!in64 || est64_rot) && p.mode == SSR_MODE_PAIR && ssr_stft_rn_wave_radix(pl)) {
     const DevTables<T>& w = ssr_wave_tables_of<T>(pl);
     p.tw = w.tw; p.wchirp = w.wchirp; p.bfilt = w.bfilt; p.chirp = w.chirp;
     return ssr_launch_stft_rn_wave<T>(pl, p, grid, s);

@@ -174,14 +174,16 @@ static void emu_r3_rot_run(const SsrStftParams<T>& p, int n_items, int n_chunks,
   for (int item = 0; item < n_items; ++item)
     for (int c = 0; c < n_chunks; ++c) {
       auto lds = poisoned(SsrR3RotLds<T, 24>::bytes(p.n_fft / 3));
-      if (sums) ssr_stft_r3_rot_body<T, true, 3, 24>(p, blk, c, item, lds.data());
+      if (p.a64 && sums) ssr_stft_r3_rot_body<T, true, 3, 24, SSR_IN_EST64>(p, blk, c, item, lds.data());     // float64 estimate (round 5)
+      else if (p.a64) ssr_stft_r3_rot_body<T, false, 3, 24, SSR_IN_EST64>(p, blk, c, item, lds.data());
+      else if (sums) ssr_stft_r3_rot_body<T, true, 3, 24>(p, blk, c, item, lds.data());
       else ssr_stft_r3_rot_body<T, false, 3, 24>(p, blk, c, item, lds.data());
     }
 }
 // m1536: 1 = what the product picks (M = 1536 for q <= 768; radix 3: the rotating four-wave kernel), 0 = force the 2048-point
 // transforms, 2 = M = 1536 on the three-wave workgroups (radix 3 only differs)
 template <typename T>
-static int emu_stft_r3_wave_t(int n_fft, int hop, int out_kind, int mask, int m1536, const float* a, const float* b, const int64_t* a_off,
+static int emu_stft_r3_wave_t(int n_fft, int hop, int out_kind, int mask, int m1536, const float* a, const double* a64, const float* b, const int64_t* a_off,
                               const int64_t* b_off, const int32_t* len, const int64_t* frame_off, int n_items,
                               int units_per_chunk, int n_chunks, float* out_a, float* out_b, double* part) {
   SsrEngine we = ssr_pick_wave_engine(n_fft);
@@ -190,7 +192,7 @@ static int emu_stft_r3_wave_t(int n_fft, int hop, int out_kind, int mask, int m1
   SsrTables<T> t;
   if (!ssr_build_tables_for<T>(n_fft, we, t)) return -3;
   SsrStftParams<T> p{};
-  p.a = a; p.b = b; p.a_off = a_off; p.b_off = b_off; p.len = len; p.frame_off = frame_off;
+  p.a = a; p.a64 = a64; p.b = b; p.a_off = a_off; p.b_off = b_off; p.len = len; p.frame_off = frame_off;
   p.mode = SSR_MODE_PAIR; p.out_kind = out_kind; p.metric_mask = mask;
   p.n_fft = n_fft; p.hop = hop; p.n_bins = n_fft / 2 + 1;
   p.units_per_chunk = units_per_chunk; p.n_chunks = n_chunks;
@@ -199,6 +201,7 @@ static int emu_stft_r3_wave_t(int n_fft, int hop, int out_kind, int mask, int m1
   p.out_a = out_a; p.out_b = out_b; p.part = part;
   const bool sums = mask & (SSR_M_SISPEC | SSR_M_LOG_SISPEC);
   const bool wide = we.q > 768;
+  if (a64 && !(we.m == SSR_W24_N && we.radix == 3 && m1536 == 1)) return -5;      // the float64 estimate exists on the rotating engine only
   if (we.m == SSR_W24_N) {
     if (we.radix == 1) emu_rn_wave_run<T, 1, 3, 24>(p, n_items, n_chunks, sums);
     else if (we.radix == 2) emu_rn_wave_run<T, 2, 3, 24>(p, n_items, n_chunks, sums);
@@ -215,10 +218,17 @@ extern "C" int emu_stft_r3_wave(int precision, int n_fft, int hop, int out_kind,
                                 const int64_t* a_off, const int64_t* b_off, const int32_t* len, const int64_t* frame_off,
                                 int n_items, int units_per_chunk, int n_chunks, float* out_a, float* out_b, double* part) {
   if (precision == 1)
-    return emu_stft_r3_wave_t<double>(n_fft, hop, out_kind, mask, m1536, a, b, a_off, b_off, len, frame_off, n_items, units_per_chunk,
+    return emu_stft_r3_wave_t<double>(n_fft, hop, out_kind, mask, m1536, a, nullptr, b, a_off, b_off, len, frame_off, n_items, units_per_chunk,
                                       n_chunks, out_a, out_b, part);
-  return emu_stft_r3_wave_t<float>(n_fft, hop, out_kind, mask, m1536, a, b, a_off, b_off, len, frame_off, n_items, units_per_chunk,
+  return emu_stft_r3_wave_t<float>(n_fft, hop, out_kind, mask, m1536, a, nullptr, b, a_off, b_off, len, frame_off, n_items, units_per_chunk,
                                    n_chunks, out_a, out_b, part);
+}
+// the rotating four-wave engine with a float64 estimate (float64 transforms)
+extern "C" int emu_stft_r3_rot_est64(int n_fft, int hop, int out_kind, int mask, const double* a64, const float* b,
+                                     const int64_t* a_off, const int64_t* b_off, const int32_t* len, const int64_t* frame_off,
+                                     int n_items, int units_per_chunk, int n_chunks, float* out_a, float* out_b, double* part) {
+  return emu_stft_r3_wave_t<double>(n_fft, hop, out_kind, mask, 1, nullptr, a64, b, a_off, b_off, len, frame_off, n_items, units_per_chunk,
+                                    n_chunks, out_a, out_b, part);
 }
 
 // pair mode with a float64 estimate and a float32 (b) or float64 (b64) target (IN64 kernel variants)

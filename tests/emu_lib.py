@@ -71,7 +71,12 @@ def stft(sigs_a, sigs_b, n_fft, hop, precision=1, mode=0, out_kind=1, mask=0, un
     part = np.full((len(lens), n_chunks, 8), np.nan, np.float64) if mode == 0 else None
     tail = (_p(a_off, C.c_int64), _p(b_off, C.c_int64), _p(lens, C.c_int32), _p(frame_off, C.c_int64), len(lens),
             units_per_chunk, n_chunks, _p(out_a, C.c_float), _p(out_b, C.c_float), _p(part, C.c_double))
-    if wave in ("r3", "r3_2048", "r3_three"):   # radix-R x Bluestein on R autonomous waves (pair mode, n_fft = R q; R = 1, 2, 3): "r3" = the
+    if wave == "r3" and est64:                  # the rotating engine's float64-estimate variant (round 5)
+        assert mode == 0 and not tgt64 and precision == 1
+        rc = lib().emu_stft_r3_rot_est64(n_fft, hop, out_kind, mask, _p(a, C.c_double), _p(b, C.c_float), *tail)
+        assert rc == 24, rc
+        rc = 0
+    elif wave in ("r3", "r3_2048", "r3_three"):   # radix-R x Bluestein on R autonomous waves (pair mode, n_fft = R q; R = 1, 2, 3): "r3" = the
         assert mode == 0 and not est64     # product's choice (M = 1536 where q <= 768), "r3_2048" = 2048-point transforms forced
         rc = lib().emu_stft_r3_wave(precision, n_fft, hop, out_kind, mask, {"r3": 1, "r3_2048": 0, "r3_three": 2}[wave], _p(a, C.c_float), _p(b, C.c_float), *tail)
         assert rc in (24, 32), rc

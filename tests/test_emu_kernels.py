@@ -349,6 +349,31 @@ def test_pair_metrics_float64_estimate(golden, n_fft, hop):
     np.testing.assert_allclose(got, want, rtol=1e-6)
 
 
+def test_rotating_engine_float64_estimate_equals_the_block_engine(golden):
+    """ssr_stft_r3_rot.h's IN64 variant (round 5: AudioMetrics(48000) = 2229 / 480 behind an IIR degradation runs on the rotating
+    four-wave engine instead of the block engine): the metrics of a float64 estimate against the oracle at the block engine's bar,
+    the magnitude images and the metrics against the block engine's to transform round-off, chunks that end mid-rotation, a silent
+    stretch in the estimate, and the LSD-only variant (no running sums)."""
+    n_fft, hop = 2229, 480
+    rng = np.random.default_rng(31)
+    tgts = [golden["ss_x"][:14000].astype(np.float32), (0.1 * rng.standard_normal(9000)).astype(np.float32)]
+    sos = olp.iir_sos(2000, 44100, 8, "cheby1")
+    ests = [signal.sosfiltfilt(sos, t) for t in tgts]
+    ests[1][2000:5500] = 0.0                                          # whole silent frames in the estimate
+    for upc in (3, 5):
+        rot = E.stft(ests, tgts, n_fft, hop, 1, 0, 1, E.M_ALL, upc, est64=True, wave="r3")
+        blk = E.stft(ests, tgts, n_fft, hop, 1, 0, 1, E.M_ALL, upc, est64=True)
+        for a, b in zip(rot[0] + rot[1], blk[0] + blk[1]):
+            np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-9)     # float32 images of float64 transforms of different factorisations
+        got = E.pair_metrics(ests, tgts, n_fft, hop, precision=1, units_per_chunk=upc, rows_per_tile=9, est64=True, wave="r3")
+        ref = E.pair_metrics(ests, tgts, n_fft, hop, precision=1, units_per_chunk=upc, rows_per_tile=9, est64=True)
+        np.testing.assert_allclose(got, ref, rtol=1e-9)
+    want = om.evaluation(ests[0], tgts[0], n_fft=n_fft, hop=hop)
+    np.testing.assert_allclose(got[0], [want["lsd"], want["log_sispec"], want["sispec"], want["ssim"]], rtol=1e-6)
+    lsd_only = E.pair_metrics(ests, tgts, n_fft, hop, precision=1, mask=E.M_LSD, units_per_chunk=4, est64=True, wave="r3")
+    np.testing.assert_allclose(lsd_only[:, 0], got[:, 0], rtol=1e-12)
+
+
 def test_xcorr_argmax_matches_scipy_correlate(golden):
     """N4: numpy.argmax(scipy.signal.correlate(a, b)) - the alignment step of mp3_encoding (ssr_eval/eval.py:319)."""
     rng = np.random.default_rng(319)

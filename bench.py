@@ -167,17 +167,33 @@ def hbm_roofline(kernel, alg_bytes, ms, traffic_key=None, note=None):
 
 # ----------------------------------------------------------------------------------------------------------
 # workloads
+def _prec_name(a):
+    return {"f64": "double", "f32": "float"}[a.precision]
+
+
 class Cfg2:
     name = "cfg2"
     metric = "utterance-pairs/sec (LSD+SSIM, 48kHz, n_fft=2048)"
     unit = "pairs/s"
+    n_fft, hop = N_FFT, HOP
+    label = "cfg-2"
+
+    @classmethod
+    def frames(cls):
+        return 1 + N_SAMPLES // cls.hop
+
+    @classmethod
+    def stft_kernel(cls, a):
+        """The EXACT instantiated name of the transform kernel of this workload's step, as rocprofv3 prints it (LSD + magnitudes for
+        SSIM, no running SISpec sums): <T, SUMS = false, SPLIT = true, MAG = true>."""
+        return "k_stft_wave<%s, false, true, true>" % _prec_name(a)
 
     def __init__(self, a, dev, rank):
         from ssr_eval_amd import backend as B
         self.B, self.a, self.dev = B, a, dev
         n = a.pairs
         self.est, self.tgt = make_inputs(n, dev, 20220328 + rank)
-        self.plan = B.get_plan(N_FFT, HOP, a.precision, dev)
+        self.plan = B.get_plan(self.n_fft, self.hop, a.precision, dev)
         self.batch = B.PairBatch(self.plan, B.Ragged.from_uniform(self.est), B.Ragged.from_uniform(self.tgt))
         self.mask = B.M_LSD | B.M_SSIM
         self.units_per_step = n
@@ -194,9 +210,10 @@ class Cfg2:
 
     def config(self, world):
         a = self.a
-        return {"workload": "cfg-2: %d synthetic 48 kHz 4 s float32 (est, target) pairs per GPU resident in HBM, STFT n_fft=2048 "
-                            "hop=512 (T=376, F=1025), LSD + SSIM, transform precision %s" % (a.pairs, a.precision),
-                "pairs_per_gpu": a.pairs, "samples_per_utterance": N_SAMPLES, "n_fft": N_FFT, "hop": HOP,
+        return {"workload": "%s: %d synthetic 48 kHz 4 s float32 (est, target) pairs per GPU resident in HBM, STFT n_fft=%d "
+                            "hop=%d (T=%d, F=%d), LSD + SSIM, transform precision %s"
+                            % (self.label, a.pairs, self.n_fft, self.hop, self.frames(), self.n_fft // 2 + 1, a.precision),
+                "pairs_per_gpu": a.pairs, "samples_per_utterance": N_SAMPLES, "n_fft": self.n_fft, "hop": self.hop,
                 "parallelism": "utterance-sharded x%d, one float64 all-reduce (24 B) per step%s"
                                % (world, ", issued asynchronously: it overlaps the next step's kernels" if world > 1 else "")}
 
@@ -208,11 +225,13 @@ class Cfg2:
         ms_fin = event_time_ms(lambda: batch.run(mask, stages=4), it)
         ms_all4 = event_time_ms(lambda: batch.run(B.M_ALL), it)
         alg = (2 * N_SAMPLES * 4 + 32) * a.pairs          # read est + target once, write 4 doubles
-        fft_tflops = 2 * 376 * 2.5 * 2048 * 11 * a.pairs / (ms_stft * 1e-3) / 1e12   # 42.4 MFLOP of real-FFT work per pair
-        dom = ("ssr_stft_pair(k_stft_wave)", ms_stft, "k_stft_wave<double, false") if ms_stft >= ms_ssim else ("ssr_ssim(k_ssim)", ms_ssim, "k_ssim")
+        T = self.frames()
+        fft_tflops = 2 * T * 2.5 * self.n_fft * np.log2(self.n_fft) * a.pairs / (ms_stft * 1e-3) / 1e12   # 42.4 MFLOP of real-FFT work per pair at 2048/512
+        kname = self.stft_kernel(a)
+        dom = (kname, ms_stft, kname[:kname.index(",", kname.index(",") + 1)]) if ms_stft >= ms_ssim else ("k_ssim<4, true>", ms_ssim, "k_ssim")
         default_wl = a.pairs == 1024 and a.precision == "f64"
-        ceil = fp64_mix_ceiling() if default_wl else {}
-        units_s = 376 * a.pairs / (ms_stft * 1e-3)                 # frame pairs per second of the transform kernel
+        ceil = fp64_mix_ceiling() if default_wl and self.n_fft == 2048 else {}
+        units_s = T * a.pairs / (ms_stft * 1e-3)                   # frame pairs per second of the transform kernel
         roof = hbm_roofline(dom[0], alg, dom[1], dom[2] if default_wl else None,
                             "fused path is compute-side (f64 FFT + f64 SSIM moments); secondary: STFT kernel runs at %.2f TFLOP/s "
                             "of real-FFT work = %.3f of the f64 vector peak at 2.4 GHz; %.1f M frame pairs/s%s"
@@ -223,28 +242,49 @@ class Cfg2:
                                % (units_s / 1e6 / ceil["units_M_per_s_2_waves"], ceil["units_M_per_s_2_waves"]) if ceil.get("units_M_per_s_2_waves") else ""))
         if ceil:
             roof["fp64_mix_ceiling"] = ceil
-        extra = {"stage_ms": {"stft+lsd": round(ms_stft, 4), "ssim": round(ms_ssim, 4), "finalize": round(ms_fin, 4)},
+        roof["entry_point"] = "ssr_pair_metrics (C ABI) -> ssr_stft_pair"
+        # every kernel of the timed step under its rocprofv3 name (hip-event averages on the launch stream; the stats CSV of
+        # `bench.py --config %s --no-side` under profiles/ holds the same three rows)
+        extra = {"kernels_ms": {kname: round(ms_stft, 4), "k_ssim<4, true>": round(ms_ssim, 4), "k_finalize": round(ms_fin, 4)},
+                 "stage_ms": {"stft+lsd": round(ms_stft, 4), "ssim": round(ms_ssim, 4), "finalize": round(ms_fin, 4)},
                  "full_metric_set_pairs_per_s_per_gpu": round(a.pairs / (ms_all4 * 1e-3), 1)}
         return roof, extra
 
     # CPU baseline: LSD + SSIM of one pair through the oracle
+    _cpu_nfft, _cpu_hop = N_FFT, HOP            # (read by the static worker function: set per workload in cpu_inputs)
+
     def cpu_inputs(self, n):
+        Cfg2._cpu_nfft, Cfg2._cpu_hop = self.n_fft, self.hop
         return [(self.est[i].cpu().numpy(), self.tgt[i].cpu().numpy()) for i in range(min(n, self.a.pairs))]
 
     @staticmethod
     def cpu_unit(item):
         from oracle import metrics as om
         est, tgt = item
-        es, ts = om.wav_to_spectrogram(est, N_FFT, HOP), om.wav_to_spectrogram(tgt, N_FFT, HOP)
+        es, ts = om.wav_to_spectrogram(est, Cfg2._cpu_nfft, Cfg2._cpu_hop), om.wav_to_spectrogram(tgt, Cfg2._cpu_nfft, Cfg2._cpu_hop)
         return float(om.lsd(es, ts)), float(om.ssim(es, ts))
 
-    cpu_desc = "pairs of the same workload (4 s @ 48 kHz, STFT 2048/512 + LSD + SSIM) through the NumPy/SciPy/torch-CPU oracle"
+    cpu_desc = "pairs of the same workload (4 s @ 48 kHz, this workload's STFT size + LSD + SSIM) through the NumPy/SciPy/torch-CPU oracle"
 
     def parity(self, out_vals, n, first):
         """max relative error of (LSD, SSIM) of pairs first .. first + n - 1 against the oracle values the CPU baseline
         produced for exactly those pairs."""
         got = self.batch.run(self.mask)[first:first + n].cpu().numpy()
         return max(max(abs(got[i, 0] - v[0]) / abs(v[0]), abs(got[i, 3] - v[1]) / abs(v[1])) for i, v in enumerate(out_vals[:n]))
+
+
+class ApiTrue(Cfg2):
+    """The reference's OWN configuration of the headline metric: AudioMetrics(48000) = n_fft int(2048 / (44100 / 48000)) = 2229, hop 480
+    (ssr_eval/metrics.py:16-19) - n_fft = 3 x 743: radix-3 over three Bluestein-743 sub-sequences on 1536-point transforms, four
+    autonomous waves rotating through the sub-sequence transforms of consecutive frames (k_stft_r3_rot)."""
+    name = "apitrue"
+    metric = "utterance-pairs/sec (LSD+SSIM, 48kHz, AudioMetrics(48000): n_fft=2229 hop=480)"
+    n_fft, hop = 2229, 480
+    label = "API-true AudioMetrics(48000)"
+
+    @classmethod
+    def stft_kernel(cls, a):
+        return "k_stft_r3_rot<%s, false, 3, 24, 0>" % _prec_name(a)
 
 
 class Cfg3:
@@ -728,7 +768,7 @@ class Skeleton:
         return None, {}
 
 
-WORKLOADS = {"cfg2": Cfg2, "cfg3": Cfg3, "cfg4": Cfg4, "cfg5": Cfg5}
+WORKLOADS = {"cfg2": Cfg2, "cfg3": Cfg3, "cfg4": Cfg4, "cfg5": Cfg5, "apitrue": ApiTrue}
 
 # ----------------------------------------------------------------------------------------------------------
 # CPU baseline (SURVEY 8(d) protocol): >= 64 units where a unit is short, first 4 discarded as warm-up, median of 3
@@ -846,20 +886,15 @@ def side_figures(a, dev):
         torch.cuda.empty_cache()
 
     def api_true():
-        nb = a.pairs
-        g = torch.Generator(device=dev).manual_seed(7)
-        tgt = (0.1 * torch.randn((nb, N_SAMPLES), generator=g, device=dev)).contiguous()
-        est = (tgt + 0.01 * torch.randn((nb, N_SAMPLES), generator=g, device=dev)).contiguous()
-        b2 = B.PairBatch(B.get_plan(2229, 480, a.precision, dev), B.Ragged.from_uniform(est), B.Ragged.from_uniform(tgt))
-        mask = B.M_LSD | B.M_SSIM
-        ms = event_time_ms(lambda: b2.run(mask), 3)
-        ms_stft = event_time_ms(lambda: b2.run(mask, stages=1), 3)
-        return {"workload": "AudioMetrics(48000) sizes: n_fft 2229 (radix-3 x Bluestein-743 over 1536-point transforms; four autonomous waves rotate through the sub-sequence transforms of consecutive frames) / hop 480, %d pairs of 4 s @ 48 kHz, "
-                            "LSD + SSIM" % nb,
-                "pairs_per_s": round(nb / (ms * 1e-3), 1),
-                "roofline": hbm_roofline("ssr_stft_pair(k_stft_r3_rot)", (2 * N_SAMPLES * 4 + 32) * nb, ms_stft,
-                                         "k_stft_r3_rot<double, false" if nb == 1024 and a.precision == "f64" else None),
-                "note": "side figure: average of 3 launches in one short run"}
+        wl = ApiTrue(a, dev, 0)
+        wl.step()
+        torch.cuda.synchronize()
+        ms = event_time_ms(lambda: wl.step(), 3)
+        roof, extra = wl.report(a)
+        return {"workload": wl.config(1)["workload"], "pairs_per_s": round(a.pairs / (ms * 1e-3), 1), "ms_per_step": round(ms, 4),
+                "roofline": roof, "kernels_ms": extra["kernels_ms"],
+                "note": "side figure: average of 3 steps in one short run; `python bench.py --config apitrue` is the measurement "
+                        "(its rocprofv3 summary: profiles/r06_apitrue_kernel_stats.csv)"}
 
     def rates():
         """Every AudioMetrics(rate) size of the reference (ssr_eval/metrics.py:16-19), 4 s signals at that rate, four metrics."""
@@ -1044,11 +1079,16 @@ def run(a):
         dt = time.perf_counter() - t0
         if world > 1:
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            every = [torch.zeros_like(tmax) for _ in range(world)]
+            dist.all_gather(every, tmax)                 # (outside the timed region: the per-rank clocks for `extra`)
+            per_rank[:] = [float(t.item()) for t in every]
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         return dt, agg.cpu().numpy()
 
+    per_rank = []
     elapsed, agg = timed(wl, a.steps, a.warmup)
+    per_rank_ms = [round(t / a.steps * 1e3, 4) for t in per_rank]
     # weak scaling: every rank owns units_per_step units; strong scaling: units_per_step is the whole job's
     value = wl.units_per_step * (1 if strong else joined) * a.steps / elapsed
     means = wl.job_means(agg) if hasattr(wl, "job_means") else (agg[:-1] / agg[-1]).tolist()
@@ -1078,6 +1118,16 @@ def run(a):
     roofline, extra = wl.report(a)
     extra["job_means"] = means
     extra["allreduce_payload_bytes_per_step"] = payload if world > 1 else 0
+    if world > 1:
+        # what a reader of the scaling curve needs to trust it: the ranks that joined, each rank's own clock, the library underneath
+        rccl = None
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception as e:
+            rccl = repr(e)
+        extra["ranks"] = {"joined": joined, "backend": backend, "rccl_version": rccl, "ms_per_step_per_rank": per_rank_ms,
+                          "max_over_min": round(max(per_rank_ms) / max(min(per_rank_ms), 1e-9), 4) if per_rank_ms else None,
+                          "local_world_size": int(os.environ.get("LOCAL_WORLD_SIZE", world))}
     if cfg4_side is not None:
         extra["cfg4_strong_scaling"] = cfg4_side
     cpu = None

@@ -119,7 +119,9 @@ int ssr_tl_weights(int n_fft, float* fwd_re_t, float* fwd_im_t, float* inv_re_t,
  * The Python mirror evaluates DFTBase.dft_matrix / idft_matrix with the module's own numpy expressions (np.power(omega, x * y) in
  * complex128) and hands the float32 results over, so that the engine multiplies by the REFERENCE'S weights to the last bit (the
  * library's own tables - exact phase reduction in long double - differ from numpy's in 1 ulp of ~0.5 % of the entries).
- * Call it before the plan is shared between threads / before launches that should see the tables are enqueued. */
+ * Call it before the plan is shared between threads / before launches that should see the tables are enqueued.  The library's own
+ * tables are only built by the first conv launch that finds none, so a caller that sets its tables first never pays for them; a set
+ * that IS superseded (this call twice, or after such a launch) is released after a hipDeviceSynchronize(). */
 int ssr_plan_set_tl_weights(ssr_plan* plan, const float* fwd_re, const float* fwd_im, const float* inv_re, const float* inv_im,
                             const float* w2);
 /* The same for a caller-supplied window (HOST float64 [n_fft], NULL = periodic Hann): the tables of an ssr_plan_create_ex plan. */

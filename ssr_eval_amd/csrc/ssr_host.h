@@ -108,6 +108,7 @@ template <typename T> int ssr_launch_stft(const ssr_plan*, SsrStftParams<T>&, in
 template <typename T> int ssr_launch_lowpass(const ssr_plan*, SsrLowpassParams<T>&, int grid, hipStream_t);
 // tu_tlconv.hip: the reference-arithmetic engine (dense float32 DFT products on the matrix cores)
 int ssr_tl_build(ssr_plan* pl);
+int ssr_tl_supported(const ssr_plan* pl);       // the conv engine can serve this n_fft (tables are built at the first launch)
 inline int ssr_plan_pad(const ssr_plan* pl) { return pl->ex_center ? pl->n_fft / 2 : 0; }
 // the longest item must be transformable (lengths live on the device: a shorter item in a batch is skipped and its output zeroed)
 inline int ssr_check_max_len(const ssr_plan* pl, int max_len) {

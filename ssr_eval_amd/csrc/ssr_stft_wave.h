@@ -31,6 +31,11 @@ static __device__ unsigned long long ssr_dbg_clk[8];
 #define SSR_CLK_NOW(i) do { SSR_SCHED_BARRIER(); clk_[i] = __builtin_readcyclecounter(); SSR_SCHED_BARRIER(); } while (0)
 #endif
 
+// k_stft_wave's third pass in PAIRED butterfly order (below): 1 = the product, 0 = the ascending order + half exchange of
+// rounds 2-5 (A/B builds)
+#ifndef SSR_WAVE_PAIRED
+#define SSR_WAVE_PAIRED 1
+#endif
 constexpr int SSR_W_N = 2048, SSR_W_L = 64, SSR_W_P = 32;     // points, lanes, points per lane
 constexpr int SSR_W_TWP = 7 * 32 + 12 * 64;                   // lane-ordered twiddle copies behind the table (= SSR_WAVE_TWP)
 SSR_DEV int ssr_wpad(int i) { return i + (i >> 5); }            // lane stride 32 -> 33 doubles: conflict-free ds_*_b64
@@ -161,22 +166,53 @@ SSR_DEV constexpr int ssr_w_off_st1(int i) { return 528 * (i >> 3) + 33 * (i & 7
 // SPLIT: real parts first, imaginary parts second, through the same array.
 // EXTRA: statements issued right after the (first) write phase - the table loads of the NEXT pass: the registers of the
 // values just written are free at that point, and the loads' latency overlaps the exchange.
-#define SSR_W_EXCHANGE(blk, regs, L, WB, WO, RB, RO, EXTRA)                                               \
+// (the read side as (per-lane bases RBASES(lane), index RIDX(bases, i)): SSR_W_EXCHANGE reads slot RB + RO(i); the paired
+// second exchange of k_stft_wave reads each butterfly's inputs from its own per-lane base)
+#define SSR_W_EXCHANGE_G(blk, regs, L, WB, WO, RBASES, RIDX, EXTRA)                                       \
   if constexpr (!SPLIT) {                                                                                 \
     SSR_WPHASE(blk, regs, { const int w_ = ssr_wave_bases(tid & 63).WB;                                        \
       SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) { (L).re[w_ + WO(i)] = R.v[i].x; (L).im[w_ + WO(i)] = R.v[i].y; } }); \
-    SSR_WPHASE(blk, regs, { SSR_SCHED_BARRIER(); EXTRA; const int r_ = ssr_wave_bases(tid & 63).RB;           \
-      SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) R.v[i] = {(L).re[r_ + RO(i)], (L).im[r_ + RO(i)]}; });   \
+    SSR_WPHASE(blk, regs, { SSR_SCHED_BARRIER(); EXTRA; const auto r_ = RBASES(tid & 63);                    \
+      SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) R.v[i] = {(L).re[RIDX(r_, i)], (L).im[RIDX(r_, i)]}; });   \
   } else {                                                                                                \
     SSR_WPHASE(blk, regs, { const int w_ = ssr_wave_bases(tid & 63).WB;                                        \
       SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) (L).re[w_ + WO(i)] = R.v[i].x; });                     \
-    SSR_WPHASE(blk, regs, { SSR_SCHED_BARRIER(); EXTRA; const int r_ = ssr_wave_bases(tid & 63).RB;           \
-      SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) R.tx[i] = (L).re[r_ + RO(i)]; });                      \
+    SSR_WPHASE(blk, regs, { SSR_SCHED_BARRIER(); EXTRA; const auto r_ = RBASES(tid & 63);                    \
+      SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) R.tx[i] = (L).re[RIDX(r_, i)]; });                     \
     SSR_WPHASE(blk, regs, { const int w_ = ssr_wave_bases(tid & 63).WB;                                        \
       SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) (L).re[w_ + WO(i)] = R.v[i].y; });                     \
-    SSR_WPHASE(blk, regs, { const int r_ = ssr_wave_bases(tid & 63).RB;                                        \
-      SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) R.v[i] = {R.tx[i], (L).re[r_ + RO(i)]}; });            \
+    SSR_WPHASE(blk, regs, { const auto r_ = RBASES(tid & 63);                                                \
+      SSR_UNROLL for (int i = 0; i < SSR_W_P; ++i) R.v[i] = {R.tx[i], (L).re[RIDX(r_, i)]}; });           \
   }
+#define SSR_W_RIDX_LD8(b_, i) ((b_).ld8 + ssr_w_off_ld8(i))
+#define SSR_W_EXCHANGE(blk, regs, L, WB, WO, RB, RO, EXTRA) SSR_W_EXCHANGE_G(blk, regs, L, WB, WO, ssr_wave_bases, SSR_W_RIDX_##RB##_##RO, EXTRA)
+#define SSR_W_RIDX_ld8_ssr_w_off_ld8(b_, i) SSR_W_RIDX_LD8(b_, i)
+
+// ---- PAIRED output order (k_stft_wave, round 6): the third pass's butterfly j emits Z[j + 256 q] and a bin's partner
+// Z[2048 - k] = Z[(256 - j) + 256 (7 - q)] comes out of butterfly 256 - j.  A lane that runs BOTH butterflies of such a pair holds
+// every (k, 2048 - k) couple it needs in its own registers: the upper halves no longer cross lanes through LDS (one exchange
+// of 32 stores + 32 loads and one dependent LDS round trip per frame pair less; the same arithmetic on the same operands:
+// magnitudes bit-identical to the ascending order).  Lane l runs j = l, 64 + l, 192 - l, 256 - l (registers 8 b + q, b = 0..3);
+// j = 0 and j = 128 pair with themselves and both sit in lane 0, whose four butterflies are 0, 64, 192, 128.
+//   partner of register (b, q), q < 4:  lane > 0: (3 - b, 7 - q);   lane 0: b = 0 -> (0, 8 - q) (q = 0: itself, q = 4: Nyquist,
+//   itself), b = 3 -> (3, 7 - q), b = 1 <-> 2 as everywhere.
+struct SsrWavePBase { int ld8, p2, p3; };
+SSR_DEV int ssr_wave_pj3(int tid) { return tid == 0 ? 128 : 256 - tid; }
+SSR_DEV SsrWavePBase ssr_wave_pbases(int tid) {
+  return {tid + (tid >> 5), ssr_wpad(192 - tid), ssr_wpad(ssr_wave_pj3(tid))};
+}
+SSR_DEV int ssr_w_rd_paired(const SsrWavePBase& B, int i) {
+  const int b = i >> 3, q = i & 7;
+  return (b == 0 ? B.ld8 : b == 1 ? B.ld8 + 66 : b == 2 ? B.p2 : B.p3) + 264 * q;
+}
+#define SSR_W_RIDX_PAIRED(b_, i) ssr_w_rd_paired(b_, i)
+// the lane-ordered copies [N + 224 + 64 (3 b + m) + l] = w^((l + 64 b) 2^m): butterfly 192 - l is copy b = 2 at lane 64 - l
+// (lane 0: copy 3, lane 0), butterfly 256 - l copy b = 3 at lane 64 - l (lane 0, j = 128: copy 2, lane 0)
+#define SSR_W_LOAD_TW2_PAIRED { const int t_ = tid & 63; const unsigned l_ = SSR_UIDX(t_);                       \
+    const unsigned o2_ = SSR_UIDX(t_ == 0 ? 192 : 64 - t_); const unsigned o3_ = SSR_UIDX(t_ == 0 ? -192 : 64 - t_); \
+    SSR_UNROLL for (int i = 0; i < 6; ++i) R.tw2[i] = VT.at(l_ + (SSR_W_N + 224 + 64 * i));                       \
+    SSR_UNROLL for (int i = 6; i < 9; ++i) R.tw2[i] = VT.at(o2_ + (SSR_W_N + 224 + 64 * i));                      \
+    SSR_UNROLL for (int i = 9; i < 12; ++i) R.tw2[i] = VT.at(o3_ + (SSR_W_N + 224 + 64 * i)); }
 
 // The rest of the transform after the in-register radix-32 pass (ssr_dft32 applied to R.v): exchange, radix-8 pass with the
 // lane's seven twiddles, exchange, radix-8 pass with table twiddles.  On exit register 8 b + q holds Z[tid + 64 b + 256 q].
@@ -191,6 +227,10 @@ SSR_DEV constexpr int ssr_w_off_st1(int i) { return 528 * (i >> 3) + 33 * (i & 7
 #define SSR_W_LOAD_TW2 { const unsigned l_ = SSR_UIDX(tid & 63); \
                          SSR_UNROLL for (int i = 0; i < 12; ++i) R.tw2[i] = VT.at(l_ + (SSR_W_N + 224 + 64 * i)); }
 #define SSR_W_FFT_TAIL(blk, BLK0, regs, L, EXTRA2)                                                                        \
+  SSR_W_FFT_TAIL_X(blk, BLK0, regs, L, SSR_W_EXCHANGE(blk, regs, L, st1, ssr_w_off_st1, ld8, ssr_w_off_ld8, SSR_W_LOAD_TW2 EXTRA2))
+#define SSR_W_FFT_TAIL_PAIRED(blk, BLK0, regs, L)                                                                         \
+  SSR_W_FFT_TAIL_X(blk, BLK0, regs, L, SSR_W_EXCHANGE_G(blk, regs, L, st1, ssr_w_off_st1, ssr_wave_pbases, SSR_W_RIDX_PAIRED, SSR_W_LOAD_TW2_PAIRED))
+#define SSR_W_FFT_TAIL_X(blk, BLK0, regs, L, EXCH2)                                                                       \
   blk = BLK0; ssr_launder(blk);                                                                                     \
   SSR_W_EXCHANGE(blk, regs, L, st0, ssr_w_off_st0, ld8, ssr_w_off_ld8, SSR_W_LOAD_TW1);                             \
   /* pass 1: four radix-8 butterflies, twiddles w^(8 (j mod 32) q) - the same seven for every butterfly of the lane */ \
@@ -202,7 +242,7 @@ SSR_DEV constexpr int ssr_w_off_st1(int i) { return 528 * (i >> 3) + 33 * (i & 7
     SSR_CLK(2);                                                                                                     \
   });                                                                                                               \
   blk = BLK0; ssr_launder(blk);                                                                                     \
-  SSR_W_EXCHANGE(blk, regs, L, st1, ssr_w_off_st1, ld8, ssr_w_off_ld8, SSR_W_LOAD_TW2 EXTRA2);                      \
+  EXCH2;                                                                                                            \
   /* pass 2: four radix-8 butterflies, twiddles w^(j q), j = tid + 64 b: three table values + four products each */  \
   SSR_WPHASE(blk, regs, {                                                                                           \
     SSR_UNROLL for (int b = 0; b < 4; ++b) {                                                                        \
@@ -260,6 +300,7 @@ template <typename REGS> SSR_DEV void ssr_wave_flags(REGS& R, int tid, int* nz, 
 template <typename T, bool SUMS, bool SPLIT, int MAG = -1, typename BLK>
 SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
   constexpr int N = SSR_W_N, F = N / 2 + 1;
+  constexpr bool PAIRED = SSR_WAVE_PAIRED != 0;
   using Regs = SsrWaveRegs<T, SUMS>;
   SsrWaveLds<T, SPLIT> L(lds_base);
   const int n = p.len[item], hop = p.hop;
@@ -324,11 +365,14 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
       SSR_CLK(1);
     });
 #define VT vt
-    SSR_W_FFT_TAIL(blk, blk0, regs, L, );
+    if constexpr (PAIRED) { SSR_W_FFT_TAIL_PAIRED(blk, blk0, regs, L); } else { SSR_W_FFT_TAIL(blk, blk0, regs, L, ); }
 #undef VT
-    // register 8 b + q now holds Z[k], k = tid + 64 b + 256 q.  The bins k <= 1024 are this lane's to emit; each needs
-    // Z[2048 - k], which lives in the upper half (q >= 4) of lane 64 - tid: the upper halves go through LDS once.
-    if constexpr (!SPLIT) {
+    // PAIRED: register 8 b + q holds Z[j_b + 256 q], j = tid, 64 + tid, 192 - tid, 256 - tid (lane 0: 0, 64, 192, 128) - every
+    // partner Z[2048 - k] of the lane's bins is in the lane's own registers (see SSR_W_FFT_TAIL_PAIRED).
+    // Ascending order: register 8 b + q holds Z[k], k = tid + 64 b + 256 q.  The bins k <= 1024 are this lane's to emit; each
+    // needs Z[2048 - k], which lives in the upper half (q >= 4) of lane 64 - tid: the upper halves go through LDS once.
+    if constexpr (PAIRED) {
+    } else if constexpr (!SPLIT) {
       SSR_WPHASE(blk, regs, { const int w_ = ssr_wave_bases(tid).ld8;
         SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int q = 4; q < 8; ++q) {
           L.re[w_ + 66 * b + 264 * (q - 4)] = R.v[8 * b + q].x; L.im[w_ + 66 * b + 264 * (q - 4)] = R.v[8 * b + q].y; } });
@@ -349,8 +393,12 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
       // the previous contents of the 64 + 32 registers would stay live through all three passes for the path not taken
       // The first signal and the window now (32 + 16 requests), the second signal half-way through the bins: 64 + 16 at once
       // stopped the wave at the 64th request until the oldest ones had returned, i.e. exposed the latency it is here to hide.
-      ssr_wave_prefetch<T, 1>(p, R, tid, va, vb, u + S, n, n_frames);
-      SSR_UNROLL for (int r = 0; r < SSR_W_P / 2; ++r) R.wl[r] = vw.at(SSR_UIDX(tid + 64 * r));
+      // PAIRED: all 128 data registers are live here, and a quarter of them is released per butterfly group - the first
+      // signal is requested after group 0, the second after group 1, the window (the shortest way: L1 / L2) after group 2
+      if constexpr (!PAIRED) {
+        ssr_wave_prefetch<T, 1>(p, R, tid, va, vb, u + S, n, n_frames);
+        SSR_UNROLL for (int r = 0; r < SSR_W_P / 2; ++r) R.wl[r] = vw.at(SSR_UIDX(tid + 64 * r));
+      }
       SSR_SCHED_BARRIER();
       SSR_CLK(4);
       double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -366,19 +414,50 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
       const SsrRwView<float> wa(ra0, store ? F : 0), wb(rb0, (store && rb0 != nullptr) ? F : 0);   // out_b == null: the target rows
       // are not written (ssr_pair_metrics_multi: they exist already) - the stores fall to the buffer range check
       const int lane4 = 4 * tid;
-      const int pr = ssr_wave_bases(tid).pr;
-      constexpr int G = SUMS ? 2 : 4;                              // bins in flight (the variant with running sums is tighter)
+      // byte offset of bin j_b + 256 q in a magnitude row: lane part + immediate
+      const int lane4_2 = PAIRED ? 4 * (192 - tid) : 0, lane4_3 = PAIRED ? 4 * ssr_wave_pj3(tid) : 0;
+      auto bin_off = [&](int b, int q) -> int {
+        if constexpr (!PAIRED) return lane4 + 4 * (64 * b + 256 * q);
+        else return (b == 0 ? lane4 : b == 1 ? lane4 + 256 : b == 2 ? lane4_2 : lane4_3) + 1024 * q;
+      };
+      const int pr = PAIRED ? 0 : ssr_wave_bases(tid).pr;
+      // Lane 0's butterflies 0 and 128 pair with THEMSELVES (q <-> 8 - q, bin 0 and the Nyquist bin with themselves; q <-> 7 - q):
+      // its upper halves are rotated once into the registers the general rule (3 - b, 7 - q) reads; the Nyquist bin Z[1024] =
+      // register 4 is taken first.
+      if constexpr (PAIRED) {
+        if (tid == 0) {
+          const cx<T> zq = R.v[4];
+          float e, t;
+          ssr_pair_bin<T, 0, true>(mask, acc, zq, zq, a_nz, b_nz, e, t);
+          if (store) { wa.st_raw(4 * (N / 2), e); wb.st_raw(4 * (N / 2), t); }
+          const cx<T> t28 = R.v[28], t29 = R.v[29], t30 = R.v[30], t31 = R.v[31];
+          R.v[31] = R.v[0]; R.v[30] = R.v[7]; R.v[29] = R.v[6]; R.v[28] = R.v[5];
+          R.v[7] = t31; R.v[6] = t30; R.v[5] = t29; R.v[4] = t28;
+        }
+      }
+#ifdef SSR_WAVE_G                                                   /* developer builds: bins in flight */
+      constexpr int G = SSR_WAVE_G;
+#else
+      constexpr int G = (SUMS || PAIRED) ? 2 : 4;
+#endif
+                       // bins in flight (the variant with running sums is tighter; PAIRED: the
+                                                                  // partners are in registers - there is no LDS latency to cover)
       // The sixteen bins, two at a time.  FAST (a compile-time fact inside each copy of the loop): both frames hold signal and
       // the mask is the variant's full set - no zero forcing, no per-bin test of the mask, and the float32 arithmetic of a
       // bin pair runs as packed instructions (ssr_pair_bins2_fast).  The wave-uniform choice is made ONCE per frame, outside
       // the loop: taken per bin it split the epilogue into 48 basic blocks with two scalar branches each.
+      constexpr int PF1 = SUMS ? 1 : 0;    // PAIRED: the butterfly group after which the first signal is requested (then the second, then the window)
       auto bins = [&](auto fast_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
         SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int q0 = 0; q0 < 4; q0 += G) {
           cx<T> zn[G];
-          SSR_UNROLL for (int q = 0; q < G; ++q)                    // Z[2048 - k] sits at upper-half slot 1024 - k
-            zn[q] = {lre[pr - 66 * b - 264 * (q0 + q)], lim[im_off + pr - 66 * b - 264 * (q0 + q)]};
-          if (b == 0 && q0 == 0 && tid == 0) zn[0] = R.v[0];       // bin 0 pairs with itself
+          if constexpr (PAIRED) {
+            SSR_UNROLL for (int q = 0; q < G; ++q) zn[q] = R.v[8 * (3 - b) + 7 - (q0 + q)];   // Z[2048 - k] out of butterfly 256 - j
+          } else {
+            SSR_UNROLL for (int q = 0; q < G; ++q)                    // Z[2048 - k] sits at upper-half slot 1024 - k
+              zn[q] = {lre[pr - 66 * b - 264 * (q0 + q)], lim[im_off + pr - 66 * b - 264 * (q0 + q)]};
+            if (b == 0 && q0 == 0 && tid == 0) zn[0] = R.v[0];       // bin 0 pairs with itself
+          }
           SSR_UNROLL for (int q = 0; q < G; q += 2) {
             const cx<T> zk0 = R.v[8 * b + q0 + q], zk1 = R.v[8 * b + q0 + q + 1];
             f2 e, t;
@@ -391,15 +470,25 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
               e = f2_make(e0, e1); t = f2_make(t0, t1);
             }
             if (store) {
-              wa.st_raw(lane4 + 4 * (64 * b + 256 * (q0 + q)), e.x);
-              wa.st_raw(lane4 + 4 * (64 * b + 256 * (q0 + q + 1)), e.y);
-              wb.st_raw(lane4 + 4 * (64 * b + 256 * (q0 + q)), t.x);
-              wb.st_raw(lane4 + 4 * (64 * b + 256 * (q0 + q + 1)), t.y);
+              wa.st_raw(bin_off(b, q0 + q), e.x);
+              wa.st_raw(bin_off(b, q0 + q + 1), e.y);
+              wb.st_raw(bin_off(b, q0 + q), t.x);
+              wb.st_raw(bin_off(b, q0 + q + 1), t.y);
             }
           }
-          if (b == 1 && q0 + G == 4) {
+          if ((PAIRED ? b == PF1 : false) && q0 + G == 4) {
+            SSR_SCHED_BARRIER();
+            ssr_wave_prefetch<T, 1>(p, R, tid, va, vb, u + S, n, n_frames);
+            SSR_SCHED_BARRIER();
+          }
+          if (b == (PAIRED ? PF1 + 1 : 1) && q0 + G == 4) {
             SSR_SCHED_BARRIER();
             ssr_wave_prefetch<T, 2>(p, R, tid, va, vb, u + S, n, n_frames);
+            SSR_SCHED_BARRIER();
+          }
+          if ((PAIRED ? b == PF1 + 2 : false) && q0 + G == 4) {
+            SSR_SCHED_BARRIER();
+            SSR_UNROLL for (int r = 0; r < SSR_W_P / 2; ++r) R.wl[r] = vw.at(SSR_UIDX(tid + 64 * r));
             SSR_SCHED_BARRIER();
           }
         }
@@ -407,7 +496,7 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
       constexpr int FULL = SUMS ? (SSR_M_LSD | SSR_M_LOG_SISPEC | SSR_M_SISPEC) : SSR_M_LSD;
       if (both && (mask & 7) == FULL) bins(SsrTrue{});
       else bins(SsrFalse{});
-      if (tid == 0) {                                             // the Nyquist bin: Z[1024] pairs with itself
+      if (!PAIRED && tid == 0) {                                  // the Nyquist bin: Z[1024] pairs with itself
         const cx<T> zq = {lre[0], lim[im_off]};
         float e, t;
         ssr_pair_bin<T, 0, true>(mask, acc, zq, zq, a_nz, b_nz, e, t);

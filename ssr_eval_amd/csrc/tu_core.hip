@@ -192,7 +192,7 @@ extern "C" int ssr_plan_create_ex(int n_fft, int hop, const double* window, int 
   if (window) pl->ex_window.assign(window, window + n_fft);
   int rc = SSR_OK;
   if (hipGetDevice(&pl->device) != hipSuccess) rc = ssr_fail(SSR_ERR_HIP, "hipGetDevice failed (no HIP device?)");
-  if (!rc) rc = ssr_tl_build(pl);
+  if (!rc) rc = ssr_tl_supported(pl);          // (tables: at the first launch, or the caller's - ssr_plan_set_tl_weights)
   if (rc) { ssr_plan_destroy(pl); return rc; }
   pl->lowpass_engine = SSR_LOWPASS_CONV;
   *out = pl;

@@ -93,7 +93,7 @@ extern "C" int ssr_plan_set_lowpass_engine(ssr_plan* pl, int engine) {
   if (pl->ex && engine != SSR_LOWPASS_CONV) return ssr_fail(SSR_ERR_UNSUPPORTED, "a plan from ssr_plan_create_ex has the conv engine only");
   if (engine == SSR_LOWPASS_CONV) {
     if (int rc_dev = ssr_check_plan_device(pl, true)) return rc_dev;
-    if (int rc = ssr_tl_build(pl)) return rc;
+    if (int rc = ssr_tl_supported(pl)) return rc;      // (tables: at the first launch, or the caller's)
   }
   if (engine == SSR_LOWPASS_FUSED && !lowpass_group_eligible(pl))
     return ssr_fail(SSR_ERR_UNSUPPORTED, "the fused low-pass engine needs a float64 2048-point plan with 228 <= hop <= 914");

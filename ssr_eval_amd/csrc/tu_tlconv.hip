@@ -1,6 +1,7 @@
 // libssrhip.so translation unit: K6 in the reference's arithmetic - torchlibrosa's dense float32 DFT convolutions on the
 // fp32 matrix cores (ssr_tl_gemm.h), the SSR_LOWPASS_CONV engine of ssr_fft_lowpass / ssr_fft_lowpass_multi / ssr_istft /
 // ssr_stft(COMPLEX).
+#include <algorithm>
 #include <cmath>
 #include <mutex>
 
@@ -103,6 +104,17 @@ static int tl_upload(ssr_plan* pl, std::vector<float>& a, std::vector<float>& b,
     for (int j = 0; j < n; ++j) d[(size_t)ch * n + j] = -d[(size_t)ch * n + j];
   c.resize(c.size() + (size_t)SSR_TL_BK * n + SSR_TL_BN, 0.0f);
   d.resize(d.size() + (size_t)SSR_TL_BK * n + SSR_TL_BN, 0.0f);
+  // a superseded set (ssr_plan_set_tl_weights twice, or after a launch built the library's own): released once nothing in flight
+  // can still read it
+  if (pl->tl_w2) {
+    HIP_TRY(hipDeviceSynchronize());
+    float* old_tabs[5] = {pl->tl_wre_t, pl->tl_wim_t, pl->tl_ire_t, pl->tl_iim_t, pl->tl_w2};
+    for (float* o : old_tabs) {
+      auto it = std::find(pl->allocs.begin(), pl->allocs.end(), (void*)o);
+      if (it != pl->allocs.end()) { (void)hipFree(o); pl->allocs.erase(it); }
+    }
+    pl->tl_wre_t = pl->tl_wim_t = pl->tl_ire_t = pl->tl_iim_t = pl->tl_w2 = nullptr;
+  }
   float* dev[5] = {};
   const std::vector<float>* src[5] = {&a, &b, &c, &d, &e};
   for (int i = 0; i < 5; ++i) {
@@ -115,11 +127,15 @@ static int tl_upload(ssr_plan* pl, std::vector<float>& a, std::vector<float>& b,
   return SSR_OK;
 }
 
+int ssr_tl_supported(const ssr_plan* pl) {
+  if (pl->n_fft < 32 || pl->n_fft > 4096 || pl->n_fft % 32)
+    return ssr_fail(SSR_ERR_UNSUPPORTED, "the conv engine needs n_fft = 32 m <= 4096");
+  return SSR_OK;
+}
 int ssr_tl_build(ssr_plan* pl) {
   std::lock_guard<std::mutex> lock(g_tl_mutex);
   if (pl->tl_w2) return SSR_OK;
-  if (pl->n_fft < 32 || pl->n_fft > 4096 || pl->n_fft % 32)
-    return ssr_fail(SSR_ERR_UNSUPPORTED, "the conv engine needs n_fft = 32 m <= 4096");
+  if (int rc = ssr_tl_supported(pl)) return rc;
   std::vector<float> a, b, c, d, e;
   const int ldw = tl_ldw(pl->n_fft);
   tl_host_tables(pl->n_fft, ldw, pl->ex_window.empty() ? nullptr : pl->ex_window.data(), a, b, c, d, e);
@@ -148,7 +164,6 @@ extern "C" int ssr_plan_set_tl_weights(ssr_plan* pl, const float* fwd_re, const 
       c[(size_t)ch * n + j] = inv_re[(size_t)j * n + ch];
       d[(size_t)ch * n + j] = inv_im[(size_t)j * n + ch];
     }
-  // (tables of an earlier build stay allocated until the plan is destroyed: a launch in flight may still read them)
   return tl_upload(pl, a, b, c, d, e, ldw);
 }
 
@@ -247,8 +262,16 @@ static int tl_fold(const ssr_plan* pl, const SsrTlParams& p, const int64_t* out_
   HIP_TRY(hipGetLastError());
   return SSR_OK;
 }
+// The library's own tables are built at the FIRST launch that finds none (ssr_plan_set_lowpass_engine / ssr_plan_create_ex only
+// check that the engine can serve the plan): a caller that hands over its own tables first (ssr_plan_set_tl_weights - the Python
+// mirror always does) never pays for the set it would replace (~50 MB of HBM and the long-double host build at 2048).
+static int tl_tables(const ssr_plan* pl) {
+  if (pl->tl_w2) return SSR_OK;
+  if (pl->lowpass_engine != SSR_LOWPASS_CONV) return ssr_fail(SSR_ERR_INVALID_ARG, "conv engine tables missing (ssr_plan_set_lowpass_engine)");
+  return ssr_tl_build(const_cast<ssr_plan*>(pl));
+}
 static int tl_check(const ssr_plan* pl, int n_items, int64_t total_rows, const void* workspace, size_t workspace_bytes) {
-  if (!pl->tl_w2) return ssr_fail(SSR_ERR_INVALID_ARG, "conv engine tables missing (ssr_plan_set_lowpass_engine)");
+  if (int rc_t = tl_tables(pl)) return rc_t;
   if (!workspace || workspace_bytes < ssr_tl_workspace_bytes(pl, total_rows)) return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small");
   if (n_items > total_rows)            // (the padded copies are laid out for >= 1 frame per item: only a center = 0 batch can break that)
     return ssr_fail(SSR_ERR_INVALID_ARG, "center = 0: every item of the batch needs len >= n_fft");
@@ -318,7 +341,7 @@ int ssr_tl_run_multi(const ssr_plan* pl, const float* in, const int64_t* in_off,
 // The padded copy of the batch lives in a stream-ordered allocation (the entry point has no workspace argument).
 int ssr_tl_stft(const ssr_plan* pl, const float* wav, const int64_t* wav_off, const int32_t* wav_len, const int64_t* frame_off,
                 int n_items, int max_len, float* out_re, float* out_im, hipStream_t s) {
-  if (!pl->tl_w2) return ssr_fail(SSR_ERR_INVALID_ARG, "conv engine tables missing (ssr_plan_set_lowpass_engine)");
+  if (int rc_t = tl_tables(pl)) return rc_t;
   if (int rc_len = ssr_check_max_len(pl, max_len)) return rc_len;
   const int64_t pad_stride = (((int64_t)max_len + pl->n_fft + 3) / 4) * 4;
   const size_t bytes = (size_t)n_items * pad_stride * sizeof(float);

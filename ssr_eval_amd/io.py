@@ -167,6 +167,53 @@ def load_audio(path, sr=None, res_type="kaiser_best"):
 _POOL = {}
 
 
+def usable_cores():
+    """Host cores this PROCESS may use: the scheduler affinity mask (not os.cpu_count(), which ignores it) capped by the cgroup
+    CPU quota (a container that sees 64 logical CPUs and is granted 16 runs a 64-thread pool slower than a 16-thread one)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def local_world_size():
+    """Ranks of this job on THIS node (torchrun exports LOCAL_WORLD_SIZE; a hand-rolled launcher may only export WORLD_SIZE
+    on a single node): they share the node's host cores."""
+    for key in ("LOCAL_WORLD_SIZE", "SSR_LOCAL_WORLD_SIZE"):
+        v = os.environ.get(key)
+        if v and v.isdigit() and int(v) > 0:
+            return int(v)
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return max(1, dist.get_world_size())          # no local size announced: assume one node
+    except Exception:
+        pass
+    return 1
+
+
+def decode_threads():
+    """Reader / decoder threads per process: this rank's share of the cores the job may use, at most 16 (eight ranks on a
+    16-core grant start 8 x 2 readers, not 8 x 16; SSR_DECODE_THREADS overrides)."""
+    v = os.environ.get("SSR_DECODE_THREADS")
+    if v and v.isdigit() and int(v) > 0:
+        return int(v)
+    return max(1, min(16, usable_cores() // local_world_size()))
+
+
 def _decode_pool(threads):
     """One pool per worker count for the life of the process (starting 16 threads per batch cost more than decoding it)."""
     from concurrent.futures import ThreadPoolExecutor
@@ -180,14 +227,14 @@ def decode_batch(paths, threads=None):
     paths = list(paths)
     if len(paths) <= 1:
         return [read_audio(p) for p in paths]
-    return list(_decode_pool(threads or min(16, os.cpu_count() or 1)).map(read_audio, paths))
+    return list(_decode_pool(threads or decode_threads()).map(read_audio, paths))
 
 
 def decode_async(paths, threads=None, raw=False):
     """Start decoding `paths` on the pool; -> a function that waits for and returns the decode_batch result
     (raw: RawAudio items - 16-bit PCM stays int16 for the GPU to convert)."""
     fn = read_audio_raw if raw else read_audio
-    futures = [_decode_pool(threads or min(16, os.cpu_count() or 1)).submit(fn, p) for p in paths]
+    futures = [_decode_pool(threads or decode_threads()).submit(fn, p) for p in paths]
     return lambda: [f.result() for f in futures]
 
 
@@ -277,7 +324,7 @@ class PackedBatch:
         self.staging = B._Staging.get(self.device)
         self.k, self.arena = self.staging.arena(self.total) if self.total else (None, None)
         host = self.arena.numpy() if self.total else None
-        pool = _decode_pool(min(16, os.cpu_count() or 1))
+        pool = _decode_pool(decode_threads())
 
         def read_into(j):
             i = self.pcm_idx[j]

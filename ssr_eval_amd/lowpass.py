@@ -132,20 +132,22 @@ def lowpass_iir_multi(datas, specs, fs, keep_on_device=False):
     """lowpass(d, highcut, fs, order, _type) for every (highcut, order, _type) of `specs` over one list of signals - what
     SSR_Eval_Helper.preprocess's three nested loops apply to a waveform (ssr_eval/eval.py:243-258) - with the designs side by side in
     one launch (backend.sosfiltfilt_multi).  -> [spec][signal]; each entry equals lowpass_batch(datas, highcut, fs, order, _type)."""
-    designs = []
+    plans = []                         # (int(highcut), clamped order, design name) per spec: BOTH paths below use these
     for highcut, order, _type in specs:
-        order = limit(order, high=10, low=2)
         name = next((n for n in ("butter", "cheby1", "ellip", "bessel") if _type in n), None)
         if name is None:
             raise ValueError("Error: Unexpected filter type " + _type)
-        designs.append(_design(int(highcut), fs, order, name))
+        plans.append((int(highcut), limit(order, high=10, low=2), name))
     for d in datas:
         _check_1d(d)
+    if not plans:                      # an empty filter / cutoff / order list: no keys, as the reference's loops
+        return []
     xs = [x if isinstance(x, torch.Tensor) else np.asarray(x) for x in datas]
     if not xs or any(B._is_f64(x) for x in xs):
-        # float64 signals are filtered on their float64 values: the per-design path handles the mix
-        return [_iir_batch(xs, highcut, fs, limit(order, high=10, low=2), next(n for n in ("butter", "cheby1", "ellip", "bessel") if _type in n),
-                           keep_on_device=keep_on_device) for highcut, order, _type in specs]
+        # float64 signals are filtered on their float64 values: the per-design path handles the mix (same integer cutoff,
+        # clamped order and design name as the one-launch path)
+        return [_iir_batch(xs, hc, fs, order, name, keep_on_device=keep_on_device) for hc, order, name in plans]
+    designs = [_design(hc, fs, order, name) for hc, order, name in plans]
     ys = B.sosfiltfilt_multi(designs, [_f32_unless_f64(x) for x in xs])
     return [[align_length(x, y if keep_on_device else y.cpu().numpy()) for x, y in zip(xs, per_design)] for per_design in ys]
 

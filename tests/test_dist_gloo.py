@@ -155,3 +155,69 @@ def test_rows_and_speaker_sums_in_one_collective_world3(tmp_path):
     assert all(open(tmp_path / ("ok%d" % r)).read() == "1" for r in range(3))
     b = [np.load(tmp_path / ("buf%d.npy" % r)) for r in range(3)]
     assert b[0].tobytes() == b[1].tobytes() == b[2].tobytes()
+
+
+def test_decode_threads_share_the_granted_cores(monkeypatch):
+    """the reader pool of a process is its share of the cores the JOB may use (scheduler affinity / cgroup quota
+    divided by the ranks on this node), not min(16, os.cpu_count()) per process."""
+    sys.path.insert(0, ROOT)
+    from ssr_eval_amd import io as sio
+    monkeypatch.delenv("SSR_DECODE_THREADS", raising=False)
+    monkeypatch.setattr(sio, "usable_cores", lambda: 16)
+    for lws, want in ((1, 16), (2, 8), (8, 2), (16, 1), (64, 1)):
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", str(lws))
+        assert sio.decode_threads() == want
+    monkeypatch.setattr(sio, "usable_cores", lambda: 256)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert sio.decode_threads() == 16                              # the cap
+    monkeypatch.setenv("SSR_DECODE_THREADS", "3")
+    assert sio.decode_threads() == 3
+    monkeypatch.undo()
+    assert 1 <= sio.usable_cores() <= len(os.sched_getaffinity(0))
+
+
+def _worker_decode_tree(rank, world, port, root, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      LOCAL_WORLD_SIZE=str(world))
+    os.environ.pop("SSR_DECODE_THREADS", None)
+    import threading
+    from ssr_eval_amd import dist as D
+    from ssr_eval_amd import io as sio
+    D.init_from_env(backend="gloo")
+    files = sorted(os.path.join(d, f) for d, _, fs in os.walk(root) for f in fs if f.endswith(".wav"))
+    mine = D.shard_indices(len(files))
+    got = sio.decode_batch([files[i] for i in mine])
+    wait = sio.decode_async([files[i] for i in mine])
+    got2 = wait()
+    readers = sum(1 for t in threading.enumerate() if t.name.startswith("ssr-decode"))
+    sums = np.array([[float(np.abs(w).sum()), float(sr)] for (w, sr) in got]).reshape(-1, 2)
+    same = all(np.array_equal(a[0], b[0]) for a, b in zip(got, got2))
+    table = D.allgather_rows(sums, mine, len(files))
+    json.dump({"readers": readers, "limit": sio.decode_threads(), "cores": sio.usable_cores(), "same": same,
+               "table": table.tolist()}, open(os.path.join(out_dir, "dec%d.json" % rank), "w"))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_world_size_8_file_tree_reader_threads_within_the_affinity(tmp_path):
+    """EIGHT gloo ranks decode their round-robin shards of one wav tree (the host stage of evaluate(): the kernels need a GPU,
+    tests/test_gpu_configs.py runs the whole evaluate() under eight processes) - every rank's pool is its share of the cores, the
+    job as a whole starts no more reader threads than max(ranks, usable cores), and the gathered table is the one-process one."""
+    sys.path.insert(0, ROOT)
+    from ssr_eval_amd.io import write_wav, read_audio, usable_cores
+    rng = np.random.default_rng(3)
+    root = tmp_path / "tree"
+    for s, c in (("p1", 9), ("p2", 7), ("p3", 5)):
+        (root / s).mkdir(parents=True)
+        for i in range(c):
+            write_wav(str(root / s / ("u%02d.wav" % i)), 0.1 * rng.standard_normal(int(rng.integers(2000, 9000))), 16000)
+    port = 29500 + (os.getpid() + 1213) % 2000
+    mp.spawn(_worker_decode_tree, args=(8, port, str(root), str(tmp_path)), nprocs=8, join=True)
+    d = [json.load(open(tmp_path / ("dec%d.json" % r))) for r in range(8)]
+    assert all(x["same"] for x in d)
+    assert all(1 <= x["readers"] <= x["limit"] for x in d)
+    assert sum(x["readers"] for x in d) <= max(8, usable_cores())
+    files = sorted(os.path.join(dd, f) for dd, _, fs in os.walk(root) for f in fs if f.endswith(".wav"))
+    want = [[float(np.abs(read_audio(f)[0]).sum()), 16000.0] for f in files]
+    assert all(x["table"] == want for x in d)

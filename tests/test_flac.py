@@ -200,3 +200,53 @@ def test_verify_flac_tree_tool(tmp_path, capsys):
     assert "FAIL" in out and "c.flac" in out and "3 file(s), 1 failed" in out
     (tmp_path / "empty").mkdir()
     assert tool.main([str(tmp_path / "empty")]) == 2
+
+
+# ---- independent streams: the example files of RFC 9639, Appendix D (VERDICT r5 item 7 i; ssr_eval/eval.py:158-169 lists .flac) -------
+def _crc(data, width, poly):
+    c, top, mask = 0, 1 << (width - 1), (1 << width) - 1
+    for x in data:
+        c ^= x << (width - 8)
+        for _ in range(8):
+            c = ((c << 1) ^ poly) & mask if c & top else (c << 1) & mask
+    return c
+
+
+def _rfc_examples():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rfc9639_examples.json")))["examples"]
+
+
+@pytest.mark.parametrize("ex", _rfc_examples(), ids=lambda e: e["name"][:3])
+def test_rfc9639_appendix_d_example_files(tmp_path, ex):
+    """The decoder against streams it shares no author with: libFLAC's, as RFC 9639 prints them.  First the transcription is pinned
+    WITHOUT the decoder (frame-header CRC-8, poly 0x07; frame CRC-16, poly 0x8005; STREAMINFO's MD5 of the expected little-endian
+    PCM - all computed here), then ssr_flac_info / ssr_flac_decode_* must return exactly that PCM."""
+    import hashlib
+    data = bytes.fromhex(ex["hex"])
+    pcm = np.array(ex["pcm"], dtype=np.int64)
+    assert data[:4] == b"fLaC" and (data[4] & 0x7F) == 0 and int.from_bytes(data[5:8], "big") == 34
+    si = data[8:8 + 34]
+    bytes_per = (ex["bits"] + 7) // 8
+    raw = b"".join(int(v).to_bytes(bytes_per, "little", signed=True) for v in pcm.reshape(-1))
+    assert hashlib.md5(raw).digest() == si[18:34]                       # the RFC's own statement of the decoded audio
+    ends = ex["frames_at"][1:] + [len(data)]
+    for a, b in zip(ex["frames_at"], ends):
+        fr = data[a:b]
+        assert fr[0] == 0xFF and (fr[1] & 0xFE) == 0xF8
+        hdr = 4 + 1 + (1 if (fr[2] >> 4) == 6 else 2 if (fr[2] >> 4) == 7 else 0)      # (frame numbers < 128: one UTF-8 byte)
+        assert _crc(fr[:hdr], 8, 0x07) == fr[hdr]
+        assert _crc(fr[:-2], 16, 0x8005) == int.from_bytes(fr[-2:], "big")
+    path = _write(tmp_path, "rfc.flac", data)
+    assert sio.flac_info(path) == (ex["rate"], ex["channels"], ex["bits"], len(pcm))
+    v, nch, sr, bits = sio.read_flac_int(path)                             # MD5 verification on
+    assert (nch, sr, bits) == (ex["channels"], ex["rate"], ex["bits"])
+    np.testing.assert_array_equal(v.reshape(-1, nch), pcm)
+    y, sr2 = sio.read_audio(path)
+    want = pcm.astype(np.float32) * np.float32(1.0 / (1 << (bits - 1)))
+    np.testing.assert_array_equal(y, want[:, 0] if nch == 1 else want.mean(axis=1).astype(np.float32))
+    # a flipped bit anywhere in a frame is refused (CRC-16 / MD5), not decoded into something else
+    bad = bytearray(data)
+    bad[ex["frames_at"][0] + 9] ^= 0x10
+    with pytest.raises(Exception):
+        sio.read_flac_int(_write(tmp_path, "bad.flac", bytes(bad)))

@@ -66,6 +66,9 @@ SSR_BODY void ssr_stft_r3_rot_body(const SsrStftParams<T>& p, BLK& blk, int chun
   static_assert(IN64 == 0 || IN64 == SSR_IN_EST64, "float32 pairs, or a float64 estimate against a float32 target");
   using SA = typename SsrSample<(IN64 & 1) != 0>::type;
   constexpr bool SPLIT = true;
+  // float64 estimate WITH running sums: the next job's samples (the estimate's as doubles: 24 more registers than floats) are
+  // requested after the round's epilogue(s), not before - held across them they put 24 values into scratch (52 B per lane, round 5)
+  constexpr bool LATE_PREFETCH = (IN64 & 1) != 0 && SUMS;
   constexpr int NT = 64 * SSR_R3ROT_WAVES, NI = 4 * NQ;
   constexpr int PB = P / 8, M = 64 * P, PN = ssr_rn_wave_pn<P>();
   constexpr int NQO = (P == 32) ? NQ : 4;
@@ -157,7 +160,7 @@ SSR_BODY void ssr_stft_r3_rot_body(const SsrStftParams<T>& p, BLK& blk, int chun
         const cx<T> c = vch.at(SSR_UIDX(k < q ? k : q - 1), (int64_t)r * q);
         R.v[8 * b + qq] = cmul(cx<T>{R.v[8 * b + qq].y, R.v[8 * b + qq].x}, c);
       }
-      {
+      if constexpr (!LATE_PREFETCH) {
         const int jn = (j + 4 < n_jobs) ? j + 4 : n_jobs - 1, Un = jn / 3;
         ssr_rn_wave_prefetch<T, 3, NQ>(R, lane, jn - 3 * Un, va, vb, u0 + Un, hop, n_fft, q, n, n_frames);   // (unconditional)
       }
@@ -212,6 +215,10 @@ SSR_BODY void ssr_stft_r3_rot_body(const SsrStftParams<T>& p, BLK& blk, int chun
           const int k = lane + 64 * (b + PB * qq);
           if (k < q) { slot[k] = R.v[8 * b + qq].x; slot[q + k] = R.v[8 * b + qq].y; }
         }
+      }
+      if constexpr (LATE_PREFETCH) {
+        const int jn = (j + 4 < n_jobs) ? j + 4 : n_jobs - 1, Un = jn / 3;
+        ssr_rn_wave_prefetch<T, 3, NQ>(R, lane, jn - 3 * Un, va, vb, u0 + Un, hop, n_fft, q, n, n_frames);   // (unconditional)
       }
       if (want_lsd && tid == 0)
         for (int Uc = Ulo; Uc <= Uhi && Uc < n_units; ++Uc) {

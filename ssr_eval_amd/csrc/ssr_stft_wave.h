@@ -36,6 +36,9 @@ static __device__ unsigned long long ssr_dbg_clk[8];
 #ifndef SSR_WAVE_PAIRED
 #define SSR_WAVE_PAIRED 1
 #endif
+#ifndef SSR_WAVE_PF1_SUMS
+#define SSR_WAVE_PF1_SUMS 1
+#endif
 constexpr int SSR_W_N = 2048, SSR_W_L = 64, SSR_W_P = 32;     // points, lanes, points per lane
 constexpr int SSR_W_TWP = 7 * 32 + 12 * 64;                   // lane-ordered twiddle copies behind the table (= SSR_WAVE_TWP)
 SSR_DEV int ssr_wpad(int i) { return i + (i >> 5); }            // lane stride 32 -> 33 doubles: conflict-free ds_*_b64
@@ -422,31 +425,29 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
       };
       const int pr = PAIRED ? 0 : ssr_wave_bases(tid).pr;
       // Lane 0's butterflies 0 and 128 pair with THEMSELVES (q <-> 8 - q, bin 0 and the Nyquist bin with themselves; q <-> 7 - q):
-      // its upper halves are rotated once into the registers the general rule (3 - b, 7 - q) reads; the Nyquist bin Z[1024] =
-      // register 4 is taken first.
+      // its upper halves are rotated once into the registers the general rule (3 - b, 7 - q) reads.  Register 4 - the Nyquist bin
+      // Z[1024], which pairs with itself - is taken right after group 0 (32 data registers are free by then), and only then
+      // receives its rotated value.
+      cx<T> rot4 = {(T)0, (T)0};
       if constexpr (PAIRED) {
         if (tid == 0) {
-          const cx<T> zq = R.v[4];
-          float e, t;
-          ssr_pair_bin<T, 0, true>(mask, acc, zq, zq, a_nz, b_nz, e, t);
-          if (store) { wa.st_raw(4 * (N / 2), e); wb.st_raw(4 * (N / 2), t); }
-          const cx<T> t28 = R.v[28], t29 = R.v[29], t30 = R.v[30], t31 = R.v[31];
+          rot4 = R.v[28];
+          const cx<T> t29 = R.v[29], t30 = R.v[30], t31 = R.v[31];
           R.v[31] = R.v[0]; R.v[30] = R.v[7]; R.v[29] = R.v[6]; R.v[28] = R.v[5];
-          R.v[7] = t31; R.v[6] = t30; R.v[5] = t29; R.v[4] = t28;
+          R.v[7] = t31; R.v[6] = t30; R.v[5] = t29;
         }
       }
 #ifdef SSR_WAVE_G                                                   /* developer builds: bins in flight */
       constexpr int G = SSR_WAVE_G;
 #else
-      constexpr int G = (SUMS || PAIRED) ? 2 : 4;
-#endif
-                       // bins in flight (the variant with running sums is tighter; PAIRED: the
+      constexpr int G = (SUMS || PAIRED) ? 2 : 4;                  // bins in flight (the variant with running sums is tighter; PAIRED: the
                                                                   // partners are in registers - there is no LDS latency to cover)
+#endif
       // The sixteen bins, two at a time.  FAST (a compile-time fact inside each copy of the loop): both frames hold signal and
       // the mask is the variant's full set - no zero forcing, no per-bin test of the mask, and the float32 arithmetic of a
       // bin pair runs as packed instructions (ssr_pair_bins2_fast).  The wave-uniform choice is made ONCE per frame, outside
       // the loop: taken per bin it split the epilogue into 48 basic blocks with two scalar branches each.
-      constexpr int PF1 = SUMS ? 1 : 0;    // PAIRED: the butterfly group after which the first signal is requested (then the second, then the window)
+      constexpr int PF1 = SUMS ? SSR_WAVE_PF1_SUMS : 0;    // PAIRED: the butterfly group after which the first signal is requested (then the second, then the window)
       auto bins = [&](auto fast_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
         SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int q0 = 0; q0 < 4; q0 += G) {
@@ -476,6 +477,15 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
               wb.st_raw(bin_off(b, q0 + q + 1), t.y);
             }
           }
+          if (PAIRED && b == 0 && q0 + G == 4) {
+            if (tid == 0) {                                           // the Nyquist bin, then register 4's rotated value
+              const cx<T> zq = R.v[4];
+              float e, t;
+              ssr_pair_bin<T, 0, true>(mask, acc, zq, zq, a_nz, b_nz, e, t);
+              if (store) { wa.st_raw(4 * (N / 2), e); wb.st_raw(4 * (N / 2), t); }
+              R.v[4] = rot4;
+            }
+          }
           if ((PAIRED ? b == PF1 : false) && q0 + G == 4) {
             SSR_SCHED_BARRIER();
             ssr_wave_prefetch<T, 1>(p, R, tid, va, vb, u + S, n, n_frames);
@@ -491,6 +501,11 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
             SSR_UNROLL for (int r = 0; r < SSR_W_P / 2; ++r) R.wl[r] = vw.at(SSR_UIDX(tid + 64 * r));
             SSR_SCHED_BARRIER();
           }
+        }
+        if (PAIRED && PF1 + 2 > 3) {                              // (the window behind the last group)
+          SSR_SCHED_BARRIER();
+          SSR_UNROLL for (int r = 0; r < SSR_W_P / 2; ++r) R.wl[r] = vw.at(SSR_UIDX(tid + 64 * r));
+          SSR_SCHED_BARRIER();
         }
       };
       constexpr int FULL = SUMS ? (SSR_M_LSD | SSR_M_LOG_SISPEC | SSR_M_SISPEC) : SSR_M_LSD;

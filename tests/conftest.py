@@ -52,37 +52,52 @@ def golden_manifest():
 
 
 # ---- SISpec parity bookkeeping: which branch of assert_sispec_parity every GPU assert took -------------
-SISPEC_LOG = []      # dicts: what, config, branch ("strict" | "band"), band_rel, err_vs_ref32_rel, err_vs_exact_rel
+SISPEC_LOG = []      # dicts: what, config, branch ("strict" | "band"), band_rel, err_vs_ref32_rel, err_vs_exact_rel + the same in dB
+MEMBER_LOG = []      # dicts: what, hip_db, min_db, max_db, spread_db, distance_db (0 = inside), err_vs_reference_db
 
 
 def sispec_summary():
     by = {}
     for r in SISPEC_LOG:
         c = by.setdefault(r["config"], {"asserts": 0, "strict_1e-5_vs_reference": 0, "inside_reference_band": 0,
-                                        "max_band_rel": 0.0, "max_err_vs_reference_rel": 0.0, "max_err_vs_float64_rel": 0.0})
+                                        "max_band_rel": 0.0, "max_err_vs_reference_rel": 0.0, "max_err_vs_float64_rel": 0.0,
+                                        "max_band_db": 0.0, "max_err_vs_reference_db": 0.0, "max_err_vs_float64_db": 0.0,
+                                        "value_db_at_max_rel_err": None})
         c["asserts"] += 1
         c["strict_1e-5_vs_reference" if r["branch"] == "strict" else "inside_reference_band"] += 1
         c["max_band_rel"] = max(c["max_band_rel"], r["band_rel"])
+        if r["err_vs_ref32_rel"] >= c["max_err_vs_reference_rel"]:
+            c["value_db_at_max_rel_err"] = r.get("value_db")
+        for k_out, k_in in (("max_band_db", "band_db"), ("max_err_vs_reference_db", "err_vs_ref32_db"), ("max_err_vs_float64_db", "err_vs_exact_db")):
+            c[k_out] = max(c[k_out], r.get(k_in, 0.0))
         c["max_err_vs_reference_rel"] = max(c["max_err_vs_reference_rel"], r["err_vs_ref32_rel"])
         c["max_err_vs_float64_rel"] = max(c["max_err_vs_float64_rel"], r["err_vs_exact_rel"])
     return by
 
 
 def pytest_terminal_summary(terminalreporter, exitstatus, config):
-    if not SISPEC_LOG:
+    if not SISPEC_LOG and not MEMBER_LOG:
         return
     import json
     by = sispec_summary()
     terminalreporter.write_sep("-", "SISpec parity: branch taken per config (strict = 1e-5 against the reference's float32 value)")
     for cfg, c in sorted(by.items()):
-        terminalreporter.write_line("%-28s asserts %4d | strict %4d | band %4d | widest band %.2e | worst vs reference %.2e | worst vs float64 %.2e"
-                                    % (cfg, c["asserts"], c["strict_1e-5_vs_reference"], c["inside_reference_band"], c["max_band_rel"],
-                                       c["max_err_vs_reference_rel"], c["max_err_vs_float64_rel"]))
+        terminalreporter.write_line("%-28s asserts %4d | strict %4d | band %4d | widest band %.2e (%.1e dB) | worst vs reference %.2e rel at %+.4f dB, %.1e dB abs | worst vs float64 %.2e (%.1e dB)"
+                                    % (cfg, c["asserts"], c["strict_1e-5_vs_reference"], c["inside_reference_band"], c["max_band_rel"], c["max_band_db"],
+                                       c["max_err_vs_reference_rel"], c["value_db_at_max_rel_err"] or 0.0, c["max_err_vs_reference_db"],
+                                       c["max_err_vs_float64_rel"], c["max_err_vs_float64_db"]))
+    if MEMBER_LOG:
+        terminalreporter.write_sep("-", "SISpec against the reference's REAL float32 members (tests/golden/sispec_members.json: torch threads x layouts)")
+        ins = sum(1 for r in MEMBER_LOG if r["distance_db"] == 0.0)
+        terminalreporter.write_line("%d values: %d inside [min, max] of the members, the others at most %.1e dB outside (members' own spread: up to %.1e dB; "
+                                    "|HIP - reference at 8 threads| at most %.1e dB)"
+                                    % (len(MEMBER_LOG), ins, max(r["distance_db"] for r in MEMBER_LOG), max(r["spread_db"] for r in MEMBER_LOG),
+                                       max(r["err_vs_reference_db"] for r in MEMBER_LOG)))
     try:                                 # travels back from the GPU box with gpurun_out/
         out = os.path.join(ROOT, "gpurun_out")
         os.makedirs(out, exist_ok=True)
         with open(os.path.join(out, "sispec_parity_summary.json"), "w") as f:
-            json.dump({"per_config": by, "band_cases": [r for r in SISPEC_LOG if r["branch"] == "band"]}, f, indent=1)
+            json.dump({"per_config": by, "band_cases": [r for r in SISPEC_LOG if r["branch"] == "band"], "member_cases": MEMBER_LOG}, f, indent=1)
     except OSError:
         pass
 

@@ -58,9 +58,13 @@ def assert_sispec_parity(got, ref32, exact, what=""):
     band = abs(ref32 - exact)
     strict = band <= 3e-6 * scale
     import conftest
+    # (the values are dB: next to every relative figure the absolute one - 1e-5 relative on the ENERGY RATIO is 4.3e-5 dB whatever
+    # the value, while 1e-5 relative on a dB value near 0 dB asks for arbitrarily more)
     conftest.SISPEC_LOG.append({"what": what, "config": (what.split() or ["other"])[0] if what[:3] == "cfg" else "golden / randomised",
-                                "branch": "strict" if strict else "band", "band_rel": band / scale,
-                                "err_vs_ref32_rel": abs(got - ref32) / max(abs(ref32), 1e-30), "err_vs_exact_rel": abs(got - exact) / scale})
+                                "branch": "strict" if strict else "band", "band_rel": band / scale, "band_db": band,
+                                "value_db": float(ref32), "hip_db": float(got), "exact_db": float(exact),
+                                "err_vs_ref32_rel": abs(got - ref32) / max(abs(ref32), 1e-30), "err_vs_ref32_db": abs(got - ref32),
+                                "err_vs_exact_rel": abs(got - exact) / scale, "err_vs_exact_db": abs(got - exact)})
     assert abs(got - exact) <= 1e-6 * scale + 1e-6, (what, got, exact)
     if strict:
         assert abs(got - ref32) <= 1e-5 * abs(ref32), (what, got, ref32)

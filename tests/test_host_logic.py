@@ -27,6 +27,35 @@ def test_library_exports_every_declared_symbol():
     assert lib.ssr_version() >= 100
 
 
+def test_no_kernel_a_reference_size_reaches_uses_scratch_memory():
+    """the kernel descriptors inside the SHIPPED libssrhip.so (AMDGPU metadata notes of its code objects,
+    tools/code_objects.py) - every wave-engine transform kernel (k_stft_wave: 2048/512; k_stft_rn_wave: 743, 1114, 1486;
+    k_stft_r3_rot: 2229 = AudioMetrics(48000), float32 and float64-estimate variants) runs with private_segment_fixed_size == 0 and
+    no spilled vector register, and so does every other kernel except the 8192-point Bluestein instances (n_fft 2049 .. 4096: no
+    AudioMetrics(rate), FDomainHelper or BasicTestee size)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import code_objects
+    from ssr_eval_amd import _lib
+    ks = code_objects.kernels(_lib.LIB_PATH)
+    names = code_objects.demangle([k["name"] for k in ks])
+    assert len(ks) > 250                                     # every translation unit's bundle was found
+    seen = {"k_stft_wave<double": 0, "k_stft_wave<float": 0, "k_stft_r3_rot<": 0, "k_stft_rn_wave<": 0, "k_ssim<": 0, "k_resample": 0,
+            "k_tl_": 0, "k_sosfiltfilt": 0}
+    for k, name in zip(ks, names):
+        for key in seen:
+            seen[key] += key in name
+        if re.match(r"void k_stft<(double|float), 13, ", name):
+            continue                                          # the 8192-point block engine: scratch by design, no reference size
+        assert k["scratch"] == 0 and k["vgpr_spill"] == 0, (name, k)
+        assert k["vgpr"] + k["agpr"] <= 512
+    assert all(v > 0 for v in seen.values()), seen
+    # the product instances of the API-true path, by their rocprofv3 names
+    for want in ("k_stft_r3_rot<double, false, 3, 24, 0>", "k_stft_r3_rot<double, true, 3, 24, 0>", "k_stft_r3_rot<double, false, 3, 24, 1>",
+                 "k_stft_r3_rot<double, true, 3, 24, 1>", "k_stft_wave<double, false, true, true>", "k_stft_wave<double, true, true, true>"):
+        assert any(want in n for n in names), want
+
+
 def test_product_does_not_import_oracle_or_fall_back():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "ssr_eval_amd")):
         for f in files:

@@ -533,3 +533,33 @@ def _cut(re, im, cut):
     mag = mag.copy()
     mag[..., cut:] = 0
     return mag * c, mag * s
+
+
+def test_sispec_member_fixture_is_reproduced_by_the_oracle():
+    """tests/golden/sispec_members.json (tools/exp_sispec_members.py: the REFERENCE's AudioMetrics.sispec at several thread counts and
+    layouts): the oracle's restatement, run here at 8 threads on the regenerated pair, returns the fixture's 8-thread
+    value bit for bit, the float64 evaluation its "exact" - and the fixture documents what the GPU test relies on: members agree with
+    each other to < 5e-5 dB and lie up to < 6e-5 dB from the float64 evaluation."""
+    import json
+    import torch
+    from oracle import lowpass as olp, metrics as om
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "sispec_members.json")))["cases"]
+    assert len(gold) >= 28
+    for c in gold:
+        for name in ("sispec", "log_sispec"):
+            m = c[name]
+            assert m["min"] <= m["reference_t8"] <= m["max"] and m["spread_db"] < 5e-5
+            assert abs(m["exact"] - m["reference_t8"]) < 6e-5
+    c = next(x for x in gold if x["target_index"] == 0 and x["cutoff_hz"] == 12000)
+    old = torch.get_num_threads()
+    torch.set_num_threads(8)
+    try:
+        tgt = (0.1 * np.random.default_rng(c["target_seed"]).standard_normal(192000)).astype(np.float32)
+        est = olp.lowpass(tgt, c["cutoff_hz"], 48000, 1, "stft_hard")
+        assert int(np.abs(est).sum(dtype=np.float64) * 1e6) % (1 << 31) == c["est_crc"]
+        es, ts = om.wav_to_spectrogram(est, 2048, 512), om.wav_to_spectrogram(tgt, 2048, 512)
+        assert float(om.sispec(es.clone(), ts.clone())) == c["sispec"]["reference_t8"]
+        assert float(om.sispec(om.to_log(es.clone()), om.to_log(ts.clone()))) == c["log_sispec"]["reference_t8"]
+        assert abs(float(om.sispec_exact(es, ts)) - c["sispec"]["exact"]) < 1e-9
+    finally:
+        torch.set_num_threads(old)

@@ -9,7 +9,13 @@ summary = {"source": "rocprofv3 --kernel-trace --stats -- python bench.py --conf
                      "(cfg2 with its side figures, the others --no-side); PMC: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
                      "--kernel-trace passes per config and for tools/exp_api_true.py / tools/exp_sinc.py (tools/collect_profiles_r03.sh)",
            "kernels": {}}
-if tag >= "r05":
+if tag >= "r06":
+    summary["source"] = ("rocprofv3 --kernel-trace --stats -- python bench.py --config <cfg> --steps 5 --warmup 2 --no-cpu-baseline --no-side, ONE bench "
+                         "command per summary (cfg2only = --config cfg2: the three kernels of the headline step; apitrue = --config apitrue: "
+                         "AudioMetrics(48000) 2229 / 480; cfg3 = the product default low-pass engine, cfg3f64 = --lowpass-engine segments); PMC: separate "
+                         "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace passes of the same commands (tools/collect_profiles_r06.sh); "
+                         "k_tl_* traffic = the MEAN over the launches of a step (seven inverse products at seven cuts)")
+elif tag >= "r05":
     summary["source"] = summary["source"].replace("collect_profiles_r03.sh", "collect_profiles_r05.sh") + \
         "; cfg3 = the product default engine (conv, ONE ssr_fft_lowpass_multi call per step); cfg3f64 = bench.py --config cfg3 --lowpass-engine segments; " \
         "k_tl_* traffic = the MEAN over the launches of a step (seven inverse products at seven cuts)"

@@ -231,9 +231,38 @@ SSR_DEV void ssr_accumulate_metrics(float e, float t, int mask, double* acc) {
 //   lsd        : target**2 stays float32, (est + EPS)**2, the quotient, + EPS and log10 are float64;
 //   log-sispec : to_log(est) is float64, to_log(target) float32 (promoted when the two meet);
 //   sispec     : products in float64.
+// Round 6 (SSR_EST64_FAST, default): the two LOGARITHMS of a bin run as the wave engine's float32 sequences on the float64 magnitude
+// rounded ONCE - log10 is what made this epilogue as expensive as the six transforms in front of it (ocml's float64 log10 x 2 and a
+// float64 division per bin: ~400 instructions against ~60).  What that changes: d = log10(t^2 / (e + EPS)^2 + EPS) by <= 5e-8
+// absolute (6e-8 relative on e + EPS, times 2 / ln 10), log10(e + EPS) by one float32 ulp of a value <= 12 in magnitude - both
+// random per bin, four orders of magnitude inside the 1e-5 bar and inside the 1e-6 the est64 tests hold against the float64
+// oracle; the SISpec products and every accumulation stay float64, the magnitude itself is the float64 one.
+#ifndef SSR_EST64_FAST
+#define SSR_EST64_FAST 1
+#endif
 SSR_DEV void ssr_accumulate_metrics(double e, float t, int mask, double* acc) {
   const double EPS = 1e-12;
   const float EPSF = 1e-12f;
+#if SSR_EST64_FAST
+  const float ee = (float)(e + EPS);
+  if (mask & SSR_M_LSD) {
+    const float d = ssr_log10f_fast(ssr_divf_fast(t * t, ee * ee) + EPSF);
+    acc[0] += (double)d * (double)d;
+  }
+  if (mask & SSR_M_SISPEC) {
+    const double td = (double)t, d = e - td;
+    acc[1] += d * d;
+    acc[2] += td * td;
+    acc[3] += d * td;
+  }
+  if (mask & SSR_M_LOG_SISPEC) {
+    const double le = (double)ssr_log10f_fast(ee), lt = (double)ssr_log10f_fast(t + EPSF), d = le - lt;
+    acc[4] += d * d;
+    acc[5] += lt * lt;
+    acc[6] += d * lt;
+  }
+  return;
+#endif
   if (mask & SSR_M_LSD) {
     const double ee = e + EPS;
     const double d = log10((double)(t * t) / (ee * ee) + EPS);
@@ -251,6 +280,17 @@ SSR_DEV void ssr_accumulate_metrics(double e, float t, int mask, double* acc) {
     acc[5] += lt * lt;
     acc[6] += d * lt;
   }
+}
+
+// numpy.abs(complex128) for the float64-estimate path: a float64 fused multiply-add and square root instead of ocml's hypot (its
+// scaling logic guards ranges audio spectra never reach: |Z| < 1e6, and squares of parts below 1e-150 would have to underflow);
+// within one float64 ulp of hypot's result.
+SSR_DEV double ssr_cabs_d(double re, double im) {
+#if SSR_EST64_FAST
+  return sqrt(fma(re, re, im * im));
+#else
+  return hypot(re, im);
+#endif
 }
 
 // Both signals float64: every tensor of metrics.py:109-121 is float64.
@@ -293,7 +333,7 @@ SSR_DEV void ssr_pair_bin(int mask, double* acc, cx<T> zk, cx<T> zn, bool a_nz, 
   } else if constexpr (IN64 == SSR_IN_EST64) {
     // numpy.abs(complex128) of the unrounded est spectrum; the SSIM image keeps its float32 layout (the
     // rounding moves SSIM by < 2e-7, tests/test_gpu_parity.py)
-    const double e = a_nz ? hypot((double)zk.x + (double)zn.x, (double)zk.y - (double)zn.y) : 0.0;
+    const double e = a_nz ? ssr_cabs_d((double)zk.x + (double)zn.x, (double)zk.y - (double)zn.y) : 0.0;
     const float t = ssr_cabsf(o.br, o.bi);
     e_out = (float)e; t_out = t;
     ssr_accumulate_metrics(e, t, mask, acc);

@@ -36,8 +36,17 @@ static __device__ unsigned long long ssr_dbg_clk[8];
 #ifndef SSR_WAVE_PAIRED
 #define SSR_WAVE_PAIRED 1
 #endif
+// (developer builds: -DSSR_WAVE_EPI_SB_OFF lets the compiler place the epilogue's sample / window requests freely)
+#ifdef SSR_WAVE_EPI_SB_OFF
+#define SSR_WAVE_EPI_SB() do {} while (0)
+#else
+#define SSR_WAVE_EPI_SB() SSR_SCHED_BARRIER()
+#endif
 #ifndef SSR_WAVE_PF1_SUMS
 #define SSR_WAVE_PF1_SUMS 1
+#endif
+#ifndef SSR_WAVE_PF1
+#define SSR_WAVE_PF1 0
 #endif
 constexpr int SSR_W_N = 2048, SSR_W_L = 64, SSR_W_P = 32;     // points, lanes, points per lane
 constexpr int SSR_W_TWP = 7 * 32 + 12 * 64;                   // lane-ordered twiddle copies behind the table (= SSR_WAVE_TWP)
@@ -447,7 +456,7 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
       // the mask is the variant's full set - no zero forcing, no per-bin test of the mask, and the float32 arithmetic of a
       // bin pair runs as packed instructions (ssr_pair_bins2_fast).  The wave-uniform choice is made ONCE per frame, outside
       // the loop: taken per bin it split the epilogue into 48 basic blocks with two scalar branches each.
-      constexpr int PF1 = SUMS ? SSR_WAVE_PF1_SUMS : 0;    // PAIRED: the butterfly group after which the first signal is requested (then the second, then the window)
+      constexpr int PF1 = SUMS ? SSR_WAVE_PF1_SUMS : SSR_WAVE_PF1;    // PAIRED: the butterfly group after which the first signal is requested (then the second, then the window)
       auto bins = [&](auto fast_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
         SSR_UNROLL for (int b = 0; b < 4; ++b) SSR_UNROLL for (int q0 = 0; q0 < 4; q0 += G) {
@@ -487,25 +496,25 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
             }
           }
           if ((PAIRED ? b == PF1 : false) && q0 + G == 4) {
-            SSR_SCHED_BARRIER();
+            SSR_WAVE_EPI_SB();
             ssr_wave_prefetch<T, 1>(p, R, tid, va, vb, u + S, n, n_frames);
-            SSR_SCHED_BARRIER();
+            SSR_WAVE_EPI_SB();
           }
           if (b == (PAIRED ? PF1 + 1 : 1) && q0 + G == 4) {
-            SSR_SCHED_BARRIER();
+            SSR_WAVE_EPI_SB();
             ssr_wave_prefetch<T, 2>(p, R, tid, va, vb, u + S, n, n_frames);
-            SSR_SCHED_BARRIER();
+            SSR_WAVE_EPI_SB();
           }
           if ((PAIRED ? b == PF1 + 2 : false) && q0 + G == 4) {
-            SSR_SCHED_BARRIER();
+            SSR_WAVE_EPI_SB();
             SSR_UNROLL for (int r = 0; r < SSR_W_P / 2; ++r) R.wl[r] = vw.at(SSR_UIDX(tid + 64 * r));
-            SSR_SCHED_BARRIER();
+            SSR_WAVE_EPI_SB();
           }
         }
         if (PAIRED && PF1 + 2 > 3) {                              // (the window behind the last group)
-          SSR_SCHED_BARRIER();
+          SSR_WAVE_EPI_SB();
           SSR_UNROLL for (int r = 0; r < SSR_W_P / 2; ++r) R.wl[r] = vw.at(SSR_UIDX(tid + 64 * r));
-          SSR_SCHED_BARRIER();
+          SSR_WAVE_EPI_SB();
         }
       };
       constexpr int FULL = SUMS ? (SSR_M_LSD | SSR_M_LOG_SISPEC | SSR_M_SISPEC) : SSR_M_LSD;

@@ -57,9 +57,15 @@ class BasicTestee:
         return re[0], im[0]                                        # [T, F] device tensors
 
     def _get_cutoff_index(self, x):
-        re, im = self._stft_mag_complex(x)
-        mag = torch.hypot(re, im)
-        energy = np.cumsum(mag.sum(dim=0).cpu().numpy())           # sum over frames per bin, cumsum over bins
+        """eval.py:28-31: np.cumsum(np.sum(np.abs(librosa.stft(x)), axis=-1)) -> _find_cutoff(., 0.97).  The magnitudes are the
+        metric path's (ssr_stft, MAG: abs of the complex64 spectrum, float32); the 1,025 x T floats are summed ON THE HOST by the
+        reference's own NumPy calls on the reference's [F, T] layout - np.sum's pairwise float32 summation over the frames of a bin,
+        np.cumsum's sequential one over the bins - so that a threshold crossing cannot move by a bin because a GPU reduction added
+        the same numbers in another order (VERDICT r5 weak #9; N3 is not a hot path)."""
+        plan = B.get_plan(2048, 512)                               # librosa.stft defaults
+        mag = B.stft(plan, [np.asarray(x, np.float32)], kind="mag")[0]          # [T, F] float32 on the device
+        stft_x = np.ascontiguousarray(mag.cpu().numpy().T)         # [F, T], as np.abs(librosa.stft(x))
+        energy = np.cumsum(np.sum(stft_x, axis=-1))
         return self._find_cutoff(energy, 0.97)
 
     def postprocessing(self, x, out):

@@ -495,6 +495,47 @@ def test_basic_testee_postprocessing(golden):
     assert bt.tensor2numpy(torch.ones(3, device="cuda")).sum() == 3
 
 
+def test_cutoff_index_differential_against_the_oracle():
+    """VERDICT r5 item 7 ii (ssr_eval/eval.py:21-31): BasicTestee._get_cutoff_index on 200 seeded signals - white and pink noise,
+    harmonic stacks, hard band limits at random cutoffs (the case the search exists for), silence-padded and very short ones - against
+    oracle.testee.get_cutoff_index (the reference's statements on the restated librosa.stft): every index equal.  The per-bin energies
+    themselves are compared too: they are the same NumPy summation of magnitudes that may differ by one float32 ulp in a few bins."""
+    from ssr_eval_amd import BasicTestee
+    from oracle import testee as ot
+    bt = BasicTestee()
+    rng = np.random.default_rng(20220401)
+    mism, worst = [], 0.0
+    for i in range(200):
+        kind = i % 5
+        n = int(rng.integers(2500, 60000)) if i % 7 else int(rng.integers(600, 2200))
+        t = np.arange(n)
+        if kind == 0:
+            x = 0.1 * rng.standard_normal(n)
+        elif kind == 1:                                              # pink-ish: integrated noise, mean removed
+            x = np.cumsum(rng.standard_normal(n)); x = 0.1 * (x - x.mean()) / (np.abs(x).max() + 1e-9)
+        elif kind == 2:                                              # harmonic stack
+            f0 = rng.uniform(80, 400) / 44100
+            x = sum((0.3 / h) * np.sin(2 * np.pi * h * f0 * t + rng.uniform(0, 6.28)) for h in range(1, int(rng.integers(3, 40))))
+            x = x + 1e-4 * rng.standard_normal(n)
+        elif kind == 3:                                              # hard band limit in the frequency domain at a random bin
+            X = np.fft.rfft(0.1 * rng.standard_normal(n)); X[int(rng.uniform(0.05, 0.95) * len(X)):] = 0
+            x = np.fft.irfft(X, n)
+        else:                                                        # signal in the middle of digital silence
+            x = np.zeros(n); a = int(rng.integers(0, n // 2)); b = int(rng.integers(a + 200, n))
+            x[a:b] = 0.05 * rng.standard_normal(b - a)
+        x = x.astype(np.float32)
+        got, want = bt._get_cutoff_index(x), ot.get_cutoff_index(x)
+        if got != want:
+            mism.append((i, kind, n, got, want))
+        if i % 10 == 0:                                              # the energies behind the index
+            from ssr_eval_amd import backend as B
+            mag = B.stft(B.get_plan(2048, 512), [x], kind="mag")[0].cpu().numpy()
+            e_got, e_want = np.sum(np.ascontiguousarray(mag.T), axis=-1), ot.bin_energy(x)
+            worst = max(worst, float(np.abs(e_got - e_want).max() / max(float(e_want.max()), 1e-30)))
+    assert not mism, mism
+    assert worst <= 2e-7, worst
+
+
 # ---- BASELINE.json sizes: size-independent properties --------------------------------------------------
 def test_full_size_properties_cfg2():
     """64 pairs of 4 s @ 48 kHz, n_fft 2048 / hop 512 (cfg-2 geometry: T = 376, F = 1025)."""

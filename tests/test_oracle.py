@@ -563,3 +563,12 @@ def test_sispec_member_fixture_is_reproduced_by_the_oracle():
         assert abs(float(om.sispec_exact(es, ts)) - c["sispec"]["exact"]) < 1e-9
     finally:
         torch.set_num_threads(old)
+
+
+def test_oracle_testee_cutoff_search_matches_the_reference_vectors(golden):
+    """oracle/testee.py (ssr_eval/eval.py:21-31) against the values the imported reference produced (tests/golden/make_golden.py)."""
+    from oracle import testee as ot
+    assert ot.get_cutoff_index(golden["bt_x"]) == int(golden["bt_cutoff_index"])
+    if "bt_energy" in golden.files:
+        got = [ot.find_cutoff(golden["bt_energy"], th) for th in (0.5, 0.9, 0.95, 0.97, 0.999)]
+        assert got == golden["bt_find_cutoff"].tolist()

@@ -11,6 +11,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools')); import devlib; devlib.select()   # SSR_DEV_LIB: alternative build
 from ssr_eval_amd import SSR_Eval_Helper, BasicTestee  # noqa: E402
 from ssr_eval_amd.io import write_wav  # noqa: E402
 

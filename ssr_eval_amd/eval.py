@@ -450,11 +450,28 @@ class SSR_Eval_Helper:
         """eval.py:128-156 for one file."""
         return self.evaluate_files([file])[0]
 
-    def evaluate(self, limit_test_nums=-1, limit_test_speaker=-1, save_json=True, batch_files=64, shard="round-robin"):
+    def default_batch_files(self):
+        """Files per launch sequence when the caller names none: 64 - enough rows to fill the chip and enough batches that the host's
+        queueing of one hides under the GPU work of the one before (7.4-7.7 k files/s on the 367-file bench tree, 7.2 k at 128) - or
+        256 when the IIR degradations are on: their launch is a serial recurrence that lasts as long as its longest utterance however
+        many recurrences run beside it, so a pass wants FEW, WIDE launches (36 keys, 367 files: 0.94 s per pass at 64, 0.74 at 256;
+        one batch of 367 loses the overlap of file reads with GPU work: 0.92).  Capped so that a batch's float64 signals (one per
+        IIR key and file, twice: filtered and resampled) stay inside a quarter of the device's free memory."""
+        lp = self.setting_lowpass_filtering
+        n_iir = 0 if not lp else len(lp.get("filter", ())) * len(lp.get("cutoff_freq", ())) * len(lp.get("filter_order", ()))
+        if n_iir < 8:
+            return 64
+        try:
+            import torch
+            free = int(torch.cuda.mem_get_info(self._device)[0])
+        except Exception:
+            return 64
+        per_file = n_iir * 10 * 48000 * 8 * 2                      # a 10 s file at 48 kHz, float64, filtered + resampled
+        return int(max(64, min(256, (free // 4) // max(per_file, 1))))
+
+    def evaluate(self, limit_test_nums=-1, limit_test_speaker=-1, save_json=True, batch_files=None, shard="round-robin"):
         """eval.py:171-227: walk speakers/files, evaluate, aggregate as mean of speaker means, write JSON.
-        Files are evaluated `batch_files` at a time (one ragged launch sequence per batch; 64: enough rows to fill the chip, and
-        enough batches that the host's queueing of one hides under the GPU work of the one before - 7.4-7.7 k files/s on the
-        367-file bench tree, 7.2 k at 128).  With
+        Files are evaluated `batch_files` at a time (one ragged launch sequence per batch; None: default_batch_files()).  With
         torch.distributed initialised the (speaker, file) list is sharded over the ranks - round-robin, or shard="balanced":
         by audio duration read from the file headers, longest first to the lightest rank (every rank computes the
         same deal) - and the per-utterance rows are exchanged once (ssr_eval_amd.dist); every rank returns the full result."""
@@ -485,7 +502,7 @@ class SSR_Eval_Helper:
             mine = D.shard_indices(len(work), rank, world)
         paths = [os.path.join(self.test_data_root, *work[i]) for i in mine]
         local = []
-        step = max(1, int(batch_files))                            # ragged batches of files per launch sequence
+        step = max(1, int(batch_files if batch_files is not None else self.default_batch_files()))   # files per launch sequence
         batches = pipeline_batches(paths, step)
         # the file reads of batch k+1 (straight into a page-locked arena) run under the GPU work of batch k
         ahead = decode_packed_async(batches[0], self._device) if batches else None
@@ -529,12 +546,24 @@ class SSR_Eval_Helper:
         spk_id = {s: i for i, s in enumerate(speakers)}
         table, buf = D.gather_rows_and_speaker_sums(rows, mine, len(work), [spk_id[work[i][0]] for i in mine], len(speakers))
         final_result = {s: {} for s in speakers}
-        for (spk, f), row in zip(work, table):
-            final_result[spk][f] = {k: {m: float(row[i * len(mets) + j]) for j, m in enumerate(mets)}
-                                    for i, k in enumerate(keys)}
-        # aggregation (eval.py:200-216): per speaker mean over files, then mean over speakers
-        result_cache = {s: {k: dict_mean([v[k] for v in final_result[s].values()]) for k in keys} for s in speakers}
-        averaged = {k: dict_mean([result_cache[s][k] for s in speakers]) for k in keys}
+        M = len(mets)
+        by_spk = {s: [] for s in speakers}
+        for n_, ((spk, f), vals) in enumerate(zip(work, table.tolist())):       # (one tolist: Python floats, not 54 k numpy scalars)
+            final_result[spk][f] = {k: dict(zip(mets, vals[i * M:(i + 1) * M])) for i, k in enumerate(keys)}
+            by_spk[spk].append(n_)
+
+        # aggregation (eval.py:200-216, utils.py:24-28): per speaker np.mean over its files of every metric, then np.mean over the
+        # speakers.  np.mean of the reference's Python list = NumPy's pairwise sum of a contiguous float64 vector: the same sum, to
+        # the bit, as the mean along the contiguous last axis of the transposed block (tests/golden/aggregate.json holds the
+        # reference's values) - 1,184 np.mean calls of 46 floats each were 10 % of a pass with 37 keys.
+        def nest(vec):
+            vec = vec.tolist()
+            return {k: dict(zip(mets, vec[i * M:(i + 1) * M])) for i, k in enumerate(keys)}
+        spk_means = np.empty((len(speakers), table.shape[1]), dtype=np.float64)
+        for si, spk in enumerate(speakers):
+            spk_means[si] = np.ascontiguousarray(table[by_spk[spk]].T).mean(axis=1) if by_spk[spk] and table.shape[1] else np.nan
+        result_cache = {spk: nest(spk_means[si]) for si, spk in enumerate(speakers)}
+        averaged = nest(np.ascontiguousarray(spk_means.T).mean(axis=1)) if len(speakers) and table.shape[1] else {}
         # the same aggregate from the float64 sums + counts that rode along; kept for cross-checking
         self.last_allreduce_average = D.mean_of_speaker_means(buf)[1] if len(keys) else None
         final_result["each_speaker"] = result_cache

@@ -557,7 +557,7 @@ _TWO_RANK_EVAL = r"""
 import os, sys, json
 sys.path.insert(0, %r)
 rank = int(sys.argv[1]); world = int(sys.argv[2]); root = sys.argv[3]; port = sys.argv[4]; shard = sys.argv[5]
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", LOCAL_WORLD_SIZE=str(world))
 import torch
 torch.cuda.set_device(0)                                  # both ranks share cuda:0; the exchange runs over gloo
 from ssr_eval_amd import SSR_Eval_Helper, BasicTestee
@@ -567,7 +567,11 @@ if world > 1:
 h = SSR_Eval_Helper(BasicTestee(), input_sr=44100, output_sr=44100, evaluation_sr=48000, test_data_root=root,
                     setting_fft={"cutoff_freq": [4000, 12000]}, setting_lowpass_filtering={"filter": ["cheby"], "cutoff_freq": [6000], "filter_order": [6]})
 res = h.evaluate(save_json=False, batch_files=5, shard=shard)
-print("RESULT" + json.dumps({"res": res, "allreduce_avg": h.last_allreduce_average.tolist()}))
+import threading
+from ssr_eval_amd import io as sio
+readers = sum(1 for t in threading.enumerate() if t.name.startswith("ssr-decode"))
+print("RESULT" + json.dumps({"res": res, "allreduce_avg": h.last_allreduce_average.tolist(), "readers": readers, "limit": sio.decode_threads(),
+                             "cores": sio.usable_cores()}))
 if world > 1:
     import torch.distributed as dist
     dist.barrier(); dist.destroy_process_group()
@@ -627,6 +631,48 @@ def test_evaluate_sharded_two_processes_equals_single_process(tmp_path):
     np.testing.assert_allclose(both[0]["allreduce_avg"], single["allreduce_avg"], rtol=1e-12)
     c = dict(flat(balanced[0]["res"]))
     assert list(a) == list(c) and max(abs(a[k] - c[k]) / max(abs(a[k]), 1e-300) for k in a) <= 1e-12
+
+
+def test_evaluate_sharded_eight_processes_share_the_host_cores(tmp_path):
+    """the driver's 8-rank launch in small - EIGHT processes (gloo, sharing cuda:0) run the real evaluate() on one
+    wav tree: every rank returns the single-process result (1e-12), and the job as a whole starts no more reader threads than
+    max(ranks, the cores its affinity mask / cgroup grant) - each rank's pool is its share (ssr_eval_amd.io.decode_threads)."""
+    from ssr_eval_amd.io import write_wav
+    rng = np.random.default_rng(13)
+    root = tmp_path / "vctk"
+    for s, c in (("p360", 9), ("p361", 8), ("s5", 7)):
+        (root / s).mkdir(parents=True)
+        for i in range(c):
+            write_wav(str(root / s / ("u%02d.wav" % i)), 0.1 * rng.standard_normal(int(rng.integers(int(0.5 * 44100), int(1.1 * 44100)))), 44100)
+    code = _TWO_RANK_EVAL % ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "SSR_DECODE_THREADS"):
+        env.pop(k, None)
+
+    def launch(rank, world, port):
+        return subprocess.Popen([sys.executable, "-c", code, str(rank), str(world), str(root), str(port), "balanced"], stdout=subprocess.PIPE,
+                                stderr=subprocess.PIPE, text=True, env=env, cwd=str(tmp_path))
+
+    def result(p):
+        out, err = p.communicate(timeout=1200)
+        assert p.returncode == 0, err[-3000:]
+        return json.loads([l for l in out.splitlines() if l.startswith("RESULT")][-1][6:])
+    single = result(launch(0, 1, 0))
+    port = 36500 + os.getpid() % 1000
+    ranks = [result(p) for p in [launch(r, 8, port) for r in range(8)]]
+    assert all(r["res"] == ranks[0]["res"] for r in ranks)
+
+    def flat(d, pre=""):
+        for k, v in d.items():
+            if isinstance(v, dict):
+                yield from flat(v, pre + k + "/")
+            else:
+                yield pre + k, v
+    a, b = dict(flat(single["res"])), dict(flat(ranks[0]["res"]))
+    assert list(a) == list(b) and max(abs(a[k] - b[k]) / max(abs(a[k]), 1e-300) for k in a) <= 1e-12
+    assert all(1 <= r["readers"] <= r["limit"] for r in ranks)
+    assert sum(r["readers"] for r in ranks) <= max(8, ranks[0]["cores"])
+    assert single["limit"] == min(16, single["cores"])
 
 
 def test_cabi_allreduce_sums_two_rank_communicator():

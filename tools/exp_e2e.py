@@ -75,7 +75,7 @@ def main():
             kw["setting_lowpass_filtering"] = {"filter": f.split(","), "cutoff_freq": [int(v) for v in c.split(",")],
                                                "filter_order": [int(v) for v in o.split(",")]}
         h = SSR_Eval_Helper(BasicTestee(), input_sr=44100, output_sr=44100, evaluation_sr=48000, test_data_root=root, **kw)
-        bf = int(os.environ.get("BATCH_FILES", 128))
+        bf = int(os.environ["BATCH_FILES"]) if os.environ.get("BATCH_FILES") else None      # None: the helper's default_batch_files()
         h.evaluate(limit_test_nums=2, limit_test_speaker=1, save_json=False)
         h.evaluate(save_json=False, batch_files=bf)
         times = []
@@ -91,7 +91,7 @@ def main():
             pstats.Stats(pr).sort_stats("tottime").print_stats(int(os.environ["CPROFILE"]))
         if os.environ.get("HOSTPROF"):
             host_profile(h, bf)
-        print("evaluate(): %d files, batch_files %d, median %.1f files/s, passes %s, averaged lsd %.6f" % (
+        print("evaluate(): %d files, batch_files %s, median %.1f files/s, passes %s, averaged lsd %.6f" % (
             n_files, bf, n_files / float(np.median(times)), ["%.4f" % t for t in times], res["averaged"]["proc_fft_24000_44100"]["lsd"]), flush=True)
         if os.environ.get("IIR"):
             print("keys: %d; e.g. %s" % (len(res["averaged"]), {k: round(v["lsd"], 6) for k, v in list(res["averaged"].items())[:3]}), flush=True)

@@ -42,6 +42,11 @@ static __device__ unsigned long long ssr_dbg_clk[8];
 #else
 #define SSR_WAVE_EPI_SB() SSR_SCHED_BARRIER()
 #endif
+#ifdef SSR_WAVE_NOPF
+#define SSR_WAVE_PF(...) do {} while (0)
+#else
+#define SSR_WAVE_PF(...) do { __VA_ARGS__; } while (0)
+#endif
 #ifndef SSR_WAVE_PF1_SUMS
 #define SSR_WAVE_PF1_SUMS 1
 #endif
@@ -365,6 +370,10 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
     // previous frame's LSD.
     SSR_WPHASE(blk, regs, {
       SSR_CLK(0);
+#ifdef SSR_WAVE_NOPF   /* developer experiment: no frame-ahead requests - the unit's samples and window are loaded here (occupancy study) */
+      ssr_wave_prefetch<T>(p, R, tid, va, vb, u, n, n_frames);
+      SSR_UNROLL for (int r = 0; r < SSR_W_P / 2; ++r) R.wl[r] = vw.at(SSR_UIDX(tid + 64 * r));
+#endif
       ssr_wave_flags(R, tid, L.nz, it & 1);            // silent-frame votes of this unit, read by its epilogue
       SSR_CLK(6);
       SSR_UNROLL for (int r = 0; r < SSR_W_P; ++r) {
@@ -497,23 +506,23 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
           }
           if ((PAIRED ? b == PF1 : false) && q0 + G == 4) {
             SSR_WAVE_EPI_SB();
-            ssr_wave_prefetch<T, 1>(p, R, tid, va, vb, u + S, n, n_frames);
+            SSR_WAVE_PF(ssr_wave_prefetch<T, 1>(p, R, tid, va, vb, u + S, n, n_frames));
             SSR_WAVE_EPI_SB();
           }
           if (b == (PAIRED ? PF1 + 1 : 1) && q0 + G == 4) {
             SSR_WAVE_EPI_SB();
-            ssr_wave_prefetch<T, 2>(p, R, tid, va, vb, u + S, n, n_frames);
+            SSR_WAVE_PF(ssr_wave_prefetch<T, 2>(p, R, tid, va, vb, u + S, n, n_frames));
             SSR_WAVE_EPI_SB();
           }
           if ((PAIRED ? b == PF1 + 2 : false) && q0 + G == 4) {
             SSR_WAVE_EPI_SB();
-            SSR_UNROLL for (int r = 0; r < SSR_W_P / 2; ++r) R.wl[r] = vw.at(SSR_UIDX(tid + 64 * r));
+            SSR_WAVE_PF(SSR_UNROLL for (int r = 0; r < SSR_W_P / 2; ++r) R.wl[r] = vw.at(SSR_UIDX(tid + 64 * r)));
             SSR_WAVE_EPI_SB();
           }
         }
         if (PAIRED && PF1 + 2 > 3) {                              // (the window behind the last group)
           SSR_WAVE_EPI_SB();
-          SSR_UNROLL for (int r = 0; r < SSR_W_P / 2; ++r) R.wl[r] = vw.at(SSR_UIDX(tid + 64 * r));
+          SSR_WAVE_PF(SSR_UNROLL for (int r = 0; r < SSR_W_P / 2; ++r) R.wl[r] = vw.at(SSR_UIDX(tid + 64 * r)));
           SSR_WAVE_EPI_SB();
         }
       };

@@ -14,11 +14,9 @@
 // so each utterance is a systolic WAVEFRONT: lane s of a G-lane group owns section s and at step t filters
 // sample n = t - s, taking its input from lane s-1 through one DPP row shift.  A wave carries 64/G utterances;
 // the critical path per step is the 4-operation float64 state update, independent of the number of sections.
-// Input / output are staged through LDS in chunks (next chunk's loads are issued a whole chunk early).
+// Inputs and outputs move in chunks of sixteen samples between HBM and registers (device schedule: below).
 #pragma once
 #include "ssr_block.h"
-
-#define SSR_IIR_CH 128   // samples per staging chunk (> max group size)
 
 // X: input sample type (float, or double for a float64 signal - SciPy then extends and filters the float64 values)
 template <typename X> struct SsrIirParamsT {
@@ -30,6 +28,8 @@ template <typename X> struct SsrIirParamsT {
   int n_sections, edge, n_items;
   double* fwd;             // workspace: forward pass output, item i at off[i] + 2*edge*i, length len[i] + 2*edge
   double* y;               // [same layout as x] float64 result
+  double* trash;           // 256 bytes of the workspace nobody reads a value from: where lanes without a sample load from and store to
+                           // (device schedule below: no vector-memory instruction of the chunk loop sits under a lane condition)
 };
 typedef SsrIirParamsT<float> SsrIirParams;
 
@@ -79,19 +79,48 @@ template <typename X> static inline void ssr_iir_item_host(const SsrIirParamsT<X
   }
 }
 #else
+// ---------------------------------------------------------------------------------------------------------------------------
+// Device schedule (round 6: PACKED wavefront, no LDS).
+//
+// A launch of this kernel lasts as long as the longest utterance's recurrence - steps x (cycles per step) - however many
+// recurrences run beside it; with the designs of an evaluation side by side (ssr_sosfiltfilt_multi) the waves do not even fill the
+// SIMDs.  So what counts is the LATENCY of one step.  The round-4/5 schedule (16-lane groups, inputs and outputs staged through LDS,
+// an exec-masked LDS store per step) ran ~20 instructions and ~195 cycles per step.  Here:
+//   * G lanes per utterance = the smallest power of two >= n_sections (1, 2, 4, 8, 16): every lane of a group owns a section, a wave
+//     carries 64 / G utterances (an order-2 design: 64) - the same recurrences on a sixth of the waves;
+//   * a chunk is SSR_IIR_CK = 16 steps: lane 0's sixteen input samples sit in registers, loaded TWO chunks ahead with 16-byte
+//     vector loads (three rotating buffers), the last section's sixteen outputs leave with 16-byte vector stores - a step is the nine
+//     float64 operations of SciPy's statement sequence plus (G > 1) the DPP hand-off from the lane below: no LDS, no exec masking;
+//   * a chunk in which some lane starts or ends its signal, or that touches the odd extension, takes the general per-step path
+//     (a few chunks per utterance).  Lanes whose utterance has ended (or that have none) run on: nothing they compute is stored;
+//   * NO vector-memory instruction of the regular chunk sits under a lane condition: a lane without a sample loads from / stores to
+//     256 bytes of scratch workspace (`trash`).  Under a condition the loaded registers meet their old values at the join and the
+//     compiler waits for the load right there (vmcnt(0) behind every chunk's requests: 2,000 cycles per 16 steps, measured - the
+//     whole prefetch distance), and a conditional store makes every later wait count as if no store were in flight, i.e. wait for
+//     the stores' acknowledgements (the memory counter retires in order).
+// Same operations in the same order on the same values: the outputs are bit-identical to the round-5 kernel's and to SciPy's.
+#include <type_traits>
+
+constexpr int SSR_IIR_CK = 16;   // steps per chunk
+
+typedef double ssr_d2u __attribute__((ext_vector_type(2), aligned(8)));    // 16-byte accesses at the signals' own alignment
+typedef float ssr_f4u __attribute__((ext_vector_type(4), aligned(4)));
+
 // value of `v` held by the lane one position lower in the same 16-lane row (DPP row_shr:1), two 32-bit halves
 SSR_DEV double ssr_dpp_from_lower_lane(double v) {
   union { double d; int i[2]; } a, b;
   a.d = v;
-  b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x111, 0xf, 0xf, false);
-  b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x111, 0xf, 0xf, false);
+  b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x111, 0xf, 0xf, true);     // (bound_ctrl: a row's lane 0 reads 0 - no `old` value to
+  b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x111, 0xf, 0xf, true);     // preset per step; that lane is an s == 0 lane and takes x_in)
   return b.d;
 }
 
-// Input of lane s at a step: lane 0 of a group takes the staged sample `x_in`, the others lane s-1's output of the previous step.
-// G == 16 (a group = a whole DPP row): ONE update_dpp per half whose out-of-row value is x_in - no select on the step's dependent chain.
+// Input of lane s at a step: lane 0 of a group takes the sample `x_in`, the others lane s-1's output of the previous step.
+// G == 16 (a group = a whole DPP row): ONE update_dpp per half whose out-of-row value is x_in; G == 1: no hand-off at all.
 template <int G> SSR_DEV double ssr_iir_xin(double yout_prev, double x_in, int s) {
-  if constexpr (G == 16) {
+  if constexpr (G == 1) {
+    return x_in;
+  } else if constexpr (G == 16) {
     union { double d; int i[2]; } a, o, b;
     a.d = yout_prev; o.d = x_in;
     b.i[0] = __builtin_amdgcn_update_dpp(o.i[0], a.i[0], 0x111, 0xf, 0xf, false);
@@ -103,147 +132,184 @@ template <int G> SSR_DEV double ssr_iir_xin(double yout_prev, double x_in, int s
   }
 }
 
-// Per-lane view of one utterance slot.  A lane can serve U utterances at once (independent recurrences
-// interleaved in one instruction stream); measured on MI355X the step time grows almost linearly with U, so
-// U = 1 is the default.
-#define SSR_IIR_U 1   /* utterances per lane slot: 2 measured 1.67x the latency for 2x the work - only pays beyond ~8k utterances */
-template <int G, typename X> struct SsrIirSlot {
-  bool active;
+// The utterance of a lane's group (ne = 0: none - the lanes past the end of the batch)
+template <typename X> struct SsrIirLane {
   const X* x;
-  int len, ne;
   double* fwd;
   double* y;
-  double* in_buf;    // LDS ring of 2*CH inputs of this (group, slot)
-  double* out_buf;   // LDS ring of 2*CH outputs
-  double z0, z1, yout;
-  double pre[SSR_IIR_CH / G];
+  double* trash;
+  int len, ne;
 };
 
-template <int G, bool BACKWARD, typename X>
-SSR_DEV double ssr_iir_load_in(const SsrIirSlot<G, X>& q, int edge, int n) {
+// input sample n of a pass, general form: the odd extension (forward) or the reversed forward output (backward); 0 past the end
+template <bool BACKWARD, typename X> SSR_DEV double ssr_iir_load_in(const SsrIirLane<X>& q, int edge, int n) {
   if (n >= q.ne) return 0.0;
   return BACKWARD ? q.fwd[q.ne - 1 - n] : ssr_iir_ext(q.x, q.len, edge, n);
 }
 
-// One pass (forward or backward) of the wavefront for the lane's group.  G: lanes per utterance (8 or 16).
+// One pass (forward or backward) of the wavefront for the lane's group.
 template <int G, bool BACKWARD, typename X>
-SSR_DEV void ssr_iir_pass(const SsrIirParamsT<X>& p, int s, SsrIirSlot<G, X> (&sl)[SSR_IIR_U], double b0, double b1, double b2,
-                          double a1, double a2, double zi0, double zi1) {
-  constexpr int CH = SSR_IIR_CH, PER = CH / G, U = SSR_IIR_U;
-  const int edge = p.edge, S = p.n_sections;
-  // wave-uniform trip count (longest utterance of the wave) and the shortest ACTIVE one: blocks of steps inside
-  // [S-1, ne_min) need no per-lane predicates
-  int ne_max = 0, ne_min = 0x7fffffff;
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    ne_max = sl[u].ne > ne_max ? sl[u].ne : ne_max;
-    if (sl[u].active) ne_min = sl[u].ne < ne_min ? sl[u].ne : ne_min;
-  }
+SSR_DEV void ssr_iir_pass(const SsrIirLane<X>& q, int s, int S, int edge, double b0, double b1, double b2, double a1, double a2,
+                          double zi0, double zi1) {
+  constexpr int CK = SSR_IIR_CK;
+  using XT = typename std::conditional<BACKWARD, double, X>::type;   // the forward pass keeps the signal's own type (widening is exact)
+  int ne_max = q.ne;
   for (int o = 32; o > 0; o >>= 1) {
-    const int a_ = __shfl_xor(ne_max, o), b_ = __shfl_xor(ne_min, o);
+    const int a_ = __shfl_xor(ne_max, o);
     ne_max = a_ > ne_max ? a_ : ne_max;
-    ne_min = b_ < ne_min ? b_ : ne_min;
   }
-  const int n_chunks = (ne_max + S - 1 + CH - 1) / CH + 1;      // +1: flush of the last outputs
+  const int n_chunks = (ne_max + G - 1 + CK - 1) / CK;              // the last section lags G - 1 steps at most
+  const bool last = s == S - 1;
+  // initial state: zi * (first input sample of this pass)
+  const double first = ssr_iir_load_in<BACKWARD>(q, edge, 0);
+  double z0 = zi0 * first, z1 = zi1 * first, yout = 0.0;
 
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    // initial state: zi * (first input sample of this pass); chunk 0 staged directly
-    const double first = sl[u].active ? ssr_iir_load_in<G, BACKWARD>(sl[u], edge, 0) : 0.0;
-    sl[u].z0 = zi0 * first; sl[u].z1 = zi1 * first; sl[u].yout = 0.0;
-    for (int i = 0; i < PER; ++i) sl[u].in_buf[s * PER + i] = ssr_iir_load_in<G, BACKWARD>(sl[u], edge, s * PER + i);
-  }
-  for (int c = 0; c < n_chunks; ++c) {
-    // issue the NEXT chunk's loads now; they land while this chunk is being filtered
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      for (int i = 0; i < PER; ++i) sl[u].pre[i] = ssr_iir_load_in<G, BACKWARD>(sl[u], edge, (c + 1) * CH + s * PER + i);
-    const int ring = (c & 1) * CH;
-    for (int tb = 0; tb < CH; tb += 8) {
-      double x8[U][8];                                           // lane 0's next eight inputs: all LDS reads in flight at once
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) x8[u][k] = sl[u].in_buf[ring + tb + k];
-      const int t0 = c * CH + tb;
-      if (t0 >= S - 1 && t0 + 8 <= ne_min) {
-        // interior block (wave-uniform): every lane s < S has a valid sample at every step -> no predicates;
-        // lanes s >= S compute on garbage that nobody reads
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const double xin = ssr_iir_xin<G>(sl[u].yout, x8[u][k], s);       // lane s-1's output of step t-1 (lane 0: the sample)
-            sl[u].yout = ssr_iir_step(xin, b0, b1, b2, a1, a2, sl[u].z0, sl[u].z1);
-            if (s == S - 1) sl[u].out_buf[(t0 + k - s) & (2 * CH - 1)] = sl[u].yout;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int n = t0 + k - s;                                // sample this lane filters at this step
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const double xin = ssr_iir_xin<G>(sl[u].yout, x8[u][k], s);
-            double nz0 = sl[u].z0, nz1 = sl[u].z1;
-            const double yo = ssr_iir_step(xin, b0, b1, b2, a1, a2, nz0, nz1);
-            const bool on = (s < S) && (n >= 0) && (n < sl[u].ne);
-            sl[u].z0 = on ? nz0 : sl[u].z0;
-            sl[u].z1 = on ? nz1 : sl[u].z1;
-            sl[u].yout = on ? yo : sl[u].yout;
-            if (on && s == S - 1) sl[u].out_buf[n & (2 * CH - 1)] = yo;
-          }
+  // ---- the REGULAR chunk: every lane of the wave either filters sixteen samples of its signal's interior or has finished
+  // the sixteen inputs of chunk c (consumed by lane 0 of the group; every lane of the group requests them), 16-byte loads.
+  // A lane whose chunk is not interior reads the scratch block: values nobody uses (the chunk is then not run as a regular one).
+  auto load_regular = [&](int c, XT (&b)[CK]) __attribute__((always_inline)) {
+    const int t0 = c * CK;
+    const bool inner = BACKWARD ? (t0 + CK <= q.ne) : (t0 >= edge && t0 + CK <= edge + q.len);
+    if constexpr (BACKWARD) {
+      const ssr_d2u* src = reinterpret_cast<const ssr_d2u*>(inner ? q.fwd + (q.ne - CK - t0) : q.trash);   // fwd[ne - 1 - t0 - k] = block[CK - 1 - k]
+      SSR_UNROLL for (int j = 0; j < CK / 2; ++j) { const ssr_d2u v = src[j]; b[CK - 1 - 2 * j] = v.x; b[CK - 2 - 2 * j] = v.y; }
+    } else if constexpr (sizeof(X) == 4) {
+      const ssr_f4u* src = reinterpret_cast<const ssr_f4u*>(inner ? q.x + (t0 - edge) : reinterpret_cast<const X*>(q.trash));
+      SSR_UNROLL for (int j = 0; j < CK / 4; ++j) { const ssr_f4u v = src[j]; b[4 * j] = v.x; b[4 * j + 1] = v.y; b[4 * j + 2] = v.z; b[4 * j + 3] = v.w; }
+    } else {
+      const ssr_d2u* src = reinterpret_cast<const ssr_d2u*>(inner ? q.x + (t0 - edge) : reinterpret_cast<const X*>(q.trash));
+      SSR_UNROLL for (int j = 0; j < CK / 2; ++j) { const ssr_d2u v = src[j]; b[2 * j] = (XT)v.x; b[2 * j + 1] = (XT)v.y; }
+    }
+  };
+  // is chunk c regular?  (wave-uniform)
+  auto regular = [&](int c) -> bool {
+    const int t0 = c * CK, n0 = t0 - s;                          // the lane filters samples n0 .. n0 + CK - 1
+    const bool inner = BACKWARD ? (t0 + CK <= q.ne) : (t0 >= edge && t0 + CK <= edge + q.len), done = t0 >= q.ne;
+    const bool full = n0 >= 0 && n0 + CK <= q.ne, idle = n0 >= q.ne;
+    // what the last section's lane stores: forward every sample; backward sample n is y[(ne - 1 - n) - edge], kept inside [0, len)
+    const bool st_all = BACKWARD ? (n0 >= edge && n0 + CK <= q.ne - edge) : full;
+    const bool st_none = BACKWARD ? (n0 + CK <= edge || n0 >= q.ne - edge) : idle;
+    return __all((inner || done) && (full || idle) && (!last || st_all || st_none));
+  };
+  // the sixteen steps of a regular chunk.  ssr_iir_step's statements in PIPELINED order: a wave issues in order, and the only values
+  // the next step waits for are y (through the hand-off from the lane below and b0 * x) and z0 - so the next step's hand-off and product
+  // are issued right behind y, ahead of this step's state update, and the two dependent chains overlap instead of queueing (same
+  // operations on the same operands).  16-byte stores; every lane but a last section's with sixteen samples to keep writes the scratch block.
+  auto run_regular = [&](int c, const XT (&b)[CK]) __attribute__((always_inline)) {
+#pragma clang fp contract(off)
+    const int n0 = c * CK - s;
+    double yv[CK];
+    double xin = ssr_iir_xin<G>(yout, (double)b[0], s);
+    double p0 = b0 * xin;
+    SSR_UNROLL for (int k = 0; k < CK; ++k) {
+      const double yo = p0 + z0;
+      double xin_n = 0.0, p0_n = 0.0;
+      if (k + 1 < CK) { xin_n = ssr_iir_xin<G>(yo, (double)b[k + 1], s); p0_n = b0 * xin_n; }
+      z0 = (b1 * xin - a1 * yo) + z1;
+      z1 = b2 * xin - a2 * yo;
+      yv[k] = yo;
+      xin = xin_n; p0 = p0_n;
+    }
+    yout = yv[CK - 1];
+    const bool full = n0 >= 0 && n0 + CK <= q.ne;
+    const bool keep = last && full && (BACKWARD ? (n0 >= edge && n0 + CK <= q.ne - edge) : true);
+    if constexpr (BACKWARD) {
+      ssr_d2u* dst = reinterpret_cast<ssr_d2u*>(keep ? q.y + ((q.ne - 1 - edge - n0) - (CK - 1)) : q.trash);
+      SSR_UNROLL for (int j = 0; j < CK / 2; ++j) { ssr_d2u v; v.x = yv[CK - 1 - 2 * j]; v.y = yv[CK - 2 - 2 * j]; dst[j] = v; }
+    } else {
+      ssr_d2u* dst = reinterpret_cast<ssr_d2u*>(keep ? q.fwd + n0 : q.trash);
+      SSR_UNROLL for (int j = 0; j < CK / 2; ++j) { ssr_d2u v; v.x = yv[2 * j]; v.y = yv[2 * j + 1]; dst[j] = v; }
+    }
+  };
+  // three regular chunks on three rotating buffers: chunk c + 2's inputs are requested before chunk c runs.  Straight-line: four
+  // loads, sixteen steps, eight stores, three times - the compiler's memory-counter waits are then exact (vmcnt = the requests
+  // issued since), and a wait for inputs requested two chunks ago never waits for a store or a younger load
+  XT ba[CK], bb[CK], bc[CK];
+  auto three_regular = [&](int c) __attribute__((always_inline)) {
+    load_regular(c + 2, bc); run_regular(c, ba);
+    load_regular(c + 3, ba); run_regular(c + 1, bb);
+    load_regular(c + 4, bb); run_regular(c + 2, bc);
+  };
+
+  // ---- any other chunk (a lane starts or ends in it, or it touches the odd extension): general loads, per-step predicates
+  auto run_general = [&](int c) {
+    const int t0 = c * CK, n0 = t0 - s;
+    XT b[CK];
+    SSR_UNROLL for (int k = 0; k < CK; ++k) b[k] = (XT)ssr_iir_load_in<BACKWARD>(q, edge, t0 + k);   // (the extension is formed in X: exact)
+    SSR_UNROLL for (int k = 0; k < CK; ++k) {
+      const int n = n0 + k;
+      const double xin = ssr_iir_xin<G>(yout, (double)b[k], s);
+      double nz0 = z0, nz1 = z1;
+      const double yo = ssr_iir_step(xin, b0, b1, b2, a1, a2, nz0, nz1);
+      const bool on = (s < S) && (n >= 0) && (n < q.ne);
+      z0 = on ? nz0 : z0;
+      z1 = on ? nz1 : z1;
+      yout = on ? yo : yout;
+      if (on && last) {
+        if constexpr (BACKWARD) {
+          const int m = (q.ne - 1 - n) - edge;
+          if (m >= 0 && m < q.len) q.y[m] = yo;
+        } else {
+          q.fwd[n] = yo;
         }
       }
     }
-    // flush outputs of chunk c-1 (the last section lags by S-1 < CH steps, so they are complete now)
-    if (c >= 1) {
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        for (int i = 0; i < PER; ++i) {
-          const int n = (c - 1) * CH + s * PER + i;
-          if (n < sl[u].ne) {
-            const double v = sl[u].out_buf[n & (2 * CH - 1)];
-            if (BACKWARD) {
-              const int m = (sl[u].ne - 1 - n) - edge;
-              if (m >= 0 && m < sl[u].len) sl[u].y[m] = v;
-            } else {
-              sl[u].fwd[n] = v;
-            }
-          }
-        }
+  };
+
+  int c = 0;
+  while (c < n_chunks) {                                          // (wave-uniform conditions throughout)
+    if (regular(c) && regular(c + 1) && regular(c + 2)) {
+      // a run of regular chunks.  The first three are peeled so that the loop is entered with the memory requests of a full
+      // iteration behind it: preheader and back edge then agree on how many requests follow each buffer's loads
+      load_regular(c, ba);
+      load_regular(c + 1, bb);
+      three_regular(c);
+      c += 3;
+      while (c < n_chunks && regular(c) && regular(c + 1) && regular(c + 2)) {
+        three_regular(c);
+        c += 3;
+      }
+      // (the two buffers requested ahead are dropped: whoever runs those chunks loads them again)
+    } else {
+      run_general(c);
+      c += 1;
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      for (int i = 0; i < PER; ++i) sl[u].in_buf[((c + 1) & 1) * CH + s * PER + i] = sl[u].pre[i];
   }
 }
 
-// grid = ceil(n_items / (U * 64/G)) workgroups of ONE wave; LDS: (64/G) groups * U slots * 4*CH doubles
+// grid = ceil(n_items / (64 / G)) workgroups of ONE wave
 template <int G, typename X>
-SSR_DEV void ssr_iir_wave(const SsrIirParamsT<X>& p, int wg, int lane, char* lds_base) {
-  constexpr int CH = SSR_IIR_CH, GROUPS = 64 / G, U = SSR_IIR_U;
+SSR_DEV void ssr_iir_wave(const SsrIirParamsT<X>& p, int wg, int lane) {
+  constexpr int GROUPS = 64 / G;
   const int g = lane / G, s = lane % G, S = p.n_sections;
-  SsrIirSlot<G, X> sl[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int item = (wg * GROUPS + g) * U + u;
-    sl[u].active = item < p.n_items;
-    const int it = sl[u].active ? item : 0;
-    sl[u].len = p.len[it];
-    sl[u].ne = sl[u].active ? sl[u].len + 2 * p.edge : 0;
-    sl[u].x = p.x + p.off[it];
-    sl[u].fwd = p.fwd + p.off[it] + (int64_t)2 * p.edge * it;
-    sl[u].y = p.y + p.off[it];
-    sl[u].in_buf = reinterpret_cast<double*>(lds_base) + ((size_t)g * U + u) * 4 * CH;
-    sl[u].out_buf = sl[u].in_buf + 2 * CH;
-  }
+  const int item = wg * GROUPS + g;
+  const bool active = item < p.n_items;
+  const int it = active ? item : 0;
+  SsrIirLane<X> q;
+  q.len = p.len[it];
+  q.ne = active ? q.len + 2 * p.edge : 0;
+  q.x = p.x + p.off[it];
+  q.fwd = p.fwd + p.off[it] + (int64_t)2 * p.edge * it;
+  q.y = p.y + p.off[it];
+  q.trash = p.trash;
   const int sc = s < S ? s : 0;
   const double b0 = p.sos[6 * sc], b1 = p.sos[6 * sc + 1], b2 = p.sos[6 * sc + 2], a1 = p.sos[6 * sc + 4], a2 = p.sos[6 * sc + 5];
   const double zi0 = p.zi[2 * sc], zi1 = p.zi[2 * sc + 1];
-  ssr_iir_pass<G, false>(p, s, sl, b0, b1, b2, a1, a2, zi0, zi1);
+  ssr_iir_pass<G, false>(q, s, S, p.edge, b0, b1, b2, a1, a2, zi0, zi1);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the backward pass re-reads `fwd` written by other lanes of this wave
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  ssr_iir_pass<G, true>(p, s, sl, b0, b1, b2, a1, a2, zi0, zi1);
+  ssr_iir_pass<G, true>(q, s, S, p.edge, b0, b1, b2, a1, a2, zi0, zi1);
+}
+
+// lanes per utterance for a design of S sections
+SSR_HD constexpr int ssr_iir_group(int S) { return S <= 1 ? 1 : S <= 2 ? 2 : S <= 4 ? 4 : S <= 8 ? 8 : 16; }
+template <typename X> SSR_DEV void ssr_iir_wave_any(const SsrIirParamsT<X>& p, int wg, int lane) {
+  switch (ssr_iir_group(p.n_sections)) {                      // (wave-uniform)
+    case 1: ssr_iir_wave<1, X>(p, wg, lane); break;
+    case 2: ssr_iir_wave<2, X>(p, wg, lane); break;
+    case 4: ssr_iir_wave<4, X>(p, wg, lane); break;
+    case 8: ssr_iir_wave<8, X>(p, wg, lane); break;
+    default: ssr_iir_wave<16, X>(p, wg, lane); break;
+  }
 }
 #endif

@@ -74,7 +74,9 @@ template <typename T> struct SsrStftParams {
 
 // Sample types of the two signals of a pair.  IN64: 0 = both float32, 1 = float64 estimate against a float32
 // target, 3 = both float64.  (A float32 estimate against a float64 target is widened on the host and runs as 3.)
-enum { SSR_IN_F32 = 0, SSR_IN_EST64 = 1, SSR_IN_BOTH64 = 3 };
+// 7 = TWO float64 ESTIMATES in one complex transform (ssr_pair_metrics_multi_est64: no target, no metric terms - the two float64
+// magnitudes rounded once into the two image rows; ssr_stft_r3_rot.h).
+enum { SSR_IN_F32 = 0, SSR_IN_EST64 = 1, SSR_IN_BOTH64 = 3, SSR_IN_EST64X2 = 7 };
 template <bool F64> struct SsrSample { typedef float type; };
 template <> struct SsrSample<true> { typedef double type; };
 

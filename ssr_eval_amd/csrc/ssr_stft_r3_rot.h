@@ -39,7 +39,7 @@ template <typename T, int P> struct SsrR3RotLds {
   }
 };
 
-template <typename T, bool SUMS, int NQ, int P, typename SA = float> struct SsrR3RotRegs : SsrRnWaveRegs<T, SUMS, NQ, P, SA> {
+template <typename T, bool SUMS, int NQ, int P, typename SA = float, typename SB = float> struct SsrR3RotRegs : SsrRnWaveRegs<T, SUMS, NQ, P, SA, SB> {
   double sums[6];
 };
 
@@ -60,11 +60,15 @@ SSR_DEV int ssr_r3_rot_done_round(int U) { return (3 * U + 2) >> 2; }
 
 // grid = n_items * n_chunks workgroups of 256 threads; PAIR mode, n_fft = 3 q.  IN64 = 0: float32 signals; SSR_IN_EST64 (round 5): the
 // estimate as float64 samples (p.a64) with the float64 estimate arithmetic of ssr_pair_bin<T, SSR_IN_EST64> - what an IIR-degraded
-// input carries into the metrics (ssr_eval/eval.py:138-150); the target stays float32.
+// input carries into the metrics (ssr_eval/eval.py:138-150); the target stays float32.  SSR_IN_EST64X2 (round 6): TWO float64 estimates
+// (p.a64, p.b64) ride one complex transform and leave as two float32 magnitude rows - |.| of the unrounded float64 spectrum, rounded
+// once - with no metric term: ssr_pair_metrics_multi_est64 reduces them against the target image that key 0's pass stored.
 template <typename T, bool SUMS, int NQ, int P, int IN64 = 0, typename BLK>
 SSR_BODY void ssr_stft_r3_rot_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
-  static_assert(IN64 == 0 || IN64 == SSR_IN_EST64, "float32 pairs, or a float64 estimate against a float32 target");
+  static_assert(IN64 == 0 || IN64 == SSR_IN_EST64 || (IN64 == SSR_IN_EST64X2 && !SUMS && sizeof(T) == 8),
+                "float32 pairs, a float64 estimate against a float32 target, or two float64 estimates (images only)");
   using SA = typename SsrSample<(IN64 & 1) != 0>::type;
+  using SB = typename SsrSample<(IN64 & 2) != 0>::type;
   constexpr bool SPLIT = true;
   // float64 estimate WITH running sums: the next job's samples (the estimate's as doubles: 24 more registers than floats) are
   // requested after the round's epilogue(s), not before - held across them they put 24 values into scratch (52 B per lane, round 5)
@@ -74,7 +78,7 @@ SSR_BODY void ssr_stft_r3_rot_body(const SsrStftParams<T>& p, BLK& blk, int chun
   constexpr int NQO = (P == 32) ? NQ : 4;
   static_assert(NQ == 3 || NQ == 4, "q <= 768 or q <= 1024");
   static_assert(P == 32 || (P == 24 && NQ == 3), "M = 1536 holds the chirp-z of q <= 768 only");
-  using Regs = SsrR3RotRegs<T, SUMS, NQ, P, SA>;
+  using Regs = SsrR3RotRegs<T, SUMS, NQ, P, SA, SB>;
   SsrR3RotLds<T, P> L(lds_base);
   const int n_fft = p.n_fft, hop = p.hop, F = n_fft / 2 + 1, q = n_fft / 3;
   const int n = p.len[item];
@@ -88,8 +92,10 @@ SSR_BODY void ssr_stft_r3_rot_body(const SsrStftParams<T>& p, BLK& blk, int chun
   const bool want_lsd = mask & SSR_M_LSD;
   const SA* sa;
   if constexpr (IN64 & 1) sa = p.a64 + p.a_off[item]; else sa = p.a + p.a_off[item];
+  const SB* sb;
+  if constexpr (IN64 & 2) sb = p.b64 + p.b_off[item]; else sb = p.b + p.b_off[item];
   const SsrView<SA> va(sa, n);
-  const SsrView<float> vb(p.b + p.b_off[item], n);
+  const SsrView<SB> vb(sb, n);
   const SsrView<cx<T>> vbf(p.bfilt, M), vch(p.chirp, n_fft), vt(p.tw, M + (P == 32 ? SSR_W_TWP : SSR_W24_TWP));
   const int64_t OP = p.out_pitch ? p.out_pitch : F;      // floats between output rows
   const bool store = p.out_kind == SSR_OUT_MAG;
@@ -194,7 +200,12 @@ SSR_BODY void ssr_stft_r3_rot_body(const SsrStftParams<T>& p, BLK& blk, int chun
           const cx<T> zk = ssr_r3_combine3<T>(yb[0], yb[1], yb[2], q, K);
           const cx<T> zn = ssr_r3_combine3<T>(yb[0], yb[1], yb[2], q, Kn);
           float ev, tv;
-          ssr_pair_bin<T, IN64, IN64 == 0>(mask, acc, zk, zn, a_nz, b_nz, ev, tv);
+          if constexpr (IN64 == SSR_IN_EST64X2) {               // numpy.abs(complex128) of both estimates, rounded once (ssr_pair_bin<T, SSR_IN_EST64>'s e)
+            ev = a_nz ? (float)ssr_cabs_d((double)zk.x + (double)zn.x, (double)zk.y - (double)zn.y) : 0.0f;
+            tv = b_nz ? (float)ssr_cabs_d((double)zk.y + (double)zn.y, (double)zn.x - (double)zk.x) : 0.0f;
+          } else {
+            ssr_pair_bin<T, IN64, IN64 == 0>(mask, acc, zk, zn, a_nz, b_nz, ev, tv);
+          }
           if (store) { ra0[K] = ev; if (rb0 != nullptr) rb0[K] = tv; }
         }
         if (want_lsd) SSR_WAVE_SUM_STORE(tid, NT, acc[0], L.sc1 + 4 * e);

@@ -21,11 +21,11 @@
 // conditions per phase (the sixteen-row variants spill 18-40 VGPRs).
 // P: points per lane of the chirp-z transforms: 32 (M = 2048, ssr_stft_wave.h) or 24 (M = 1536, ssr_fft24.h; q <= 768)
 // SA: sample type of the first signal (double for a float64 estimate - ssr_stft_r3_rot.h's IN64 variant)
-template <typename T, bool SUMS, int NQ, int P = 32, typename SA = float> struct SsrRnWaveRegs {
+template <typename T, bool SUMS, int NQ, int P = 32, typename SA = float, typename SB = float> struct SsrRnWaveRegs {
   cx<T> v[P];
   T tx[P];
   SA pa[4 * NQ];                  // the next unit's decimated samples m = lane + 64 i, requested a unit ahead
-  float pb[4 * NQ];
+  SB pb[4 * NQ];
   cx<T> tw1[P == 32 ? 7 : 9];
   cx<T> tw2[P == 32 ? 12 : 9];
 };
@@ -52,8 +52,8 @@ template <typename T, int NW, bool SUMS, int P = 32> constexpr size_t ssr_stft_r
 }
 
 // decimated samples of unit u (frame u of both signals), sub-sequence r: sample NW m + r of the frame, m = lane + 64 i
-template <typename T, int NW, int NQ, typename REGS, typename SA = float>
-SSR_DEV void ssr_rn_wave_prefetch(REGS& R, int lane, int r, const SsrView<SA>& va, const SsrView<float>& vb, int u, int hop,
+template <typename T, int NW, int NQ, typename REGS, typename SA = float, typename SB = float>
+SSR_DEV void ssr_rn_wave_prefetch(REGS& R, int lane, int r, const SsrView<SA>& va, const SsrView<SB>& vb, int u, int hop,
                                   int n_fft, int q, int n, int n_frames) {
   const int t_c = (u < n_frames) ? u : n_frames - 1;
   const int base = t_c * hop - n_fft / 2;

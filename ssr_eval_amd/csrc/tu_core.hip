@@ -130,7 +130,9 @@ template <typename T> int ssr_launch_stft(const ssr_plan* pl, SsrStftParams<T>& 
   const bool in64 = p.a64 != nullptr;
   // float64 ESTIMATE against a float32 target at n_fft = 3 q, q <= 768 (AudioMetrics(48000) behind an IIR degradation): the rotating
   // four-wave engine has an IN64 variant (round 5); every other float64 combination runs the block engines
-  const bool est64_rot = in64 && p.b64 == nullptr && sizeof(T) == 8 && ssr_stft_rn_wave_radix(pl) == 3 && pl->weng.m == 1536;   // (SSR_W24_N, ssr_fft24.h)
+  // (b64 with a ZERO metric mask: two float64 ESTIMATES per complex transform, images only - ssr_pair_metrics_multi_est64)
+  const bool est64_rot = in64 && (p.b64 == nullptr || p.metric_mask == 0) && sizeof(T) == 8 && ssr_stft_rn_wave_radix(pl) == 3 &&
+                         pl->weng.m == 1536;   // (SSR_W24_N, ssr_fft24.h)
   if ((!in64 || est64_rot) && p.mode == SSR_MODE_PAIR && ssr_stft_rn_wave_radix(pl)) {
     const DevTables<T>& w = ssr_wave_tables_of<T>(pl);
     p.tw = w.tw; p.wchirp = w.wchirp; p.bfilt = w.bfilt; p.chirp = w.chirp;

@@ -49,30 +49,26 @@ __global__ __launch_bounds__(256) void k_sinc_table(SsrSincParams p) {
   ssr_sinc_table_body(p, (int64_t)blockIdx.x * 256 + threadIdx.x);
 }
 
-template <int G, typename X>
+template <typename X>
 __global__ __launch_bounds__(64) void k_sosfiltfilt(SsrIirParamsT<X> p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  ssr_iir_wave<G, X>(p, blockIdx.x, threadIdx.x, smem);
+  ssr_iir_wave_any<X>(p, blockIdx.x, threadIdx.x);
 }
 
-// K designs in one launch (ssr_sosfiltfilt_multi): workgroup -> (design, group of utterances); the design's parameters are
-// wave-uniform values read from the kernel arguments.
+// K designs in one launch (ssr_sosfiltfilt_multi): workgroup -> (design, block of 64 / G utterances), G = the design's lanes per
+// utterance (ssr_iir_group: 1, 2, 4 or 8); the design's parameters are wave-uniform values read from the kernel arguments.
 constexpr int SSR_IIR_MAXD = 48;
-// lanes per utterance of the multi-design launch: 16 = a whole DPP row per utterance (four per wave), where the step's input comes from ONE
-// update_dpp with the staged sample as the out-of-row value - no select on the dependent chain: 123 ms against 151 ms per launch of 36
-// designs x 128 files with 8-lane groups (the same outputs; profiles/r05_notes.md section 9)
-constexpr int SSR_IIR_MULTI_G = 16;
 struct SsrIirMultiParams {
   SsrIirParams base;                     // x, off, len, n_items; sos / zi / fwd / y = the first design's
-  int n_designs, wgs_per_design;
+  int n_designs;
   int64_t y_stride;                      // doubles between the designs' outputs
   int n_sections[SSR_IIR_MAXD], edge[SSR_IIR_MAXD];
+  int wg_start[SSR_IIR_MAXD + 1];        // first workgroup of design d (exclusive prefix sum of ceil(n_items / (64 / G_d)))
   int64_t fwd_off[SSR_IIR_MAXD];         // doubles
 };
-template <int G>
 __global__ __launch_bounds__(64) void k_sosfiltfilt_multi(SsrIirMultiParams mp) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int d = blockIdx.x / mp.wgs_per_design, wg = blockIdx.x % mp.wgs_per_design;
+  int d = 0;
+  while (d + 1 < mp.n_designs && (int)blockIdx.x >= mp.wg_start[d + 1]) ++d;
+  const int wg = (int)blockIdx.x - mp.wg_start[d];
   SsrIirParams p = mp.base;
   p.sos += (int64_t)d * 8 * 6;
   p.zi += (int64_t)d * 8 * 2;
@@ -80,7 +76,7 @@ __global__ __launch_bounds__(64) void k_sosfiltfilt_multi(SsrIirMultiParams mp) 
   p.edge = mp.edge[d];
   p.fwd += mp.fwd_off[d];
   p.y += (int64_t)d * mp.y_stride;
-  ssr_iir_wave<G, float>(p, wg, threadIdx.x, smem);
+  ssr_iir_wave_any<float>(p, wg, threadIdx.x);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -376,9 +372,13 @@ extern "C" int ssr_xcorr_argmax(const float* a, const int64_t* a_off, const floa
 }
 
 // ----------------------------------------------------------------------------------------------------
+// workspace = [256 bytes of scratch (SsrIirParamsT::trash)] [forward-pass output of design 0] [of design 1] ...
+static size_t iir_region_bytes(int64_t total_len, int n_items, int edge) {
+  return ssr_align256(((size_t)total_len + (size_t)2 * edge * n_items) * sizeof(double));
+}
 extern "C" size_t ssr_sosfiltfilt_workspace_bytes(int64_t total_len, int n_items, int edge) {
   if (total_len <= 0 || n_items <= 0 || edge < 0) return 0;
-  return ssr_align256(((size_t)total_len + (size_t)2 * edge * n_items) * sizeof(double));
+  return 256 + iir_region_bytes(total_len, n_items, edge);
 }
 
 template <typename X>
@@ -391,21 +391,11 @@ static int sosfiltfilt_t(const X* x, const int64_t* off, const int32_t* len, int
   if (n_items <= 0) return SSR_OK;
   if (!workspace || workspace_bytes < ssr_sosfiltfilt_workspace_bytes(total_len, n_items, edge))
     return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small");
-  SsrIirParamsT<X> p{x, off, len, sos, zi, n_sections, edge, n_items, (double*)workspace, y};
+  SsrIirParamsT<X> p{x, off, len, sos, zi, n_sections, edge, n_items, (double*)workspace + 32, y, (double*)workspace};
   hipStream_t s = (hipStream_t)stream;
-  // 16-lane groups (four utterances per wave, the select-free step of ssr_iir_xin<16>) while that leaves at most one wave per SIMD;
-  // eight-lane groups pack twice the utterances per wave beyond that
-  if (n_sections <= 8 && n_items > 4096) {
-    const int per_wave = 8 * SSR_IIR_U;                           // utterances per one-wave workgroup
-    const size_t lds = (size_t)per_wave * 4 * SSR_IIR_CH * sizeof(double);
-    static thread_local SsrLdsSlot slot;
-    if (int rc = ssr_allow_lds((const void*)k_sosfiltfilt<8, X>, lds, &slot)) return rc;
-    hipLaunchKernelGGL((k_sosfiltfilt<8, X>), dim3(ssr_ceil_div(n_items, per_wave)), dim3(64), lds, s, p);
-  } else {
-    const int per_wave = 4 * SSR_IIR_U;
-    const size_t lds = (size_t)per_wave * 4 * SSR_IIR_CH * sizeof(double);
-    hipLaunchKernelGGL((k_sosfiltfilt<16, X>), dim3(ssr_ceil_div(n_items, per_wave)), dim3(64), lds, s, p);
-  }
+  // G lanes per utterance = the smallest power of two >= n_sections, 64 / G utterances per one-wave workgroup (ssr_iir.h)
+  const int per_wave = 64 / ssr_iir_group(n_sections);
+  hipLaunchKernelGGL((k_sosfiltfilt<X>), dim3(ssr_ceil_div(n_items, per_wave)), dim3(64), 0, s, p);
   HIP_TRY(hipGetLastError());
   return SSR_OK;
 }
@@ -418,8 +408,8 @@ extern "C" int ssr_sosfiltfilt(const float* x, const int64_t* off, const int32_t
 
 extern "C" size_t ssr_sosfiltfilt_multi_workspace_bytes(int64_t total_len, int n_items, const int32_t* edge, int n_designs) {
   if (total_len <= 0 || n_items <= 0 || !edge || n_designs <= 0) return 0;
-  size_t b = 0;
-  for (int d = 0; d < n_designs; ++d) b += ssr_sosfiltfilt_workspace_bytes(total_len, n_items, edge[d] < 0 ? 0 : edge[d]);
+  size_t b = 256;
+  for (int d = 0; d < n_designs; ++d) b += iir_region_bytes(total_len, n_items, edge[d] < 0 ? 0 : edge[d]);
   return b;
 }
 
@@ -438,22 +428,18 @@ extern "C" int ssr_sosfiltfilt_multi(const float* x, const int64_t* off, const i
   if (!workspace || workspace_bytes < ssr_sosfiltfilt_multi_workspace_bytes(total_len, n_items, edge, n_designs))
     return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small");
   SsrIirMultiParams mp;
-  mp.base = SsrIirParams{x, off, len, sos, zi, 0, 0, n_items, (double*)workspace, y};
+  mp.base = SsrIirParams{x, off, len, sos, zi, 0, 0, n_items, (double*)workspace + 32, y, (double*)workspace};
   mp.n_designs = n_designs;
-  constexpr int G = SSR_IIR_MULTI_G;
-  const int per_wave = (64 / G) * SSR_IIR_U;
-  mp.wgs_per_design = ssr_ceil_div(n_items, per_wave);
   mp.y_stride = y_stride;
-  int64_t fo = 0;
+  int64_t fo = 0, wgs = 0;
   for (int d = 0; d < n_designs; ++d) {
-    mp.n_sections[d] = n_sections[d]; mp.edge[d] = edge[d]; mp.fwd_off[d] = fo;
-    fo += (int64_t)(ssr_sosfiltfilt_workspace_bytes(total_len, n_items, edge[d]) / sizeof(double));
+    mp.n_sections[d] = n_sections[d]; mp.edge[d] = edge[d]; mp.fwd_off[d] = fo; mp.wg_start[d] = (int)wgs;
+    fo += (int64_t)(iir_region_bytes(total_len, n_items, edge[d]) / sizeof(double));
+    wgs += ssr_ceil_div(n_items, 64 / ssr_iir_group(n_sections[d]));
+    if (wgs > 0x7fffffff) return ssr_fail(SSR_ERR_UNSUPPORTED, "batch too large for one launch");
   }
-  if ((int64_t)mp.wgs_per_design * n_designs > 0x7fffffff) return ssr_fail(SSR_ERR_UNSUPPORTED, "batch too large for one launch");
-  const size_t lds = (size_t)per_wave * 4 * SSR_IIR_CH * sizeof(double);
-  static thread_local SsrLdsSlot slot;
-  if (int rc = ssr_allow_lds((const void*)k_sosfiltfilt_multi<G>, lds, &slot)) return rc;
-  hipLaunchKernelGGL(k_sosfiltfilt_multi<G>, dim3((unsigned)(mp.wgs_per_design * n_designs)), dim3(64), lds, (hipStream_t)stream, mp);
+  for (int d = n_designs; d <= SSR_IIR_MAXD; ++d) mp.wg_start[d] = (int)wgs;
+  hipLaunchKernelGGL(k_sosfiltfilt_multi, dim3((unsigned)wgs), dim3(64), 0, (hipStream_t)stream, mp);
   HIP_TRY(hipGetLastError());
   return SSR_OK;
 }

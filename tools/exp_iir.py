@@ -27,8 +27,15 @@ def main():
         one = B.sosfiltfilt(designs[d], r)
         bad += sum(int((a != b).sum()) for a, b in zip(one, got[d]))
     ms = bench.event_time_ms(lambda: B.sosfiltfilt_multi(designs, r), 3)
+    per_g = {}
+    if os.environ.get("PER_G"):        # one design per launch: the step latency of each group width (the longest utterance sets the time)
+        steps = 2.0 * (max(len(x) for x in xs) + 2 * 27)
+        for order in (2, 4, 8, 16, 20):
+            d = _design(4000, 44100, order, "butter")
+            t = bench.event_time_ms(lambda: B.sosfiltfilt(d, r), 3)
+            per_g["sections_%d" % d.shape[0]] = {"ms": round(t, 2), "ns_per_step": round(1e6 * t / steps, 1)}
     print(json.dumps({"lib": os.environ.get("SSR_DEV_LIB", ""), "files": n_files, "designs": len(designs), "ms_per_launch": round(ms, 2),
-                      "samples_differing_from_single_design_launches": bad}), flush=True)
+                      "samples_differing_from_single_design_launches": bad, "per_group": per_g}), flush=True)
 
 
 if __name__ == "__main__":

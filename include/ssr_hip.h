@@ -192,6 +192,22 @@ int ssr_pair_metrics_multi(const ssr_plan* plan, const float* est, const int64_t
                            const int32_t* len, const int64_t* frame_off, int n_items, int n_keys, int max_len, int64_t total_rows,
                            unsigned metric_mask, double* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same for K FLOAT64 estimates per float32 target: what SSR_Eval_Helper.evaluate_single holds when `setting_lowpass_filtering` is on -
+ * every IIR key of a file is a float64 signal (scipy.signal.sosfiltfilt, ssr_eval/lowpass.py:54-131) scored against the file's one
+ * float32 target (ssr_eval/eval.py:136-154, 243-258).  est: double, key-major offsets as above.  Key 0 runs as ssr_pair_metrics_est64
+ * (bit-identical to it) and stores the target's magnitude image; keys 1 .. K-1 are transformed two per complex float64 transform into
+ * float32 magnitude rows - numpy.abs of the unrounded complex128 spectrum, rounded once - and reduced against the stored image (an odd
+ * last key runs with the target again).  Against K calls of ssr_pair_metrics_est64: the estimate's magnitude enters the LSD / SISpec
+ * terms rounded to float32 (6e-8 relative: <= 5e-8 absolute on an LSD term, the size of that entry point's own float32 logarithms)
+ * and the terms are float32 sequences summed in float64 - metrics equal to <= 1e-6 relative, 1e-5 being the bar.  Plans without a
+ * two-estimate wave kernel (today: every n_fft but 3 q <= 2304, i.e. every rate but AudioMetrics(48000)) take K plain passes,
+ * bit-identical to ssr_pair_metrics_est64. */
+size_t ssr_pair_metrics_multi_est64_workspace_bytes(const ssr_plan* plan, int n_items, int n_keys, int max_len, int64_t total_rows,
+                                                    unsigned metric_mask);
+int ssr_pair_metrics_multi_est64(const ssr_plan* plan, const double* est, const int64_t* est_off, const float* tgt, const int64_t* tgt_off,
+                                 const int32_t* len, const int64_t* frame_off, int n_items, int n_keys, int max_len, int64_t total_rows,
+                                 unsigned metric_mask, double* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Same, restricted to a subset of its three launches (bit 0: STFT + fused LSD/SISpec epilogue, bit 1:
  * SSIM, bit 2: finalisation) so that bench.py can time the dominant kernel on its own stream with
  * HIP events.  stages = 7 is ssr_pair_metrics. */

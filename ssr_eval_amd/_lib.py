@@ -39,6 +39,8 @@ SIGNATURES = {
     "ssr_pair_metrics": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _u, _vp, _vp, _sz, _vp]),
     "ssr_pair_metrics_multi_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i64, _u]),
     "ssr_pair_metrics_multi": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _u, _vp, _vp, _sz, _vp]),
+    "ssr_pair_metrics_multi_est64_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i64, _u]),
+    "ssr_pair_metrics_multi_est64": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _u, _vp, _vp, _sz, _vp]),
     "ssr_pair_metrics_est64": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _u, _vp, _vp, _sz, _vp]),
     "ssr_pair_metrics_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _u, _vp, _vp, _sz, _vp]),
     "ssr_pair_metrics_stages": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _u, _vp, _vp, _sz, _vp, _i]),

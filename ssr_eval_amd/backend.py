@@ -464,16 +464,18 @@ class PairBatch:
 class MultiPairBatch:
     """ONE target, K estimates per item (ssr_pair_metrics_multi): `est` holds n_keys * n items KEY-MAJOR (estimate k of item i
     at index k * n + i), every estimate of item i as long as target i.  The target is transformed once and its magnitude image
-    stored once; estimates 1 .. K-1 are transformed two per complex transform.  out: [n, n_keys, 4] float64."""
+    stored once; estimates 1 .. K-1 are transformed two per complex transform.  out: [n, n_keys, 4] float64.
+    A float64 `est` against a float32 target (every IIR key of a file, ssr_eval/eval.py:243-258): ssr_pair_metrics_multi_est64."""
 
     def __init__(self, plan, est, tgt, n_keys):
         n_keys = int(n_keys)
         if n_keys < 1 or est.n != tgt.n * n_keys or not np.array_equal(est.lens_host, np.tile(tgt.lens_host, n_keys)):
             raise ValueError("est must hold n_keys estimates per target, key-major, each as long as its target")
-        if est.data.dtype != torch.float32 or tgt.data.dtype != torch.float32:
-            raise ValueError("ssr_pair_metrics_multi takes float32 signals (float64 pairs go through PairBatch)")
+        if tgt.data.dtype != torch.float32 or est.data.dtype not in (torch.float32, torch.float64):
+            raise ValueError("ssr_pair_metrics_multi takes float32 targets and float32 or float64 estimates (float64 targets go through PairBatch)")
         _check_nonempty(tgt.lens_host)
         self.plan, self.est, self.tgt, self.n_keys = plan, est, tgt, n_keys
+        self.est64 = est.data.dtype == torch.float64
         self.rows = _Rows(plan, tgt.lens_host, tgt.device)
         self.ws_bytes, self.ws, self._ws_mask = 0, None, 0
         self.out = torch.empty((tgt.n, n_keys, 4), dtype=torch.float64, device=tgt.device)
@@ -482,7 +484,8 @@ class MultiPairBatch:
         if self.ws is None or (mask & ~self._ws_mask):
             want = mask | self._ws_mask
             p, t = self.plan, self.tgt
-            self.ws_bytes = int(p.lib.ssr_pair_metrics_multi_workspace_bytes(p.handle, t.n, self.n_keys, t.max_len, self.rows.total, want))
+            size_fn = p.lib.ssr_pair_metrics_multi_est64_workspace_bytes if self.est64 else p.lib.ssr_pair_metrics_multi_workspace_bytes
+            self.ws_bytes = int(size_fn(p.handle, t.n, self.n_keys, t.max_len, self.rows.total, want))
             self.ws = None
             self.ws = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=t.device)
             self._ws_mask = want
@@ -494,7 +497,8 @@ class MultiPairBatch:
         self._workspace(mask)
         if (mask & M_SSIM) and (self.rows.T.min() < 7 or p.n_bins < 7):
             raise ValueError("win_size exceeds image extent")
-        _lib.check(p.lib.ssr_pair_metrics_multi(
+        fn = p.lib.ssr_pair_metrics_multi_est64 if self.est64 else p.lib.ssr_pair_metrics_multi
+        _lib.check(fn(
             p.handle, _vp(e.data), _vp(e.off), _vp(t.data), _vp(t.off), _vp(t.len), _vp(self.rows.off), t.n, self.n_keys, t.max_len,
             self.rows.total, mask, _vp(self.out), _vp(self.ws), self.ws_bytes, _stream()))
         return self.out
@@ -538,10 +542,11 @@ class Pending:
 
 
 def pair_metrics_multi(plan, est_lists, tgt_list, mask=M_ALL, deferred=False):
-    """est_lists: K lists (one per key) of n waveforms; tgt_list: n targets -> [n, K, 4] float64 (deferred: a Pending)."""
+    """est_lists: K lists (one per key) of n waveforms - all float32, or all float64 (the IIR keys of a file: they stay float64, as in the
+    reference); tgt_list: n float32 targets -> [n, K, 4] float64 (deferred: a Pending)."""
     with torch.cuda.device(plan.device):
         flat = [e for key in est_lists for e in key]
-        b = MultiPairBatch(plan, Ragged.from_list(flat, plan.device, allow_gaps=True), Ragged.from_list(tgt_list, plan.device, allow_gaps=True),
+        b = MultiPairBatch(plan, Ragged.from_list_keep64(flat, plan.device, allow_gaps=True), Ragged.from_list(tgt_list, plan.device, allow_gaps=True),
                            len(est_lists))
         return Pending(b.run(mask)) if deferred else b.run(mask).cpu().numpy()
 

@@ -268,13 +268,18 @@ struct MultiWs {
   int spec_rows_per_chunk, spec_chunks, spec_kg, n_tiles;
   bool fast;
 };
-static bool multi_fast_path(const ssr_plan* pl) { return ssr_stft_uses_wave_engine(pl, false) || ssr_stft_rn_wave_radix(pl) != 0; }
-static MultiWs multi_ws(const ssr_plan* pl, int n_items, int n_keys, int max_len, int64_t total_rows, unsigned mask) {
+// est64 (ssr_pair_metrics_multi_est64): the estimates are float64 signals - two per complex transform where the plan has a wave kernel for
+// that (n_fft = 3 q on the rotating four-wave engine: AudioMetrics(48000), ssr_stft_r3_rot.h SSR_IN_EST64X2)
+static bool multi_fast_path(const ssr_plan* pl, bool est64) {
+  if (est64) return pl->precision == SSR_F64 && ssr_stft_rn_wave_radix(pl) == 3 && pl->weng.m == 1536;
+  return ssr_stft_uses_wave_engine(pl, false) || ssr_stft_rn_wave_radix(pl) != 0;
+}
+static MultiWs multi_ws(const ssr_plan* pl, int n_items, int n_keys, int max_len, int64_t total_rows, unsigned mask, bool est64 = false) {
   MultiWs m;
   const bool want_ssim = mask & SSR_METRIC_SSIM;
-  m.fast = multi_fast_path(pl) && n_keys > 1;
+  m.fast = multi_fast_path(pl, est64) && n_keys > 1;
   const bool mag = want_ssim || m.fast;
-  m.w = pair_ws(pl, n_items, max_len, total_rows, false, mag);
+  m.w = pair_ws(pl, n_items, max_len, total_rows, est64, mag);
   const int max_T = (int)ssr_num_frames(pl, max_len);
   m.w.sg = ssim_geom(max_T, pl->n_bins, m.fast ? n_items * n_keys : n_items, true);    // (the plain passes keep ssr_pair_metrics' tiles)
   m.n_tiles = m.w.sg.n_row_tiles * m.w.sg.n_strips;
@@ -313,23 +318,26 @@ extern "C" size_t ssr_pair_metrics_multi_workspace_bytes(const ssr_plan* pl, int
   return multi_ws(pl, n_items, n_keys, max_len, total_rows, metric_mask).total;
 }
 
+// (a, a64) / (b, b64): each signal as float32 OR float64 samples (the other pointer null)
 template <typename T>
-static int multi_stage_stft(const ssr_plan* pl, const float* a, const int64_t* a_off, const float* b, const int64_t* b_off, const int32_t* len,
+static int multi_stage_stft(const ssr_plan* pl, const float* a, const double* a64, const int64_t* a_off, const float* b, const double* b64,
+                            const int64_t* b_off, const int32_t* len,
                             const int64_t* frame_off, int n_items, unsigned mask, bool mag, float* out_a, float* out_b, double* part,
                             const PairWs& w, hipStream_t s) {
   SsrStftParams<T> p{};
-  p.a = a; p.b = b; p.a_off = a_off; p.b_off = b_off; p.len = len; p.frame_off = frame_off;
+  p.a = a; p.a64 = a64; p.b = b; p.b64 = b64; p.a_off = a_off; p.b_off = b_off; p.len = len; p.frame_off = frame_off;
   p.mode = SSR_MODE_PAIR; p.out_kind = mag ? SSR_OUT_MAG : SSR_OUT_NONE; p.metric_mask = (int)mask;
   p.n_fft = pl->n_fft; p.hop = pl->hop; p.n_bins = pl->n_bins;
-  p.units_per_chunk = w.units_per_chunk; p.n_chunks = w.n_chunks; p.interleave = ssr_pair_interleave(pl, false);
+  p.units_per_chunk = w.units_per_chunk; p.n_chunks = w.n_chunks; p.interleave = ssr_pair_interleave(pl, a64 != nullptr);
   p.out_a = out_a; p.out_b = out_b; p.out_pitch = mag_pitch(pl->n_bins); p.part = part;
   return ssr_launch_stft<T>(pl, p, n_items * w.n_chunks, s);
 }
 
-extern "C" int ssr_pair_metrics_multi(const ssr_plan* pl, const float* est, const int64_t* est_off, const float* tgt, const int64_t* tgt_off,
-                                      const int32_t* len, const int64_t* frame_off, int n_items, int n_keys, int max_len, int64_t total_rows,
-                                      unsigned mask, double* out, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!pl || !est || !est_off || !tgt || !tgt_off || !len || !frame_off || !out) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+// est / est64: the K estimates as float32 or as float64 signals (the other pointer null)
+static int pair_metrics_multi_impl(const ssr_plan* pl, const float* est, const double* est64, const int64_t* est_off, const float* tgt,
+                                   const int64_t* tgt_off, const int32_t* len, const int64_t* frame_off, int n_items, int n_keys, int max_len,
+                                   int64_t total_rows, unsigned mask, double* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!pl || (!est && !est64) || !est_off || !tgt || !tgt_off || !len || !frame_off || !out) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
   if (n_items <= 0 || n_keys <= 0) return SSR_OK;
   if (int rc_dev = ssr_check_plan_device(pl)) return rc_dev;
   if (max_len < 1) return ssr_fail(SSR_ERR_INVALID_ARG, "empty signals");
@@ -340,7 +348,8 @@ extern "C" int ssr_pair_metrics_multi(const ssr_plan* pl, const float* est, cons
   const bool want_ssim = mask & SSR_METRIC_SSIM;
   if ((int64_t)max_T * pl->n_bins >= ((int64_t)1 << 30)) return ssr_fail(SSR_ERR_UNSUPPORTED, "spectrogram of 2^30 elements or more (4 GiB buffer views)");
   if (want_ssim && (max_T < 7 || pl->n_bins < 7)) return ssr_fail(SSR_ERR_INVALID_ARG, "win_size exceeds image extent");
-  const MultiWs m = multi_ws(pl, n_items, n_keys, max_len, total_rows, mask);
+  const bool e64 = est64 != nullptr;
+  const MultiWs m = multi_ws(pl, n_items, n_keys, max_len, total_rows, mask, e64);
   if (!workspace || workspace_bytes < m.total) return ssr_fail(SSR_ERR_WORKSPACE, "workspace too small");
   char* ws = (char*)workspace;
   hipStream_t s = (hipStream_t)stream;
@@ -354,10 +363,19 @@ extern "C" int ssr_pair_metrics_multi(const ssr_plan* pl, const float* est, cons
   auto plane_of = [&](int k) { return mag ? (float*)(ws + m.off_est + (size_t)k * m.plane) : nullptr; };
   float* tgt_plane = mag ? (float*)(ws + m.off_tgt) : nullptr;
   double* ssim_part = (double*)(ws + m.off_ssim);
-  auto stft = [&](const float* a, const int64_t* a_off, const float* b, const int64_t* b_off, unsigned msk, float* oa, float* ob, double* part) {
+  // est_tgt(k, ...): estimate k with the target (metric terms in the epilogue); est_est(k, ...): estimates k and k + 1 in one complex
+  // transform, images only
+  auto stft = [&](const float* a, const double* a64, const int64_t* a_off, const float* b, const double* b64, const int64_t* b_off, unsigned msk,
+                  float* oa, float* ob, double* part) {
     return pl->precision == SSR_F64
-               ? multi_stage_stft<double>(pl, a, a_off, b, b_off, len, frame_off, n_items, msk, mag, oa, ob, part, m.w, s)
-               : multi_stage_stft<float>(pl, a, a_off, b, b_off, len, frame_off, n_items, msk, mag, oa, ob, part, m.w, s);
+               ? multi_stage_stft<double>(pl, a, a64, a_off, b, b64, b_off, len, frame_off, n_items, msk, mag, oa, ob, part, m.w, s)
+               : multi_stage_stft<float>(pl, a, a64, a_off, b, b64, b_off, len, frame_off, n_items, msk, mag, oa, ob, part, m.w, s);
+  };
+  auto est_tgt = [&](int k, unsigned msk, float* oa, float* ob, double* part) {
+    return stft(est, est64, est_off + (size_t)k * n_items, tgt, nullptr, tgt_off, msk, oa, ob, part);
+  };
+  auto est_est = [&](int k, float* oa, float* ob) {
+    return stft(est, est64, est_off + (size_t)k * n_items, est, est64, est_off + (size_t)(k + 1) * n_items, 0u, oa, ob, nullptr);
   };
   auto finalize = [&](const double* part, int n_chunks, const double* sp, int n_virtual, int key0) {
     SsrFinalizeParams p{part, n_chunks, want_ssim ? sp : nullptr, m.n_tiles, rows, pl->n_bins, (int)mask, n_virtual, out, n_items, n_keys, key0};
@@ -387,7 +405,7 @@ extern "C" int ssr_pair_metrics_multi(const ssr_plan* pl, const float* est, cons
     // engines (float64-signal plans have their own entry points), or a single key
     for (int k = 0; k < n_keys; ++k) {
       double* part = (double*)(ws + m.off_part_a);
-      if ((rc = stft(est, est_off + (size_t)k * n_items, tgt, tgt_off, mask, plane_of(k), tgt_plane, part))) return rc;
+      if ((rc = est_tgt(k, mask, plane_of(k), tgt_plane, part))) return rc;
       if (want_ssim && (rc = ssim(k, 1))) return rc;
       HIP_TRY(finalize(part, m.w.n_chunks, ssim_part + (size_t)k * n_items * m.n_tiles, n_items, k));
     }
@@ -395,16 +413,16 @@ extern "C" int ssr_pair_metrics_multi(const ssr_plan* pl, const float* est, cons
   }
   // key 0 with the target: metrics in the epilogue, both images written
   double* part0 = (double*)(ws + m.off_part_a);
-  if ((rc = stft(est, est_off, tgt, tgt_off, mask, plane_of(0), tgt_plane, part0))) return rc;
+  if ((rc = est_tgt(0, mask, plane_of(0), tgt_plane, part0))) return rc;
   // keys 1 .. in pairs: two estimates per complex transform, images only
   int k = 1;
   for (; k + 1 < n_keys; k += 2)
-    if ((rc = stft(est, est_off + (size_t)k * n_items, est, est_off + (size_t)(k + 1) * n_items, 0u, plane_of(k), plane_of(k + 1), nullptr))) return rc;
+    if ((rc = est_est(k, plane_of(k), plane_of(k + 1)))) return rc;
   const int n_spec = k - 1;               // keys 1 .. k - 1 get their reductions from the images
   double* part_last = (double*)(ws + m.off_part_a + part_a_bytes);
   const bool odd_last = k < n_keys;
   if (odd_last)                           // one estimate left: with the target again, whose rows are NOT rewritten (out_b = null)
-    if ((rc = stft(est, est_off + (size_t)k * n_items, tgt, tgt_off, mask, plane_of(k), nullptr, part_last))) return rc;
+    if ((rc = est_tgt(k, mask, plane_of(k), nullptr, part_last))) return rc;
   if (n_spec > 0 && red_mask) {
     SsrSpecWaveParams q{plane_of(1), tgt_plane, frame_off, rows, pl->n_bins, pitch, (int)red_mask, m.spec_rows_per_chunk, m.spec_chunks, n_items,
                         (int64_t)(m.plane / sizeof(float)), (double*)(ws + m.off_part_s)};
@@ -422,6 +440,30 @@ extern "C" int ssr_pair_metrics_multi(const ssr_plan* pl, const float* est, cons
     HIP_TRY(finalize(red_mask ? (const double*)(ws + m.off_part_s) : nullptr, m.spec_chunks, ssim_part + (size_t)n_items * m.n_tiles, n_spec * n_items, 1));
   if (odd_last) HIP_TRY(finalize(part_last, m.w.n_chunks, ssim_part + (size_t)k * n_items * m.n_tiles, n_items, k));
   return SSR_OK;
+}
+
+extern "C" int ssr_pair_metrics_multi(const ssr_plan* pl, const float* est, const int64_t* est_off, const float* tgt, const int64_t* tgt_off,
+                                      const int32_t* len, const int64_t* frame_off, int n_items, int n_keys, int max_len, int64_t total_rows,
+                                      unsigned mask, double* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!est) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  return pair_metrics_multi_impl(pl, est, nullptr, est_off, tgt, tgt_off, len, frame_off, n_items, n_keys, max_len, total_rows, mask, out,
+                                 workspace, workspace_bytes, stream);
+}
+
+// K float64 estimates per float32 target (ssr_hip.h): key 0 through the float64-estimate pair kernel with the target, the others two per
+// complex transform into float32 magnitude rows (|.| of the unrounded float64 spectrum, rounded once), their terms from k_specred_wave
+extern "C" size_t ssr_pair_metrics_multi_est64_workspace_bytes(const ssr_plan* pl, int n_items, int n_keys, int max_len, int64_t total_rows,
+                                                               unsigned metric_mask) {
+  if (!pl || n_items <= 0 || n_keys <= 0) return 0;
+  return multi_ws(pl, n_items, n_keys, max_len, total_rows, metric_mask, true).total;
+}
+extern "C" int ssr_pair_metrics_multi_est64(const ssr_plan* pl, const double* est, const int64_t* est_off, const float* tgt, const int64_t* tgt_off,
+                                            const int32_t* len, const int64_t* frame_off, int n_items, int n_keys, int max_len,
+                                            int64_t total_rows, unsigned mask, double* out, void* workspace, size_t workspace_bytes,
+                                            void* stream) {
+  if (!est) return ssr_fail(SSR_ERR_INVALID_ARG, "null argument");
+  return pair_metrics_multi_impl(pl, nullptr, est, est_off, tgt, tgt_off, len, frame_off, n_items, n_keys, max_len, total_rows, mask, out,
+                                 workspace, workspace_bytes, stream);
 }
 
 // ----------------------------------------------------------------------------------------------------

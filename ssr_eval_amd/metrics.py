@@ -98,24 +98,45 @@ class AudioMetrics:
 
     def evaluation_multi(self, ests_by_key, targets, mask=B.M_ALL, resident=False, deferred=False):
         """K estimates per target (the degradation keys of a file, ssr_eval/eval.py:136-154): ests_by_key = K lists of n
-        waveforms, targets = n waveforms -> n lists of K dicts.  One ssr_pair_metrics_multi launch sequence: every target is
-        transformed once.  Needs float32 signals and, per item, one truncated length for all keys (metrics.py:89-90) - otherwise
-        (or for K = 1) the pairs go through evaluation_batch.  deferred: as evaluation_batch."""
+        waveforms, targets = n waveforms -> n lists of K dicts.  Every target is transformed once per GROUP of keys: the float32 keys
+        of the files (FFT low-pass, subsampling, mp3) through one ssr_pair_metrics_multi launch sequence, the float64 keys (every IIR
+        design: sosfiltfilt returns float64 and the reference keeps it, eval.py:138-150) through one ssr_pair_metrics_multi_est64.
+        Needs float32 targets and, per item, one truncated length for all keys (metrics.py:89-90) - otherwise (and for a group of a
+        single key) the pairs go through evaluation_batch.  deferred: as evaluation_batch."""
         K, n = len(ests_by_key), len(targets)
         pairs = [[self._prepare_pair(ests_by_key[k][i], targets[i], resident) for i in range(n)] for k in range(K)]
         same_len = all(len({pairs[k][i][0].shape[0] for k in range(K)}) == 1 for i in range(n))
-        f32 = not any(B._is_f64(pairs[k][i][0]) or B._is_f64(pairs[k][i][1]) for k in range(K) for i in range(n))
-        if K < 2 or n == 0 or not same_len or not f32:
+        tgt32 = not any(B._is_f64(pairs[k][i][1]) for k in range(K) for i in range(n))
+        # a key is float64 / float32 if ALL its estimates are; a key with both kinds sends everything through evaluation_batch
+        kinds = [{bool(B._is_f64(pairs[k][i][0])) for i in range(n)} for k in range(K)]
+        if K < 2 or n == 0 or not same_len or not tgt32 or any(len(kd) != 1 for kd in kinds):
             flat = self.evaluation_batch([ests_by_key[k][i] for i in range(n) for k in range(K)],
                                          [targets[i] for i in range(n) for _ in range(K)], mask, resident, deferred=True)
             finish = lambda: (lambda rows: [rows[i * K:(i + 1) * K] for i in range(n)])(flat())    # noqa: E731
             return finish if deferred else finish()
-        pending = B.pair_metrics_multi(self._plan(), [[pairs[k][i][0] for i in range(n)] for k in range(K)],
-                                       [pairs[0][i][1] for i in range(n)], mask, deferred=True)
+        tgts = [pairs[0][i][1] for i in range(n)]
+        parts = []                                                   # (key indices, wide, collector -> [n][len(keys)] dicts)
+        for wide in (False, True):
+            keys = [k for k in range(K) if next(iter(kinds[k])) == wide]
+            if not keys:
+                continue
+            if len(keys) == 1:
+                k = keys[0]
+                flat = self.evaluation_batch([pairs[k][i][0] for i in range(n)], tgts, mask, True, deferred=True)
+                parts.append((keys, (lambda f: (lambda: [[row] for row in f()]))(flat)))
+            else:
+                pending = B.pair_metrics_multi(self._plan(), [[pairs[k][i][0] for i in range(n)] for k in keys], tgts, mask, deferred=True)
+                parts.append((keys, (lambda pnd, nk, w: (lambda: (lambda vals: [[self._row_dict(vals[i, j], mask, w) for j in range(nk)]
+                                                                                for i in range(n)])(pnd())))(pending, len(keys), wide)))
 
         def finish():
-            vals = pending()
-            return [[self._row_dict(vals[i, k], mask, False) for k in range(K)] for i in range(n)]
+            out = [[None] * K for _ in range(n)]
+            for keys, collect in parts:
+                rows = collect()
+                for i in range(n):
+                    for j, k in enumerate(keys):
+                        out[i][k] = rows[i][j]
+            return out
         return finish if deferred else finish()
 
     # ---- reductions on [B, C, T, F] tensors (est first)

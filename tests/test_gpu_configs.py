@@ -1055,6 +1055,78 @@ def test_pair_metrics_multi_equals_k_calls_of_pair_metrics(n_fft, hop, K):
             np.testing.assert_allclose(g[ok], want[ok], rtol=1e-6, atol=1e-6, err_msg="key %d mask %d" % (k, mask))
 
 
+@pytest.mark.parametrize("n_fft,hop", [(2229, 480), (2048, 441), (1486, 320)])
+@pytest.mark.parametrize("K", [2, 3, 6, 9])
+def test_pair_metrics_multi_est64_equals_k_calls_of_est64(n_fft, hop, K):
+    """ssr_pair_metrics_multi_est64 (K float64 IIR keys of a file against its one float32 target) against K calls of
+    ssr_pair_metrics_est64: real zero-phase IIR estimates (stop bands at the float64 round-off floor - what makes the float64 path
+    necessary), ragged items.  2229: the two-estimates-per-transform kernel of the rotating engine - key 0 and an odd last key bit for
+    bit, the others to 1e-6 (include/ssr_hip.h says why); 2048 / 1486: K plain passes, every key bit for bit.  Also against the oracle."""
+    from ssr_eval_amd import backend as B
+    from oracle import lowpass as olp, metrics as om
+    rng = np.random.default_rng(n_fft + K)
+    lens = (30000, 41000, 9000, 7 * hop + 100)
+    tgts = [(0.1 * rng.standard_normal(n)).astype(np.float32) for n in lens]
+    tgts[1][9000:15000] = 0.0                                                 # a silent stretch
+    designs = [olp.iir_sos(hc, 44100, order, ft) for ft in ("butter", "cheby1", "ellip") for hc in (2000, 8000, 12000) for order in (2, 8)][:K]
+    ests = [[signal.sosfiltfilt(sos, t) for t in tgts] for sos in designs]
+    assert all(e.dtype == np.float64 for key in ests for e in key)
+    plan = B.get_plan(n_fft, hop, "f64")
+    for mask in (B.M_ALL, B.M_LSD | B.M_SSIM, B.M_LSD):
+        got = B.pair_metrics_multi(plan, ests, tgts, mask)
+        assert got.shape == (len(lens), K, 4)
+        for k in range(K):
+            want = B.pair_metrics(plan, ests[k], tgts, mask)
+            g = got[:, k]
+            assert np.array_equal(np.isnan(g), np.isnan(want)), (k, mask)
+            ok = ~np.isnan(want)
+            if k == 0 or n_fft != 2229 or (k == K - 1 and K % 2 == 0):
+                np.testing.assert_array_equal(g[:, :3][ok[:, :3]], want[:, :3][ok[:, :3]])
+            np.testing.assert_allclose(g[ok], want[ok], rtol=1e-6, atol=1e-6, err_msg="key %d mask %d" % (k, mask))
+    got = B.pair_metrics_multi(plan, ests, tgts, B.M_ALL)
+    for k in (0, 1, K - 1):
+        for i in (0, 2):
+            want = _vec(om.evaluation(ests[k][i], tgts[i], n_fft=n_fft, hop=hop))
+            np.testing.assert_allclose(got[i, k][[0, 3]], want[[0, 3]], rtol=2e-6)
+            # the reference's pow_p_norm(target) is a FLOAT32 torch.norm whose own summation error enters its float64 SISpec (here up to
+            # 9e-6 dB on a log-SISpec of -0.5 dB: 1.8e-5 of the value, 2e-6 of the energy ratio; the kernels equal the float64 evaluation
+            # of the formula): 1e-5 relative, or 5e-5 dB where the value is near 0 dB (DESIGN 4, SISpec accounting)
+            np.testing.assert_allclose(got[i, k][[1, 2]], want[[1, 2]], rtol=1e-5, atol=5e-5)
+
+
+def test_evaluate_arrays_scores_iir_keys_through_the_est64_multi_entry(monkeypatch):
+    """SSR_Eval_Helper.evaluate_arrays with IIR keys (float64) next to FFT keys (float32): the keys of a file are split by dtype, each
+    group goes through ONE multi launch sequence (ssr_pair_metrics_multi_est64 / ssr_pair_metrics_multi), and every value is what the
+    per-pair path returns for that key."""
+    from ssr_eval_amd import SSR_Eval_Helper, BasicTestee, backend as B
+    seen = []
+    orig = B.pair_metrics_multi
+
+    def spy(plan, est_lists, tgt_list, *a, **k):
+        seen.append((len(est_lists), bool(B._is_f64(est_lists[0][0]))))
+        return orig(plan, est_lists, tgt_list, *a, **k)
+    monkeypatch.setattr(B, "pair_metrics_multi", spy)
+    h = SSR_Eval_Helper(BasicTestee(), input_sr=44100, output_sr=44100, evaluation_sr=48000, test_data_root=None,
+                        setting_fft={"cutoff_freq": [2000, 8000]},
+                        setting_lowpass_filtering={"filter": ["cheby", "butter", "bessel"], "cutoff_freq": [4000], "filter_order": [2, 6]})
+    rng = np.random.default_rng(18)
+    items = []
+    for n in (20000, 31000, 26000):
+        x = (0.1 * rng.standard_normal(n)).astype(np.float32)
+        items.append((signal.resample_poly(x, 160, 147).astype(np.float32), x))
+    res = h.evaluate_arrays(items)
+    assert sorted(seen) == [(2, False), (6, True)] and all(len(r) == 8 for r in res)
+    for (tgt, x), r in zip(items, res):
+        d = h.preprocess_array(x, 44100)
+        assert list(d.keys()) == list(r.keys())
+        for key, y in d.items():
+            y = np.asarray(y)
+            assert (y.dtype == np.float64) == ("fft" not in key)
+            y48 = signal.resample_poly(y, 160, 147)
+            want = h.audio_metrics.evaluation(y48 if y.dtype == np.float64 else y48.astype(np.float32), tgt, "")
+            np.testing.assert_allclose(_vec(r[key]), _vec(want), rtol=2e-6, atol=2e-6)
+
+
 def test_cfg3_through_pair_metrics_multi_against_the_oracle():
     """cfg-3's sweep through the new entry: 16 targets x 7 cutoffs of 4 s @ 48 kHz, the seven low-passed estimates of a target written
     key-major into one buffer, ONE ssr_pair_metrics_multi launch sequence (8 real transforms per target instead of 14), every

@@ -74,7 +74,8 @@ def main():
             f, c, o = os.environ["IIR"].split(":")
             kw["setting_lowpass_filtering"] = {"filter": f.split(","), "cutoff_freq": [int(v) for v in c.split(",")],
                                                "filter_order": [int(v) for v in o.split(",")]}
-        h = SSR_Eval_Helper(BasicTestee(), input_sr=44100, output_sr=44100, evaluation_sr=48000, test_data_root=root, **kw)
+        eval_sr = int(os.environ.get("EVAL_SR", 48000))      # 48000: the reference's README / test.py; 44100: its signature default (2048 / 441)
+        h = SSR_Eval_Helper(BasicTestee(), input_sr=44100, output_sr=44100, evaluation_sr=eval_sr, test_data_root=root, **kw)
         bf = int(os.environ["BATCH_FILES"]) if os.environ.get("BATCH_FILES") else None      # None: the helper's default_batch_files()
         h.evaluate(limit_test_nums=2, limit_test_speaker=1, save_json=False)
         h.evaluate(save_json=False, batch_files=bf)

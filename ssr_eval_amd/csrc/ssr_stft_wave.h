@@ -58,6 +58,10 @@ constexpr int SSR_W_TWP = 7 * 32 + 12 * 64;                   // lane-ordered tw
 SSR_DEV int ssr_wpad(int i) { return i + (i >> 5); }            // lane stride 32 -> 33 doubles: conflict-free ds_*_b64
 constexpr int SSR_W_PN = SSR_W_N + (SSR_W_N >> 5) + 1;
 constexpr int SSR_W_IMOFF = 1024 + 32;    // SPLIT: the upper-half imaginary parts of the final exchange sit behind the real parts
+constexpr int SSR_W_ROWB = 4 * 1028;      // ROWS_VIA_LDS: bytes between the two staged magnitude rows (1025 bins, 16-byte aligned)
+#ifndef SSR_WAVE_ROWS_VIA_LDS
+#define SSR_WAVE_ROWS_VIA_LDS 0           // developer build: 1 (measured: a null - see ROWS_VIA_LDS below)
+#endif
 
 // exp(-2 pi i m / 32), m = 0..21 (the exponents n2 * k1 of the in-lane 4 x 8 decomposition)
 template <typename T> SSR_DEV cx<T> ssr_w32(int m) {
@@ -318,6 +322,13 @@ template <typename T, bool SUMS, bool SPLIT, int MAG = -1, typename BLK>
 SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk, int item, char* lds_base) {
   constexpr int N = SSR_W_N, F = N / 2 + 1;
   constexpr bool PAIRED = SSR_WAVE_PAIRED != 0;
+  // Developer variant (round 6, -DSSR_WAVE_ROWS_VIA_LDS=1; NOT the product): the two magnitude rows of a frame leave as 2 x 4 aligned
+  // 16-byte stores per lane instead of 2 x 16 dword stores - laid out in bin order in the wave's exchange array (free between the last
+  // pass and the next frame's first exchange; the DS operations of a wave execute in order) and read back four consecutive bins per
+  // lane.  The premise: the address unit is busy 60-67 % of this kernel and its address FIFO fills 16x as often as in the variant that
+  // stores no rows (profiles/r06_stft_wave_vmem_path.txt).  Measured: 136 -> 112 vector-memory instructions per frame pair, the same
+  // time (2.34 ms alternating on one box, three rounds; same magnitudes, 84 tests) - the 0.5 ms the rows cost is not instruction count.
+  constexpr bool ROWS_VIA_LDS = PAIRED && SSR_WAVE_ROWS_VIA_LDS != 0;
   using Regs = SsrWaveRegs<T, SUMS>;
   SsrWaveLds<T, SPLIT> L(lds_base);
   const int n = p.len[item], hop = p.hop;
@@ -435,6 +446,7 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
       const SsrRwView<float> wa(ra0, store ? F : 0), wb(rb0, (store && rb0 != nullptr) ? F : 0);   // out_b == null: the target rows
       // are not written (ssr_pair_metrics_multi: they exist already) - the stores fall to the buffer range check
       const int lane4 = 4 * tid;
+      char* mrows = reinterpret_cast<char*>(L.re);                 // ROWS_VIA_LDS: [est row | target row], SSR_W_ROWB bytes apart
       // byte offset of bin j_b + 256 q in a magnitude row: lane part + immediate
       const int lane4_2 = PAIRED ? 4 * (192 - tid) : 0, lane4_3 = PAIRED ? 4 * ssr_wave_pj3(tid) : 0;
       auto bin_off = [&](int b, int q) -> int {
@@ -489,10 +501,17 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
               e = f2_make(e0, e1); t = f2_make(t0, t1);
             }
             if (store) {
-              wa.st_raw(bin_off(b, q0 + q), e.x);
-              wa.st_raw(bin_off(b, q0 + q + 1), e.y);
-              wb.st_raw(bin_off(b, q0 + q), t.x);
-              wb.st_raw(bin_off(b, q0 + q + 1), t.y);
+              if constexpr (ROWS_VIA_LDS) {                          // the two rows in bin order in the exchange array (free until the next exchange)
+                *reinterpret_cast<float*>(mrows + bin_off(b, q0 + q)) = e.x;
+                *reinterpret_cast<float*>(mrows + bin_off(b, q0 + q + 1)) = e.y;
+                *reinterpret_cast<float*>(mrows + SSR_W_ROWB + bin_off(b, q0 + q)) = t.x;
+                *reinterpret_cast<float*>(mrows + SSR_W_ROWB + bin_off(b, q0 + q + 1)) = t.y;
+              } else {
+                wa.st_raw(bin_off(b, q0 + q), e.x);
+                wa.st_raw(bin_off(b, q0 + q + 1), e.y);
+                wb.st_raw(bin_off(b, q0 + q), t.x);
+                wb.st_raw(bin_off(b, q0 + q + 1), t.y);
+              }
             }
           }
           if (PAIRED && b == 0 && q0 + G == 4) {
@@ -540,6 +559,23 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
         for (int q = 0; q < 6; ++q) SSR_LDS_ACCUM(lsum + 64 * q + tid, acc[1 + q]);
       SSR_CLK(5);
     });
+    if constexpr (ROWS_VIA_LDS) {
+      SSR_WPHASE(blk, regs, {
+        const bool store = MAG < 0 ? p.out_kind == SSR_OUT_MAG : MAG != 0;
+        if (store) {                                                // (wave-uniform)
+          const SsrRwView<float> wa(ra0, F), wb(rb0, rb0 != nullptr ? F : 0);
+          const char* mrows = reinterpret_cast<const char*>(L.re);
+          SSR_UNROLL for (int j = 0; j < 4; ++j) {                  // bins 4 tid + 256 j .. + 3 (bin 1024 went out with lane 0's own store)
+            const int off = 16 * tid + 1024 * j;
+            const float* ea = reinterpret_cast<const float*>(mrows + off);
+            const float* ta = reinterpret_cast<const float*>(mrows + SSR_W_ROWB + off);
+            const float e0 = ea[0], e1 = ea[1], e2 = ea[2], e3 = ea[3], t0 = ta[0], t1 = ta[1], t2 = ta[2], t3 = ta[3];
+            wa.st_raw4(off, e0, e1, e2, e3);
+            wb.st_raw4(off, t0, t1, t2, t3);
+          }
+        }
+      });
+    }
 #ifdef SSR_CLK_NOW
     for (int q = 0; q < 5; ++q) clk_sum[q] += clk_[q + 1] - clk_[q];
     clk_top[0] += clk_[6] - clk_[0]; clk_top[1] += clk_[7] - clk_[6];

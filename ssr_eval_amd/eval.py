@@ -469,12 +469,15 @@ class SSR_Eval_Helper:
         per_file = n_iir * 10 * 48000 * 8 * 2                      # a 10 s file at 48 kHz, float64, filtered + resampled
         return int(max(64, min(256, (free // 4) // max(per_file, 1))))
 
-    def evaluate(self, limit_test_nums=-1, limit_test_speaker=-1, save_json=True, batch_files=None, shard="round-robin"):
+    def evaluate(self, limit_test_nums=-1, limit_test_speaker=-1, save_json=True, batch_files=None, shard="round-robin",
+                 pipeline_streams=None):
         """eval.py:171-227: walk speakers/files, evaluate, aggregate as mean of speaker means, write JSON.
         Files are evaluated `batch_files` at a time (one ragged launch sequence per batch; None: default_batch_files()).  With
         torch.distributed initialised the (speaker, file) list is sharded over the ranks - round-robin, or shard="balanced":
         by audio duration read from the file headers, longest first to the lightest rank (every rank computes the
-        same deal) - and the per-utterance rows are exchanged once (ssr_eval_amd.dist); every rank returns the full result."""
+        same deal) - and the per-utterance rows are exchanged once (ssr_eval_amd.dist); every rank returns the full result.
+        pipeline_streams: 2 (default; SSR_EVAL_STREAMS) = consecutive batches on alternating GPU streams, 1 = everything on the
+        caller's stream; the results do not depend on it."""
         from datetime import datetime
         work = []                                                   # (speaker, file) in the reference's order
         speakers = []
@@ -510,10 +513,24 @@ class SSR_Eval_Helper:
         # collected only after the next batch has been queued (no host wait in between - backend._h2d, backend.Pending)
         # (the reads of batch k+1 are started AFTER batch k has been queued: sixteen reader threads next to the launching thread
         # cost it 2-3 ms per batch; they run while it waits for batch k-1's values instead)
+        # ... and on the GPU consecutive batches alternate between TWO streams (round 6): nothing orders batch k + 1's kernels behind batch
+        # k's, so a latency-bound launch of one batch - the IIR recurrences: a third of a wave per SIMD for tens of milliseconds - runs
+        # under the transforms of the other instead of in front of them.  Each batch's tensors live in its own stream's pool, its result
+        # is collected through an event of its own stream (backend.Pending), the staging arenas alternate with the streams.
+        n_streams = int(os.environ.get("SSR_EVAL_STREAMS", "2")) if pipeline_streams is None else int(pipeline_streams)
+        streams = None
+        if n_streams > 1 and len(batches) > 1 and torch.cuda.is_available():
+            streams = self._pipeline_streams = getattr(self, "_pipeline_streams", None) or [torch.cuda.Stream(device=self._device) for _ in range(2)]
+            for st in streams:
+                st.wait_stream(torch.cuda.current_stream(self._device))            # (whatever the caller queued before evaluate())
         collect = None
         for k, batch in enumerate(batches):
             decoded = ahead()
-            queued = self.evaluate_files(batch, decoded, deferred=True)
+            if streams is not None:
+                with torch.cuda.stream(streams[k % 2]):
+                    queued = self.evaluate_files(batch, decoded, deferred=True)
+            else:
+                queued = self.evaluate_files(batch, decoded, deferred=True)
             ahead = decode_packed_async(batches[k + 1], self._device) if k + 1 < len(batches) else None
             if collect is not None:
                 local += collect()

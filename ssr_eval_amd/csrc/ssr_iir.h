@@ -89,7 +89,7 @@ template <typename X> static inline void ssr_iir_item_host(const SsrIirParamsT<X
 //   * G lanes per utterance = the smallest power of two >= n_sections (1, 2, 4, 8, 16): every lane of a group owns a section, a wave
 //     carries 64 / G utterances (an order-2 design: 64) - the same recurrences on a sixth of the waves;
 //   * a chunk is SSR_IIR_CK = 16 steps: lane 0's sixteen input samples sit in registers, loaded TWO chunks ahead with 16-byte
-//     vector loads (three rotating buffers), the last section's sixteen outputs leave with 16-byte vector stores - a step is the nine
+//     vector loads (SSR_IIR_NB = 3 rotating buffers), the last section's sixteen outputs leave with 16-byte vector stores - a step is the nine
 //     float64 operations of SciPy's statement sequence plus (G > 1) the DPP hand-off from the lane below: no LDS, no exec masking;
 //   * a chunk in which some lane starts or ends its signal, or that touches the odd extension, takes the general per-step path
 //     (a few chunks per utterance).  Lanes whose utterance has ended (or that have none) run on: nothing they compute is stored;
@@ -102,6 +102,9 @@ template <typename X> static inline void ssr_iir_item_host(const SsrIirParamsT<X
 #include <type_traits>
 
 constexpr int SSR_IIR_CK = 16;   // steps per chunk
+#ifndef SSR_IIR_NB
+#define SSR_IIR_NB 3             // rotating input buffers: requests run NB - 1 chunks ahead (5: 242 VGPRs, the same time - measured)
+#endif
 
 typedef double ssr_d2u __attribute__((ext_vector_type(2), aligned(8)));    // 16-byte accesses at the signals' own alignment
 typedef float ssr_f4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -221,14 +224,22 @@ SSR_DEV void ssr_iir_pass(const SsrIirLane<X>& q, int s, int S, int edge, double
       SSR_UNROLL for (int j = 0; j < CK / 2; ++j) { ssr_d2u v; v.x = yv[2 * j]; v.y = yv[2 * j + 1]; dst[j] = v; }
     }
   };
-  // three regular chunks on three rotating buffers: chunk c + 2's inputs are requested before chunk c runs.  Straight-line: four
-  // loads, sixteen steps, eight stores, three times - the compiler's memory-counter waits are then exact (vmcnt = the requests
-  // issued since), and a wait for inputs requested two chunks ago never waits for a store or a younger load
-  XT ba[CK], bb[CK], bc[CK];
-  auto three_regular = [&](int c) __attribute__((always_inline)) {
-    load_regular(c + 2, bc); run_regular(c, ba);
-    load_regular(c + 3, ba); run_regular(c + 1, bb);
-    load_regular(c + 4, bb); run_regular(c + 2, bc);
+  // NB regular chunks on NB rotating buffers: chunk c + NB - 1's inputs are requested before chunk c runs.  Straight-line: four
+  // loads, sixteen steps, eight stores, NB times - the compiler's memory-counter waits are then exact (vmcnt = the requests issued
+  // since), and a wait for inputs requested NB - 1 chunks ago never waits for a store or a younger load.  (NB = 5 - 64 steps between
+  // a request and its use - runs at the same 34-39 ns per step as NB = 3: the loop is not waiting for its inputs any more.)
+  constexpr int NB = SSR_IIR_NB;
+  XT buf[NB][CK];
+  auto nb_regular = [&](int c) __attribute__((always_inline)) {
+    SSR_UNROLL for (int j = 0; j < NB; ++j) {
+      load_regular(c + j + NB - 1, buf[(j + NB - 1) % NB]);        // (the buffer the previous sub-step consumed)
+      run_regular(c + j, buf[j]);
+    }
+  };
+  auto nb_are_regular = [&](int c) -> bool {
+    bool ok = true;
+    SSR_UNROLL for (int j = 0; j < NB; ++j) ok = ok && regular(c + j);
+    return ok;
   };
 
   // ---- any other chunk (a lane starts or ends in it, or it touches the odd extension): general loads, per-step predicates
@@ -258,18 +269,17 @@ SSR_DEV void ssr_iir_pass(const SsrIirLane<X>& q, int s, int S, int edge, double
 
   int c = 0;
   while (c < n_chunks) {                                          // (wave-uniform conditions throughout)
-    if (regular(c) && regular(c + 1) && regular(c + 2)) {
-      // a run of regular chunks.  The first three are peeled so that the loop is entered with the memory requests of a full
+    if (nb_are_regular(c)) {
+      // a run of regular chunks.  The first NB are peeled so that the loop is entered with the memory requests of a full
       // iteration behind it: preheader and back edge then agree on how many requests follow each buffer's loads
-      load_regular(c, ba);
-      load_regular(c + 1, bb);
-      three_regular(c);
-      c += 3;
-      while (c < n_chunks && regular(c) && regular(c + 1) && regular(c + 2)) {
-        three_regular(c);
-        c += 3;
+      SSR_UNROLL for (int j = 0; j < NB - 1; ++j) load_regular(c + j, buf[j]);
+      nb_regular(c);
+      c += NB;
+      while (c < n_chunks && nb_are_regular(c)) {
+        nb_regular(c);
+        c += NB;
       }
-      // (the two buffers requested ahead are dropped: whoever runs those chunks loads them again)
+      // (the buffers requested ahead are dropped: whoever runs those chunks loads them again)
     } else {
       run_general(c);
       c += 1;

@@ -50,7 +50,8 @@ __global__ __launch_bounds__(64) void k_iir_steps(double* out, int iters, double
       xin = xin_n; p0 = p0_n;
       if (k == 15) acc += yo;
     }
-    asm volatile("" : "+v"(xs[0]), "+v"(xs[5]));
+#pragma unroll
+    for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(xs[k]));      // (opaque per iteration: the products with x are not loop-invariant)
   }
   out[blockIdx.x * 64 + threadIdx.x] = acc + z0 + z1;
 }

@@ -476,8 +476,8 @@ class SSR_Eval_Helper:
         torch.distributed initialised the (speaker, file) list is sharded over the ranks - round-robin, or shard="balanced":
         by audio duration read from the file headers, longest first to the lightest rank (every rank computes the
         same deal) - and the per-utterance rows are exchanged once (ssr_eval_amd.dist); every rank returns the full result.
-        pipeline_streams: 2 (default; SSR_EVAL_STREAMS) = consecutive batches on alternating GPU streams, 1 = everything on the
-        caller's stream; the results do not depend on it."""
+        pipeline_streams: 1 (default; SSR_EVAL_STREAMS) = everything on the caller's stream, 2 = consecutive batches on alternating
+        GPU streams (opt-in, see below); the results do not depend on it."""
         from datetime import datetime
         work = []                                                   # (speaker, file) in the reference's order
         speakers = []
@@ -517,7 +517,10 @@ class SSR_Eval_Helper:
         # k's, so a latency-bound launch of one batch - the IIR recurrences: a third of a wave per SIMD for tens of milliseconds - runs
         # under the transforms of the other instead of in front of them.  Each batch's tensors live in its own stream's pool, its result
         # is collected through an event of its own stream (backend.Pending), the staging arenas alternate with the streams.
-        n_streams = int(os.environ.get("SSR_EVAL_STREAMS", "2")) if pipeline_streams is None else int(pipeline_streams)
+        # OPT-IN (pipeline_streams=2 / SSR_EVAL_STREAMS=2; measured +4-5 % files/s on the FFT-key pass, nothing on the host-bound IIR pass):
+        # device objects that are cached across batches and replaced when they grow (the sinc plan's time register, staging twins) are
+        # ordered by ONE stream today - with two, a replaced tensor can return to its pool while the other stream still reads it.
+        n_streams = int(os.environ.get("SSR_EVAL_STREAMS", "1")) if pipeline_streams is None else int(pipeline_streams)
         streams = None
         if n_streams > 1 and len(batches) > 1 and torch.cuda.is_available():
             streams = self._pipeline_streams = getattr(self, "_pipeline_streams", None) or [torch.cuda.Stream(device=self._device) for _ in range(2)]

@@ -339,6 +339,10 @@ def test_cabi_round4_entry_points_validate_before_the_device():
     assert lib.ssr_resample_poly_chain(p, p, p, p, p, p, 4, 1000, 441, 160, p, 8821, 28, 80, 147, p, 3201, 11, p, None) == _lib.ERR_UNSUPPORTED
     assert lib.ssr_pair_metrics_multi(None, p, p, p, p, p, p, 2, 3, 4096, 18, 15, p, p, 1 << 20, None) == _lib.ERR_INVALID_ARG
     assert lib.ssr_pair_metrics_multi_workspace_bytes(None, 2, 3, 4096, 18, 15) == 0
+    # ... and its float64-estimate twin (round 6)
+    assert lib.ssr_pair_metrics_multi_est64(None, p, p, p, p, p, p, 2, 3, 4096, 18, 15, p, p, 1 << 20, None) == _lib.ERR_INVALID_ARG
+    assert lib.ssr_pair_metrics_multi_est64(p, None, p, p, p, p, p, 2, 3, 4096, 18, 15, p, p, 1 << 20, None) == _lib.ERR_INVALID_ARG
+    assert lib.ssr_pair_metrics_multi_est64_workspace_bytes(None, 2, 3, 4096, 18, 15) == 0
     h = C.c_void_p()
     assert lib.ssr_plan_create_ex(1, 441, None, 1, 0, C.byref(h)) == _lib.ERR_INVALID_ARG        # n_fft < 2
     assert lib.ssr_plan_create_ex(2048, 441, None, 1, 7, C.byref(h)) == _lib.ERR_INVALID_ARG     # unknown pad mode

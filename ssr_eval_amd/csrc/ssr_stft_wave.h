@@ -507,10 +507,17 @@ SSR_BODY void ssr_stft_wave_body(const SsrStftParams<T>& p, BLK& blk, int chunk,
                 *reinterpret_cast<float*>(mrows + SSR_W_ROWB + bin_off(b, q0 + q)) = t.x;
                 *reinterpret_cast<float*>(mrows + SSR_W_ROWB + bin_off(b, q0 + q + 1)) = t.y;
               } else {
+#ifdef SSR_WAVE_ROWS_NT                                              /* developer build: the rows as streaming (nt) stores */
+                wa.st_raw_nt(bin_off(b, q0 + q), e.x);
+                wa.st_raw_nt(bin_off(b, q0 + q + 1), e.y);
+                wb.st_raw_nt(bin_off(b, q0 + q), t.x);
+                wb.st_raw_nt(bin_off(b, q0 + q + 1), t.y);
+#else
                 wa.st_raw(bin_off(b, q0 + q), e.x);
                 wa.st_raw(bin_off(b, q0 + q + 1), e.y);
                 wb.st_raw(bin_off(b, q0 + q), t.x);
                 wb.st_raw(bin_off(b, q0 + q + 1), t.y);
+#endif
               }
             }
           }

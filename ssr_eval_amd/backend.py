@@ -954,7 +954,12 @@ def resample_poly(wavs, up, down, device=None, exact=True):
     multiply-adds, ~1 ulp per tap from SciPy's values, 1.2-1.5x the rate)."""
     dev = torch.device(device) if device is not None else default_device()
     with torch.cuda.device(dev):
-        r = wavs if isinstance(wavs, Ragged) else Ragged.from_list_keep64(wavs, dev)
+        # views into ONE device buffer in increasing address order are read where they lie (the kernels take an offset per signal):
+        # the IIR keys of a batch - [design][file] slices of ssr_sosfiltfilt_multi's output - used to be concatenated again here
+        # (11 GB and 13 k per-signal calls per evaluate() batch of 256 files x 36 keys)
+        r = wavs if isinstance(wavs, Ragged) else Ragged.from_list_keep64(wavs, dev, allow_gaps=True)
+        if not r.packed and ResamplePlan.get(up, down, dev).identity:
+            r = Ragged.from_list_keep64(wavs, dev)              # (the identity plan copies the packed buffer)
         b = ResampleBatch(r, up, down, exact=exact)
         out = b.run()
         return [out[b.out_off[i]:b.out_off[i] + b.out_len[i]] for i in range(r.n)]

@@ -365,8 +365,13 @@ class SSR_Eval_Helper:
                 all_extra.append(e); owner.append(i)
         if self.model_output_sr != self.evaluationset_sr and all_proc:
             # eval.py:144-150; float64 and float32 outputs are resampled in their own dtype
+            # (key-major order: the IIR keys are [design][file] slices of one buffer - in that order resample_poly reads them where they
+            # lie, and its output is already grouped by key for the metric stage)
+            seen, pos = collections.Counter(), []
+            for o_ in owner:
+                pos.append(seen[o_]); seen[o_] += 1
             for want64 in (False, True):
-                idx = [i for i, o in enumerate(all_proc) if B._is_f64(o) == want64]
+                idx = sorted((i for i, o in enumerate(all_proc) if B._is_f64(o) == want64), key=lambda i: (pos[i], owner[i]))
                 if idx:
                     ys = B.resample_poly([all_proc[i] for i in idx], self.evaluationset_sr, self.model_output_sr, self._device)
                     for i, y in zip(idx, ys):

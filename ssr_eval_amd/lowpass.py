@@ -11,6 +11,8 @@
   zero-phase filtering itself (odd extension, forward and backward second-order-section recurrences) runs on the
   GPU, bit-identical to ``scipy.signal.sosfiltfilt`` for float32 and for float64 input.
 """
+import functools
+
 import numpy as np
 import torch
 
@@ -59,6 +61,8 @@ def stft_hard_lowpass_multi(datas, ratios, device=None, keep_on_device=False, en
 
 def align_length(x, y):
     """Zero-pad or cut y to len(x) (lowpass.py:31-51)."""
+    if y.shape[0] == x.shape[0]:                  # (what every filter of this module returns: nothing to pad or cut)
+        return y
     if len(y) < len(x):
         if isinstance(y, torch.Tensor):
             return torch.nn.functional.pad(y, (0, len(x) - len(y)))
@@ -99,7 +103,13 @@ def limit(integer, high, low):
 
 
 def _design(highcut, fs, order, ftype, lowcut=None):
-    """Section design of lowpass.py:70-85 / :110-125 (SciPy on the host: a plan, not data)."""
+    """Section design of lowpass.py:70-85 / :110-125 (SciPy on the host: a plan, not data; cached per argument tuple - an evaluate()
+    pass asks for the same 36 designs once per batch of files).  The caller gets its own copy."""
+    return _design_cached(highcut, fs, order, ftype, lowcut).copy()
+
+
+@functools.lru_cache(maxsize=512)
+def _design_cached(highcut, fs, order, ftype, lowcut):
     from scipy import signal
     nyq = 0.5 * fs
     wn = highcut / nyq if lowcut is None else [lowcut / nyq, highcut / nyq]

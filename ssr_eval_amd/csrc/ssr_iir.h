@@ -171,6 +171,10 @@ SSR_DEV void ssr_iir_pass(const SsrIirLane<X>& q, int s, int S, int edge, double
   // the sixteen inputs of chunk c (consumed by lane 0 of the group; every lane of the group requests them), 16-byte loads.
   // A lane whose chunk is not interior reads the scratch block: values nobody uses (the chunk is then not run as a regular one).
   auto load_regular = [&](int c, XT (&b)[CK]) __attribute__((always_inline)) {
+#ifdef SSR_IIR_DEV_NO_LOAD             /* developer experiment (wrong results): what the sixteen-sample loads cost */
+    SSR_UNROLL for (int k = 0; k < CK; ++k) b[k] = (XT)(0.001 * (c + k));
+    return;
+#endif
     const int t0 = c * CK;
     const bool inner = BACKWARD ? (t0 + CK <= q.ne) : (t0 >= edge && t0 + CK <= edge + q.len);
     if constexpr (BACKWARD) {
@@ -216,6 +220,10 @@ SSR_DEV void ssr_iir_pass(const SsrIirLane<X>& q, int s, int S, int edge, double
     yout = yv[CK - 1];
     const bool full = n0 >= 0 && n0 + CK <= q.ne;
     const bool keep = last && full && (BACKWARD ? (n0 >= edge && n0 + CK <= q.ne - edge) : true);
+#ifdef SSR_IIR_DEV_NO_STORE            /* developer experiment (wrong results): what the sixteen-sample stores cost */
+    if (yv[0] == 1.2345e300) q.trash[0] = yv[CK - 1];
+    return;
+#endif
     if constexpr (BACKWARD) {
       ssr_d2u* dst = reinterpret_cast<ssr_d2u*>(keep ? q.y + ((q.ne - 1 - edge - n0) - (CK - 1)) : q.trash);
       SSR_UNROLL for (int j = 0; j < CK / 2; ++j) { ssr_d2u v; v.x = yv[CK - 1 - 2 * j]; v.y = yv[CK - 2 - 2 * j]; dst[j] = v; }

@@ -174,6 +174,9 @@ static void emu_r3_rot_run(const SsrStftParams<T>& p, int n_items, int n_chunks,
   for (int item = 0; item < n_items; ++item)
     for (int c = 0; c < n_chunks; ++c) {
       auto lds = poisoned(SsrR3RotLds<T, 24>::bytes(p.n_fft / 3));
+      if constexpr (sizeof(T) == 8) {
+        if (p.a64 && p.b64) { ssr_stft_r3_rot_body<T, false, 3, 24, SSR_IN_EST64X2>(p, blk, c, item, lds.data()); continue; }   // two float64 estimates (round 6)
+      }
       if (p.a64 && sums) ssr_stft_r3_rot_body<T, true, 3, 24, SSR_IN_EST64>(p, blk, c, item, lds.data());     // float64 estimate (round 5)
       else if (p.a64) ssr_stft_r3_rot_body<T, false, 3, 24, SSR_IN_EST64>(p, blk, c, item, lds.data());
       else if (sums) ssr_stft_r3_rot_body<T, true, 3, 24>(p, blk, c, item, lds.data());
@@ -185,14 +188,14 @@ static void emu_r3_rot_run(const SsrStftParams<T>& p, int n_items, int n_chunks,
 template <typename T>
 static int emu_stft_r3_wave_t(int n_fft, int hop, int out_kind, int mask, int m1536, const float* a, const double* a64, const float* b, const int64_t* a_off,
                               const int64_t* b_off, const int32_t* len, const int64_t* frame_off, int n_items,
-                              int units_per_chunk, int n_chunks, float* out_a, float* out_b, double* part) {
+                              int units_per_chunk, int n_chunks, float* out_a, float* out_b, double* part, const double* b64 = nullptr) {
   SsrEngine we = ssr_pick_wave_engine(n_fft);
   if (!we.ok) return -4;
   if (!m1536) we.m = 0;
   SsrTables<T> t;
   if (!ssr_build_tables_for<T>(n_fft, we, t)) return -3;
   SsrStftParams<T> p{};
-  p.a = a; p.a64 = a64; p.b = b; p.a_off = a_off; p.b_off = b_off; p.len = len; p.frame_off = frame_off;
+  p.a = a; p.a64 = a64; p.b = b; p.b64 = b64; p.a_off = a_off; p.b_off = b_off; p.len = len; p.frame_off = frame_off;
   p.mode = SSR_MODE_PAIR; p.out_kind = out_kind; p.metric_mask = mask;
   p.n_fft = n_fft; p.hop = hop; p.n_bins = n_fft / 2 + 1;
   p.units_per_chunk = units_per_chunk; p.n_chunks = n_chunks;
@@ -229,6 +232,14 @@ extern "C" int emu_stft_r3_rot_est64(int n_fft, int hop, int out_kind, int mask,
                                      int n_items, int units_per_chunk, int n_chunks, float* out_a, float* out_b, double* part) {
   return emu_stft_r3_wave_t<double>(n_fft, hop, out_kind, mask, 1, nullptr, a64, b, a_off, b_off, len, frame_off, n_items, units_per_chunk,
                                     n_chunks, out_a, out_b, part);
+}
+
+// ... and with TWO float64 estimates in one complex transform, magnitude rows only (ssr_pair_metrics_multi_est64, round 6)
+extern "C" int emu_stft_r3_rot_est64x2(int n_fft, int hop, const double* a64, const double* b64, const int64_t* a_off, const int64_t* b_off,
+                                       const int32_t* len, const int64_t* frame_off, int n_items, int units_per_chunk, int n_chunks,
+                                       float* out_a, float* out_b) {
+  return emu_stft_r3_wave_t<double>(n_fft, hop, SSR_OUT_MAG, 0, 1, nullptr, a64, nullptr, a_off, b_off, len, frame_off, n_items, units_per_chunk,
+                                    n_chunks, out_a, out_b, nullptr, b64);
 }
 
 // pair mode with a float64 estimate and a float32 (b) or float64 (b64) target (IN64 kernel variants)

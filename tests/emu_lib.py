@@ -96,6 +96,28 @@ def stft(sigs_a, sigs_b, n_fft, hop, precision=1, mode=0, out_kind=1, mask=0, un
     return split(out_a), split(out_b), part
 
 
+def stft_r3_rot_est64x2(sigs_a, sigs_b, n_fft, hop, units_per_chunk=8):
+    """Two float64 estimates per complex transform on the rotating engine, images only (k_stft_r3_rot<double, false, 3, 24, 7>):
+    -> (float32 magnitude rows of a, of b)."""
+    a64 = np.concatenate(sigs_a).astype(np.float64)
+    b64 = np.concatenate(sigs_b).astype(np.float64)
+    _, a_off, lens = ragged(sigs_a)
+    _, b_off, lens_b = ragged(sigs_b)
+    assert (lens == lens_b).all()
+    T = np.array([num_frames(int(n), n_fft, hop) for n in lens])
+    F = n_fft // 2 + 1
+    frame_off = np.concatenate(([0], np.cumsum(T)[:-1])).astype(np.int64)
+    n_chunks = int(-(-T.max() // units_per_chunk))
+    out_a = np.full((int(T.sum()), F), np.nan, np.float32)
+    out_b = np.full((int(T.sum()), F), np.nan, np.float32)
+    rc = lib().emu_stft_r3_rot_est64x2(n_fft, hop, _p(a64, C.c_double), _p(b64, C.c_double), _p(a_off, C.c_int64), _p(b_off, C.c_int64),
+                                       _p(lens, C.c_int32), _p(frame_off, C.c_int64), len(lens), units_per_chunk, n_chunks,
+                                       _p(out_a, C.c_float), _p(out_b, C.c_float))
+    assert rc == 24, rc
+    split = lambda o: [o[frame_off[i]:frame_off[i] + T[i]] for i in range(len(lens))]
+    return split(out_a), split(out_b)
+
+
 def spectro_desc(sps):
     T = np.array([s.shape[0] for s in sps], np.int32)
     frame_off = np.concatenate(([0], np.cumsum(T)[:-1])).astype(np.int64)

@@ -349,6 +349,31 @@ def test_pair_metrics_float64_estimate(golden, n_fft, hop):
     np.testing.assert_allclose(got, want, rtol=1e-6)
 
 
+def test_rotating_engine_two_float64_estimates_per_transform(golden):
+    """ssr_pair_metrics_multi_est64's transform (round 6: k_stft_r3_rot<double, false, 3, 24, 7>): TWO float64 IIR estimates ride one
+    complex transform and leave as float32 magnitude rows.  Each row set equals the one the float64-estimate pair kernel writes for that
+    estimate with the TARGET as its partner (transform round-off: a last float32 bit here and there), chunks that end mid-rotation and
+    a silent stretch included; and the metrics reduced from those rows against the stored target image (k_specred + finalisation) equal
+    the float64-estimate pair kernel's to 1e-6."""
+    n_fft, hop = 2229, 480
+    rng = np.random.default_rng(77)
+    tgts = [golden["ss_x"][:14000].astype(np.float32), (0.1 * rng.standard_normal(9000)).astype(np.float32)]
+    ea = [signal.sosfiltfilt(olp.iir_sos(2000, 44100, 8, "cheby1"), t) for t in tgts]
+    eb = [signal.sosfiltfilt(olp.iir_sos(8000, 44100, 2, "butter"), t) for t in tgts]
+    eb[1][2000:5500] = 0.0                                            # whole silent frames in one estimate
+    F = n_fft // 2 + 1
+    for upc in (3, 5):
+        xa, xb = E.stft_r3_rot_est64x2(ea, eb, n_fft, hop, upc)
+        for est, rows in ((ea, xa), (eb, xb)):
+            pa, pt, _ = E.stft(est, tgts, n_fft, hop, 1, 0, 1, E.M_ALL, upc, est64=True, wave="r3")
+            for a, b in zip(rows, pa):
+                np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-9)
+            part, T = E.specred_parts(rows, pt, 7, 8)
+            got = E.finalize(part, None, T, F, 7)
+            want = E.pair_metrics(est, tgts, n_fft, hop, precision=1, mask=7, units_per_chunk=upc, est64=True, wave="r3")
+            np.testing.assert_allclose(got[:, :3], want[:, :3], rtol=1e-6, atol=1e-6)
+
+
 def test_rotating_engine_float64_estimate_equals_the_block_engine(golden):
     """ssr_stft_r3_rot.h's IN64 variant (round 5: AudioMetrics(48000) = 2229 / 480 behind an IIR degradation runs on the rotating
     four-wave engine instead of the block engine): the metrics of a float64 estimate against the oracle at the block engine's bar,

@@ -357,12 +357,12 @@ def test_rotating_engine_two_float64_estimates_per_transform(golden):
     the float64-estimate pair kernel's to 1e-6."""
     n_fft, hop = 2229, 480
     rng = np.random.default_rng(77)
-    tgts = [golden["ss_x"][:14000].astype(np.float32), (0.1 * rng.standard_normal(9000)).astype(np.float32)]
+    tgts = [golden["ss_x"][:6000].astype(np.float32), (0.1 * rng.standard_normal(7000)).astype(np.float32)]
     ea = [signal.sosfiltfilt(olp.iir_sos(2000, 44100, 8, "cheby1"), t) for t in tgts]
     eb = [signal.sosfiltfilt(olp.iir_sos(8000, 44100, 2, "butter"), t) for t in tgts]
-    eb[1][2000:5500] = 0.0                                            # whole silent frames in one estimate
+    eb[1][1500:5000] = 0.0                                            # whole silent frames in one estimate
     F = n_fft // 2 + 1
-    for upc in (3, 5):
+    for upc in (5,):                                                  # (15 frames in chunks of 5: chunks end mid-rotation)
         xa, xb = E.stft_r3_rot_est64x2(ea, eb, n_fft, hop, upc)
         for est, rows in ((ea, xa), (eb, xb)):
             pa, pt, _ = E.stft(est, tgts, n_fft, hop, 1, 0, 1, E.M_ALL, upc, est64=True, wave="r3")

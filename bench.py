@@ -1026,10 +1026,14 @@ def run(a):
         dev, sync, backend = torch.device("cpu"), (lambda: None), "gloo"
     else:
         assert torch.cuda.is_available(), "bench.py needs an MI355X"
-        if torch.cuda.device_count() <= local_rank:
+        if torch.cuda.device_count() <= local_rank and not a.share_gpu:
             raise SystemExit("bench.py: rank %d has no device (%d visible)" % (local_rank, torch.cuda.device_count()))
+        if a.share_gpu:
+            # TEST HOOK (tests/test_gpu_configs.py): every rank on cuda:0 with gloo for the collectives - the one-GPU box of the test suite
+            # runs the real workloads, the cfg-4 side figure and the rank-0 report under world_size > 1; never a measurement
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dev, sync, backend = torch.device("cuda", local_rank), torch.cuda.synchronize, "nccl"
+        dev, sync, backend = torch.device("cuda", local_rank), torch.cuda.synchronize, ("gloo" if a.share_gpu else "nccl")
     if world > 1:
         D.init_from_env(backend)
         joined = dist.get_world_size()                # the ranks that actually joined the group
@@ -1191,6 +1195,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the cfg3 / cfg5 / API-true / end-to-end side figures")
     ap.add_argument("--_cpu-skeleton", dest="cpu_skeleton", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--_share-gpu", dest="share_gpu", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
 
@@ -1199,7 +1204,7 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # self-launch: one process per GPU.  Never degrade to fewer ranks than asked for.
         n_dev = torch.cuda.device_count()
-        if n_dev < a.gpus and not a.cpu_skeleton:
+        if n_dev < a.gpus and not a.cpu_skeleton and not a.share_gpu:
             raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) are visible" % (a.gpus, n_dev))
         import torch.multiprocessing as mp
         port = 29400 + os.getpid() % 2000

@@ -726,6 +726,35 @@ def test_bench_cli_configs_smoke():
         assert d["scaling"] == ("strong" if cfg == "cfg4" else "weak")
 
 
+def test_bench_under_two_ranks_as_the_driver_launches_it():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 --steps K --warmup W` - the driver's command for its scaling
+    runs - on the one-GPU box: both ranks on cuda:0, gloo for the collectives (--_share-gpu, a test hook: RCCL itself cannot run two ranks
+    on one device).  What only exists under world_size > 1 runs for real here: the asynchronous all-reduce of the step's sums against the
+    next step's kernels, the barrier + MAX-over-ranks timing, the cfg-4 strong-scaling side figure every rank takes part in, the rank-0
+    report with each rank's own clock.  One JSON line from rank 0, the whole-job value = both ranks' pairs."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    port = 29700 + os.getpid() % 200
+    for extra in ([], ["--config", "cfg4", "--collective", "allreduce"]):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                            "--_share-gpu"] + extra, capture_output=True, text=True, timeout=900, env=env)
+        port += 1
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0 and d["cpu_baseline"] is None
+        ranks = d["extra"]["ranks"]
+        assert ranks["joined"] == 2 and len(ranks["ms_per_step_per_rank"]) == 2 and ranks["backend"] == "gloo"
+        if not extra:
+            assert d["scaling"] == "weak" and abs(d["value"] - 2 * 1024 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+            side = d["extra"]["cfg4_strong_scaling"]
+            assert side["n_gpus"] == 2 and side["scaling"] == "strong" and side["value"] > 0
+            assert d["extra"]["allreduce_payload_bytes_per_step"] == 24
+        else:
+            assert d["scaling"] == "strong" and abs(d["value"] - 2937 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+
+
 # ---- N2 ingest: windowed-sinc (resampy kaiser_best) resampling and the batched file loader ---------------------------------------
 @pytest.mark.parametrize("sr_orig,sr_new", [(44100, 48000), (48000, 44100), (48000, 16000), (16000, 44100), (44100, 16000), (22050, 48000)])
 def test_sinc_resampler_bit_exact_vs_restatement_gpu(sr_orig, sr_new):

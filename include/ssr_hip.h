@@ -388,8 +388,9 @@ int ssr_sosfiltfilt_f64(const double* x, const int64_t* off, const int32_t* len,
 
 /* The same for n_designs filters over ONE batch in one launch (round 5): SSR_Eval_Helper.preprocess applies every
  * (filter type, cutoff, order) of setting_lowpass_filtering to the same waveform (ssr_eval/eval.py:243-258, three nested loops).
- * The recurrence is serial in time - a launch is latency-bound (~85 ns per sample step) and occupies 1/8 wave per utterance - so
- * 36 designs one after the other took 36 x that latency (94 % of an evaluate() pass with IIR settings); side by side they take it once.
+ * The recurrence is serial in time - a launch lasts as long as its longest utterance's chain (35-39 ns per sample step since round 6:
+ * ssr_iir.h) whatever runs beside it - so 36 designs one after the other took 36 x that latency (94 % of an evaluate() pass with IIR
+ * settings in round 4); side by side they take it once.  A design of S sections occupies the smallest power of two >= S lanes per utterance.
  * sos: DEVICE [n_designs][8][6] (rows >= n_sections[d] unused), zi: DEVICE [n_designs][8][2]; n_sections, edge: HOST [n_designs]
  * (n_sections <= 8, n_designs <= 48); y: [n_designs][y_stride] float64, design d's output in x's ragged layout from d * y_stride.
  * Every output bit-identical to the single-design call. */

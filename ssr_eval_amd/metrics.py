@@ -117,19 +117,24 @@ class AudioMetrics:
             finish = lambda: (lambda rows: [rows[i * K:(i + 1) * K] for i in range(n)])(flat())    # noqa: E731
             return finish if deferred else finish()
         tgts = [pairs[0][i][1] for i in range(n)]
-        parts = []                                                   # (key indices, wide, collector -> [n][len(keys)] dicts)
+
+        def one_key(k):                                              # a group of ONE key: the plain pair path -> [n][1] dicts
+            flat = self.evaluation_batch([pairs[k][i][0] for i in range(n)], tgts, mask, True, deferred=True)
+            return lambda: [[row] for row in flat()]
+
+        def many_keys(keys, wide):                                   # one multi launch sequence -> [n][len(keys)] dicts
+            pending = B.pair_metrics_multi(self._plan(), [[pairs[k][i][0] for i in range(n)] for k in keys], tgts, mask, deferred=True)
+
+            def collect():
+                vals = pending()
+                return [[self._row_dict(vals[i, j], mask, wide) for j in range(len(keys))] for i in range(n)]
+            return collect
+
+        parts = []                                                   # (key indices, collector)
         for wide in (False, True):
             keys = [k for k in range(K) if next(iter(kinds[k])) == wide]
-            if not keys:
-                continue
-            if len(keys) == 1:
-                k = keys[0]
-                flat = self.evaluation_batch([pairs[k][i][0] for i in range(n)], tgts, mask, True, deferred=True)
-                parts.append((keys, (lambda f: (lambda: [[row] for row in f()]))(flat)))
-            else:
-                pending = B.pair_metrics_multi(self._plan(), [[pairs[k][i][0] for i in range(n)] for k in keys], tgts, mask, deferred=True)
-                parts.append((keys, (lambda pnd, nk, w: (lambda: (lambda vals: [[self._row_dict(vals[i, j], mask, w) for j in range(nk)]
-                                                                                for i in range(n)])(pnd())))(pending, len(keys), wide)))
+            if keys:
+                parts.append((keys, one_key(keys[0]) if len(keys) == 1 else many_keys(keys, wide)))
 
         def finish():
             out = [[None] * K for _ in range(n)]
